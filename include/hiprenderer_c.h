@@ -1,0 +1,296 @@
+/* hiprenderer_c.h -- C-ABI of the HIPRenderer path-tracing kernels for MI355X (gfx950).
+ *
+ * This is the drop-in boundary between a Bifrost host renderer and the hand-written HIP
+ * wavefront path tracer. Every entry point replaces one interaction the reference
+ * OptiXRenderer host code has with the OptiX 6.5 runtime. Paths below are relative to
+ * /root/reference/extensions/OptiXRenderer/OptiXRenderer/ ("OR/").
+ *
+ * Conventions
+ *  - All functions return an int status: HIPR_OK (0) or a negative HiprStatus. No exceptions
+ *    cross the ABI. hipr_last_error() returns a thread-local human readable message.
+ *  - The library never takes ownership of caller memory: uploads copy.
+ *  - Pointers named *_device are device (HBM) pointers, everything else is host memory.
+ *  - Single-threaded contract per context, as the reference (BF/Core/Engine.cpp:36-49).
+ *  - Image rows: row 0 is the bottom row (the reference adaptor flips Y when blitting,
+ *    extensions/DX11OptiXAdapter/DX11OptiXAdapter/Adaptor.cpp:113-115).
+ */
+#ifndef HIPRENDERER_C_H
+#define HIPRENDERER_C_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------- */
+/* Status codes                                                                                */
+/* ------------------------------------------------------------------------------------------- */
+typedef enum HiprStatus {
+    HIPR_OK = 0,
+    HIPR_ERROR_INVALID_ARGUMENT = -1,
+    HIPR_ERROR_NO_DEVICE = -2,      /* OR/Renderer.cpp:280-281 returns an invalid renderer */
+    HIPR_ERROR_OUT_OF_MEMORY = -3,
+    HIPR_ERROR_HIP = -4,            /* a HIP runtime call failed, see hipr_last_error() */
+    HIPR_ERROR_NOT_READY = -5,      /* render before tables/scene/frame were set */
+    HIPR_ERROR_UNSUPPORTED = -6
+} HiprStatus;
+
+/* ------------------------------------------------------------------------------------------- */
+/* Device PODs. Layouts follow the reference's device structs so the host code fills them the  */
+/* same way (OR/Types.h). All are tightly packed little-endian.                                */
+/* ------------------------------------------------------------------------------------------- */
+
+/* OR/Types.h:353-383, 64 bytes. flags: 1 = ThinWalled, 2 = Cutout. shading_model: 0 Default,
+ * 1 Diffuse, 2 Transmissive. coat / coat_roughness are UNorm16 (OR/Types.h:76-93). Texture IDs
+ * are indices into HiprSceneDesc::textures, 0 = none. */
+typedef struct HiprMaterial {
+    uint16_t flags;
+    uint16_t shading_model;
+    float tint[3];
+    float roughness;
+    int32_t tint_roughness_texture_ID;
+    int32_t roughness_texture_ID;
+    float specularity;
+    float metallic;
+    int32_t metallic_texture_ID;
+    float coverage;
+    int32_t coverage_texture_ID;
+    float emission[3];
+    uint16_t coat;
+    uint16_t coat_roughness;
+} HiprMaterial;
+
+enum { HIPR_MATERIAL_THIN_WALLED = 1, HIPR_MATERIAL_CUTOUT = 2 };
+enum { HIPR_SHADING_DEFAULT = 0, HIPR_SHADING_DIFFUSE = 1, HIPR_SHADING_TRANSMISSIVE = 2 };
+
+/* OR/Types.h:290-312, 48 bytes. `data` is the union payload:
+ *   Sphere      : power[0..2] position[3..5] radius[6]
+ *   Spot        : power[0..2] position[3..5] radius[6] direction[7..9] cos_angle[10]
+ *   Directional : radiance[0..2] direction[3..5]
+ * flags & 7 is the light type. */
+typedef struct HiprLight {
+    float data[11];
+    uint32_t flags;
+} HiprLight;
+
+enum { HIPR_LIGHT_NONE = 0, HIPR_LIGHT_SPHERE = 1, HIPR_LIGHT_DIRECTIONAL = 2, HIPR_LIGHT_ENVIRONMENT = 3,
+       HIPR_LIGHT_PRESAMPLED_ENVIRONMENT = 4, HIPR_LIGHT_SPOT = 5, HIPR_LIGHT_TYPE_MASK = 7 };
+
+/* OR/Types.h:116-119, 16 bytes: float3 position + octahedral SNORM16 normal
+ * (encode BF/Math/OctahedralNormal.h:53-83, decode OR/Types.h:62-69). Positions are in
+ * OBJECT space, the normal as well. */
+typedef struct HiprVertexGeometry {
+    float position[3];
+    int16_t oct_normal[2];
+} HiprVertexGeometry;
+
+/* OR/Types.h:46-52 */
+enum { HIPR_MESH_NORMALS = 1, HIPR_MESH_TEXCOORDS = 2, HIPR_MESH_TINTS = 4, HIPR_MESH_EMISSIVE = 8 };
+
+/* One per mesh model. Replaces the OptiX Transform -> GeometryGroup -> GeometryInstance chain
+ * and its ModelState / mesh_flags variables (OR/Renderer.cpp:138-182, OR/Types.h:477-480).
+ * Offsets index the pooled attribute arrays of HiprSceneDesc; an unused attribute's offset is
+ * ignored (gated by mesh_flags exactly as ORS/TriangleAttributes.cu:50-83). */
+typedef struct HiprInstance {
+    float object_to_world[12];  /* row-major 3x4, to_matrix3x4(Transform) (BF/Math/Conversions.h:69-75) */
+    uint32_t index_offset;      /* first uint3 of this mesh in `indices` */
+    uint32_t vertex_offset;     /* first vertex of this mesh in `geometry` / `texcoords` / `tints` / `emissions` */
+    int32_t instance_id;        /* InstanceID bits: (1 << 30) | mesh model index (OR/Types.h:121-138) */
+    int32_t material_index;
+    uint32_t mesh_flags;
+    uint32_t _pad[3];
+} HiprInstance;
+
+/* World-space triangle in BVH leaf order, 48 bytes. Built by the host flattening the
+ * instances (replaces the OptiX "Trbvh" build, OR/Renderer.cpp:161-182,471-476). */
+typedef struct HiprTriangle {
+    float v0[3];
+    float v1[3];
+    float v2[3];
+    uint32_t instance_index;   /* index into HiprSceneDesc::instances */
+    uint32_t primitive_index;  /* rtGetPrimitiveIndex() equivalent within the mesh */
+    uint32_t flags;            /* HIPR_TRIANGLE_* */
+} HiprTriangle;
+
+enum { HIPR_TRIANGLE_OPAQUE = 1 /* shadow rays terminate here: coverage is statically 1 (ORS/MonteCarlo.cu:278-285) */ };
+
+/* BVH2 node, 64 bytes. Child c spans lo/hi boxes stored Aila-Laine style:
+ *   c0xy = { c0.lo.x, c0.hi.x, c0.lo.y, c0.hi.y }
+ *   c1xy = { c1.lo.x, c1.hi.x, c1.lo.y, c1.hi.y }
+ *   cz   = { c0.lo.z, c0.hi.z, c1.lo.z, c1.hi.z }
+ * child >= 0 : index of an inner node.
+ * child <  0 : leaf, ~child = (first_triangle << 3) | (triangle_count - 1), count in [1, 8]. */
+typedef struct HiprBvhNode {
+    float c0xy[4];
+    float c1xy[4];
+    float cz[4];
+    int32_t child[2];
+    uint32_t _pad[2];
+} HiprBvhNode;
+
+/* Software replacement for the reference's texture samplers (OR/Renderer.cpp:703-751).
+ * Texels live in HiprSceneDesc::texels at `texel_offset` (bytes). */
+typedef struct HiprTexture {
+    uint32_t width, height;
+    uint32_t texel_offset;
+    uint8_t format;        /* HIPR_TEXEL_* */
+    uint8_t wrap_u, wrap_v;/* 0 clamp, 1 repeat (BF/Assets/Texture.h:21-35) */
+    uint8_t filter;        /* bit0: linear magnification, bit1: linear minification */
+    uint8_t is_sRGB;       /* RT_TEXTURE_READ_NORMALIZED_FLOAT_SRGB (OR/Renderer.cpp:736-739) */
+    uint8_t _pad[3];
+} HiprTexture;
+
+enum { HIPR_TEXEL_R8 = 1, HIPR_TEXEL_RGBA8 = 4, HIPR_TEXEL_R32F = 17, HIPR_TEXEL_RGBA32F = 20 };
+
+/* The flat scene the host produces in handle_updates() (OR/Renderer.cpp:578-1205). */
+typedef struct HiprSceneDesc {
+    const HiprBvhNode* nodes;            uint32_t node_count;
+    const HiprTriangle* triangles;       uint32_t triangle_count;
+    const HiprInstance* instances;       uint32_t instance_count;
+    const uint32_t* indices;             uint32_t index_count;      /* uint3 per primitive, count in uints */
+    const HiprVertexGeometry* geometry;  uint32_t vertex_count;
+    const float* texcoords;              /* float2 per vertex or NULL */
+    const uint32_t* tints;               /* uchar4 (tint rgb, roughness) per vertex or NULL */
+    const float* emissions;              /* float3 per vertex or NULL */
+    const HiprMaterial* materials;       uint32_t material_count;   /* slot 0 = invalid material */
+    const HiprLight* lights;             uint32_t light_count;
+    const HiprTexture* textures;         uint32_t texture_count;    /* slot 0 = none */
+    const uint8_t* texels;               uint32_t texel_bytes;
+    uint32_t bvh_max_depth;              /* deepest leaf, root = 1; selects the LDS stack size */
+} HiprSceneDesc;
+
+/* OR/Types.h:507-523 SceneStateGPU, without OptiX buffer ids. */
+typedef struct HiprSceneState {
+    float environment_tint[3];
+    int32_t next_event_sample_count;   /* default 3 (OR/Renderer.cpp:479), clamped to 256 (:1390-1392) */
+} HiprSceneState;
+
+/* OR/Types.h:486-501 CameraStateGPU, matrices row-major as Matrix4x4f::begin(). */
+typedef struct HiprCameraState {
+    float view_to_world_rotation[9];
+    float inverse_projection_matrix[16];
+    float inverse_view_projection_matrix[16];
+    uint32_t accumulations;
+    uint32_t max_bounce_count;
+    float path_regularization_PDF_scale;
+} HiprCameraState;
+
+/* Precomputed tables uploaded at init (OR/Renderer.cpp:380-467). Float inputs are quantised to
+ * unorm16 by the library exactly as the reference (`unsigned short(v * 65535 + 0.5f)`). */
+typedef struct HiprTables {
+    const float* ggx_with_fresnel_rho;  /* 32x32, F0 = 0, "base" */
+    const float* ggx_rho;               /* 32x32, F0 = 1, "full" */
+    const float* dielectric_light_rho;  /* 16x16x16 float2 (total, reflected), ior in [0.331492, 0.789474] */
+    const float* dielectric_dense_rho;  /* 16x16x16 float2, ior in [1.26667, 3.01667] */
+    const float* ggx_alpha_from_max_PDF;/* 32x32, x = encoded PDF, y = cos_theta */
+} HiprTables;
+
+/* Which pixels this context renders. The framebuffer is cut into 8x8 pixel tiles (one
+ * wavefront of camera rays each), numbered row-major; the context owns tiles with
+ * tile_id % tile_stride == tile_phase. tile_stride = 1 is the single GPU case. */
+typedef struct HiprFrameDesc {
+    uint32_t width, height;
+    uint32_t tile_phase, tile_stride;
+    uint32_t samples_per_pass;   /* accumulations traced per hipr_render_pass, >= 1 */
+} HiprFrameDesc;
+
+/* Ray / traversal counters of the last pass. */
+typedef struct HiprCounters {
+    uint64_t camera_rays;        /* P: pixel-samples generated */
+    uint64_t closest_rays;       /* R_mc: closest-hit traces incl. retraces */
+    uint64_t shadow_rays;        /* R_sh */
+    uint64_t shaded_hits;        /* H: accepted surface hits */
+    uint64_t closest_nodes;      /* N_mc (only when instrumented counting is enabled) */
+    uint64_t closest_triangles;  /* T_mc */
+    uint64_t shadow_nodes;       /* N_sh */
+    uint64_t shadow_triangles;   /* T_sh */
+    uint64_t iterations;         /* trace/shade rounds of the wavefront loop */
+} HiprCounters;
+
+/* Per-kernel device time of the passes since hipr_reset_timers(), measured with HIP events
+ * on the context's stream. Index with HIPR_KERNEL_*. */
+enum { HIPR_KERNEL_GENERATE = 0, HIPR_KERNEL_TRACE_CLOSEST = 1, HIPR_KERNEL_SHADE = 2,
+       HIPR_KERNEL_TRACE_SHADOW = 3, HIPR_KERNEL_ACCUMULATE = 4, HIPR_KERNEL_COUNT = 5 };
+typedef struct HiprKernelTimes {
+    double milliseconds[HIPR_KERNEL_COUNT];
+    uint64_t launches[HIPR_KERNEL_COUNT];
+} HiprKernelTimes;
+
+typedef struct HiprContext HiprContext;
+
+/* ------------------------------------------------------------------------------------------- */
+/* Lifetime: Renderer::initialize / ~Renderer (OR/Renderer.cpp:273-574, 1365-1387)             */
+/* ------------------------------------------------------------------------------------------- */
+int hipr_create(int device_id, HiprContext** out_context);
+int hipr_destroy(HiprContext* context);
+const char* hipr_last_error(void);
+/* Number of HIP devices visible; 0 mirrors Context::getDeviceCount() == 0 (OR/Renderer.cpp:280). */
+int hipr_device_count(void);
+
+/* Use an externally owned hipStream_t (e.g. torch's current stream); NULL = the context's own. */
+int hipr_set_stream(HiprContext* context, void* hip_stream);
+
+/* ------------------------------------------------------------------------------------------- */
+/* Uploads: the tables of OR/Renderer.cpp:380-467 and the scene of handle_updates :578-1205     */
+/* ------------------------------------------------------------------------------------------- */
+int hipr_upload_tables(HiprContext* context, const HiprTables* tables);
+int hipr_upload_scene(HiprContext* context, const HiprSceneDesc* scene);
+int hipr_set_scene_state(HiprContext* context, const HiprSceneState* state);
+
+/* (Re)allocates the f64 accumulation buffer and the wavefront queues for the owned tiles;
+ * resets nothing else. Replaces accumulation_buffer->setSize (OR/Renderer.cpp:1215-1219). */
+int hipr_set_frame(HiprContext* context, const HiprFrameDesc* frame);
+/* Number of pixels this context owns under the current frame description. */
+int hipr_owned_pixel_count(HiprContext* context, uint32_t* out_count);
+
+/* ------------------------------------------------------------------------------------------- */
+/* Rendering: context->launch(entry, w, h) of OR/IBackend.h:37-39 / OR/Renderer.cpp:1250-1265   */
+/* ------------------------------------------------------------------------------------------- */
+/* Traces frame.samples_per_pass accumulations starting at camera->accumulations for every owned
+ * pixel, folds them into the f64 running mean (ORS/SimpleRGPs.cu:74-107) and writes half4 pixels.
+ * out_half4_device:
+ *   tile_stride == 1 : full frame, pixel (x, y) at out[x + y * out_pitch_pixels]  (ORS/SimpleRGPs.cu:106)
+ *   tile_stride  > 1 : compact, owned pixel k at out[k] in owned-tile-major order (see hipr_scatter_tiles)
+ * May be NULL to skip the half4 output. Asynchronous on the context stream unless `synchronize`. */
+int hipr_render_pass(HiprContext* context, const HiprCameraState* camera,
+                     void* out_half4_device, uint32_t out_pitch_pixels, int synchronize);
+
+/* Copies the f64 accumulation (double4 per owned pixel, compact owned-tile-major order or full
+ * frame row-major when tile_stride == 1) to host memory. Blocking. */
+int hipr_read_accumulation(HiprContext* context, double* out_rgba, uint64_t capacity_pixels);
+/* Scatter `rank_count` compact half4 buffers (as gathered over RCCL, rank r at
+ * compact_device + r * pixels_per_rank_stride) into a full frame. Runs on the context stream. */
+int hipr_scatter_tiles(HiprContext* context, const void* compact_half4_device, uint64_t pixels_per_rank_stride,
+                       uint32_t rank_count, uint32_t width, uint32_t height,
+                       void* out_half4_device, uint32_t out_pitch_pixels);
+
+int hipr_synchronize(HiprContext* context);
+int hipr_get_counters(HiprContext* context, HiprCounters* out);
+/* Enables per-ray node / triangle visit counting in the trace kernels (slower, off by default). */
+int hipr_set_instrumentation(HiprContext* context, int count_traversal_steps);
+int hipr_reset_timers(HiprContext* context);
+int hipr_get_kernel_times(HiprContext* context, HiprKernelTimes* out);
+
+/* ------------------------------------------------------------------------------------------- */
+/* Stage-level entry points used by the parity tests: each runs ONE kernel of the path on       */
+/* host-provided inputs and returns its raw output, so the kernels can be compared with the     */
+/* CPU oracle bit for bit where the arithmetic is integer or correctly rounded f32.             */
+/* ------------------------------------------------------------------------------------------- */
+/* K1: camera rays for all owned pixels (ORS/SimpleRGPs.cu:44-72). Outputs host arrays of
+ * owned_pixel_count entries: origin_tmin (float4), direction (float4, w unused), pixel (uint2 as x | y << 16). */
+int hipr_debug_generate(HiprContext* context, const HiprCameraState* camera, uint32_t accumulation,
+                        float* out_origin_tmin, float* out_direction, uint32_t* out_pixel);
+/* RNG: PracticalScrambledSobol::sample4ui (OR/RNG.h:280-287) for n (accumulation, pixel_hash, dimension) triples. */
+int hipr_debug_sobol(HiprContext* context, const uint32_t* accumulation_pixelhash_dimension, uint32_t n, uint32_t* out_uint4);
+/* K2: closest hit for n rays. rays: float4 origin_tmin + float4 direction_tmax per ray; skip: global triangle index
+ * to ignore per ray (0xFFFFFFFF = none). out_hits: float4 {t, u, v, bits(tri_or_light)} per ray. */
+int hipr_debug_trace_closest(HiprContext* context, const float* rays, const uint32_t* skip, uint32_t n, float* out_hits);
+/* K4: shadow transmittance for n rays (float4 origin_tmin + float4 direction_tmax) -> one float per ray. */
+int hipr_debug_trace_shadow(HiprContext* context, const float* rays, uint32_t n, float* out_transmittance);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* HIPRENDERER_C_H */

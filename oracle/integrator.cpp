@@ -1,0 +1,587 @@
+// oracle/integrator.cpp -- see integrator.h. TEST INFRASTRUCTURE ONLY.
+#include "integrator.h"
+
+#include <cmath>
+
+namespace oracle {
+
+// ---------------------------------------------------------------------------------------------
+// Camera rays: fill_ray_info + initialize_monte_carlo_payload (ORS/SimpleRGPs.cu:44-72)
+// ---------------------------------------------------------------------------------------------
+static inline float4 mul4x4(const float* m, float4 v) {
+    return {m[0] * v.x + m[1] * v.y + m[2] * v.z + m[3] * v.w,
+            m[4] * v.x + m[5] * v.y + m[6] * v.z + m[7] * v.w,
+            m[8] * v.x + m[9] * v.y + m[10] * v.z + m[11] * v.w,
+            m[12] * v.x + m[13] * v.y + m[14] * v.z + m[15] * v.w};
+}
+static inline float3 mul3x3(const float* m, float3 v) {
+    return {m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z, m[6] * v.x + m[7] * v.y + m[8] * v.z};
+}
+
+void generate_camera_ray(const HiprCameraState& cam, int x, int y, int width, int height, uint32_t accumulation,
+                         float3& origin, float3& direction) {
+    uint32_t pixel_hash = rng::pcg2d(uint32_t(x), uint32_t(y)).x;
+    float2 jitter = {0.5f, 0.5f};
+    if (accumulation != 0) {
+        float4 s = rng::sample4f(accumulation, pixel_hash, 0u);   // dimension = 8 * bounces(0) + CAMERA_PARAMETERS(0)
+        jitter = {s.x, s.y};
+    }
+    float2 screen_pos = {float(x) + jitter.x, float(y) + jitter.y};
+    float2 viewport_pos = {screen_pos.x / float(width), screen_pos.y / float(height)};
+
+    float4 ndc_near = {viewport_pos.x * 2.0f - 1.0f, viewport_pos.y * 2.0f - 1.0f, -1.0f, 1.0f};
+    float4 scaled_near_world = mul4x4(cam.inverse_view_projection_matrix, ndc_near);
+    origin = make_float3(scaled_near_world) / scaled_near_world.w;
+
+    float4 ndc_far = {ndc_near.x, ndc_near.y, 1.0f, 1.0f};
+    float4 scaled_view = mul4x4(cam.inverse_projection_matrix, ndc_far);
+    direction = normalize(mul3x3(cam.view_to_world_rotation, make_float3(scaled_view)));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Intersection arithmetic shared (by specification, not by code) with the HIP kernels.
+// ---------------------------------------------------------------------------------------------
+static inline float dot_fma(float3 a, float3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+static inline float3 cross_fma(float3 a, float3 b) {
+    return {fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x))};
+}
+
+bool intersect_triangle(const HiprTriangle& tri, float3 o, float3 d, float& t, float& u, float& v) {
+    float3 v0 = {tri.v0[0], tri.v0[1], tri.v0[2]};
+    float3 e1 = make_float3(tri.v1[0], tri.v1[1], tri.v1[2]) - v0;
+    float3 e2 = make_float3(tri.v2[0], tri.v2[1], tri.v2[2]) - v0;
+    float3 p = cross_fma(d, e2);
+    float det = dot_fma(e1, p);
+    if (!(det != 0.0f))
+        return false;
+    float inv = 1.0f / det;
+    float3 tv = o - v0;
+    u = dot_fma(tv, p) * inv;
+    if (!(u >= 0.0f && u <= 1.0f))
+        return false;
+    float3 q = cross_fma(tv, e1);
+    v = dot_fma(d, q) * inv;
+    if (!(v >= 0.0f && u + v <= 1.0f))
+        return false;
+    t = dot_fma(e2, q) * inv;
+    return true;
+}
+
+static inline void consider_triangle(const HiprSceneDesc& scene, uint32_t i, const Ray& ray, uint32_t skip, Hit& best) {
+    if (i == skip)
+        return;
+    float t, u, v;
+    if (!intersect_triangle(scene.triangles[i], ray.origin, ray.direction, t, u, v))
+        return;
+    if (!(t > ray.tmin))
+        return;
+    if (t < best.t || (t == best.t && i < best.id))
+        best = {t, u, v, i};
+}
+
+Hit closest_hit_bruteforce(const HiprSceneDesc& scene, const Ray& ray, uint32_t skip) {
+    Hit best = {ray.tmax, 0, 0, HIT_MISS};
+    for (uint32_t i = 0; i < scene.triangle_count; ++i)
+        consider_triangle(scene, i, ray, skip, best);
+    return best;
+}
+
+struct SlabRay { float3 inv_d, ood; };
+static inline SlabRay make_slab_ray(const Ray& ray) {
+    auto safe = [](float d) { return fabsf(d) > 1e-20f ? d : copysignf(1e-20f, d); };
+    float3 inv = {1.0f / safe(ray.direction.x), 1.0f / safe(ray.direction.y), 1.0f / safe(ray.direction.z)};
+    return {inv, ray.origin * inv};
+}
+// Returns entry distance or -1 if the child box is missed within [tmin, tmax].
+static inline bool slab(const SlabRay& r, float lox, float hix, float loy, float hiy, float loz, float hiz, float tmin, float tmax, float& tnear) {
+    float x0 = fmaf(lox, r.inv_d.x, -r.ood.x), x1 = fmaf(hix, r.inv_d.x, -r.ood.x);
+    float y0 = fmaf(loy, r.inv_d.y, -r.ood.y), y1 = fmaf(hiy, r.inv_d.y, -r.ood.y);
+    float z0 = fmaf(loz, r.inv_d.z, -r.ood.z), z1 = fmaf(hiz, r.inv_d.z, -r.ood.z);
+    tnear = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
+    float tfar = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+    tfar = fminf(tfar * 1.0000004f, tmax);
+    return tnear <= tfar;
+}
+
+// Ordered BVH2 traversal; the visiting order is part of the specification so that the node /
+// triangle counters of the oracle and the HIP kernels agree ("Traversal order").
+template <typename LeafFn>
+static inline void traverse(const HiprSceneDesc& scene, const Ray& ray, float& tmax, TraversalCounters* counters, LeafFn&& leaf) {
+    if (scene.node_count == 0)
+        return;
+    SlabRay sr = make_slab_ray(ray);
+    int32_t stack[128];
+    int sp = 0;
+    int32_t cur = 0;
+    for (;;) {
+        const HiprBvhNode& n = scene.nodes[cur];
+        if (counters) counters->nodes++;
+        float t0, t1;
+        bool h0 = slab(sr, n.c0xy[0], n.c0xy[1], n.c0xy[2], n.c0xy[3], n.cz[0], n.cz[1], ray.tmin, tmax, t0);
+        bool h1 = slab(sr, n.c1xy[0], n.c1xy[1], n.c1xy[2], n.c1xy[3], n.cz[2], n.cz[3], ray.tmin, tmax, t1);
+        int32_t c0 = n.child[0], c1 = n.child[1];
+        if (h0 && h1 && t1 < t0) { int32_t tmp = c0; c0 = c1; c1 = tmp; }
+        if (!h0 && h1) { c0 = c1; h0 = true; h1 = false; }
+        int32_t next = INT32_MIN;
+        bool stop = false;
+        if (h0) {
+            if (c0 < 0) stop = leaf(uint32_t(~c0));
+            else next = c0;
+        }
+        if (h1 && !stop) {
+            if (c1 < 0) stop = leaf(uint32_t(~c1));
+            else if (next == INT32_MIN) next = c1;
+            else stack[sp++] = c1;
+        }
+        if (stop)
+            return;
+        if (next == INT32_MIN) {
+            if (sp == 0)
+                return;
+            next = stack[--sp];
+        }
+        cur = next;
+    }
+}
+
+Hit closest_hit_bvh(const HiprSceneDesc& scene, const Ray& ray, uint32_t skip, TraversalCounters* counters) {
+    Hit best = {ray.tmax, 0, 0, HIT_MISS};
+    traverse(scene, ray, best.t, counters, [&](uint32_t leaf) {
+        uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
+        for (uint32_t i = first; i < first + count; ++i) {
+            if (counters) counters->triangles++;
+            consider_triangle(scene, i, ray, skip, best);
+        }
+        return false;
+    });
+    return best;
+}
+
+// LightSources.cu:31-70: sphere and disk lights take part in closest-hit selection.
+void intersect_lights(const HiprSceneDesc& scene, const Ray& ray, Hit& hit) {
+    for (uint32_t li = 0; li < scene.light_count; ++li) {
+        const HiprLight& light = scene.lights[li];
+        uint32_t type = light.flags & HIPR_LIGHT_TYPE_MASK;
+        float t = -1e30f;
+        if (type == HIPR_LIGHT_SPHERE) {
+            SphereLight s = as_sphere(light);
+            if (!(s.radius > 0.0f)) continue;   // bounds program invalidates the AABB (LightSources.cu:83-90)
+            t = ray_sphere(ray.origin, ray.direction, s.position, s.radius);
+        } else if (type == HIPR_LIGHT_SPOT) {
+            SpotLight s = as_spot(light);
+            if (!(s.radius > 0.0f)) continue;
+            t = ray_disk(ray.origin, ray.direction, s.position, s.direction, s.radius);
+        } else
+            continue;
+        if (t > ray.tmin && t < hit.t)
+            hit = {t, 0, 0, HIT_LIGHT_BIT | li};
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Textures: software replacement of the samplers configured at OR/Renderer.cpp:703-751.
+// ---------------------------------------------------------------------------------------------
+static inline float srgb_to_linear(float c) {
+    return c <= 0.04045f ? c / 12.92f : powf((c + 0.055f) / 1.055f, 2.4f);
+}
+
+static inline float4 fetch_texel(const HiprSceneDesc& scene, const HiprTexture& tex, int x, int y) {
+    const uint8_t* base = scene.texels + tex.texel_offset;
+    size_t i = size_t(y) * tex.width + size_t(x);
+    float4 r;
+    switch (tex.format) {
+    case HIPR_TEXEL_R8: { float v = base[i] / 255.0f; r = {v, 0, 0, 1}; break; }
+    case HIPR_TEXEL_RGBA8: r = {base[4 * i] / 255.0f, base[4 * i + 1] / 255.0f, base[4 * i + 2] / 255.0f, base[4 * i + 3] / 255.0f}; break;
+    case HIPR_TEXEL_R32F: { float v; std::memcpy(&v, base + 4 * i, 4); r = {v, 0, 0, 1}; break; }
+    default: std::memcpy(&r, base + 16 * i, 16); break;
+    }
+    if (tex.is_sRGB) {
+        r.x = srgb_to_linear(r.x);
+        if (tex.format == HIPR_TEXEL_RGBA8 || tex.format == HIPR_TEXEL_RGBA32F) { r.y = srgb_to_linear(r.y); r.z = srgb_to_linear(r.z); }
+    }
+    return r;
+}
+
+static inline int wrap_coord(int i, int n, int repeat) {
+    if (repeat) { i %= n; return i < 0 ? i + n : i; }
+    return i < 0 ? 0 : (i >= n ? n - 1 : i);
+}
+
+float4 sample_texture(const HiprSceneDesc& scene, int texture_ID, float2 uv) {
+    const HiprTexture& tex = scene.textures[texture_ID];
+    int w = int(tex.width), h = int(tex.height);
+    if (tex.filter & 1) {   // linear (magnification filter at LOD 0)
+        float xb = uv.x * w - 0.5f, yb = uv.y * h - 0.5f;
+        float xf = floorf(xb), yf = floorf(yb);
+        float fx = xb - xf, fy = yb - yf;
+        int x0 = wrap_coord(int(xf), w, tex.wrap_u), x1 = wrap_coord(int(xf) + 1, w, tex.wrap_u);
+        int y0 = wrap_coord(int(yf), h, tex.wrap_v), y1 = wrap_coord(int(yf) + 1, h, tex.wrap_v);
+        float4 a = fetch_texel(scene, tex, x0, y0), b = fetch_texel(scene, tex, x1, y0);
+        float4 c = fetch_texel(scene, tex, x0, y1), d = fetch_texel(scene, tex, x1, y1);
+        float4 lo = a + (b - a) * fx, hi = c + (d - c) * fx;
+        return lo + (hi - lo) * fy;
+    }
+    int x = wrap_coord(int(floorf(uv.x * w)), w, tex.wrap_u);
+    int y = wrap_coord(int(floorf(uv.y * h)), h, tex.wrap_v);
+    return fetch_texel(scene, tex, x, y);
+}
+
+static inline float4 material_tint_roughness(const HiprSceneDesc& scene, const HiprMaterial& m, float2 uv) {
+    float4 tr = {m.tint[0], m.tint[1], m.tint[2], m.roughness};
+    if (m.tint_roughness_texture_ID)
+        tr = tr * sample_texture(scene, m.tint_roughness_texture_ID, uv);
+    if (m.roughness_texture_ID)
+        tr.w *= sample_texture(scene, m.roughness_texture_ID, uv).x;
+    return tr;
+}
+static inline float material_metallic(const HiprSceneDesc& scene, const HiprMaterial& m, float2 uv) {
+    return m.metallic_texture_ID ? m.metallic * sample_texture(scene, m.metallic_texture_ID, uv).x : m.metallic;
+}
+float material_coverage(const HiprSceneDesc& scene, const HiprMaterial& m, float2 uv) {
+    float tex = 1.0f;
+    if (m.coverage_texture_ID)
+        tex = sample_texture(scene, m.coverage_texture_ID, uv).x;
+    if (m.flags & HIPR_MATERIAL_CUTOUT)
+        return tex < m.coverage ? 0.0f : 1.0f;
+    return m.coverage * tex;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Attribute interpolation (ORS/TriangleAttributes.cu:35-84) on the flattened scene.
+// ---------------------------------------------------------------------------------------------
+static inline float3 decode_octahedral(const int16_t e[2]) {
+    float2 f = {float(e[0]), float(e[1])};
+    float3 n = {f.x, f.y, 32767.0f - fabsf(f.x) - fabsf(f.y)};
+    float t = fmaxf(-n.z, 0.0f);
+    n.x += n.x >= 0 ? -t : t;
+    n.y += n.y >= 0 ? -t : t;
+    return normalize(n);
+}
+
+struct SurfaceAttributes {
+    float3 position, geometric_normal, shading_normal;   // world space
+    float2 texcoord;
+    float4 tint_and_roughness_scale;
+    float3 emission;
+};
+
+static inline float2 triangle_texcoord(const HiprSceneDesc& scene, const HiprTriangle& tri, float u, float v) {
+    const HiprInstance& inst = scene.instances[tri.instance_index];
+    if (!(inst.mesh_flags & HIPR_MESH_TEXCOORDS))
+        return {0, 0};   // undefined in the reference (TriangleAttributes.cu:63-64), defined as 0 here
+    const uint32_t* idx = scene.indices + 3 * size_t(inst.index_offset + tri.primitive_index);
+    const float* tc = scene.texcoords + 2 * size_t(inst.vertex_offset);
+    float w = 1.0f - u - v;
+    float2 t0 = {tc[2 * idx[0]], tc[2 * idx[0] + 1]}, t1 = {tc[2 * idx[1]], tc[2 * idx[1] + 1]}, t2 = {tc[2 * idx[2]], tc[2 * idx[2] + 1]};
+    return t1 * u + t2 * v + t0 * w;
+}
+
+static SurfaceAttributes interpolate_attributes(const HiprSceneDesc& scene, const HiprTriangle& tri, float u, float v) {
+    const HiprInstance& inst = scene.instances[tri.instance_index];
+    const uint32_t* idx = scene.indices + 3 * size_t(inst.index_offset + tri.primitive_index);
+    float w = 1.0f - u - v;
+    float3 p0 = {tri.v0[0], tri.v0[1], tri.v0[2]}, p1 = {tri.v1[0], tri.v1[1], tri.v1[2]}, p2 = {tri.v2[0], tri.v2[1], tri.v2[2]};
+
+    SurfaceAttributes a;
+    a.geometric_normal = normalize(cross(p1 - p0, p2 - p0));
+    a.position = p1 * u + p2 * v + p0 * w;
+
+    if (inst.mesh_flags & HIPR_MESH_NORMALS) {
+        const HiprVertexGeometry* g = scene.geometry + inst.vertex_offset;
+        float3 n = decode_octahedral(g[idx[1]].oct_normal) * u + decode_octahedral(g[idx[2]].oct_normal) * v + decode_octahedral(g[idx[0]].oct_normal) * w;
+        n = normalize(n);
+        // rtTransformNormal(RT_OBJECT_TO_WORLD) for rotation + uniform scale, then normalize (MonteCarlo.cu:176).
+        const float* M = inst.object_to_world;
+        float3 wn = {M[0] * n.x + M[1] * n.y + M[2] * n.z, M[4] * n.x + M[5] * n.y + M[6] * n.z, M[8] * n.x + M[9] * n.y + M[10] * n.z};
+        a.shading_normal = normalize(wn);
+    } else
+        a.shading_normal = a.geometric_normal;
+
+    a.texcoord = triangle_texcoord(scene, tri, u, v);
+
+    if (inst.mesh_flags & HIPR_MESH_TINTS) {
+        const uint32_t* tints = scene.tints + inst.vertex_offset;
+        auto ch = [&](uint32_t packed, int c) { return float((packed >> (8 * c)) & 0xFFu); };
+        uint32_t t0 = tints[idx[0]], t1 = tints[idx[1]], t2 = tints[idx[2]];
+        const float s = 1.0f / 255.0f;
+        a.tint_and_roughness_scale = {(ch(t1, 0) * u + ch(t2, 0) * v + ch(t0, 0) * w) * s, (ch(t1, 1) * u + ch(t2, 1) * v + ch(t0, 1) * w) * s,
+                                      (ch(t1, 2) * u + ch(t2, 2) * v + ch(t0, 2) * w) * s, (ch(t1, 3) * u + ch(t2, 3) * v + ch(t0, 3) * w) * s};
+    } else
+        a.tint_and_roughness_scale = {1, 1, 1, 1};
+
+    if (inst.mesh_flags & HIPR_MESH_EMISSIVE) {
+        const float* e = scene.emissions + 3 * size_t(inst.vertex_offset);
+        auto em = [&](uint32_t i) { return make_float3(e[3 * i], e[3 * i + 1], e[3 * i + 2]); };
+        a.emission = em(idx[1]) * u + em(idx[2]) * v + em(idx[0]) * w;
+    } else
+        a.emission = {1, 1, 1};
+    return a;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Shadow rays: shadow_any_hit (ORS/MonteCarlo.cu:278-285) over every hit in (tmin, tmax).
+// ---------------------------------------------------------------------------------------------
+static inline bool shadow_triangle(const HiprSceneDesc& scene, uint32_t i, const Ray& ray, float3& radiance) {
+    float t, u, v;
+    const HiprTriangle& tri = scene.triangles[i];
+    if (!intersect_triangle(tri, ray.origin, ray.direction, t, u, v))
+        return false;
+    if (!(t > ray.tmin && t < ray.tmax))
+        return false;
+    float coverage;
+    if (tri.flags & HIPR_TRIANGLE_OPAQUE)
+        coverage = 1.0f;
+    else {
+        const HiprInstance& inst = scene.instances[tri.instance_index];
+        coverage = material_coverage(scene, scene.materials[inst.material_index], triangle_texcoord(scene, tri, u, v));
+    }
+    radiance *= 1.0f - coverage;
+    if (radiance.x < 0.0000001f && radiance.y < 0.0000001f && radiance.z < 0.0000001f) {
+        radiance = {0, 0, 0};
+        return true;   // rtTerminateRay
+    }
+    return false;
+}
+
+float3 shadow_bruteforce(const HiprSceneDesc& scene, const Ray& ray, float3 radiance) {
+    for (uint32_t i = 0; i < scene.triangle_count; ++i)
+        if (shadow_triangle(scene, i, ray, radiance))
+            break;
+    return radiance;
+}
+
+float3 shadow_bvh(const HiprSceneDesc& scene, const Ray& ray, float3 radiance, TraversalCounters* counters) {
+    float tmax = ray.tmax;
+    traverse(scene, ray, tmax, counters, [&](uint32_t leaf) {
+        uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
+        for (uint32_t i = first; i < first + count; ++i) {
+            if (counters) counters->triangles++;
+            if (shadow_triangle(scene, i, ray, radiance))
+                return true;
+        }
+        return false;
+    });
+    return radiance;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The path tracer
+// ---------------------------------------------------------------------------------------------
+static inline float3 fix_backfacing_shading_normal(float3 w, float3 n, float target_cos_theta) {
+    float cos_theta = dot(w, n);
+    if (cos_theta < target_cos_theta)
+        return normalize(n - (cos_theta - target_cos_theta) * w);
+    return n;
+}
+
+static inline float3 offset_ray_origin(float3 p, float3 n) {
+    const float origin = 1.0f / 32.0f, float_scale = 1.0f / 65536.0f, int_scale = 256.0f;
+    int ox = int(int_scale * n.x), oy = int(int_scale * n.y), oz = int(int_scale * n.z);
+    float3 p_i = {int_as_float(float_as_int(p.x) + (p.x < 0 ? -ox : ox)),
+                  int_as_float(float_as_int(p.y) + (p.y < 0 ? -oy : oy)),
+                  int_as_float(float_as_int(p.z) + (p.z < 0 ? -oz : oz))};
+    return {fabsf(p.x) < origin ? p.x + float_scale * n.x : p_i.x,
+            fabsf(p.y) < origin ? p.y + float_scale * n.y : p_i.y,
+            fabsf(p.z) < origin ? p.z + float_scale * n.z : p_i.z};
+}
+static inline float3 offset_ray_origin(float3 p, float3 direction, float3 geometric_normal) {
+    float cos_theta = dot(geometric_normal, direction);
+    return offset_ray_origin(p, cos_theta >= 0 ? geometric_normal : -geometric_normal);
+}
+
+static inline float4 toroidal_shift(float4 base, float4 shift) {
+    float4 s = base + shift;
+    return {s.x - floorf(s.x), s.y - floorf(s.y), s.z - floorf(s.z), s.w - floorf(s.w)};
+}
+
+struct Payload {
+    float3 radiance = {0, 0, 0};
+    uint32_t last_triangle = HIT_MISS;   // PrimitiveID of the last accepted hit, as a global triangle index
+    float3 throughput = {1, 1, 1};
+    uint32_t bounces = 0;
+    float3 position, direction;
+    float ray_min_t = 0.0f;
+    PDF bsdf_PDF = PDF::delta_dirac(1);
+    LightSample light_sample = LightSample::none();
+    float3 light_sample_origin = {0, 0, 0};
+    uint32_t pixel_hash = 0, accumulation = 0;
+    float4 sample4f(uint32_t d) const { return rng::sample4f(accumulation, pixel_hash, 8u * bounces + d); }
+};
+
+template <typename Model>
+static LightSample sample_single_light(const HiprSceneDesc& scene, const Model& material, float3 p, float3 wo, const TBN& tbn, float3 u) {
+    int light_count = int(scene.light_count);
+    int li = int(u.z * light_count);
+    if (li > light_count - 1) li = light_count - 1;
+    LightSample ls = Lights::sample_radiance(scene.lights[li], p, make_float2(u.x, u.y));
+    ls.radiance *= float(light_count);
+    float N_dot_L = dot(tbn.normal, ls.direction_to_light);
+    ls.radiance *= fabsf(N_dot_L) / ls.pdf.value();
+    BSDFResponse f = material.evaluate_with_PDF(wo, tbn.to_local(ls.direction_to_light));
+    if (!ls.pdf.is_delta_dirac())
+        ls.radiance *= MIS_weight(ls.pdf, f.pdf);
+    else
+        f.reflectance = fminf3(f.reflectance, make_float3(32.0f));
+    ls.radiance *= f.reflectance;
+    return ls;
+}
+
+template <typename Model>
+static LightSample reestimated_light_samples(const HiprSceneDesc& scene, const HiprSceneState& state, const float4* offsets,
+                                             const Payload& payload, const Model& material, float3 p, float3 wo, const TBN& tbn) {
+    if (scene.light_count == 0)
+        return LightSample::none();
+    float4 base = payload.sample4f(1);   // NEXT_EVENT_ESTIMATION
+    LightSample kept = LightSample::none();
+    int n = state.next_event_sample_count;
+    for (int s = 0; s < n; ++s) {
+        float4 r = toroidal_shift(base, offsets[s]);
+        LightSample candidate = sample_single_light(scene, material, p, wo, tbn, make_float3(r.x, r.y, r.z));
+        float w_old = sum(kept.radiance), w_new = sum(candidate.radiance);
+        float p_new = w_new / (w_old + w_new);
+        if (r.w < p_new) {
+            kept = candidate;
+            kept.radiance /= p_new;
+        } else
+            kept.radiance /= 1.0f - p_new;
+    }
+    kept.radiance /= float(n);
+    return kept;
+}
+
+template <typename Model>
+static void finish_closest_hit(const HiprSceneDesc& scene, const HiprSceneState& state, const float4* offsets, Payload& payload,
+                               const Model& material, const HiprMaterial& mp, const SurfaceAttributes& a, float3 ray_direction,
+                               float3 geometric_normal, const TBN& tbn, float3 wo, float3 bsdf_u) {
+    payload.radiance += payload.throughput * a.emission * make_float3(mp.emission[0], mp.emission[1], mp.emission[2]);
+
+    payload.light_sample = reestimated_light_samples(scene, state, offsets, payload, material, a.position, wo, tbn);
+    payload.light_sample_origin = offset_ray_origin(a.position, payload.light_sample.direction_to_light, geometric_normal);
+    payload.light_sample.radiance *= payload.throughput;
+
+    BSDFSample s = material.sample(wo, bsdf_u);
+    bool is_reflection = s.direction.z >= 0;
+    payload.direction = tbn.to_world(s.direction);
+    payload.bsdf_PDF = s.pdf;
+    if (s.pdf.is_valid())
+        payload.throughput *= (s.reflectance * fabsf(s.direction.z)) / s.pdf.value();   // f * |cos| / pdf, optix float3 / float
+    else
+        payload.throughput = {0, 0, 0};
+
+    float cos_geometric = dot(payload.direction, geometric_normal);
+    if (is_reflection ? cos_geometric < 0.0f : cos_geometric >= 0.0f)
+        payload.direction = reflect(payload.direction, geometric_normal);
+
+    payload.position = offset_ray_origin(a.position, payload.direction, geometric_normal);
+    payload.ray_min_t = 0.0f;
+    payload.bounces += 1u;
+    if (!payload.light_sample.pdf.is_valid())
+        payload.bsdf_PDF.disable_MIS();
+    (void)ray_direction;
+}
+
+// path_tracing_closest_hit<> (ORS/MonteCarlo.cu:129-233). Returns true when the hit was accepted.
+static bool closest_hit_program(const HiprSceneDesc& scene, const HiprSceneState& state, const HiprCameraState& cam, const float4* offsets,
+                                Payload& payload, const Hit& hit, float3 ray_direction) {
+    payload.light_sample = LightSample::none();
+    const HiprTriangle& tri = scene.triangles[hit.id];
+    const HiprInstance& inst = scene.instances[tri.instance_index];
+    const HiprMaterial& mp = scene.materials[inst.material_index];
+    SurfaceAttributes a = interpolate_attributes(scene, tri, hit.u, hit.v);
+
+    bool thin_walled = (mp.flags & (HIPR_MATERIAL_CUTOUT | HIPR_MATERIAL_THIN_WALLED)) != 0;
+    bool transmissive = mp.shading_model == HIPR_SHADING_TRANSMISSIVE;
+    float3 geometric_normal = a.geometric_normal;
+    bool hit_from_front = dot(geometric_normal, ray_direction) < 0.0f;
+    bool backside_cull = !hit_from_front && !thin_walled && !transmissive;
+
+    float4 bsdf_coverage_u = payload.sample4f(2);   // BSDF dimension, always drawn
+    float coverage = material_coverage(scene, mp, a.texcoord);
+    bool discard_from_coverage = coverage < bsdf_coverage_u.w;
+    if (backside_cull || discard_from_coverage) {
+        payload.ray_min_t = nextafterf(hit.t, INFINITY);
+        return false;
+    }
+
+    payload.last_triangle = hit.id;
+    // float_to_unorm8 round trip of the vertex tint scale (MonteCarlo.cu:170 stores it, AOVs read it);
+    // the shading model itself receives the unquantised attribute (MonteCarlo.cu:242,252,264).
+    geometric_normal = hit_from_front ? geometric_normal : -geometric_normal;
+    float3 shading_normal = hit_from_front ? a.shading_normal : -a.shading_normal;
+    shading_normal = fix_backfacing_shading_normal(-ray_direction, shading_normal, 0.002f);
+    const TBN tbn(shading_normal);
+    float3 wo = tbn.to_local(-ray_direction);
+    float cos_theta = (hit_from_front || thin_walled) ? wo.z : -wo.z;
+
+    float4 tr = material_tint_roughness(scene, mp, a.texcoord) * a.tint_and_roughness_scale;
+    MaterialInputs in;
+    in.tint = make_float3(tr);
+    in.roughness = tr.w;
+    in.specularity = mp.specularity;
+    in.metallic = material_metallic(scene, mp, a.texcoord);
+    in.coat = unorm16(mp.coat);
+    in.coat_roughness = unorm16(mp.coat_roughness);
+    float3 bsdf_u = {bsdf_coverage_u.x, bsdf_coverage_u.y, bsdf_coverage_u.z};
+    PDF max_PDF_hint = payload.bsdf_PDF * cam.path_regularization_PDF_scale;
+
+    if (mp.shading_model == HIPR_SHADING_DIFFUSE) {
+        DiffuseShading m = {in.tint, in.roughness};
+        finish_closest_hit(scene, state, offsets, payload, m, mp, a, ray_direction, geometric_normal, tbn, wo, bsdf_u);
+    } else if (transmissive) {
+        TransmissiveShading m = TransmissiveShading::with_max_PDF_hint(in, cos_theta, max_PDF_hint);
+        finish_closest_hit(scene, state, offsets, payload, m, mp, a, ray_direction, geometric_normal, tbn, wo, bsdf_u);
+    } else {
+        DefaultShading m = DefaultShading::with_max_PDF_hint(in, cos_theta, max_PDF_hint);
+        finish_closest_hit(scene, state, offsets, payload, m, mp, a, ray_direction, geometric_normal, tbn, wo, bsdf_u);
+    }
+    return true;
+}
+
+float3 path_trace_pixel(const HiprSceneDesc& scene, const HiprSceneState& state, const HiprCameraState& cam,
+                        const float4* offsets, int x, int y, int width, int height, uint32_t accumulation,
+                        const RenderSettings& settings, RenderCounters* counters) {
+    Payload payload;
+    payload.pixel_hash = rng::pcg2d(uint32_t(x), uint32_t(y)).x;
+    payload.accumulation = accumulation;
+    generate_camera_ray(cam, x, y, width, height, accumulation, payload.position, payload.direction);
+    if (counters) counters->camera_rays++;
+
+    do {
+        Ray ray = {payload.position, payload.ray_min_t, payload.direction, INFINITY};
+        Hit hit = settings.use_bvh ? closest_hit_bvh(scene, ray, payload.last_triangle, counters ? &counters->closest : nullptr)
+                                   : closest_hit_bruteforce(scene, ray, payload.last_triangle);
+        intersect_lights(scene, ray, hit);
+        if (counters) counters->closest_rays++;
+
+        if (hit.id == HIT_MISS) {
+            // miss program (SimpleRGPs.cu:349-362); environment maps are a later tier, tint only.
+            float3 env = {state.environment_tint[0], state.environment_tint[1], state.environment_tint[2]};
+            payload.radiance += payload.throughput * env;
+            payload.throughput = {0, 0, 0};
+        } else if (hit.id & HIT_LIGHT_BIT) {
+            // light_closest_hit (MonteCarlo.cu:291-302)
+            const HiprLight& light = scene.lights[hit.id & ~HIT_LIGHT_BIT];
+            float3 L = Lights::evaluate_intersection(light, ray.origin, ray.direction, payload.bsdf_PDF);
+            payload.throughput = fminf3(payload.throughput, make_float3(4));
+            payload.radiance += payload.throughput * L;
+            payload.throughput = {0, 0, 0};
+        } else {
+            bool accepted = closest_hit_program(scene, state, cam, offsets, payload, hit, ray.direction);
+            if (accepted && counters) counters->shaded_hits++;
+        }
+
+        const LightSample& ls = payload.light_sample;
+        if (ls.radiance.x > 0 || ls.radiance.y > 0 || ls.radiance.z > 0) {
+            Ray shadow = {payload.light_sample_origin, 0.0f, ls.direction_to_light, ls.distance};
+            float3 r = settings.use_bvh ? shadow_bvh(scene, shadow, ls.radiance, counters ? &counters->shadow : nullptr)
+                                        : shadow_bruteforce(scene, shadow, ls.radiance);
+            if (counters) counters->shadow_rays++;
+            payload.radiance += r;
+        }
+        payload.light_sample = LightSample::none();
+    } while (payload.bounces <= cam.max_bounce_count && !is_black(payload.throughput));
+
+    return payload.radiance;
+}
+
+} // namespace oracle

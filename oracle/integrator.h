@@ -1,0 +1,67 @@
+// oracle/integrator.h -- CPU restatement of the reference's path tracing integrator, structured
+// like the reference's megakernel (one loop per pixel), NOT like the wavefront kernels it checks.
+// TEST INFRASTRUCTURE ONLY (see oracle/vecmath.h).
+//
+// Reference files followed (relative to /root/reference/extensions/OptiXRenderer/OptiXRenderer/):
+//   Shading/SimpleRGPs.cu:44-140 (camera rays, accumulate, path loop), :349-362 (miss)
+//   Shading/MonteCarlo.cu:61-302 (RIS next event estimation, closest hit, shadow any hit, light hit)
+//   Shading/TriangleAttributes.cu:35-84 (attribute interpolation)
+//   Shading/LightSources/LightSources.cu:31-70 (analytic light intersection)
+//   Types.h:389-414 (material texture lookups), Utils.h:67-74, 372-397
+//
+// Parity status: closest-hit selection, BVH traversal and triangle intersection happen inside
+// NVIDIA OptiX 6.5 in the reference (closed, not under /root/reference) -- "parity unpinned" for
+// those; this file states the arithmetic the HIP kernels and the oracle agree on.
+#pragma once
+
+#include "rng.h"
+#include "shading.h"
+
+#include <vector>
+
+namespace oracle {
+
+struct Ray { float3 origin; float tmin; float3 direction; float tmax; };
+
+struct Hit {
+    float t, u, v;
+    uint32_t id;   // 0xFFFFFFFF miss, 0x80000000 | light index, else global triangle index
+};
+static const uint32_t HIT_MISS = 0xFFFFFFFFu;
+static const uint32_t HIT_LIGHT_BIT = 0x80000000u;
+
+struct TraversalCounters { uint64_t nodes = 0, triangles = 0; };
+
+// --- camera -----------------------------------------------------------------------------------
+void generate_camera_ray(const HiprCameraState& cam, int x, int y, int width, int height, uint32_t accumulation,
+                         float3& origin, float3& direction);
+
+// --- intersection -----------------------------------------------------------------------------
+bool intersect_triangle(const HiprTriangle& tri, float3 o, float3 d, float& t, float& u, float& v);
+Hit closest_hit_bruteforce(const HiprSceneDesc& scene, const Ray& ray, uint32_t skip_triangle);
+Hit closest_hit_bvh(const HiprSceneDesc& scene, const Ray& ray, uint32_t skip_triangle, TraversalCounters* counters);
+void intersect_lights(const HiprSceneDesc& scene, const Ray& ray, Hit& hit);
+// Shadow any-hit accumulation over all triangles in (tmin, tmax); returns the attenuated radiance.
+float3 shadow_bruteforce(const HiprSceneDesc& scene, const Ray& ray, float3 radiance);
+float3 shadow_bvh(const HiprSceneDesc& scene, const Ray& ray, float3 radiance, TraversalCounters* counters);
+
+// --- textures / materials ---------------------------------------------------------------------
+float4 sample_texture(const HiprSceneDesc& scene, int texture_ID, float2 uv);
+float material_coverage(const HiprSceneDesc& scene, const HiprMaterial& m, float2 uv);
+
+// --- integrator -------------------------------------------------------------------------------
+struct RenderSettings {
+    bool use_bvh = true;          // false: brute force over all triangles (tiny scenes)
+};
+
+struct RenderCounters {
+    uint64_t camera_rays = 0, closest_rays = 0, shadow_rays = 0, shaded_hits = 0;
+    TraversalCounters closest, shadow;
+};
+
+// Radiance of one pixel-sample: the lambda of path_tracing_RPG (SimpleRGPs.cu:131-140).
+float3 path_trace_pixel(const HiprSceneDesc& scene, const HiprSceneState& state, const HiprCameraState& cam,
+                        const float4* sample_offsets, int x, int y, int width, int height, uint32_t accumulation,
+                        const RenderSettings& settings, RenderCounters* counters);
+
+} // namespace oracle

@@ -1,0 +1,114 @@
+// oracle/vecmath.h -- minimal f32 vector algebra for the CPU oracle.
+//
+// TEST INFRASTRUCTURE ONLY: nothing under oracle/ is linked into or called by the product
+// (bifrost3d_amd/, include/). Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+// leg may use it.
+//
+// Semantics follow the optix:: vector helpers the reference's shading headers are written
+// against (dot, cross, normalize, lerp, reflect, refract, clamp) -- see the call sites in
+// /root/reference/extensions/OptiXRenderer/OptiXRenderer/*.h. Compiled with -ffp-contract=off so
+// every operation rounds once, like the device code.
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+namespace oracle {
+
+struct float2 { float x, y; };
+struct float3 { float x, y, z; };
+struct float4 { float x, y, z, w; };
+struct uint2 { uint32_t x, y; };
+struct uint4 { uint32_t x, y, z, w; };
+struct double3 { double x, y, z; };
+
+inline float2 make_float2(float x, float y) { return {x, y}; }
+inline float2 make_float2(float3 v) { return {v.x, v.y}; }
+inline float2 make_float2(float4 v) { return {v.x, v.y}; }
+inline float3 make_float3(float x, float y, float z) { return {x, y, z}; }
+inline float3 make_float3(float v) { return {v, v, v}; }
+inline float3 make_float3(float2 v, float z) { return {v.x, v.y, z}; }
+inline float3 make_float3(float4 v) { return {v.x, v.y, v.z}; }
+inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
+inline float4 make_float4(float3 v, float w) { return {v.x, v.y, v.z, w}; }
+
+inline float2 operator+(float2 a, float2 b) { return {a.x + b.x, a.y + b.y}; }
+inline float2 operator-(float2 a, float2 b) { return {a.x - b.x, a.y - b.y}; }
+inline float2 operator*(float2 a, float s) { return {a.x * s, a.y * s}; }
+inline float2 operator*(float s, float2 a) { return {a.x * s, a.y * s}; }
+inline float2 operator*(float2 a, float2 b) { return {a.x * b.x, a.y * b.y}; }
+inline float2 operator/(float2 a, float s) { float inv = 1.0f / s; return {a.x * inv, a.y * inv}; }
+inline float2 operator-(float2 a, float s) { return {a.x - s, a.y - s}; }
+
+inline float3 operator+(float3 a, float3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline float3 operator-(float3 a, float3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline float3 operator-(float3 a) { return {-a.x, -a.y, -a.z}; }
+inline float3 operator*(float3 a, float3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+inline float3 operator*(float3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+inline float3 operator*(float s, float3 a) { return {a.x * s, a.y * s, a.z * s}; }
+// optix::operator/(float3, float) multiplies by the reciprocal.
+inline float3 operator/(float3 a, float s) { float inv = 1.0f / s; return {a.x * inv, a.y * inv, a.z * inv}; }
+inline float3 operator/(float3 a, float3 b) { return {a.x / b.x, a.y / b.y, a.z / b.z}; }
+inline float3 operator+(float3 a, float s) { return {a.x + s, a.y + s, a.z + s}; }
+inline float3 operator+(float s, float3 a) { return {a.x + s, a.y + s, a.z + s}; }
+inline float3 operator-(float3 a, float s) { return {a.x - s, a.y - s, a.z - s}; }
+inline float3 operator-(float s, float3 a) { return {s - a.x, s - a.y, s - a.z}; }
+inline float3& operator+=(float3& a, float3 b) { a = a + b; return a; }
+inline float3& operator*=(float3& a, float3 b) { a = a * b; return a; }
+inline float3& operator*=(float3& a, float s) { a = a * s; return a; }
+inline float3& operator/=(float3& a, float s) { a = a / s; return a; }
+
+inline float4 operator+(float4 a, float4 b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+inline float4 operator-(float4 a, float4 b) { return {a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}; }
+inline float4 operator*(float4 a, float4 b) { return {a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w}; }
+inline float4 operator*(float4 a, float s) { return {a.x * s, a.y * s, a.z * s, a.w * s}; }
+
+inline float dot(float2 a, float2 b) { return a.x * b.x + a.y * b.y; }
+inline float dot(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline float3 cross(float3 a, float3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline float length(float2 v) { return sqrtf(dot(v, v)); }
+inline float length(float3 v) { return sqrtf(dot(v, v)); }
+// optix::normalize: v * (1 / sqrt(dot(v, v)))
+inline float3 normalize(float3 v) { float inv = 1.0f / sqrtf(dot(v, v)); return v * inv; }
+inline float lerp(float a, float b, float t) { return a + t * (b - a); }
+inline float3 lerp(float3 a, float3 b, float t) { return a + t * (b - a); }
+inline float clampf(float v, float lo, float hi) { return fmaxf(lo, fminf(v, hi)); }
+inline float3 fminf3(float3 a, float3 b) { return {fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)}; }
+// optix::reflect(i, n) = i - 2 n dot(n, i)
+inline float3 reflect(float3 i, float3 n) { return i - 2.0f * n * dot(n, i); }
+
+// optix::refract(r, i, n, ior) from optixu_math_namespace.h as documented by the reference's
+// own copy with n = (0,0,1) (OR/Utils.h:242-256) and pinned by ORT/MiscTest.h:292-322.
+inline bool refract(float3& r, float3 i, float3 n, float ior) {
+    float3 nn = n;
+    float negNdotV = dot(i, nn);
+    float eta;
+    if (negNdotV > 0.0f) {
+        eta = ior;
+        nn = -n;
+        negNdotV = -negNdotV;
+    } else
+        eta = 1.0f / ior;
+    const float k = 1.0f - eta * eta * (1.0f - negNdotV * negNdotV);
+    if (k < 0.0f) {
+        r = make_float3(0.0f);
+        return false;
+    }
+    r = normalize(eta * i - (eta * negNdotV + sqrtf(k)) * nn);
+    return true;
+}
+
+inline uint32_t float_as_uint(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+inline int32_t float_as_int(float f) { int32_t u; std::memcpy(&u, &f, 4); return u; }
+inline float uint_as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+inline float int_as_float(int32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+
+struct Matrix2x2 {
+    float m[4]; // row major
+    void setCol(int c, float2 v) { m[c] = v.x; m[2 + c] = v.y; }
+    Matrix2x2 transpose() const { return {{m[0], m[2], m[1], m[3]}}; }
+};
+inline float2 operator*(const Matrix2x2& M, float2 v) { return {M.m[0] * v.x + M.m[1] * v.y, M.m[2] * v.x + M.m[3] * v.y}; }
+
+} // namespace oracle
