@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the HIP path tracer: Mrays/s and ms per accumulation pass at 1080p.
+
+  python bench.py --gpus N --steps K --warmup W
+(for N > 1 the driver launches it under torch.distributed.run, one rank per GPU over RCCL).
+
+A "step" is one pass of the hot path over one batch of synthetic input: one accumulation (1 sample per pixel)
+of the 1920x1080 frame = 2 073 600 camera paths traced to completion (<= 5 surface interactions, next event
+estimation with 3 RIS candidates, shadow rays), folded into the f64 running mean and written as half4.
+Workload (BASELINE.json configs[1]): SimpleViewer Cornell box, every material forced to the Diffuse shading
+model, max_bounce_count 4. Inputs (scene, BVH, tables) are resident in HBM before the timed region; the output
+frame stays in HBM. N > 1: tiles of 8x8 pixels are dealt round-robin to the ranks and a step traces N
+accumulations of the frame, so every GPU keeps the same 2 073 600 paths per step as N grows ("weak" scaling;
+no data-path collective). The timed region ends with the RCCL gather of the half4 tiles to rank 0 plus the
+scatter kernel that assembles the frame.
+
+Prints ONE JSON line on rank 0 with the contract keys plus `roofline` (dominant kernel = trace_closest) and
+`cpu_baseline` (SmallPT restatement on the host cores, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=64)
+    p.add_argument("--warmup", type=int, default=4)
+    p.add_argument("--width", type=int, default=1920)
+    p.add_argument("--height", type=int, default=1080)
+    p.add_argument("--scene", default="cornell_diffuse", choices=["cornell_diffuse", "cornell", "atrium"])
+    p.add_argument("--atrium-triangles", type=int, default=260000)
+    p.add_argument("--bounces", type=int, default=4)
+    p.add_argument("--spp-per-pass", type=int, default=1)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
+    return p.parse_args()
+
+
+def make_scene(args):
+    from bifrost3d_amd.host import Scene
+    if args.scene == "cornell_diffuse":
+        return Scene("cornell", diffuse_only=True), "SimpleViewer Cornell box (34 triangles, 1 sphere light), all materials Diffuse"
+    if args.scene == "cornell":
+        return Scene("cornell"), "SimpleViewer Cornell box (34 triangles, 1 sphere light), reference materials"
+    return Scene("atrium", param0=args.atrium_triangles, param1=1), f"procedural atrium ({args.atrium_triangles} triangles target), DefaultShading"
+
+
+def cpu_baseline(seconds: float):
+    """SmallPT restatement (oracle/smallpt.cpp, follows apps/SmallPT/smallpt.h:22-147) on the host cores: 256x256,
+    as many accumulations as fit the time budget (at most 64, BASELINE.json config 1)."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import ctypes as C
+    import numpy as np
+    from oracle_bindings import get_oracle
+    o = get_oracle(False)
+    w = h = 256
+    buf = np.zeros((h, w, 3), np.float32)
+    acc = C.c_int(0)
+    fp = C.POINTER(C.c_float)
+    rays = 0
+    t0 = time.perf_counter()
+    while acc.value < 64:
+        rays += o.lib.oracle_smallpt_accumulate(w, h, buf.ctypes.data_as(fp), C.byref(acc))
+        if time.perf_counter() - t0 > seconds:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": int(o.lib.oracle_smallpt_threads()), "kind": "port",
+            "sample": f"SmallPT 9-sphere scene, 256x256, {acc.value} accumulations, {rays} radiance() rays in {dt:.1f} s, OpenMP dynamic,16"}
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from bifrost3d_amd import distributed
+    from bifrost3d_amd.renderer import Context
+
+    rank, world, local_rank = distributed.env_rank_world()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    device = torch.device("cuda", local_rank if world > 1 else 0)
+
+    W, H = args.width, args.height
+    S = args.spp_per_pass * world   # accumulations per step: per-GPU paths per step stay W*H*spp_per_pass for every N
+    scene, scene_text = make_scene(args)
+    ctx = Context(local_rank if world > 1 else 0)
+    ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
+    ctx.upload_scene(scene)
+    ctx.set_frame(W, H, tile_phase=rank, tile_stride=world, samples_per_pass=S)
+
+    n_compact = distributed.padded_pixels_per_rank(W, H, world)
+    frame = torch.zeros((H, W, 4), dtype=torch.float16, device=device) if rank == 0 else None
+    compact = torch.zeros((n_compact, 4), dtype=torch.float16, device=device) if world > 1 else None
+
+    def run_pass(accumulation):
+        cam = scene.camera(W, H, accumulations=accumulation, max_bounce_count=args.bounces)
+        if world == 1:
+            ctx.render_pass(cam, frame.data_ptr(), W)
+        else:
+            ctx.render_pass(cam, compact.data_ptr(), 0)
+
+    def finish_frame():
+        if world == 1:
+            return
+        gathered = distributed.gather_to_root(compact, world, rank)
+        if rank == 0:
+            ctx.scatter_tiles(gathered.data_ptr(), n_compact, world, W, H, frame.data_ptr(), W)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    # ---- instrumented passes: average BVH nodes / triangles per closest-hit ray (roofline numerator) ----------
+    ctx.set_instrumentation(True)
+    ctx.reset_counters()
+    for a in (0, S):
+        run_pass(a)
+    ctx.synchronize()
+    ic = ctx.counters()
+    ctx.set_instrumentation(False)
+    nodes_per_ray = ic["closest_nodes"] / max(1, ic["closest_rays"])
+    tris_per_ray = ic["closest_triangles"] / max(1, ic["closest_rays"])
+    shadow_nodes_per_ray = ic["shadow_nodes"] / max(1, ic["shadow_rays"])
+    shadow_tris_per_ray = ic["shadow_triangles"] / max(1, ic["shadow_rays"])
+
+    # ---- warmup -------------------------------------------------------------------------------------------------
+    a = 2 * S
+    for _ in range(args.warmup):
+        run_pass(a)
+        a += S
+    finish_frame()
+    barrier()
+    ctx.reset_counters()
+    ctx.reset_timers()
+
+    # ---- timed region: exactly K steps ------------------------------------------------------------------------------
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run_pass(a)
+        a += S
+    finish_frame()
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    ctx.synchronize()
+    counters = ctx.counters()
+    times = ctx.kernel_times()
+    stats = torch.tensor([elapsed, counters["closest_rays"], counters["shadow_rays"], counters["camera_rays"],
+                          times["trace_closest"]["ms"], times["trace_closest"]["launches"]], dtype=torch.float64, device=device)
+    if world > 1:
+        mx = stats.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        elapsed = float(mx[0])
+    total_closest, total_shadow, total_camera = float(stats[1]), float(stats[2]), float(stats[3])
+    total_rays = total_closest + total_shadow
+
+    if rank == 0:
+        ok = bool(torch.isfinite(frame.float()).all().item()) and float(frame[..., :3].float().mean()) > 0
+        # Roofline of the dominant kernel (rank 0's launches): algorithmic bytes per closest-hit ray =
+        # 48 B path state read (origin+tmin, direction+pdf, meta) + 16 B hit record written + 64 B per BVH node
+        # visited + 48 B per triangle tested (DESIGN.md "Kernels").
+        k = times["trace_closest"]
+        bytes_per_ray = 48 + 16 + 64 * nodes_per_ray + 48 * tris_per_ray
+        kernel_bytes = counters["closest_rays"] * bytes_per_ray
+        launches = max(1, k["launches"])
+        achieved = kernel_bytes / (k["ms"] * 1e-3) / 1e9 if k["ms"] > 0 else 0.0
+        out = {
+            "metric": "Mrays/sec + ms/frame at 1080p/256spp; per-pixel RMSE vs OptiXRenderer",
+            "value": total_rays / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{scene_text}; {W}x{H}, {S} accumulation(s) per step ({W * H * args.spp_per_pass} paths per GPU per step), max_bounce_count {args.bounces}, "
+                            f"next_event_sample_count 3, path regularisation PDF_scale 0.5; f64 accumulation + half4 output",
+                "frame": [W, H], "spp_per_step": S,
+                "parallelism": f"tiles8x8-round-robin-x{world}" if world > 1 else "single-gpu",
+                "ms_per_256spp_frame": elapsed / (args.steps * S) * 1e3 * 256,
+                "rays_per_step": total_rays / args.steps,
+                "closest_rays": total_closest, "shadow_rays": total_shadow, "pixel_samples": total_camera,
+                "frame_finite_and_lit": ok,
+                "rmse_note": "per-pixel RMSE vs the CPU oracle is asserted in tests/test_gpu_parity.py; no OptiX image exists (DESIGN.md)",
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "k_trace_closest", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "avg_launch_ms": k["ms"] / launches, "launches": launches,
+                "algorithmic_bytes_per_launch": kernel_bytes / launches, "bytes_per_ray": bytes_per_ray,
+                "nodes_per_ray": nodes_per_ray, "triangles_per_ray": tris_per_ray,
+                "shadow_nodes_per_ray": shadow_nodes_per_ray, "shadow_triangles_per_ray": shadow_tris_per_ray,
+            },
+            "kernel_ms_per_step": {name: v["ms"] / args.steps for name, v in times.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_seconds)
+        print(json.dumps(out))
+        sys.stdout.flush()
+
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -114,7 +114,7 @@ C_ABI_SYMBOLS = (
     "hipr_create", "hipr_destroy", "hipr_last_error", "hipr_device_count", "hipr_set_stream",
     "hipr_upload_tables", "hipr_upload_scene", "hipr_set_scene_state", "hipr_set_frame", "hipr_owned_pixel_count",
     "hipr_render_pass", "hipr_read_accumulation", "hipr_scatter_tiles", "hipr_synchronize", "hipr_get_counters",
-    "hipr_set_instrumentation", "hipr_reset_timers", "hipr_get_kernel_times",
+    "hipr_reset_counters", "hipr_set_instrumentation", "hipr_reset_timers", "hipr_get_kernel_times",
     "hipr_debug_generate", "hipr_debug_sobol", "hipr_debug_trace_closest", "hipr_debug_trace_shadow",
 )
 
@@ -150,6 +150,7 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.hipr_scatter_tiles.argtypes = [vp, vp, c_u64, c_u32, c_u32, c_u32, vp, c_u32]
     lib.hipr_synchronize.argtypes = [vp]
     lib.hipr_get_counters.argtypes = [vp, C.POINTER(HiprCounters)]
+    lib.hipr_reset_counters.argtypes = [vp]
     lib.hipr_set_instrumentation.argtypes = [vp, C.c_int]
     lib.hipr_reset_timers.argtypes = [vp]
     lib.hipr_get_kernel_times.argtypes = [vp, C.POINTER(HiprKernelTimes)]

@@ -1,0 +1,659 @@
+// hiprenderer.hip -- implementation of the C-ABI declared in include/hiprenderer_c.h.
+//
+// Host side of the MI355X wavefront path tracer: owns the device copies of the scene, the SoA
+// path / hit / shadow queues and the f64 accumulation buffer, and drives the per-pass kernel loop
+//   generate -> { trace_closest -> shade(+compact) -> trace_shadow } until no path is alive -> accumulate.
+// Replaces the OptiX context + context->launch() of OR/Renderer.cpp:273-574,1250-1265.
+// There is no CPU fallback: every entry point that needs the GPU fails with a status code.
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace hipr;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int status, const char* fmt, ...) {
+    char buf[512];
+    va_list args;
+    va_start(args, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, args);
+    va_end(args);
+    g_last_error = buf;
+    fprintf(stderr, "hiprenderer: %s\n", buf);
+    return status;
+}
+
+#define HIP_TRY(call)                                                                                          \
+    do {                                                                                                       \
+        hipError_t err__ = (call);                                                                             \
+        if (err__ != hipSuccess)                                                                               \
+            return fail(err__ == hipErrorOutOfMemory ? HIPR_ERROR_OUT_OF_MEMORY : HIPR_ERROR_HIP, "%s failed: %s (%s:%d)", #call, \
+                        hipGetErrorString(err__), __FILE__, __LINE__);                                         \
+    } while (0)
+
+struct DeviceBuffer {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    int resize(size_t new_bytes) {
+        if (new_bytes <= bytes && ptr) return HIPR_OK;
+        if (ptr) { (void)hipFree(ptr); ptr = nullptr; bytes = 0; }
+        if (new_bytes == 0) return HIPR_OK;
+        HIP_TRY(hipMalloc(&ptr, new_bytes));
+        bytes = new_bytes;
+        return HIPR_OK;
+    }
+    int upload(const void* src, size_t n, hipStream_t stream) {
+        if (n == 0) return HIPR_OK;
+        if (int s = resize(n)) return s;
+        HIP_TRY(hipMemcpyAsync(ptr, src, n, hipMemcpyHostToDevice, stream));
+        return HIPR_OK;
+    }
+    void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; bytes = 0; }
+    template <typename T> T* as() const { return static_cast<T*>(ptr); }
+};
+
+struct TimedLaunch { int kernel; hipEvent_t start, stop; };
+
+} // namespace
+
+struct HiprContext {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr, copy_stream = nullptr;
+    hipEvent_t shade_done = nullptr;
+
+    // scene
+    DeviceBuffer nodes, triangles, instances, indices, geometry, texcoords, tints, emissions, materials, lights, textures, texels;
+    DeviceBuffer ggx_rho, dielectric_rho, alpha, sample_offsets;
+    DeviceScene scene = {};
+    bool tables_ready = false, scene_ready = false;
+    int stack_size = 16;
+
+    // frame
+    FrameInfo frame = {};
+    bool frame_ready = false;
+    uint32_t n_slots = 0;   // owned_tiles * 64 * samples_per_pass
+    DeviceBuffer path[2][4], hits, shadow[3], radiance, accumulation, queue_counts, counters;
+    uint32_t* host_counts = nullptr;   // pinned: next, shadow
+
+    // bookkeeping
+    HiprCounters total = {};   // since hipr_reset_counters
+    bool instrument = false;
+    bool timing = true;
+    std::vector<hipEvent_t> event_pool;
+    size_t events_used = 0;
+    std::vector<TimedLaunch> timed;
+    HiprKernelTimes times = {};
+
+    DeviceBuffer debug_a, debug_b, debug_c;
+
+    PathState path_state(int which) const {
+        return {path[which][0].as<float4>(), path[which][1].as<float4>(), path[which][2].as<float4>(), path[which][3].as<uint4>()};
+    }
+    ShadowQueue shadow_queue() const { return {shadow[0].as<float4>(), shadow[1].as<float4>(), shadow[2].as<float4>()}; }
+
+    hipEvent_t next_event() {
+        if (events_used == event_pool.size()) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            event_pool.push_back(e);
+        }
+        return event_pool[events_used++];
+    }
+    void begin_timed(int kernel) {
+        if (!timing) return;
+        TimedLaunch t = {kernel, next_event(), next_event()};
+        if (!t.start || !t.stop) return;
+        (void)hipEventRecord(t.start, stream);
+        timed.push_back(t);
+    }
+    void end_timed() {
+        if (!timing || timed.empty()) return;
+        (void)hipEventRecord(timed.back().stop, stream);
+    }
+    // Requires the stream to be idle (called after a synchronize).
+    void collect_times() {
+        for (const TimedLaunch& t : timed) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess) {
+                times.milliseconds[t.kernel] += ms;
+                times.launches[t.kernel] += 1;
+            }
+        }
+        timed.clear();
+        events_used = 0;
+    }
+};
+
+namespace {
+
+uint32_t grid_for(uint32_t items, uint32_t block, uint32_t max_blocks) {
+    uint32_t blocks = (items + block - 1) / block;
+    blocks = std::max(1u, std::min(blocks, max_blocks));
+    return (blocks + 7u) & ~7u;   // multiple of 8: xcd_chunk() needs every XCD to own the same number of chunks
+}
+
+template <bool INSTRUMENT>
+void launch_trace_closest(HiprContext* c, const PathState& in, const uint32_t* count_ptr, uint32_t upper_bound) {
+    const uint32_t grid = grid_for(upper_bound, TRACE_BLOCK, 256u * 16u);
+    DeviceCounters* dc = c->counters.as<DeviceCounters>();
+    float4* hits = c->hits.as<float4>();
+    switch (c->stack_size) {
+    case 16: hipLaunchKernelGGL((k_trace_closest<16, INSTRUMENT>), dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->scene, in, hits, count_ptr, dc); break;
+    case 32: hipLaunchKernelGGL((k_trace_closest<32, INSTRUMENT>), dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->scene, in, hits, count_ptr, dc); break;
+    default: hipLaunchKernelGGL((k_trace_closest<64, INSTRUMENT>), dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->scene, in, hits, count_ptr, dc); break;
+    }
+}
+
+template <bool INSTRUMENT>
+void launch_trace_shadow(HiprContext* c, const uint32_t* count_ptr, uint32_t upper_bound) {
+    const uint32_t grid = grid_for(upper_bound, TRACE_BLOCK, 256u * 16u);
+    DeviceCounters* dc = c->counters.as<DeviceCounters>();
+    float4* rad = c->radiance.as<float4>();
+    ShadowQueue q = c->shadow_queue();
+    switch (c->stack_size) {
+    case 16: hipLaunchKernelGGL((k_trace_shadow<16, INSTRUMENT>), dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->scene, q, rad, count_ptr, dc); break;
+    case 32: hipLaunchKernelGGL((k_trace_shadow<32, INSTRUMENT>), dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->scene, q, rad, count_ptr, dc); break;
+    default: hipLaunchKernelGGL((k_trace_shadow<64, INSTRUMENT>), dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->scene, q, rad, count_ptr, dc); break;
+    }
+}
+
+int check_context(HiprContext* c) {
+    if (!c) return fail(HIPR_ERROR_INVALID_ARGUMENT, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    return HIPR_OK;
+}
+
+unsigned short to_unorm16(float v) { return (unsigned short)(v * 65535 + 0.5f); }
+
+// Reverse Halton offsets of OR/Renderer.cpp:323-336 (OR/RNG.h:196-231): primes 2, 3, 5, 7, digits d -> p - d, f64 inside.
+float reverse_halton(int prime, int i) {
+    double h = 0.0, f = 1.0 / double(prime), fct = f;
+    while (i > 0) {
+        int digit = i % prime;
+        h += (digit == 0 ? 0 : prime - digit) * fct;
+        i /= prime;
+        fct *= f;
+    }
+    return float(h);
+}
+
+} // namespace
+
+extern "C" {
+
+const char* hipr_last_error(void) { return g_last_error.c_str(); }
+
+int hipr_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int hipr_create(int device_id, HiprContext** out_context) {
+    if (!out_context) return fail(HIPR_ERROR_INVALID_ARGUMENT, "out_context is null");
+    *out_context = nullptr;
+    int n = hipr_device_count();
+    if (n == 0) return fail(HIPR_ERROR_NO_DEVICE, "no HIP device available");
+    if (device_id < 0 || device_id >= n) return fail(HIPR_ERROR_INVALID_ARGUMENT, "device %d out of range [0, %d)", device_id, n);
+    HIP_TRY(hipSetDevice(device_id));
+    HiprContext* c = new HiprContext();
+    c->device = device_id;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->shade_done, hipEventDisableTiming) != hipSuccess || hipHostMalloc((void**)&c->host_counts, 4 * sizeof(uint32_t)) != hipSuccess) {
+        delete c;
+        return fail(HIPR_ERROR_HIP, "stream / event / pinned allocation failed");
+    }
+    c->stream = c->own_stream;
+    if (c->queue_counts.resize(4 * sizeof(uint32_t)) || c->counters.resize(sizeof(DeviceCounters))) { delete c; return HIPR_ERROR_OUT_OF_MEMORY; }
+    HIP_TRY(hipMemsetAsync(c->counters.ptr, 0, sizeof(DeviceCounters), c->stream));
+
+    float offsets[256 * 4];
+    const int primes[4] = {2, 3, 5, 7};
+    for (int i = 0; i < 256; ++i)
+        for (int d = 0; d < 4; ++d) offsets[4 * i + d] = reverse_halton(primes[d], i);
+    if (int s = c->sample_offsets.upload(offsets, sizeof(offsets), c->stream)) { delete c; return s; }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->scene.sample_offsets = c->sample_offsets.as<float4>();
+    c->scene.next_event_sample_count = 3;   // OR/Renderer.cpp:479
+    *out_context = c;
+    return HIPR_OK;
+}
+
+int hipr_destroy(HiprContext* c) {
+    if (!c) return HIPR_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    DeviceBuffer* all[] = {&c->nodes, &c->triangles, &c->instances, &c->indices, &c->geometry, &c->texcoords, &c->tints, &c->emissions, &c->materials,
+                           &c->lights, &c->textures, &c->texels, &c->ggx_rho, &c->dielectric_rho, &c->alpha, &c->sample_offsets, &c->hits, &c->radiance,
+                           &c->accumulation, &c->queue_counts, &c->counters, &c->debug_a, &c->debug_b, &c->debug_c, &c->shadow[0], &c->shadow[1], &c->shadow[2]};
+    for (DeviceBuffer* b : all) b->release();
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) c->path[i][j].release();
+    for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+    if (c->shade_done) (void)hipEventDestroy(c->shade_done);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->host_counts) (void)hipHostFree(c->host_counts);
+    delete c;
+    return HIPR_OK;
+}
+
+int hipr_set_stream(HiprContext* c, void* hip_stream) {
+    if (int s = check_context(c)) return s;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->collect_times();
+    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return HIPR_OK;
+}
+
+int hipr_upload_tables(HiprContext* c, const HiprTables* t) {
+    if (int s = check_context(c)) return s;
+    if (!t || !t->ggx_with_fresnel_rho || !t->ggx_rho || !t->dielectric_light_rho || !t->dielectric_dense_rho || !t->ggx_alpha_from_max_PDF)
+        return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_upload_tables: null table");
+    std::vector<unsigned short> rho(2 * 32 * 32), diel(2 * 32 * 16 * 16), alpha(32 * 32);
+    for (int i = 0; i < 32 * 32; ++i) {
+        rho[2 * i] = to_unorm16(t->ggx_with_fresnel_rho[i]);   // F0 = 0
+        rho[2 * i + 1] = to_unorm16(t->ggx_rho[i]);            // F0 = 1
+        alpha[i] = to_unorm16(t->ggx_alpha_from_max_PDF[i]);
+    }
+    const int per_medium = 16 * 16 * 16;
+    for (int i = 0; i < 2 * per_medium; ++i) {
+        diel[i] = to_unorm16(t->dielectric_light_rho[i]);
+        diel[2 * per_medium + i] = to_unorm16(t->dielectric_dense_rho[i]);
+    }
+    if (int s = c->ggx_rho.upload(rho.data(), rho.size() * 2, c->stream)) return s;
+    if (int s = c->dielectric_rho.upload(diel.data(), diel.size() * 2, c->stream)) return s;
+    if (int s = c->alpha.upload(alpha.data(), alpha.size() * 2, c->stream)) return s;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->scene.tables = {c->ggx_rho.as<ushort2>(), c->dielectric_rho.as<ushort2>(), c->alpha.as<unsigned short>()};
+    c->tables_ready = true;
+    return HIPR_OK;
+}
+
+int hipr_upload_scene(HiprContext* c, const HiprSceneDesc* s) {
+    if (int st = check_context(c)) return st;
+    if (!s) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_upload_scene: null scene");
+    if (s->triangle_count && (!s->nodes || !s->triangles || !s->instances || !s->indices || !s->geometry || !s->materials))
+        return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_upload_scene: missing geometry arrays");
+    if (s->bvh_max_depth > 64) return fail(HIPR_ERROR_UNSUPPORTED, "BVH depth %u exceeds the 64 entry LDS stack", s->bvh_max_depth);
+    for (uint32_t i = 0; i < s->instance_count; ++i)
+        if ((s->instances[i].mesh_flags & HIPR_MESH_TEXCOORDS && !s->texcoords) || (s->instances[i].mesh_flags & HIPR_MESH_TINTS && !s->tints) ||
+            (s->instances[i].mesh_flags & HIPR_MESH_EMISSIVE && !s->emissions))
+            return fail(HIPR_ERROR_INVALID_ARGUMENT, "instance %u flags an attribute whose pool is null", i);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    hipStream_t st = c->stream;
+    int r = 0;
+    r |= c->nodes.upload(s->nodes, size_t(s->node_count) * sizeof(HiprBvhNode), st);
+    r |= c->triangles.upload(s->triangles, size_t(s->triangle_count) * sizeof(HiprTriangle), st);
+    r |= c->instances.upload(s->instances, size_t(s->instance_count) * sizeof(HiprInstance), st);
+    r |= c->indices.upload(s->indices, size_t(s->index_count) * 4, st);
+    r |= c->geometry.upload(s->geometry, size_t(s->vertex_count) * sizeof(HiprVertexGeometry), st);
+    if (s->texcoords) r |= c->texcoords.upload(s->texcoords, size_t(s->vertex_count) * 8, st);
+    if (s->tints) r |= c->tints.upload(s->tints, size_t(s->vertex_count) * 4, st);
+    if (s->emissions) r |= c->emissions.upload(s->emissions, size_t(s->vertex_count) * 12, st);
+    r |= c->materials.upload(s->materials, size_t(s->material_count) * sizeof(HiprMaterial), st);
+    r |= c->lights.upload(s->lights, size_t(s->light_count) * sizeof(HiprLight), st);
+    r |= c->textures.upload(s->textures, size_t(s->texture_count) * sizeof(HiprTexture), st);
+    r |= c->texels.upload(s->texels, s->texel_bytes, st);
+    if (r) return r < 0 ? r : HIPR_ERROR_HIP;
+    HIP_TRY(hipStreamSynchronize(st));
+    DeviceScene& d = c->scene;
+    d.nodes = c->nodes.as<float4>();
+    d.triangles = c->triangles.as<float4>();
+    d.instances = c->instances.as<HiprInstance>();
+    d.indices = c->indices.as<uint32_t>();
+    d.geometry = c->geometry.as<float4>();
+    d.texcoords = c->texcoords.as<float2>();
+    d.tints = c->tints.as<uint32_t>();
+    d.emissions = c->emissions.as<float>();
+    d.materials = c->materials.as<HiprMaterial>();
+    d.lights = c->lights.as<HiprLight>();
+    d.textures = c->textures.as<HiprTexture>();
+    d.texels = c->texels.as<uint8_t>();
+    d.node_count = s->node_count;
+    d.triangle_count = s->triangle_count;
+    d.light_count = s->light_count;
+    c->stack_size = s->bvh_max_depth <= 16 ? 16 : (s->bvh_max_depth <= 32 ? 32 : 64);
+    c->scene_ready = true;
+    return HIPR_OK;
+}
+
+int hipr_set_scene_state(HiprContext* c, const HiprSceneState* state) {
+    if (int s = check_context(c)) return s;
+    if (!state) return fail(HIPR_ERROR_INVALID_ARGUMENT, "null scene state");
+    for (int i = 0; i < 3; ++i) c->scene.env_tint[i] = state->environment_tint[i];
+    c->scene.next_event_sample_count = std::min(std::max(state->next_event_sample_count, 0), 256);
+    return HIPR_OK;
+}
+
+int hipr_set_frame(HiprContext* c, const HiprFrameDesc* f) {
+    if (int s = check_context(c)) return s;
+    if (!f || f->width == 0 || f->height == 0 || f->tile_stride == 0 || f->tile_phase >= f->tile_stride || f->samples_per_pass == 0)
+        return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_set_frame: bad frame description");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    FrameInfo fi;
+    fi.width = f->width; fi.height = f->height;
+    fi.tiles_x = (f->width + 7) / 8;
+    fi.tiles_total = fi.tiles_x * ((f->height + 7) / 8);
+    fi.tile_phase = f->tile_phase; fi.tile_stride = f->tile_stride;
+    fi.owned_tiles = (fi.tiles_total + f->tile_stride - 1 - f->tile_phase) / f->tile_stride;
+    fi.samples_per_pass = f->samples_per_pass;
+    const uint64_t slots = uint64_t(fi.owned_tiles) * 64u * fi.samples_per_pass;
+    if (slots == 0 || slots > 0x7FFFFFFFull) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_set_frame: %llu path slots per pass", (unsigned long long)slots);
+    c->frame = fi;
+    c->n_slots = uint32_t(slots);
+    int r = 0;
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) r |= c->path[i][j].resize(slots * 16);
+    r |= c->hits.resize(slots * 16);
+    for (int j = 0; j < 3; ++j) r |= c->shadow[j].resize(slots * 16);
+    r |= c->radiance.resize(slots * 16);
+    const size_t acc_bytes = size_t(fi.owned_tiles) * 64 * sizeof(double4);
+    c->accumulation.release();
+    r |= c->accumulation.resize(acc_bytes);
+    if (r) return HIPR_ERROR_OUT_OF_MEMORY;
+    HIP_TRY(hipMemsetAsync(c->accumulation.ptr, 0, acc_bytes, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->frame_ready = true;
+    return HIPR_OK;
+}
+
+int hipr_owned_pixel_count(HiprContext* c, uint32_t* out_count) {
+    if (!c || !out_count) return fail(HIPR_ERROR_INVALID_ARGUMENT, "null argument");
+    if (!c->frame_ready) return fail(HIPR_ERROR_NOT_READY, "no frame set");
+    *out_count = c->frame.owned_tiles * 64u;
+    return HIPR_OK;
+}
+
+int hipr_render_pass(HiprContext* c, const HiprCameraState* camera, void* out_half4_device, uint32_t out_pitch_pixels, int synchronize) {
+    if (int s = check_context(c)) return s;
+    if (!camera) return fail(HIPR_ERROR_INVALID_ARGUMENT, "null camera");
+    if (!c->tables_ready || !c->scene_ready || !c->frame_ready) return fail(HIPR_ERROR_NOT_READY, "tables, scene and frame must be set before rendering");
+    if (out_half4_device && c->frame.tile_stride == 1 && out_pitch_pixels < c->frame.width) return fail(HIPR_ERROR_INVALID_ARGUMENT, "output pitch smaller than the frame width");
+
+    const FrameInfo& f = c->frame;
+    const uint32_t n = c->n_slots;
+    uint32_t* counts = c->queue_counts.as<uint32_t>();
+    HiprCounters pass = {};
+
+    // valid pixel-samples (edge tiles may hang over the frame)
+    uint64_t valid_pixels = 0;
+    if (f.tile_stride == 1) valid_pixels = uint64_t(f.width) * f.height;
+    else {
+        const uint32_t tiles_y = (f.height + 7) / 8;
+        for (uint32_t t = f.tile_phase; t < f.tiles_total; t += f.tile_stride) {
+            uint32_t tx = t % f.tiles_x, ty = t / f.tiles_x;
+            uint32_t w = std::min(8u, f.width - tx * 8), h = std::min(8u, f.height - ty * 8);
+            (void)tiles_y;
+            valid_pixels += uint64_t(w) * h;
+        }
+    }
+    pass.camera_rays = valid_pixels * f.samples_per_pass;
+
+    c->host_counts[2] = n;   // pinned staging word, rewritten only after the syncs of the next pass
+    HIP_TRY(hipMemcpyAsync(counts + 0, c->host_counts + 2, 4, hipMemcpyHostToDevice, c->stream));
+
+    c->begin_timed(HIPR_KERNEL_GENERATE);
+    hipLaunchKernelGGL(k_generate, dim3((n + 255) / 256), dim3(256), 0, c->stream, f, *camera, c->path_state(0), c->radiance.as<float4>(), n);
+    c->end_timed();
+
+    int cur = 0;
+    uint32_t alive = n;
+    uint32_t first_dead = n - uint32_t(std::min<uint64_t>(n, pass.camera_rays));   // dead lanes of partial tiles are never traced
+    while (alive > 0) {
+        uint32_t* in_count = counts + cur;
+        uint32_t* out_count = counts + (1 - cur);
+        HIP_TRY(hipMemsetAsync(out_count, 0, 4, c->stream));
+        HIP_TRY(hipMemsetAsync(counts + 2, 0, 4, c->stream));
+
+        c->begin_timed(HIPR_KERNEL_TRACE_CLOSEST);
+        if (c->instrument) launch_trace_closest<true>(c, c->path_state(cur), in_count, alive);
+        else launch_trace_closest<false>(c, c->path_state(cur), in_count, alive);
+        c->end_timed();
+
+        c->begin_timed(HIPR_KERNEL_SHADE);
+        hipLaunchKernelGGL(k_shade, dim3(grid_for(alive, SHADE_BLOCK, 256u * 8u)), dim3(SHADE_BLOCK), 0, c->stream, c->scene, *camera, c->path_state(cur),
+                           c->hits.as<float4>(), c->path_state(1 - cur), c->shadow_queue(), c->radiance.as<float4>(), in_count, out_count, counts + 2,
+                           c->counters.as<DeviceCounters>());
+        c->end_timed();
+        HIP_TRY(hipEventRecord(c->shade_done, c->stream));
+
+        // The shadow kernel reads its count on the device; it is launched for the upper bound so the
+        // host can fetch the queue sizes (on the copy stream) while it runs.
+        c->begin_timed(HIPR_KERNEL_TRACE_SHADOW);
+        if (c->instrument) launch_trace_shadow<true>(c, counts + 2, alive);
+        else launch_trace_shadow<false>(c, counts + 2, alive);
+        c->end_timed();
+
+        HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->shade_done, 0));
+        HIP_TRY(hipMemcpyAsync(c->host_counts, out_count, 4, hipMemcpyDeviceToHost, c->copy_stream));
+        HIP_TRY(hipMemcpyAsync(c->host_counts + 1, counts + 2, 4, hipMemcpyDeviceToHost, c->copy_stream));
+        HIP_TRY(hipStreamSynchronize(c->copy_stream));
+
+        pass.closest_rays += alive - (pass.iterations == 0 ? first_dead : 0);
+        pass.shadow_rays += c->host_counts[1];
+        pass.iterations += 1;
+        alive = c->host_counts[0];
+        cur = 1 - cur;
+        if (pass.iterations > 4096) return fail(HIPR_ERROR_HIP, "wavefront loop did not terminate");
+    }
+
+    c->begin_timed(HIPR_KERNEL_ACCUMULATE);
+    hipLaunchKernelGGL(k_accumulate, dim3((f.owned_tiles * 64 + 255) / 256), dim3(256), 0, c->stream, f, camera->accumulations, c->radiance.as<float4>(),
+                       c->accumulation.as<double4>(), static_cast<ushort4*>(out_half4_device), out_pitch_pixels);
+    c->end_timed();
+    HIP_TRY(hipGetLastError());
+
+    c->total.camera_rays += pass.camera_rays;
+    c->total.closest_rays += pass.closest_rays;
+    c->total.shadow_rays += pass.shadow_rays;
+    c->total.iterations += pass.iterations;
+    if (synchronize || c->instrument || c->timed.size() > 2048) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->collect_times();
+    }
+    return HIPR_OK;
+}
+
+int hipr_synchronize(HiprContext* c) {
+    if (int s = check_context(c)) return s;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->collect_times();
+    return HIPR_OK;
+}
+
+int hipr_get_counters(HiprContext* c, HiprCounters* out) {
+    if (int s = check_context(c)) return s;
+    if (!out) return fail(HIPR_ERROR_INVALID_ARGUMENT, "null counters");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->collect_times();
+    DeviceCounters dc;
+    HIP_TRY(hipMemcpy(&dc, c->counters.ptr, sizeof(dc), hipMemcpyDeviceToHost));
+    *out = c->total;
+    out->shaded_hits = dc.shaded_hits;
+    out->closest_nodes = dc.closest_nodes;
+    out->closest_triangles = dc.closest_triangles;
+    out->shadow_nodes = dc.shadow_nodes;
+    out->shadow_triangles = dc.shadow_triangles;
+    return HIPR_OK;
+}
+
+int hipr_reset_counters(HiprContext* c) {
+    if (int s = check_context(c)) return s;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->collect_times();
+    HIP_TRY(hipMemset(c->counters.ptr, 0, sizeof(DeviceCounters)));
+    c->total = {};
+    return HIPR_OK;
+}
+
+int hipr_set_instrumentation(HiprContext* c, int count_traversal_steps) {
+    if (!c) return fail(HIPR_ERROR_INVALID_ARGUMENT, "null context");
+    c->instrument = count_traversal_steps != 0;
+    return HIPR_OK;
+}
+
+int hipr_reset_timers(HiprContext* c) {
+    if (int s = check_context(c)) return s;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->collect_times();
+    c->times = {};
+    return HIPR_OK;
+}
+
+int hipr_get_kernel_times(HiprContext* c, HiprKernelTimes* out) {
+    if (int s = check_context(c)) return s;
+    if (!out) return fail(HIPR_ERROR_INVALID_ARGUMENT, "null output");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->collect_times();
+    *out = c->times;
+    return HIPR_OK;
+}
+
+int hipr_read_accumulation(HiprContext* c, double* out_rgba, uint64_t capacity_pixels) {
+    if (int s = check_context(c)) return s;
+    if (!c->frame_ready) return fail(HIPR_ERROR_NOT_READY, "no frame set");
+    const FrameInfo& f = c->frame;
+    const uint64_t owned = uint64_t(f.owned_tiles) * 64;
+    const uint64_t needed = f.tile_stride == 1 ? uint64_t(f.width) * f.height : owned;
+    if (!out_rgba || capacity_pixels < needed) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_read_accumulation: need room for %llu pixels", (unsigned long long)needed);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->collect_times();
+    if (f.tile_stride != 1) {
+        HIP_TRY(hipMemcpy(out_rgba, c->accumulation.ptr, owned * 32, hipMemcpyDeviceToHost));
+        return HIPR_OK;
+    }
+    std::vector<double> compact(owned * 4);
+    HIP_TRY(hipMemcpy(compact.data(), c->accumulation.ptr, owned * 32, hipMemcpyDeviceToHost));
+    for (uint32_t y = 0; y < f.height; ++y)
+        for (uint32_t x = 0; x < f.width; ++x) {
+            const uint64_t k = (uint64_t(y >> 3) * f.tiles_x + (x >> 3)) * 64 + ((x & 7) + ((y & 7) << 3));
+            std::memcpy(out_rgba + 4 * (uint64_t(y) * f.width + x), compact.data() + 4 * k, 32);
+        }
+    return HIPR_OK;
+}
+
+int hipr_scatter_tiles(HiprContext* c, const void* compact, uint64_t rank_stride, uint32_t rank_count, uint32_t width, uint32_t height, void* out,
+                       uint32_t out_pitch) {
+    if (int s = check_context(c)) return s;
+    if (!compact || !out || rank_count == 0 || out_pitch < width) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_scatter_tiles: bad argument");
+    hipLaunchKernelGGL(k_scatter_tiles, dim3((width + 15) / 16, (height + 15) / 16), dim3(256), 0, c->stream, static_cast<const ushort4*>(compact),
+                       (unsigned long long)rank_stride, rank_count, width, height, static_cast<ushort4*>(out), out_pitch);
+    HIP_TRY(hipGetLastError());
+    return HIPR_OK;
+}
+
+// ------------------------------------------------------------------------------------------- debug / parity entry points
+int hipr_debug_generate(HiprContext* c, const HiprCameraState* camera, uint32_t accumulation, float* out_origin_tmin, float* out_direction, uint32_t* out_pixel) {
+    if (int s = check_context(c)) return s;
+    if (!camera || !c->frame_ready) return fail(HIPR_ERROR_NOT_READY, "hipr_debug_generate needs a camera and a frame");
+    FrameInfo f = c->frame;
+    f.samples_per_pass = 1;
+    const uint32_t n = f.owned_tiles * 64;
+    HiprCameraState cam = *camera;
+    cam.accumulations = accumulation;
+    hipLaunchKernelGGL(k_generate, dim3((n + 255) / 256), dim3(256), 0, c->stream, f, cam, c->path_state(0), c->radiance.as<float4>(), n);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (out_origin_tmin) HIP_TRY(hipMemcpy(out_origin_tmin, c->path[0][0].ptr, size_t(n) * 16, hipMemcpyDeviceToHost));
+    if (out_direction) HIP_TRY(hipMemcpy(out_direction, c->path[0][1].ptr, size_t(n) * 16, hipMemcpyDeviceToHost));
+    if (out_pixel) {
+        for (uint32_t k = 0; k < n; ++k) {
+            uint32_t tile = (k >> 6) * f.tile_stride + f.tile_phase, lane = k & 63;
+            uint32_t x = (tile % f.tiles_x) * 8 + (lane & 7), y = (tile / f.tiles_x) * 8 + (lane >> 3);
+            out_pixel[k] = (tile < f.tiles_total && x < f.width && y < f.height) ? (x | (y << 16)) : 0xFFFFFFFFu;
+        }
+    }
+    return HIPR_OK;
+}
+
+int hipr_debug_sobol(HiprContext* c, const uint32_t* triples, uint32_t n, uint32_t* out_uint4) {
+    if (int s = check_context(c)) return s;
+    if (!triples || !out_uint4) return fail(HIPR_ERROR_INVALID_ARGUMENT, "null argument");
+    if (n == 0) return HIPR_OK;
+    if (int s = c->debug_a.upload(triples, size_t(n) * 12, c->stream)) return s;
+    if (int s = c->debug_b.resize(size_t(n) * 16)) return s;
+    hipLaunchKernelGGL(k_debug_sobol, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->debug_a.as<uint32_t>(), n, c->debug_b.as<uint32_t>());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out_uint4, c->debug_b.ptr, size_t(n) * 16, hipMemcpyDeviceToHost));
+    return HIPR_OK;
+}
+
+static int debug_prepare_rays(HiprContext* c, const float* rays, uint32_t n, std::vector<float>& o, std::vector<float>& d) {
+    o.resize(size_t(n) * 4);
+    d.resize(size_t(n) * 4);
+    for (uint32_t i = 0; i < n; ++i) {
+        std::memcpy(&o[4 * i], rays + 8 * size_t(i), 16);
+        std::memcpy(&d[4 * i], rays + 8 * size_t(i) + 4, 16);
+    }
+    return HIPR_OK;
+}
+
+int hipr_debug_trace_closest(HiprContext* c, const float* rays, const uint32_t* skip, uint32_t n, float* out_hits) {
+    if (int s = check_context(c)) return s;
+    if (!c->scene_ready) return fail(HIPR_ERROR_NOT_READY, "no scene uploaded");
+    if (!rays || !out_hits) return fail(HIPR_ERROR_INVALID_ARGUMENT, "null argument");
+    if (n == 0) return HIPR_OK;
+    std::vector<float> o, d;
+    debug_prepare_rays(c, rays, n, o, d);
+    std::vector<uint32_t> meta(size_t(n) * 4);
+    for (uint32_t i = 0; i < n; ++i) { meta[4 * i] = i; meta[4 * i + 1] = skip ? skip[i] : HIPR_NO_TRIANGLE; meta[4 * i + 2] = 0; meta[4 * i + 3] = 0; }
+    DeviceBuffer bo, bd, bm, bh, bc;
+    int r = bo.upload(o.data(), o.size() * 4, c->stream) | bd.upload(d.data(), d.size() * 4, c->stream) | bm.upload(meta.data(), meta.size() * 4, c->stream) |
+            bh.resize(size_t(n) * 16) | bc.upload(&n, 4, c->stream);
+    if (r) return HIPR_ERROR_OUT_OF_MEMORY;
+    HIP_TRY(hipMemsetAsync(c->counters.ptr, 0, sizeof(DeviceCounters), c->stream));
+    PathState in = {bo.as<float4>(), bd.as<float4>(), nullptr, bm.as<uint4>()};
+    DeviceBuffer saved_hits = c->hits;
+    c->hits = bh;
+    if (c->instrument) launch_trace_closest<true>(c, in, bc.as<uint32_t>(), n);
+    else launch_trace_closest<false>(c, in, bc.as<uint32_t>(), n);
+    c->hits = saved_hits;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out_hits, bh.ptr, size_t(n) * 16, hipMemcpyDeviceToHost));
+    c->total = {};
+    c->total.closest_rays = n;
+    bo.release(); bd.release(); bm.release(); bh.release(); bc.release();
+    return HIPR_OK;
+}
+
+int hipr_debug_trace_shadow(HiprContext* c, const float* rays, uint32_t n, float* out_transmittance) {
+    if (int s = check_context(c)) return s;
+    if (!c->scene_ready) return fail(HIPR_ERROR_NOT_READY, "no scene uploaded");
+    if (!rays || !out_transmittance) return fail(HIPR_ERROR_INVALID_ARGUMENT, "null argument");
+    if (n == 0) return HIPR_OK;
+    std::vector<float> o(size_t(n) * 4), d(size_t(n) * 4), rad(size_t(n) * 4, 0.0f), ones(size_t(n) * 4, 1.0f);
+    for (uint32_t i = 0; i < n; ++i) {
+        std::memcpy(&o[4 * i], rays + 8 * size_t(i), 12);
+        o[4 * i + 3] = rays[8 * size_t(i) + 7];               // tmax
+        std::memcpy(&d[4 * i], rays + 8 * size_t(i) + 4, 12);
+        std::memcpy(&d[4 * i + 3], &i, 4);                    // slot
+    }
+    DeviceBuffer bo, bd, br, bacc, bc;
+    int r = bo.upload(o.data(), o.size() * 4, c->stream) | bd.upload(d.data(), d.size() * 4, c->stream) | br.upload(ones.data(), ones.size() * 4, c->stream) |
+            bacc.upload(rad.data(), rad.size() * 4, c->stream) | bc.upload(&n, 4, c->stream);
+    if (r) return HIPR_ERROR_OUT_OF_MEMORY;
+    HIP_TRY(hipMemsetAsync(c->counters.ptr, 0, sizeof(DeviceCounters), c->stream));
+    DeviceBuffer s0 = c->shadow[0], s1 = c->shadow[1], s2 = c->shadow[2], sr = c->radiance;
+    c->shadow[0] = bo; c->shadow[1] = bd; c->shadow[2] = br; c->radiance = bacc;
+    if (c->instrument) launch_trace_shadow<true>(c, bc.as<uint32_t>(), n);
+    else launch_trace_shadow<false>(c, bc.as<uint32_t>(), n);
+    c->shadow[0] = s0; c->shadow[1] = s1; c->shadow[2] = s2; c->radiance = sr;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::vector<float> result(size_t(n) * 4);
+    HIP_TRY(hipMemcpy(result.data(), bacc.ptr, result.size() * 4, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; ++i) out_transmittance[i] = result[4 * i];
+    c->total = {};
+    c->total.shadow_rays = n;
+    bo.release(); bd.release(); br.release(); bacc.release(); bc.release();
+    return HIPR_OK;
+}
+
+} // extern "C"

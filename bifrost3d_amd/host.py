@@ -1,0 +1,77 @@
+"""ctypes wrapper of host/libhiprenderer_host.so (scene construction, BVH build). No GPU needed."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+_lib = None
+
+
+def load_host_library() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not capi.HOST_LIB_PATH.exists():
+        raise capi.HiprError(f"{capi.HOST_LIB_PATH} is missing: run __graft_entry__.build()")
+    lib = C.CDLL(str(capi.HOST_LIB_PATH))
+    vp = C.c_void_p
+    lib.hiprh_scene_create.argtypes = [C.c_char_p, C.c_uint, C.c_uint, C.c_uint]
+    lib.hiprh_scene_create.restype = vp
+    lib.hiprh_scene_destroy.argtypes = [vp]
+    lib.hiprh_scene_desc.argtypes = [vp]
+    lib.hiprh_scene_desc.restype = C.POINTER(capi.HiprSceneDesc)
+    lib.hiprh_scene_state.argtypes = [vp, C.POINTER(capi.HiprSceneState)]
+    lib.hiprh_scene_camera.argtypes = [vp, C.c_uint, C.c_uint, C.c_uint, C.c_int, C.c_float, C.POINTER(capi.HiprCameraState)]
+    lib.hiprh_bvh_build.argtypes = [C.POINTER(capi.HiprTriangle), C.c_uint, C.c_uint]
+    lib.hiprh_bvh_build.restype = vp
+    lib.hiprh_bvh_node_count.argtypes = [vp]; lib.hiprh_bvh_node_count.restype = C.c_uint
+    lib.hiprh_bvh_max_depth.argtypes = [vp]; lib.hiprh_bvh_max_depth.restype = C.c_uint
+    lib.hiprh_bvh_nodes.argtypes = [vp]; lib.hiprh_bvh_nodes.restype = C.POINTER(capi.HiprBvhNode)
+    lib.hiprh_bvh_order.argtypes = [vp]; lib.hiprh_bvh_order.restype = C.POINTER(C.c_uint)
+    lib.hiprh_bvh_destroy.argtypes = [vp]
+    lib.hiprh_encode_octahedral.argtypes = [C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_short)]
+    _lib = lib
+    return lib
+
+
+class Scene:
+    """A flattened scene owned by the C++ host library (what handle_updates() would hand to hipr_upload_scene)."""
+
+    def __init__(self, name: str, diffuse_only: bool = False, param0: int = 0, param1: int = 0):
+        self.lib = load_host_library()
+        self.handle = self.lib.hiprh_scene_create(name.encode(), 1 if diffuse_only else 0, param0, param1)
+        if not self.handle:
+            raise capi.HiprError(f"unknown scene '{name}'")
+        self.name = name
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            self.lib.hiprh_scene_destroy(self.handle)
+            self.handle = None
+
+    @property
+    def desc(self) -> capi.HiprSceneDesc:
+        return self.lib.hiprh_scene_desc(self.handle).contents
+
+    @property
+    def state(self) -> capi.HiprSceneState:
+        s = capi.HiprSceneState()
+        self.lib.hiprh_scene_state(self.handle, C.byref(s))
+        return s
+
+    def camera(self, width: int, height: int, accumulations: int = 0, max_bounce_count: int = -1, pdf_scale: float = 0.5) -> capi.HiprCameraState:
+        cam = capi.HiprCameraState()
+        if self.lib.hiprh_scene_camera(self.handle, width, height, accumulations, max_bounce_count, pdf_scale, C.byref(cam)) != 0:
+            raise capi.HiprError("hiprh_scene_camera failed")
+        return cam
+
+    def triangles(self) -> np.ndarray:
+        d = self.desc
+        return np.ctypeslib.as_array(C.cast(d.triangles, C.POINTER(C.c_uint32)), shape=(d.triangle_count, 12)).copy()
+
+    def nodes(self) -> np.ndarray:
+        d = self.desc
+        return np.ctypeslib.as_array(C.cast(d.nodes, C.POINTER(C.c_uint32)), shape=(d.node_count, 16)).copy()

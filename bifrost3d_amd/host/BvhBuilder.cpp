@@ -1,0 +1,199 @@
+// host/BvhBuilder.cpp -- deterministic binned-SAH BVH2 builder for the HIP traversal kernels.
+//
+// Replaces the OptiX "Trbvh" acceleration build the reference requests at
+// OptiXRenderer/Renderer.cpp:161-182,471-476 (closed source, so the tree itself is new design).
+// Output: HiprBvhNode[] (64 B, both child boxes in the parent, Aila-Laine layout) in depth-first
+// order with node 0 the root, and the triangle permutation in leaf order. Guarantees:
+//   * every triangle is referenced by exactly one leaf, leaves hold 1..4 triangles;
+//   * the deepest leaf is at most `max_depth` levels below the root (median splits take over when
+//     the SAH tree would exceed the LDS stack of the kernels);
+//   * the result depends only on the input order and values (single threaded, stable partition).
+#include "BvhBuilder.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+
+namespace HIPRenderer {
+
+namespace {
+
+struct Box {
+    float lo[3], hi[3];
+    void reset() { for (int a = 0; a < 3; ++a) { lo[a] = FLT_MAX; hi[a] = -FLT_MAX; } }
+    void grow(const float* p) { for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]); } }
+    void grow(const Box& b) { for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], b.lo[a]); hi[a] = std::max(hi[a], b.hi[a]); } }
+    float half_area() const {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+constexpr int BIN_COUNT = 16;
+constexpr uint32_t LEAF_MAX = 4;
+
+struct Builder {
+    const std::vector<HiprTriangle>& tris;
+    std::vector<Box> boxes;
+    std::vector<float> centroids;   // 3 per triangle
+    std::vector<uint32_t> order;
+    std::vector<HiprBvhNode> nodes;
+    uint32_t max_depth_limit;
+    uint32_t deepest = 0;
+
+    explicit Builder(const std::vector<HiprTriangle>& t, uint32_t limit) : tris(t), max_depth_limit(limit) {}
+
+    Box bounds_of(uint32_t begin, uint32_t end) const {
+        Box b; b.reset();
+        for (uint32_t i = begin; i < end; ++i) b.grow(boxes[order[i]]);
+        return b;
+    }
+
+    static uint32_t levels_needed(uint32_t count) {   // levels a balanced median tree needs below this node
+        uint32_t leaves = (count + LEAF_MAX - 1) / LEAF_MAX, levels = 0;
+        while ((1u << levels) < leaves) ++levels;
+        return levels;
+    }
+
+    // Returns the split position in [begin+1, end-1].
+    uint32_t split(uint32_t begin, uint32_t end, uint32_t depth) {
+        const uint32_t count = end - begin;
+        Box cb; cb.reset();
+        for (uint32_t i = begin; i < end; ++i) cb.grow(&centroids[3 * order[i]]);
+
+        // Depth budget: once only enough levels remain for a balanced tree, split at the median.
+        const bool force_median = depth + levels_needed(count) >= max_depth_limit;
+
+        int best_axis = -1, best_bin = -1;
+        float best_cost = FLT_MAX;
+        if (!force_median) {
+            for (int axis = 0; axis < 3; ++axis) {
+                const float extent = cb.hi[axis] - cb.lo[axis];
+                if (!(extent > 0.0f)) continue;
+                Box bin_box[BIN_COUNT];
+                uint32_t bin_n[BIN_COUNT] = {};
+                for (auto& b : bin_box) b.reset();
+                const float scale = BIN_COUNT / extent;
+                for (uint32_t i = begin; i < end; ++i) {
+                    const uint32_t t = order[i];
+                    int b = int((centroids[3 * t + axis] - cb.lo[axis]) * scale);
+                    b = std::min(std::max(b, 0), BIN_COUNT - 1);
+                    bin_box[b].grow(boxes[t]);
+                    bin_n[b]++;
+                }
+                float right_area[BIN_COUNT];
+                uint32_t right_n[BIN_COUNT];
+                Box acc; acc.reset();
+                uint32_t n = 0;
+                for (int b = BIN_COUNT - 1; b > 0; --b) {
+                    if (bin_n[b]) acc.grow(bin_box[b]);
+                    n += bin_n[b];
+                    right_area[b] = n ? acc.half_area() : 0.0f;
+                    right_n[b] = n;
+                }
+                acc.reset();
+                n = 0;
+                for (int b = 0; b < BIN_COUNT - 1; ++b) {
+                    if (bin_n[b]) acc.grow(bin_box[b]);
+                    n += bin_n[b];
+                    if (n == 0 || right_n[b + 1] == 0) continue;
+                    const float cost = acc.half_area() * float(n) + right_area[b + 1] * float(right_n[b + 1]);
+                    if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
+                }
+            }
+        }
+
+        if (best_axis >= 0) {
+            const float extent = cb.hi[best_axis] - cb.lo[best_axis];
+            const float scale = BIN_COUNT / extent;
+            const float lo = cb.lo[best_axis];
+            auto mid = std::stable_partition(order.begin() + begin, order.begin() + end, [&](uint32_t t) {
+                int b = int((centroids[3 * t + best_axis] - lo) * scale);
+                b = std::min(std::max(b, 0), BIN_COUNT - 1);
+                return b <= best_bin;
+            });
+            const uint32_t m = uint32_t(mid - order.begin());
+            if (m > begin && m < end) return m;
+        }
+
+        // Median split along the widest centroid axis (also the fallback for coincident centroids).
+        int axis = 0;
+        for (int a = 1; a < 3; ++a)
+            if (cb.hi[a] - cb.lo[a] > cb.hi[axis] - cb.lo[axis]) axis = a;
+        const uint32_t m = begin + count / 2;
+        std::stable_sort(order.begin() + begin, order.begin() + end,
+                         [&](uint32_t a, uint32_t b) { return centroids[3 * a + axis] < centroids[3 * b + axis]; });
+        return m;
+    }
+
+    static int32_t leaf_ref(uint32_t first, uint32_t count) { return ~int32_t((first << 3) | (count - 1)); }
+
+    static void store_child(HiprBvhNode& n, int c, const Box& b, int32_t ref) {
+        float* xy = c == 0 ? n.c0xy : n.c1xy;
+        xy[0] = b.lo[0]; xy[1] = b.hi[0]; xy[2] = b.lo[1]; xy[3] = b.hi[1];
+        n.cz[2 * c] = b.lo[2]; n.cz[2 * c + 1] = b.hi[2];
+        n.child[c] = ref;
+    }
+
+    // Builds the node covering order[begin, end) (count > LEAF_MAX) and returns its index.
+    uint32_t build(uint32_t begin, uint32_t end, uint32_t depth) {
+        const uint32_t index = uint32_t(nodes.size());
+        nodes.emplace_back();
+        HiprBvhNode scratch = {};
+        const uint32_t mid = split(begin, end, depth);
+        const uint32_t range[2][2] = {{begin, mid}, {mid, end}};
+        for (int c = 0; c < 2; ++c) {
+            const uint32_t b = range[c][0], e = range[c][1];
+            const Box box = bounds_of(b, e);
+            if (e - b <= LEAF_MAX) {
+                store_child(scratch, c, box, leaf_ref(b, e - b));
+                deepest = std::max(deepest, depth + 1);
+            } else
+                store_child(scratch, c, box, int32_t(build(b, e, depth + 1)));
+        }
+        nodes[index] = scratch;
+        return index;
+    }
+};
+
+} // namespace
+
+BvhBuildResult build_bvh(const std::vector<HiprTriangle>& triangles, uint32_t max_depth) {
+    BvhBuildResult result;
+    const uint32_t n = uint32_t(triangles.size());
+    result.max_depth = 0;
+    if (n == 0) return result;
+
+    Builder b(triangles, std::max(max_depth, 8u));
+    b.boxes.resize(n);
+    b.centroids.resize(3 * size_t(n));
+    b.order.resize(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        const HiprTriangle& t = triangles[i];
+        Box& box = b.boxes[i];
+        box.reset();
+        box.grow(t.v0); box.grow(t.v1); box.grow(t.v2);
+        for (int a = 0; a < 3; ++a) b.centroids[3 * i + a] = 0.5f * (box.lo[a] + box.hi[a]);
+        b.order[i] = i;
+    }
+
+    if (n <= LEAF_MAX) {
+        // A single leaf: both children reference it (the duplicate test cannot change the result).
+        HiprBvhNode root = {};
+        Box box = b.bounds_of(0, n);
+        Builder::store_child(root, 0, box, Builder::leaf_ref(0, n));
+        Builder::store_child(root, 1, box, Builder::leaf_ref(0, n));
+        b.nodes.push_back(root);
+        b.deepest = 1;
+    } else {
+        b.nodes.reserve(n);
+        b.build(0, n, 1);
+    }
+
+    result.nodes = std::move(b.nodes);
+    result.order = std::move(b.order);
+    result.max_depth = b.deepest + 1;   // stack entries needed is bounded by the node depth; keep one spare
+    return result;
+}
+
+} // namespace HIPRenderer

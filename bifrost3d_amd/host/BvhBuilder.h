@@ -1,0 +1,20 @@
+// host/BvhBuilder.h -- see BvhBuilder.cpp.
+#pragma once
+
+#include "../../include/hiprenderer_c.h"
+
+#include <cstdint>
+#include <vector>
+
+namespace HIPRenderer {
+
+struct BvhBuildResult {
+    std::vector<HiprBvhNode> nodes;   // node 0 is the root; empty for an empty scene
+    std::vector<uint32_t> order;      // order[k] = index of the input triangle stored at leaf slot k
+    uint32_t max_depth = 0;           // upper bound of the traversal stack entries the tree needs
+};
+
+// `max_depth`: the deepest leaf the builder may produce (root = 1). 62 fits the 64 entry LDS stack.
+BvhBuildResult build_bvh(const std::vector<HiprTriangle>& world_triangles, uint32_t max_depth = 62);
+
+} // namespace HIPRenderer

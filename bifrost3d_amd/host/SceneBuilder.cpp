@@ -1,0 +1,233 @@
+// host/SceneBuilder.cpp -- see SceneBuilder.h.
+#include "SceneBuilder.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace HIPRenderer {
+
+SceneBuilder::SceneBuilder() {
+    // Slot 0 holds the invalid material / "no texture", as in the reference where per-ID arrays are
+    // sized capacity() and index 0 is the invalid sentinel (OptiXRenderer/Renderer.cpp:821, :528-562).
+    HiprMaterial invalid = {};
+    m_materials.push_back(invalid);
+    HiprTexture none = {};
+    m_textures.push_back(none);
+    m_state.next_event_sample_count = 3;   // Renderer.cpp:479
+}
+
+uint16_t SceneBuilder::unorm16(float v) {
+    v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+    return (uint16_t)(v * 65535.0f + 0.5f);
+}
+
+HiprMaterial SceneBuilder::make_material(RGB tint, float roughness, float specularity, float metallic, uint16_t flags, uint16_t shading_model) {
+    HiprMaterial m = {};
+    m.flags = flags;
+    m.shading_model = shading_model;
+    m.tint[0] = tint.r; m.tint[1] = tint.g; m.tint[2] = tint.b;
+    m.roughness = roughness;
+    m.specularity = specularity;
+    m.metallic = metallic;
+    m.coverage = 1.0f;
+    return m;
+}
+
+HiprLight SceneBuilder::sphere_light(Vector3f position, RGB power, float radius) {
+    HiprLight l = {};
+    l.flags = HIPR_LIGHT_SPHERE;
+    l.data[0] = power.r; l.data[1] = power.g; l.data[2] = power.b;
+    l.data[3] = position.x; l.data[4] = position.y; l.data[5] = position.z;
+    l.data[6] = radius;
+    return l;
+}
+
+HiprLight SceneBuilder::spot_light(Vector3f position, Vector3f direction, RGB power, float radius, float cos_angle) {
+    HiprLight l = sphere_light(position, power, radius);
+    l.flags = HIPR_LIGHT_SPOT;
+    l.data[7] = direction.x; l.data[8] = direction.y; l.data[9] = direction.z;
+    l.data[10] = cos_angle;
+    return l;
+}
+
+HiprLight SceneBuilder::directional_light(Vector3f direction, RGB radiance) {
+    HiprLight l = {};
+    l.flags = HIPR_LIGHT_DIRECTIONAL;
+    l.data[0] = radiance.r; l.data[1] = radiance.g; l.data[2] = radiance.b;
+    l.data[3] = direction.x; l.data[4] = direction.y; l.data[5] = direction.z;
+    return l;
+}
+
+uint32_t SceneBuilder::add_mesh(MeshData mesh) {
+    // load_mesh, OptiXRenderer/Renderer.cpp:92-136
+    MeshRecord r;
+    r.index_offset = uint32_t(m_indices.size() / 3);
+    r.vertex_offset = uint32_t(m_geometry.size());
+    r.primitive_count = uint32_t(mesh.primitives.size());
+    r.vertex_count = uint32_t(mesh.positions.size());
+    r.flags = 0;
+    if (!mesh.normals.empty()) r.flags |= HIPR_MESH_NORMALS;
+    if (!mesh.texcoords.empty()) r.flags |= HIPR_MESH_TEXCOORDS;
+    if (!mesh.tints.empty()) r.flags |= HIPR_MESH_TINTS;
+    if (!mesh.emission.empty()) r.flags |= HIPR_MESH_EMISSIVE;
+
+    for (const Vector3ui& p : mesh.primitives) { m_indices.push_back(p.x); m_indices.push_back(p.y); m_indices.push_back(p.z); }
+    for (uint32_t i = 0; i < r.vertex_count; ++i) {
+        HiprVertexGeometry g = {};
+        g.position[0] = mesh.positions[i].x; g.position[1] = mesh.positions[i].y; g.position[2] = mesh.positions[i].z;
+        if (r.flags & HIPR_MESH_NORMALS) {
+            OctahedralNormal e = OctahedralNormal::encode_precise(mesh.normals[i]);
+            g.oct_normal[0] = e.encoding.x; g.oct_normal[1] = e.encoding.y;
+        }
+        m_geometry.push_back(g);
+        Vector2f tc = (r.flags & HIPR_MESH_TEXCOORDS) ? mesh.texcoords[i] : Vector2f{0, 0};
+        m_texcoords.push_back(tc.x); m_texcoords.push_back(tc.y);
+        m_tints.push_back((r.flags & HIPR_MESH_TINTS) ? mesh.tints[i] : 0xFFFFFFFFu);
+        Vector3f em = (r.flags & HIPR_MESH_EMISSIVE) ? mesh.emission[i] : Vector3f(0, 0, 0);
+        m_emissions.push_back(em.x); m_emissions.push_back(em.y); m_emissions.push_back(em.z);
+    }
+    m_any_texcoords |= (r.flags & HIPR_MESH_TEXCOORDS) != 0;
+    m_any_tints |= (r.flags & HIPR_MESH_TINTS) != 0;
+    m_any_emission |= (r.flags & HIPR_MESH_EMISSIVE) != 0;
+    m_meshes.push_back(r);
+    return uint32_t(m_meshes.size() - 1);
+}
+
+uint32_t SceneBuilder::add_material(const HiprMaterial& material) {
+    m_materials.push_back(material);
+    return uint32_t(m_materials.size() - 1);
+}
+
+uint32_t SceneBuilder::add_texture(const ImageData& image, bool repeat_u, bool repeat_v, bool linear_mag, bool linear_min) {
+    HiprTexture t = {};
+    t.width = image.width; t.height = image.height;
+    while (m_texels.size() % 16) m_texels.push_back(0);
+    t.texel_offset = uint32_t(m_texels.size());
+    t.format = image.format;
+    t.wrap_u = repeat_u; t.wrap_v = repeat_v;
+    t.filter = uint8_t((linear_mag ? 1 : 0) | (linear_min ? 2 : 0));
+    t.is_sRGB = image.is_sRGB;
+    m_texels.insert(m_texels.end(), image.pixels.begin(), image.pixels.end());
+    m_textures.push_back(t);
+    return uint32_t(m_textures.size() - 1);
+}
+
+uint32_t SceneBuilder::add_model(uint32_t mesh, uint32_t material, const Transform& transform) {
+    // create_model + transformable_model, OptiXRenderer/Renderer.cpp:138-182
+    const MeshRecord& r = m_meshes[mesh];
+    HiprInstance inst = {};
+    Matrix3x4f m = to_matrix3x4(transform);
+    std::memcpy(inst.object_to_world, m.begin(), sizeof(inst.object_to_world));
+    inst.index_offset = r.index_offset;
+    inst.vertex_offset = r.vertex_offset;
+    const uint32_t model_index = uint32_t(m_instances.size()) + 1;        // UID index, 0 is invalid
+    inst.instance_id = int32_t((1u << 30) | model_index);                 // InstanceID::make(MeshModel, index)
+    inst.material_index = int32_t(material);
+    inst.mesh_flags = r.flags;
+    m_instances.push_back(inst);
+    m_instance_mesh.push_back(mesh);
+    return model_index;
+}
+
+void SceneBuilder::add_light(const HiprLight& light) { m_lights.push_back(light); }
+
+void SceneBuilder::force_shading_model(uint16_t shading_model) {
+    for (size_t i = 1; i < m_materials.size(); ++i) m_materials[i].shading_model = shading_model;
+}
+
+static bool statically_opaque(const HiprMaterial& m) {
+    // get_coverage (OptiXRenderer/Types.h:405-414) with no coverage texture: cutout -> (1 < threshold ? 0 : 1), else coverage.
+    if (m.coverage_texture_ID) return false;
+    if (m.flags & HIPR_MATERIAL_CUTOUT) return !(1.0f < m.coverage);
+    return m.coverage >= 1.0f;
+}
+
+void SceneBuilder::finalize(uint32_t bvh_max_depth) {
+    std::vector<HiprTriangle> world;
+    m_bounds = AABB::invalid();
+    for (uint32_t i = 0; i < m_instances.size(); ++i) {
+        const HiprInstance& inst = m_instances[i];
+        const MeshRecord& mesh = m_meshes[m_instance_mesh[i]];
+        const float* M = inst.object_to_world;
+        const bool opaque = statically_opaque(m_materials[inst.material_index]);
+        auto to_world = [&](uint32_t v, float* out) {
+            const float* p = m_geometry[mesh.vertex_offset + v].position;
+            for (int r = 0; r < 3; ++r) out[r] = M[4 * r] * p[0] + M[4 * r + 1] * p[1] + M[4 * r + 2] * p[2] + M[4 * r + 3];
+            m_bounds.grow_to_contain(Vector3f(out[0], out[1], out[2]));
+        };
+        for (uint32_t p = 0; p < mesh.primitive_count; ++p) {
+            const uint32_t* idx = &m_indices[3 * size_t(mesh.index_offset + p)];
+            HiprTriangle t = {};
+            to_world(idx[0], t.v0); to_world(idx[1], t.v1); to_world(idx[2], t.v2);
+            t.instance_index = i;
+            t.primitive_index = p;
+            t.flags = opaque ? HIPR_TRIANGLE_OPAQUE : 0;
+            world.push_back(t);
+        }
+    }
+
+    m_bvh = build_bvh(world, bvh_max_depth);
+    m_triangles.resize(world.size());
+    for (size_t k = 0; k < world.size(); ++k) m_triangles[k] = world[m_bvh.order[k]];
+
+    HiprSceneDesc& d = m_desc;
+    d = {};
+    d.nodes = m_bvh.nodes.data(); d.node_count = uint32_t(m_bvh.nodes.size());
+    d.triangles = m_triangles.data(); d.triangle_count = uint32_t(m_triangles.size());
+    d.instances = m_instances.data(); d.instance_count = uint32_t(m_instances.size());
+    d.indices = m_indices.data(); d.index_count = uint32_t(m_indices.size());
+    d.geometry = m_geometry.data(); d.vertex_count = uint32_t(m_geometry.size());
+    d.texcoords = m_any_texcoords ? m_texcoords.data() : nullptr;
+    d.tints = m_any_tints ? m_tints.data() : nullptr;
+    d.emissions = m_any_emission ? m_emissions.data() : nullptr;
+    d.materials = m_materials.data(); d.material_count = uint32_t(m_materials.size());
+    d.lights = m_lights.data(); d.light_count = uint32_t(m_lights.size());
+    d.textures = m_textures.data(); d.texture_count = uint32_t(m_textures.size());
+    d.texels = m_texels.data(); d.texel_bytes = uint32_t(m_texels.size());
+    d.bvh_max_depth = m_bvh.max_depth;
+}
+
+HiprCameraState make_camera_state(const CameraDescription& camera, float aspect_ratio, uint32_t accumulations, float path_regularization_PDF_scale) {
+    Matrix4x4f inverse_projection = {};
+    if (camera.orthographic) {
+        // compute_orthographic_projection, Bifrost/Scene/Camera.cpp:268-286
+        inverse_projection[0][0] = 0.5f * camera.ortho_width;
+        inverse_projection[1][1] = 0.5f * camera.ortho_height;
+        inverse_projection[2][2] = 0.5f * camera.ortho_depth;
+        inverse_projection[2][3] = 0.5f * camera.ortho_depth;
+        inverse_projection[3][3] = 1.0f;
+    } else {
+        // compute_perspective_projection, Bifrost/Scene/Camera.cpp:237-266
+        const float n = camera.near_plane, fa = camera.far_plane;
+        const float f = 1.0f / std::tan(camera.field_of_view * 0.5f);
+        const float a = (fa + n) / (n - fa);
+        const float b = (2.0f * fa * n) / (n - fa);
+        Matrix4x4f projection = {};
+        projection[0][0] = f / aspect_ratio;
+        projection[1][1] = f;
+        projection[2][2] = -a;
+        projection[2][3] = b;
+        projection[3][2] = 1.0f;
+        inverse_projection[0][0] = 1.0f / projection[0][0];
+        inverse_projection[1][1] = 1.0f / projection[1][1];
+        inverse_projection[2][3] = 1.0f;
+        inverse_projection[3][2] = 1.0f / projection[2][3];
+        inverse_projection[3][3] = -projection[2][2] / projection[2][3];
+    }
+
+    // Cameras::get_inverse_view_projection_matrix = to_matrix4x4(inverse view transform) * inverse projection (Camera.h:112-114)
+    Matrix4x4f inverse_view_projection = to_matrix4x4(camera.transform) * inverse_projection;
+    Matrix3x3f rotation = to_matrix3x3(camera.transform.rotation);   // Renderer.cpp:1238-1239
+
+    HiprCameraState s = {};
+    std::memcpy(s.view_to_world_rotation, rotation.begin(), sizeof(s.view_to_world_rotation));
+    std::memcpy(s.inverse_projection_matrix, inverse_projection.begin(), sizeof(s.inverse_projection_matrix));
+    std::memcpy(s.inverse_view_projection_matrix, inverse_view_projection.begin(), sizeof(s.inverse_view_projection_matrix));
+    s.accumulations = accumulations;
+    s.max_bounce_count = camera.max_bounce_count;
+    s.path_regularization_PDF_scale = path_regularization_PDF_scale;
+    return s;
+}
+
+} // namespace HIPRenderer

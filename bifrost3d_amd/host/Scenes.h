@@ -1,0 +1,18 @@
+// host/Scenes.h -- see Scenes.cpp.
+#pragma once
+
+#include "SceneBuilder.h"
+
+namespace HIPRenderer {
+namespace Scenes {
+
+MeshData plane(unsigned quads_per_edge, bool normals, bool texcoords);
+MeshData box(unsigned quads_per_edge, Vector3f size, bool tints);
+
+void create_cornell_box(SceneBuilder& scene);
+void create_atrium(SceneBuilder& scene, unsigned target_triangles, unsigned seed);
+void create_quad_scene(SceneBuilder& scene, unsigned width, unsigned height);
+void create_empty_ortho_scene(SceneBuilder& scene, unsigned width, unsigned height, RGB environment_tint);
+
+} // namespace Scenes
+} // namespace HIPRenderer

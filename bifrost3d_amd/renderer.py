@@ -1,0 +1,124 @@
+"""Thin Python handle on a HiprContext (include/hiprenderer_c.h). Plumbing only; fails loudly without the HIP library."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+class Context:
+    def __init__(self, device_id: int = 0):
+        self.lib = capi.load_library()
+        self.handle = C.c_void_p()
+        capi.check(self.lib, self.lib.hipr_create(device_id, C.byref(self.handle)), "hipr_create")
+        self._tables = capi.load_tables()
+        t = capi.HiprTables(*[a.ctypes.data_as(C.POINTER(C.c_float)) for a in self._tables])
+        capi.check(self.lib, self.lib.hipr_upload_tables(self.handle, C.byref(t)), "hipr_upload_tables")
+        self.frame = None
+
+    def close(self):
+        if self.handle:
+            self.lib.hipr_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, status, what):
+        capi.check(self.lib, status, what)
+
+    def set_stream(self, stream_ptr: int | None):
+        self._check(self.lib.hipr_set_stream(self.handle, C.c_void_p(stream_ptr or 0)), "hipr_set_stream")
+
+    def upload_scene(self, scene):
+        self._scene = scene   # keep the host arrays alive until uploaded (copy happens inside)
+        self._check(self.lib.hipr_upload_scene(self.handle, C.byref(scene.desc)), "hipr_upload_scene")
+        state = scene.state
+        self._check(self.lib.hipr_set_scene_state(self.handle, C.byref(state)), "hipr_set_scene_state")
+
+    def set_scene_state(self, state: capi.HiprSceneState):
+        self._check(self.lib.hipr_set_scene_state(self.handle, C.byref(state)), "hipr_set_scene_state")
+
+    def set_frame(self, width, height, tile_phase=0, tile_stride=1, samples_per_pass=1):
+        f = capi.HiprFrameDesc(width, height, tile_phase, tile_stride, samples_per_pass)
+        self._check(self.lib.hipr_set_frame(self.handle, C.byref(f)), "hipr_set_frame")
+        self.frame = f
+
+    def owned_pixel_count(self) -> int:
+        n = C.c_uint32()
+        self._check(self.lib.hipr_owned_pixel_count(self.handle, C.byref(n)), "hipr_owned_pixel_count")
+        return n.value
+
+    def render_pass(self, camera: capi.HiprCameraState, out_ptr: int = 0, out_pitch: int = 0, synchronize: bool = False):
+        self._check(self.lib.hipr_render_pass(self.handle, C.byref(camera), C.c_void_p(out_ptr), out_pitch, int(synchronize)), "hipr_render_pass")
+
+    def synchronize(self):
+        self._check(self.lib.hipr_synchronize(self.handle), "hipr_synchronize")
+
+    def read_accumulation(self) -> np.ndarray:
+        f = self.frame
+        if f.tile_stride == 1:
+            out = np.zeros((f.height, f.width, 4), np.float64)
+        else:
+            out = np.zeros((self.owned_pixel_count(), 4), np.float64)
+        self._check(self.lib.hipr_read_accumulation(self.handle, out.ctypes.data_as(C.POINTER(C.c_double)), out.size // 4), "hipr_read_accumulation")
+        return out
+
+    def counters(self) -> dict:
+        c = capi.HiprCounters()
+        self._check(self.lib.hipr_get_counters(self.handle, C.byref(c)), "hipr_get_counters")
+        return {name: int(getattr(c, name)) for name, _ in capi.HiprCounters._fields_}
+
+    def reset_counters(self):
+        self._check(self.lib.hipr_reset_counters(self.handle), "hipr_reset_counters")
+
+    def set_instrumentation(self, on: bool):
+        self._check(self.lib.hipr_set_instrumentation(self.handle, int(on)), "hipr_set_instrumentation")
+
+    def reset_timers(self):
+        self._check(self.lib.hipr_reset_timers(self.handle), "hipr_reset_timers")
+
+    def kernel_times(self) -> dict:
+        t = capi.HiprKernelTimes()
+        self._check(self.lib.hipr_get_kernel_times(self.handle, C.byref(t)), "hipr_get_kernel_times")
+        return {name: dict(ms=t.milliseconds[i], launches=int(t.launches[i])) for i, name in enumerate(capi.HIPR_KERNEL_NAMES)}
+
+    def scatter_tiles(self, compact_ptr, rank_stride, rank_count, width, height, out_ptr, out_pitch):
+        self._check(self.lib.hipr_scatter_tiles(self.handle, C.c_void_p(compact_ptr), rank_stride, rank_count, width, height, C.c_void_p(out_ptr), out_pitch),
+                    "hipr_scatter_tiles")
+
+    # ---- stage-level parity entry points -------------------------------------------------------
+    def debug_generate(self, camera, accumulation):
+        n = self.owned_pixel_count()
+        o = np.zeros((n, 4), np.float32); d = np.zeros((n, 4), np.float32); px = np.zeros(n, np.uint32)
+        fp, up = C.POINTER(C.c_float), C.POINTER(C.c_uint32)
+        self._check(self.lib.hipr_debug_generate(self.handle, C.byref(camera), accumulation, o.ctypes.data_as(fp), d.ctypes.data_as(fp), px.ctypes.data_as(up)),
+                    "hipr_debug_generate")
+        return o, d, px
+
+    def debug_sobol(self, triples):
+        triples = np.ascontiguousarray(triples, np.uint32).reshape(-1, 3)
+        out = np.zeros((len(triples), 4), np.uint32)
+        up = C.POINTER(C.c_uint32)
+        self._check(self.lib.hipr_debug_sobol(self.handle, triples.ctypes.data_as(up), len(triples), out.ctypes.data_as(up)), "hipr_debug_sobol")
+        return out
+
+    def debug_trace_closest(self, rays, skip=None):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        hits = np.zeros((len(rays), 4), np.float32)
+        fp, up = C.POINTER(C.c_float), C.POINTER(C.c_uint32)
+        sk = np.ascontiguousarray(skip, np.uint32).ctypes.data_as(up) if skip is not None else None
+        self._check(self.lib.hipr_debug_trace_closest(self.handle, rays.ctypes.data_as(fp), sk, len(rays), hits.ctypes.data_as(fp)), "hipr_debug_trace_closest")
+        return hits
+
+    def debug_trace_shadow(self, rays):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        out = np.zeros(len(rays), np.float32)
+        fp = C.POINTER(C.c_float)
+        self._check(self.lib.hipr_debug_trace_shadow(self.handle, rays.ctypes.data_as(fp), len(rays), out.ctypes.data_as(fp)), "hipr_debug_trace_shadow")
+        return out

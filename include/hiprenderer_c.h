@@ -195,7 +195,7 @@ typedef struct HiprFrameDesc {
     uint32_t samples_per_pass;   /* accumulations traced per hipr_render_pass, >= 1 */
 } HiprFrameDesc;
 
-/* Ray / traversal counters of the last pass. */
+/* Ray / traversal counters accumulated since hipr_reset_counters(). */
 typedef struct HiprCounters {
     uint64_t camera_rays;        /* P: pixel-samples generated */
     uint64_t closest_rays;       /* R_mc: closest-hit traces incl. retraces */
@@ -267,6 +267,7 @@ int hipr_scatter_tiles(HiprContext* context, const void* compact_half4_device, u
 
 int hipr_synchronize(HiprContext* context);
 int hipr_get_counters(HiprContext* context, HiprCounters* out);
+int hipr_reset_counters(HiprContext* context);
 /* Enables per-ray node / triangle visit counting in the trace kernels (slower, off by default). */
 int hipr_set_instrumentation(HiprContext* context, int count_traversal_steps);
 int hipr_reset_timers(HiprContext* context);

@@ -1,0 +1,200 @@
+"""CPU tests of the host side: C-ABI surface, scene flattening, BVH builder, camera, tiling. No GPU."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from bifrost3d_amd import capi, distributed
+from bifrost3d_amd.host import Scene, load_host_library
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    header = (ROOT / "include" / "hiprenderer_c.h").read_text()
+    declared = set(re.findall(r"\b(hipr_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(capi.C_ABI_SYMBOLS), declared ^ set(capi.C_ABI_SYMBOLS)
+    lib = capi.load_library()
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_create_without_a_device_fails_loudly():
+    lib = capi.load_library()
+    if lib.hipr_device_count() > 0:
+        pytest.skip("a GPU is present")
+    handle = C.c_void_p()
+    assert lib.hipr_create(0, C.byref(handle)) == -2   # HIPR_ERROR_NO_DEVICE, initialize() -> nullptr in the reference
+    assert not handle.value
+    assert b"no HIP device" in lib.hipr_last_error()
+
+
+def test_struct_layouts_match_the_reference_device_structs():
+    assert C.sizeof(capi.HiprMaterial) == 64    # OR/Types.h:353-383
+    assert C.sizeof(capi.HiprLight) == 48       # OR/Types.h:290-312
+    assert C.sizeof(capi.HiprVertexGeometry) == 16
+    assert capi.HiprMaterial.coat.offset == 60 and capi.HiprMaterial.emission.offset == 48
+
+
+def test_cornell_box_flattening():
+    s = Scene("cornell")
+    d = s.desc
+    assert (d.triangle_count, d.instance_count, d.light_count) == (34, 7, 1)
+    assert d.material_count == 6 and d.vertex_count == 4 + 24 + 24
+    tris = s.triangles()
+    v = tris[:, :9].view(np.float32).reshape(-1, 3)
+    assert v.min() >= -0.5 - 1e-6 and v.max() <= 0.5 + 1e-6
+    inst = tris[:, 9]
+    assert sorted(np.bincount(inst).tolist()) == [2, 2, 2, 2, 2, 12, 12]
+    light = d.lights[0]
+    assert light.flags == 1 and list(light.data)[:7] == pytest.approx([2, 2, 2, 0, 0.45, 0, 0.05])
+    mats = [d.materials[i] for i in range(d.material_count)]
+    assert mats[1].flags == 1 and mats[1].roughness == 1.0 and mats[1].specularity == pytest.approx(0.02)
+    assert mats[4].metallic == 1.0 and mats[4].roughness == pytest.approx(0.4)
+    assert s.state.next_event_sample_count == 3
+    # floor triangles face up, roof faces down (winding of MeshCreation::plane + the reference's transforms)
+    for k in range(d.triangle_count):
+        if inst[k] == 0:
+            p = v[3 * k: 3 * k + 3]
+            assert np.cross(p[1] - p[0], p[2] - p[0])[1] > 0
+
+
+def check_bvh(nodes_u32, tris_u32, max_depth):
+    nodes_f = nodes_u32.view(np.float32)
+    children = nodes_u32[:, 12:14].view(np.int32)
+    seen = np.zeros(len(tris_u32), np.int32)
+    verts = tris_u32[:, :9].view(np.float32).reshape(-1, 3, 3)
+
+    def box_of(node, c):
+        xy = nodes_f[node, 4 * c: 4 * c + 4]
+        z = nodes_f[node, 8 + 2 * c: 10 + 2 * c]
+        return np.array([xy[0], xy[2], z[0]]), np.array([xy[1], xy[3], z[1]])
+
+    deepest = 0
+    stack = [(0, 1)]
+    visited = set()
+    while stack:
+        node, depth = stack.pop()
+        assert node not in visited
+        visited.add(node)
+        for c in range(2):
+            lo, hi = box_of(node, c)
+            ref = int(children[node, c])
+            if ref < 0:
+                leaf = ~ref
+                first, count = leaf >> 3, (leaf & 7) + 1
+                assert 1 <= count <= 4
+                seen[first:first + count] += 1
+                p = verts[first:first + count].reshape(-1, 3)
+                assert (p >= lo - 1e-6).all() and (p <= hi + 1e-6).all()
+                deepest = max(deepest, depth + 1)
+            else:
+                clo = np.minimum(*[box_of(ref, k)[0] for k in range(2)])
+                chi = np.maximum(*[box_of(ref, k)[1] for k in range(2)])
+                assert (clo >= lo - 1e-6).all() and (chi <= hi + 1e-6).all()
+                stack.append((ref, depth + 1))
+    assert len(visited) == len(nodes_u32)
+    return seen, deepest
+
+
+def test_bvh_structure_cornell_and_atrium():
+    for scene in (Scene("cornell"), Scene("atrium", param0=20000, param1=3)):
+        d = scene.desc
+        seen, deepest = check_bvh(scene.nodes(), scene.triangles(), d.bvh_max_depth)
+        if d.triangle_count > 4:
+            assert (seen == 1).all()
+        assert deepest <= d.bvh_max_depth <= 64
+
+
+def test_bvh_depth_cap_holds_for_adversarial_input():
+    # exponentially spaced slivers drive SAH towards a degenerate chain; the builder must cap the depth
+    n = 3000
+    tris = (capi.HiprTriangle * n)()
+    for i in range(n):
+        x = 1.0001 ** i
+        tris[i].v0[:] = [x, 0.0, 0.0]
+        tris[i].v1[:] = [x, 1e-3, 0.0]
+        tris[i].v2[:] = [x + 1e-7, 0.0, 1e-3]
+        tris[i].primitive_index = i
+    lib = load_host_library()
+    for cap in (14, 30):
+        h = lib.hiprh_bvh_build(tris, n, cap)
+        assert lib.hiprh_bvh_max_depth(h) <= cap + 1
+        order = np.ctypeslib.as_array(lib.hiprh_bvh_order(h), shape=(n,))
+        assert sorted(order.tolist()) == list(range(n))
+        lib.hiprh_bvh_destroy(h)
+
+
+def test_bvh_traversal_equals_exhaustive_search(oracle):
+    scene = Scene("atrium", param0=6000, param1=5)
+    rng = np.random.default_rng(3)
+    n = 3000
+    rays = np.zeros((n, 8), np.float32)
+    rays[:, 0:3] = rng.uniform(-12, 12, (n, 3))
+    rays[:, 1] = np.abs(rays[:, 1]) * 0.6
+    d = rng.normal(size=(n, 3))
+    rays[:, 4:7] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    rays[:, 7] = np.inf
+    bvh, (nodes, tris) = oracle.trace_closest(scene.desc, rays, use_bvh=True)
+    brute, _ = oracle.trace_closest(scene.desc, rays, use_bvh=False)
+    assert np.array_equal(bvh.view(np.uint32), brute.view(np.uint32))
+    assert tris < 0.05 * n * scene.desc.triangle_count   # the tree actually culls
+    shadow_rays = rays.copy()
+    shadow_rays[:, 7] = rng.uniform(0.5, 20, n)
+    a, _ = oracle.trace_shadow(scene.desc, shadow_rays, use_bvh=True)
+    b, _ = oracle.trace_shadow(scene.desc, shadow_rays, use_bvh=False)
+    assert np.array_equal(a, b)
+
+
+def test_octahedral_encode_precise_roundtrip(oracle):
+    """OctahedralNormal.equality_with_bifrost_implementation, ORT/MiscTest.h:32-52: host encoder + device decoder."""
+    lib = load_host_library()
+    normals = np.array([[x, y, z] for x in range(-10, 11) for y in range(-10, 11) for z in range(-10, 11) if (x, y, z) != (0, 0, 0)], np.float32)
+    normals /= np.linalg.norm(normals, axis=1, keepdims=True)
+    normals = np.ascontiguousarray(normals, np.float32)
+    enc = np.zeros((len(normals), 2), np.int16)
+    lib.hiprh_encode_octahedral(normals.ctypes.data_as(C.POINTER(C.c_float)), len(normals), enc.ctypes.data_as(C.POINTER(C.c_short)))
+    dec = np.zeros((len(normals), 3), np.float32)
+    oracle.lib.oracle_decode_octahedral(enc.ctypes.data_as(C.POINTER(C.c_int16)), len(normals), dec.ctypes.data_as(C.POINTER(C.c_float)))
+    assert np.abs(dec - normals).max() < 6e-5
+
+
+def test_camera_state_of_the_cornell_scene(oracle):
+    s = Scene("cornell")
+    w, h = 64, 36
+    cam = s.camera(w, h, max_bounce_count=4)
+    assert cam.max_bounce_count == 4 and cam.path_regularization_PDF_scale == 0.5
+    assert s.camera(w, h).max_bounce_count == 32   # SimpleViewer built-in scenes, main.cpp:353
+    o, d = oracle.generate_rays(cam, w, h, 0, np.array([[w // 2, h // 2], [0, 0]], np.uint32))
+    assert abs(d[0, 2] - 1.0) < 1e-3 and abs(o[0, 2] + 1.5) < 1e-2          # looks down +Z from (0, 0, -1.5)
+    assert d[1, 0] < 0 and d[1, 1] < 0                                      # pixel (0, 0) is bottom-left
+    tan_half = np.tan(np.pi / 8)
+    assert abs(d[1, 1] / d[1, 2] + tan_half * (1 - 1 / h)) < 1e-3           # vertical fov pi/4
+
+
+def test_oracle_image_is_tiling_invariant_and_deterministic(oracle):
+    s = Scene("cornell", diffuse_only=True)
+    w, h = 24, 16
+    cam = s.camera(w, h, max_bounce_count=3)
+    a, counters, _ = oracle.render(s.desc, s.state, cam, w, h, 2)
+    oracle.lib.oracle_set_threads(1)
+    b, _, _ = oracle.render(s.desc, s.state, cam, w, h, 2)
+    oracle.lib.oracle_set_threads(oracle.lib.oracle_max_threads())
+    assert np.array_equal(a, b)
+    assert counters["camera_rays"] == w * h * 2 and counters["closest_rays"] >= counters["camera_rays"]
+    assert a[..., :3].min() >= 0 and np.isfinite(a).all()
+
+
+def test_tile_partition_covers_every_pixel_once():
+    for (w, h) in ((1920, 1080), (37, 23), (8, 8)):
+        for world in (1, 2, 3, 8):
+            seen = np.zeros((h, w), np.int32)
+            for rank in range(world):
+                coords = distributed.compact_pixel_coords(w, h, rank, world)
+                assert len(coords) == distributed.owned_tile_count(w, h, rank, world) * 64
+                assert len(coords) <= distributed.padded_pixels_per_rank(w, h, world)
+                valid = coords[:, 0] >= 0
+                np.add.at(seen, (coords[valid, 1], coords[valid, 0]), 1)
+            assert (seen == 1).all()
