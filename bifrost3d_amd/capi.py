@@ -134,6 +134,13 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     p = Path(path) if path else LIB_PATH
     if not p.exists():
         raise HiprError(f"{p} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()')")
+    try:
+        # PyTorch-ROCm bundles its own libamdhip64; a process that loads the system runtime first and torch second
+        # ends up with two HIP runtimes and torch then reports "No HIP GPUs are available". Loading torch first makes
+        # this library bind to the runtime torch uses (device memory, streams and RCCL come from torch).
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(str(p))
     vp = C.c_void_p
     lib.hipr_last_error.restype = C.c_char_p

@@ -137,7 +137,7 @@ HD bool slab(f3 inv, f3 ood, float lox, float hix, float loy, float hiy, float l
     float z0 = fmaf(loz, inv.z, -ood.z), z1 = fmaf(hiz, inv.z, -ood.z);
     tnear = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
     float tfar = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-    tfar = fminf(tfar * 1.0000004f, tmax);
+    tfar = fminf(tfar, tmax) * 1.0000004f;   // ~3 ulp slack: boxes and hits that tie within rounding are still visited
     return tnear <= tfar;
 }
 

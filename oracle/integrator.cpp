@@ -99,7 +99,7 @@ static inline bool slab(const SlabRay& r, float lox, float hix, float loy, float
     float z0 = fmaf(loz, r.inv_d.z, -r.ood.z), z1 = fmaf(hiz, r.inv_d.z, -r.ood.z);
     tnear = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
     float tfar = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-    tfar = fminf(tfar * 1.0000004f, tmax);
+    tfar = fminf(tfar, tmax) * 1.0000004f;   // ~3 ulp slack: boxes and hits that tie within rounding are still visited
     return tnear <= tfar;
 }
 
