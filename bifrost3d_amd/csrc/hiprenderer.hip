@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -82,7 +83,13 @@ struct HiprContext {
     FrameInfo frame = {};
     bool frame_ready = false;
     uint32_t n_slots = 0;   // owned_tiles * 64 * samples_per_pass
-    DeviceBuffer path[2][4], hits, shadow[3], radiance, accumulation, queue_counts, counters;
+    DeviceBuffer path[2][4], hits, shadow[3], radiance, accumulation, queue_counts, counters, work_counters;
+    uint32_t work_index = 0;            // next unused persistent-kernel work counter (zeroed 256 at a time)
+    int trace_variant = -1;             // 1: persistent kernels, 0: one ray per lane, -1: pick by BVH size (HIPR_TRACE_VARIANT)
+    bool use_persistent() const { return trace_variant < 0 ? scene.node_count > 64 : trace_variant == 1; }
+    int cu_count = 256;
+    int refill_below = 40;              // persistent kernels refill a wave once fewer lanes than this are busy (HIPR_REFILL_BELOW)
+    int persistent_blocks_per_cu[2][3] = {{0, 0, 0}, {0, 0, 0}};   // [shadow][stack bucket]
     uint32_t* host_counts = nullptr;   // pinned: next, shadow
 
     // bookkeeping
@@ -142,11 +149,54 @@ uint32_t grid_for(uint32_t items, uint32_t block, uint32_t max_blocks) {
     return (blocks + 7u) & ~7u;   // multiple of 8: xcd_chunk() needs every XCD to own the same number of chunks
 }
 
+constexpr uint32_t WORK_SETS = 64;                                        // launches served before the ring is re-zeroed
+constexpr uint32_t WORK_SET_WORDS = TRACE_SHARDS * TRACE_SHARD_STRIDE;   // one claim counter per shard, 64 B apart
+constexpr uint32_t WORK_COUNTERS = WORK_SETS * WORK_SET_WORDS;
+
+// Hands out a zeroed work counter for one persistent launch; re-zeroes the ring when it wraps (stream ordered).
+uint32_t* next_work_counter(HiprContext* c) {
+    if (c->work_index >= WORK_SETS) {
+        (void)hipMemsetAsync(c->work_counters.ptr, 0, WORK_COUNTERS * sizeof(uint32_t), c->stream);
+        c->work_index = 0;
+    }
+    return c->work_counters.as<uint32_t>() + size_t(c->work_index++) * WORK_SET_WORDS;
+}
+
+template <int STACK, bool SHADOW, bool INSTRUMENT>
+void launch_persistent(HiprContext* c, const PathState& in, float4* hits, const uint32_t* count_ptr, uint32_t upper_bound, int bucket) {
+    int& per_cu = c->persistent_blocks_per_cu[SHADOW ? 1 : 0][bucket];
+    if (per_cu == 0) {
+        int blocks = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_trace_persistent<STACK, SHADOW, INSTRUMENT>, TRACE_BLOCK, 0) != hipSuccess || blocks <= 0) blocks = 4;
+        per_cu = blocks;
+    }
+    const uint32_t waves_per_block = TRACE_BLOCK / 64;
+    uint32_t grid = uint32_t(c->cu_count) * uint32_t(per_cu);
+    grid = std::max(1u, std::min(grid, (upper_bound + 63u) / 64u / waves_per_block + 1u));
+    // every wave should get several chunks so the tail balances; small launches fall back to one wave-load per claim
+    uint32_t chunk = upper_bound / (grid * waves_per_block * 2u);
+    chunk = std::min(TRACE_CHUNK_MAX, std::max(64u, chunk & ~63u));
+    hipLaunchKernelGGL((k_trace_persistent<STACK, SHADOW, INSTRUMENT>), dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->scene, in, hits, c->shadow_queue(),
+                       c->radiance.as<float4>(), count_ptr, next_work_counter(c), chunk, c->refill_below, c->counters.as<DeviceCounters>());
+}
+
+template <bool SHADOW, bool INSTRUMENT>
+void launch_persistent_for_stack(HiprContext* c, const PathState& in, float4* hits, const uint32_t* count_ptr, uint32_t upper_bound) {
+    switch (c->stack_size) {
+    case 16: launch_persistent<16, SHADOW, INSTRUMENT>(c, in, hits, count_ptr, upper_bound, 0); break;
+    case 32: launch_persistent<32, SHADOW, INSTRUMENT>(c, in, hits, count_ptr, upper_bound, 1); break;
+    default: launch_persistent<64, SHADOW, INSTRUMENT>(c, in, hits, count_ptr, upper_bound, 2); break;
+    }
+}
+
 template <bool INSTRUMENT>
 void launch_trace_closest(HiprContext* c, const PathState& in, const uint32_t* count_ptr, uint32_t upper_bound) {
+    float4* hits = c->hits.as<float4>();
+    // Scenes whose whole BVH sits in the L1 / scalar cache (a few dozen nodes) are VALU-issue bound and run fastest with
+    // the plain one-ray-per-lane kernel; everything larger wants the persistent kernel (measured: profiles/).
+    if (c->use_persistent()) { launch_persistent_for_stack<false, INSTRUMENT>(c, in, hits, count_ptr, upper_bound); return; }
     const uint32_t grid = grid_for(upper_bound, TRACE_BLOCK, 256u * 16u);
     DeviceCounters* dc = c->counters.as<DeviceCounters>();
-    float4* hits = c->hits.as<float4>();
     switch (c->stack_size) {
     case 16: hipLaunchKernelGGL((k_trace_closest<16, INSTRUMENT>), dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->scene, in, hits, count_ptr, dc); break;
     case 32: hipLaunchKernelGGL((k_trace_closest<32, INSTRUMENT>), dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->scene, in, hits, count_ptr, dc); break;
@@ -156,6 +206,7 @@ void launch_trace_closest(HiprContext* c, const PathState& in, const uint32_t* c
 
 template <bool INSTRUMENT>
 void launch_trace_shadow(HiprContext* c, const uint32_t* count_ptr, uint32_t upper_bound) {
+    if (c->use_persistent()) { launch_persistent_for_stack<true, INSTRUMENT>(c, PathState{}, nullptr, count_ptr, upper_bound); return; }
     const uint32_t grid = grid_for(upper_bound, TRACE_BLOCK, 256u * 16u);
     DeviceCounters* dc = c->counters.as<DeviceCounters>();
     float4* rad = c->radiance.as<float4>();
@@ -214,7 +265,15 @@ int hipr_create(int device_id, HiprContext** out_context) {
         return fail(HIPR_ERROR_HIP, "stream / event / pinned allocation failed");
     }
     c->stream = c->own_stream;
-    if (c->queue_counts.resize(4 * sizeof(uint32_t)) || c->counters.resize(sizeof(DeviceCounters))) { delete c; return HIPR_ERROR_OUT_OF_MEMORY; }
+    if (c->queue_counts.resize(4 * sizeof(uint32_t)) || c->counters.resize(sizeof(DeviceCounters)) || c->work_counters.resize(WORK_COUNTERS * sizeof(uint32_t))) {
+        delete c;
+        return HIPR_ERROR_OUT_OF_MEMORY;
+    }
+    c->work_index = WORK_SETS;   // forces the first launch to zero the ring
+    hipDeviceProp_t props;
+    if (hipGetDeviceProperties(&props, device_id) == hipSuccess && props.multiProcessorCount > 0) c->cu_count = props.multiProcessorCount;
+    if (const char* v = getenv("HIPR_TRACE_VARIANT")) c->trace_variant = atoi(v);
+    if (const char* v = getenv("HIPR_REFILL_BELOW")) c->refill_below = atoi(v);
     HIP_TRY(hipMemsetAsync(c->counters.ptr, 0, sizeof(DeviceCounters), c->stream));
 
     float offsets[256 * 4];
@@ -235,7 +294,7 @@ int hipr_destroy(HiprContext* c) {
     (void)hipDeviceSynchronize();
     DeviceBuffer* all[] = {&c->nodes, &c->triangles, &c->instances, &c->indices, &c->geometry, &c->texcoords, &c->tints, &c->emissions, &c->materials,
                            &c->lights, &c->textures, &c->texels, &c->ggx_rho, &c->dielectric_rho, &c->alpha, &c->sample_offsets, &c->hits, &c->radiance,
-                           &c->accumulation, &c->queue_counts, &c->counters, &c->debug_a, &c->debug_b, &c->debug_c, &c->shadow[0], &c->shadow[1], &c->shadow[2]};
+                           &c->accumulation, &c->queue_counts, &c->counters, &c->work_counters, &c->debug_a, &c->debug_b, &c->debug_c, &c->shadow[0], &c->shadow[1], &c->shadow[2]};
     for (DeviceBuffer* b : all) b->release();
     for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) c->path[i][j].release();
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);

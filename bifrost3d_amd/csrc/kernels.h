@@ -387,6 +387,204 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_shadow(DeviceScene sc, Sh
 }
 
 // ---------------------------------------------------------------------------------------------
+// K2 / K4, persistent form. Same per-ray visiting order as traverse() above (so results and the
+// node / triangle counters are identical), restructured for wave64 efficiency:
+//   * persistent waves: a wave claims TRACE_CHUNK consecutive rays with one global atomic and
+//     refills finished lanes from its private range, so a wave is never held hostage by its longest
+//     ray (rays visit between a handful and a few hundred nodes);
+//   * one work item per loop iteration and lane -- either one BVH node or ONE triangle. Leaves are
+//     stack items like inner nodes, so a lane that reached a leaf does not make the other 63 lanes
+//     wait for up to four sequential triangle tests.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t TRACE_CHUNK_MAX = 512; // rays a wave claims per global atomic (the launch passes min(this, fair share))
+// The ray range of a launch is cut into TRACE_SHARDS contiguous shards, each with its own claim counter on its
+// own 64 B line: 64 x the atomic throughput of a single word (one word saturates near 88 atomics/us), and blocks
+// that start on the same shard work on neighbouring rays. A wave that drains its shard steals from the next.
+constexpr uint32_t TRACE_SHARDS = 64;
+constexpr uint32_t TRACE_SHARD_STRIDE = 16;   // uint32 words between shard counters
+
+template <int STACK, bool SHADOW, bool INSTRUMENT>
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_persistent(DeviceScene sc, PathState in, float4* hits, ShadowQueue q, float4* radiance,
+                                                                  const uint32_t* count_ptr, uint32_t* work_counter, uint32_t chunk_size,
+                                                                  int refill_below, DeviceCounters* counters) {
+    __shared__ int s_stack[STACK * TRACE_BLOCK];
+    int* stack = s_stack + threadIdx.x;
+    const uint32_t n = *count_ptr;
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+
+    uint32_t chunk_next = 0, chunk_end = 0;   // wave uniform
+    uint32_t shard = blockIdx.x % TRACE_SHARDS, shards_drained = 0;
+    bool exhausted = false;
+
+    bool active = false, finished = false;    // finished: traversal done, result still in registers
+    uint32_t ray_index = 0;
+    f3 o = {0, 0, 0}, d = {0, 0, 1}, inv = {0, 0, 0}, ood = {0, 0, 0};
+    float tmin = 0.0f, tmax = 0.0f;                       // tmax: best distance so far (closest) or the ray extent (shadow)
+    float best_u = 0.0f, best_v = 0.0f;
+    uint32_t best_id = HIPR_HIT_MISS, skip = HIPR_NO_TRIANGLE;
+    f3 rad = {0, 0, 0};
+    uint32_t slot = 0;
+    int cur = 0, sp = 0;
+    uint32_t tri_cur = 0, tri_end = 0;
+    uint32_t nodes = 0, tris = 0;
+
+    auto set_item = [&](int item) {
+        if (item >= 0) { cur = item; tri_cur = tri_end = 0; }
+        else { const uint32_t leaf = uint32_t(~item); tri_cur = leaf >> 3; tri_end = tri_cur + (leaf & 7u) + 1u; }
+    };
+    auto pop_next = [&]() {
+        if (sp == 0) { active = false; finished = true; return; }
+        --sp;
+        set_item(stack[sp * TRACE_BLOCK]);
+    };
+
+    for (;;) {
+        // ---- retire finished lanes (converged: every lane of the wave is here) --------------------------------------
+        if (finished) {
+            if constexpr (SHADOW) {
+                float4 acc = radiance[slot];
+                acc.x += rad.x; acc.y += rad.y; acc.z += rad.z;
+                radiance[slot] = acc;
+            } else {
+                for (uint32_t li = 0; li < sc.light_count; ++li) {   // analytic area lights, LightSources.cu:31-70
+                    const HiprLight& l = sc.lights[li];
+                    const uint32_t type = l.flags & HIPR_LIGHT_TYPE_MASK;
+                    float t = -1e30f;
+                    if (type == HIPR_LIGHT_SPHERE) { if (!(l.data[6] > 0.0f)) continue; t = ray_sphere(o, d, L3(l, 3), l.data[6]); }
+                    else if (type == HIPR_LIGHT_SPOT) { if (!(l.data[6] > 0.0f)) continue; t = ray_disk(o, d, L3(l, 3), L3(l, 7), l.data[6]); }
+                    else continue;
+                    if (t > tmin && t < tmax) { tmax = t; best_u = 0; best_v = 0; best_id = HIPR_HIT_LIGHT | li; }
+                }
+                hits[ray_index] = make_float4(tmax, best_u, best_v, __uint_as_float(best_id));
+            }
+            finished = false;
+        }
+        // ---- refill idle lanes from the wave's private range -------------------------------------------------------
+        const unsigned long long idle = __ballot(!active);
+        if (idle && !exhausted) {
+            while (chunk_next >= chunk_end && !exhausted) {
+                const uint32_t shard_begin = uint32_t((unsigned long long)n * shard / TRACE_SHARDS);
+                const uint32_t shard_end = uint32_t((unsigned long long)n * (shard + 1u) / TRACE_SHARDS);
+                uint32_t base = 0;
+                if (lane == 0) {
+                    uint32_t* counter = work_counter + shard * TRACE_SHARD_STRIDE;
+                    // probe with a plain L2 load first: at the end of a launch every wave walks the drained shards
+                    base = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (base < shard_end - shard_begin) base = atomicAdd(counter, chunk_size);
+                }
+                base = __shfl(base, 0);
+                if (base < shard_end - shard_begin) { chunk_next = shard_begin + base; chunk_end = min(chunk_next + chunk_size, shard_end); }
+                else {
+                    shard = (shard + 1u) % TRACE_SHARDS;
+                    if (++shards_drained >= TRACE_SHARDS) exhausted = true;
+                }
+            }
+            if (chunk_next < chunk_end) {
+                const uint32_t idx = chunk_next + __popcll(idle & lt);
+                if (!active && idx < chunk_end) {
+                    ray_index = idx;
+                    bool dead = false;
+                    float4 ro, rdv;
+                    if constexpr (SHADOW) {
+                        ro = q.o_tmax[idx]; rdv = q.d_slot[idx];
+                        const float4 rr = q.radiance[idx];
+                        rad = mk3(rr.x, rr.y, rr.z);
+                        slot = __float_as_uint(rdv.w);
+                        tmin = 0.0f; tmax = ro.w;
+                    } else {
+                        const uint4 meta = in.meta[idx];
+                        dead = meta.x == HIPR_DEAD_SLOT;
+                        skip = meta.y;
+                        ro = in.o_tmin[idx]; rdv = in.d_pdf[idx];
+                        tmin = ro.w; tmax = __builtin_inff();
+                        best_u = best_v = 0.0f; best_id = HIPR_HIT_MISS;
+                    }
+                    if (dead) hits[idx] = make_float4(0, 0, 0, __uint_as_float(HIPR_HIT_MISS));
+                    else {
+                        o = mk3(ro.x, ro.y, ro.z); d = mk3(rdv.x, rdv.y, rdv.z);
+                        const f3 sd = {fabsf(d.x) > 1e-20f ? d.x : copysignf(1e-20f, d.x), fabsf(d.y) > 1e-20f ? d.y : copysignf(1e-20f, d.y),
+                                       fabsf(d.z) > 1e-20f ? d.z : copysignf(1e-20f, d.z)};
+                        inv = {1.0f / sd.x, 1.0f / sd.y, 1.0f / sd.z};
+                        ood = o * inv;
+                        sp = 0; cur = 0; tri_cur = tri_end = 0;
+                        if (sc.node_count == 0) finished = true;
+                        else active = true;
+                    }
+                }
+                chunk_next = min(chunk_next + uint32_t(__popcll(idle)), chunk_end);
+            }
+        }
+        unsigned long long busy = __ballot(active);
+        if (!busy) {
+            if (__ballot(finished)) continue;
+            if (exhausted) break;
+            continue;
+        }
+
+        // ---- traverse. Every iteration runs ONE of the two blocks -- the one more lanes are waiting for -- so the
+        // ---- 64 lanes are not serialised through both; a lane's own visiting order is unchanged.
+        do {
+            const bool tri_mode = active && tri_cur < tri_end;
+            const bool node_mode = active && !tri_mode;
+            const unsigned long long tmask = __ballot(tri_mode), nmask = __ballot(node_mode);
+            if (__popcll(tmask) > __popcll(nmask)) {
+                if (tri_mode) {
+                    const uint32_t i = tri_cur++;
+                    ++tris;
+                    const float4* tp = sc.triangles + 3 * size_t(i);
+                    const float4 a = tp[0], b = tp[1], c = tp[2];
+                    float t, u, v;
+                    bool stop = false;
+                    if ((SHADOW || i != skip) && intersect_triangle(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), o, d, t, u, v)) {
+                        if constexpr (SHADOW) {
+                            if (t > tmin && t < tmax) {
+                                float coverage = 1.0f;
+                                if (!(__float_as_uint(c.w) & HIPR_TRIANGLE_OPAQUE)) {
+                                    const HiprInstance& inst = sc.instances[__float_as_uint(c.y)];
+                                    coverage = material_coverage(sc, sc.materials[inst.material_index], triangle_texcoord(sc, inst, __float_as_uint(c.z), u, v));
+                                }
+                                rad *= 1.0f - coverage;
+                                if (rad.x < 0.0000001f && rad.y < 0.0000001f && rad.z < 0.0000001f) { rad = mk3(0.0f); stop = true; }
+                            }
+                        } else {
+                            if (t > tmin && (t < tmax || (t == tmax && i < best_id))) { tmax = t; best_u = u; best_v = v; best_id = i; }
+                        }
+                    }
+                    if (stop) { active = false; finished = true; }
+                    else if (tri_cur == tri_end) pop_next();
+                }
+            } else if (node_mode) {
+                const float4* np = sc.nodes + 4 * size_t(cur);
+                const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+                ++nodes;
+                float t0, t1;
+                bool h0 = slab(inv, ood, n0.x, n0.y, n0.z, n0.w, n2.x, n2.y, tmin, tmax, t0);
+                bool h1 = slab(inv, ood, n1.x, n1.y, n1.z, n1.w, n2.z, n2.w, tmin, tmax, t1);
+                int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+                if (h0 && h1 && t1 < t0) { const int tmp = c0; c0 = c1; c1 = tmp; }
+                if (!h0 && h1) { c0 = c1; h0 = true; h1 = false; }
+                if (h0 && h1) {
+                    // Visiting order of the specification: a leaf child is intersected before descending into an inner sibling.
+                    int first = c0, second = c1;
+                    if (c0 >= 0 && c1 < 0) { first = c1; second = c0; }
+                    stack[sp * TRACE_BLOCK] = second;
+                    ++sp;
+                    set_item(first);
+                } else if (h0) set_item(c0);
+                else pop_next();
+            }
+            busy = __ballot(active);
+        } while (busy && (exhausted || __popcll(busy) >= refill_below));
+    }
+
+    if (INSTRUMENT) {
+        wave_add(SHADOW ? &counters->shadow_nodes : &counters->closest_nodes, nodes);
+        wave_add(SHADOW ? &counters->shadow_triangles : &counters->closest_triangles, tris);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K3: shade + next event estimation + BSDF sampling + stream compaction
 // ---------------------------------------------------------------------------------------------
 HD f3 fix_backfacing_shading_normal(f3 w, f3 n, float target) {
