@@ -36,6 +36,16 @@ struct Sample { f3 f; float pdf; f3 dir; };
 HD Response response_none() { return {{0, 0, 0}, 0.0f}; }
 HD Sample sample_none() { return {{0, 0, 0}, 0.0f, {0, 0, 0}}; }
 
+// HIPR_FAST_MATH (set for the shade translation unit): hardware sin / cos / exp2 / log2 like the reference's
+// --use_fast_math PTX (extensions/OptiXRenderer/CMakeLists.txt:82-83); otherwise the correctly rounded-ish ocml versions.
+#if HIPR_FAST_MATH
+HD void sincos_(float a, float& s, float& c) { s = __sinf(a); c = __cosf(a); }
+HD float pow_(float x, float y) { return __powf(x, y); }
+#else
+HD void sincos_(float a, float& s, float& c) { s = sinf(a); c = cosf(a); }
+HD float pow_(float x, float y) { return powf(x, y); }
+#endif
+
 HD float sgn(float v) { return v >= 0.0f ? 1.0f : -1.0f; }
 HD float pow2(float x) { return x * x; }
 HD f3 pow2(f3 x) { return x * x; }
@@ -67,7 +77,7 @@ HD float dielectric_schlick_fresnel(float f0, float abs_cos, float ior_i_over_o)
 }
 HD float modulate_roughness_under_coat(float base, float coat) {
     float x_coat = 1 - HIPR_AIR_IOR / HIPR_COAT_IOR;
-    return powf(fminf(1, pow4(base) + 2.0f * x_coat * pow4(coat)), 0.25f);
+    return pow_(fminf(1, pow4(base) + 2.0f * x_coat * pow4(coat)), 0.25f);
 }
 HD bool refract_z(f3& out, f3 wi, float ior) {
     float nz = 1, c = wi.z;
@@ -142,7 +152,7 @@ HD float min_roughness_from_PDF(const DeviceTables& t, float abs_cos, float max_
 // ---------------------------------------------------------------------------------------------
 // Distributions
 // ---------------------------------------------------------------------------------------------
-HD void sincos_(float a, float& s, float& c) { s = sinf(a); c = cosf(a); }
+
 
 HD f3 cone_sample(float cos_theta_max, f2 u, float& pdf) {
     float cos_theta = (1.0f - u.x) + u.x * cos_theta_max;
@@ -290,7 +300,7 @@ HD float evaluate(float roughness, f3 wo, f3 wi) {
     return single + multi;
 }
 HD float uniform_probability(float roughness, float cos_theta) {
-    return powf(roughness, 0.1f) * (0.162925f + cos_theta * (-0.372058f + (0.538233f - 0.290822f * cos_theta) * cos_theta));
+    return pow_(roughness, 0.1f) * (0.162925f + cos_theta * (-0.372058f + (0.538233f - 0.290822f * cos_theta) * cos_theta));
 }
 HD float pdf(float roughness, f3 wo, f3 wi) {
     float up = uniform_probability(roughness, wo.z);
@@ -553,17 +563,25 @@ HD Shading make_transmissive(const DeviceTables& t, const MaterialInputs& m, flo
     return s;
 }
 
+// MODELS: bit i set = shading model i occurs in the scene. Kernels are instantiated per mask so a scene that only
+// uses one model (the common case) carries neither the registers nor the branches of the others.
+#define HIPR_HAS_DEFAULT(M) (((M) & 1) != 0)
+#define HIPR_HAS_DIFFUSE(M) (((M) & 2) != 0)
+#define HIPR_HAS_TRANSMISSIVE(M) (((M) & 4) != 0)
+
+template <int MODELS>
 HD Response shading_evaluate_with_PDF(const Shading& s, f3 wo, f3 wi) {
-    if (s.model == HIPR_SHADING_DIFFUSE) {
+    if (HIPR_HAS_DIFFUSE(MODELS) && (MODELS == 2 || s.model == HIPR_SHADING_DIFFUSE)) {
         if (wo.z < 0.000001f || wi.z < 0.000001f) return response_none();
         return oren_nayar::evaluate_with_PDF(s.a, s.s0, wo, wi);
     }
-    if (s.model == HIPR_SHADING_TRANSMISSIVE) {
+    if (HIPR_HAS_TRANSMISSIVE(MODELS) && (MODELS == 4 || s.model == HIPR_SHADING_TRANSMISSIVE)) {
         if (wo.z < 0.000001f) return response_none();
         Response r = {ggx_rt::evaluate(s.a, s.s1, s.s0, s.s2, wo, wi), ggx_rt::pdf(s.a, s.s1, s.s0, s.s2, wo, wi)};
         r.f *= s.s3;
         return r;
     }
+    if (!HIPR_HAS_DEFAULT(MODELS)) return response_none();
     if (wo.z < 0.000001f || wi.z < 0.000001f) return response_none();
     float sp = s.p0 / 65535.0f, cp = s.p1 / 65535.0f;
     float dp = 1.0f - (s.p0 + s.p1) / 65535.0f;
@@ -582,15 +600,17 @@ HD Response shading_evaluate_with_PDF(const Shading& s, f3 wo, f3 wi) {
     return r;
 }
 
+template <int MODELS>
 HD Sample shading_sample(const Shading& s, f3 wo, f3 u) {
     if (wo.z < 0.000001f) return sample_none();
-    if (s.model == HIPR_SHADING_DIFFUSE)
+    if (HIPR_HAS_DIFFUSE(MODELS) && (MODELS == 2 || s.model == HIPR_SHADING_DIFFUSE))
         return oren_nayar::sample(s.a, s.s0, wo, mk2(u.x, u.y));
-    if (s.model == HIPR_SHADING_TRANSMISSIVE) {
+    if (HIPR_HAS_TRANSMISSIVE(MODELS) && (MODELS == 4 || s.model == HIPR_SHADING_TRANSMISSIVE)) {
         Sample r = ggx_rt::sample(s.a, s.s1, s.s0, s.s2, wo, u);
         r.f *= s.s3;
         return r;
     }
+    if (!HIPR_HAS_DEFAULT(MODELS)) return sample_none();
     float sp = s.p0 / 65535.0f, cp = s.p1 / 65535.0f;
     float dp = 1 - cp - sp;
     float alpha = ggx_alpha_from_roughness(s.s0);
@@ -752,7 +772,9 @@ HD LightSample light_sample_radiance(const HiprLight& l, f3 p, f2 u) {
         } else {
             float r = sqrtf(u.x) * radius;
             float phi = 2.0f * HIPR_PI * u.y;
-            f3 sampled = lpos + to_world(f, mk3(r * cosf(phi), r * sinf(phi), 0.0f));
+            float sphi, cphi;
+            sincos_(phi, sphi, cphi);
+            f3 sampled = lpos + to_world(f, mk3(r * cphi, r * sphi, 0.0f));
             s.dir = sampled - p;
             s.distance = length(s.dir);
             s.dir /= s.distance;

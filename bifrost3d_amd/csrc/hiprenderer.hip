@@ -6,6 +6,7 @@
 // Replaces the OptiX context + context->launch() of OR/Renderer.cpp:273-574,1250-1265.
 // There is no CPU fallback: every entry point that needs the GPU fails with a status code.
 #include "kernels.h"
+#include "launch.h"
 
 #include <hip/hip_runtime.h>
 
@@ -74,10 +75,11 @@ struct HiprContext {
 
     // scene
     DeviceBuffer nodes, triangles, instances, indices, geometry, texcoords, tints, emissions, materials, lights, textures, texels;
-    DeviceBuffer ggx_rho, dielectric_rho, alpha, sample_offsets;
+    DeviceBuffer ggx_rho, dielectric_rho, alpha, sample_offsets, sobol_tables;
     DeviceScene scene = {};
     bool tables_ready = false, scene_ready = false;
     int stack_size = 16;
+    int shading_models = 7;             // bit mask of the shading models the scene's instances reference
 
     // frame
     FrameInfo frame = {};
@@ -218,6 +220,12 @@ void launch_trace_shadow(HiprContext* c, const uint32_t* count_ptr, uint32_t upp
     }
 }
 
+void launch_shade(HiprContext* c, const HiprCameraState& camera, int cur, uint32_t alive, const uint32_t* in_count, uint32_t* out_count, uint32_t* shadow_count) {
+    ShadeLaunch a = {grid_for(alive, SHADE_BLOCK, 256u * 8u), c->stream, c->scene, camera, c->path_state(cur), c->hits.as<float4>(), c->path_state(1 - cur),
+                     c->shadow_queue(), c->radiance.as<float4>(), in_count, out_count, shadow_count, c->counters.as<DeviceCounters>()};
+    hipr::launch_shade(c->shading_models, a);
+}
+
 int check_context(HiprContext* c) {
     if (!c) return fail(HIPR_ERROR_INVALID_ARGUMENT, "null context");
     HIP_TRY(hipSetDevice(c->device));
@@ -281,7 +289,19 @@ int hipr_create(int device_id, HiprContext** out_context) {
     for (int i = 0; i < 256; ++i)
         for (int d = 0; d < 4; ++d) offsets[4 * i + d] = reverse_halton(primes[d], i);
     if (int s = c->sample_offsets.upload(offsets, sizeof(offsets), c->stream)) { delete c; return s; }
+    // Byte-indexed Sobol tables: entry [d][k][b] = XOR of the direction numbers of dimension d + 1 selected by byte k = b.
+    std::vector<uint32_t> sobol(SOBOL_TABLE_WORDS);
+    for (int d = 0; d < 3; ++d)
+        for (int k = 0; k < 4; ++k)
+            for (int b = 0; b < 256; ++b) {
+                uint32_t v = 0;
+                for (int j = 0; j < 8; ++j)
+                    if (b & (1 << j)) v ^= SOBOL_DIRECTIONS[d][8 * k + j];
+                sobol[(d * 4 + k) * 256 + b] = v;
+            }
+    if (int s = c->sobol_tables.upload(sobol.data(), sobol.size() * 4, c->stream)) { delete c; return s; }
     HIP_TRY(hipStreamSynchronize(c->stream));
+    c->scene.sobol_tables = c->sobol_tables.as<uint32_t>();
     c->scene.sample_offsets = c->sample_offsets.as<float4>();
     c->scene.next_event_sample_count = 3;   // OR/Renderer.cpp:479
     *out_context = c;
@@ -293,7 +313,7 @@ int hipr_destroy(HiprContext* c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     DeviceBuffer* all[] = {&c->nodes, &c->triangles, &c->instances, &c->indices, &c->geometry, &c->texcoords, &c->tints, &c->emissions, &c->materials,
-                           &c->lights, &c->textures, &c->texels, &c->ggx_rho, &c->dielectric_rho, &c->alpha, &c->sample_offsets, &c->hits, &c->radiance,
+                           &c->lights, &c->textures, &c->texels, &c->ggx_rho, &c->dielectric_rho, &c->alpha, &c->sample_offsets, &c->sobol_tables, &c->hits, &c->radiance,
                            &c->accumulation, &c->queue_counts, &c->counters, &c->work_counters, &c->debug_a, &c->debug_b, &c->debug_c, &c->shadow[0], &c->shadow[1], &c->shadow[2]};
     for (DeviceBuffer* b : all) b->release();
     for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) c->path[i][j].release();
@@ -382,6 +402,13 @@ int hipr_upload_scene(HiprContext* c, const HiprSceneDesc* s) {
     d.triangle_count = s->triangle_count;
     d.light_count = s->light_count;
     c->stack_size = s->bvh_max_depth <= 16 ? 16 : (s->bvh_max_depth <= 32 ? 32 : 64);
+    int models = 0;
+    for (uint32_t i = 0; i < s->instance_count; ++i) {
+        const int32_t m = s->instances[i].material_index;
+        if (m < 0 || uint32_t(m) >= s->material_count) return fail(HIPR_ERROR_INVALID_ARGUMENT, "instance %u references material %d of %u", i, m, s->material_count);
+        models |= 1 << std::min<int>(s->materials[m].shading_model, 2);
+    }
+    c->shading_models = models ? models : 7;
     c->scene_ready = true;
     return HIPR_OK;
 }
@@ -479,9 +506,7 @@ int hipr_render_pass(HiprContext* c, const HiprCameraState* camera, void* out_ha
         c->end_timed();
 
         c->begin_timed(HIPR_KERNEL_SHADE);
-        hipLaunchKernelGGL(k_shade, dim3(grid_for(alive, SHADE_BLOCK, 256u * 8u)), dim3(SHADE_BLOCK), 0, c->stream, c->scene, *camera, c->path_state(cur),
-                           c->hits.as<float4>(), c->path_state(1 - cur), c->shadow_queue(), c->radiance.as<float4>(), in_count, out_count, counts + 2,
-                           c->counters.as<DeviceCounters>());
+        launch_shade(c, *camera, cur, alive, in_count, out_count, counts + 2);
         c->end_timed();
         HIP_TRY(hipEventRecord(c->shade_done, c->stream));
 
@@ -639,7 +664,7 @@ int hipr_debug_sobol(HiprContext* c, const uint32_t* triples, uint32_t n, uint32
     if (n == 0) return HIPR_OK;
     if (int s = c->debug_a.upload(triples, size_t(n) * 12, c->stream)) return s;
     if (int s = c->debug_b.resize(size_t(n) * 16)) return s;
-    hipLaunchKernelGGL(k_debug_sobol, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->debug_a.as<uint32_t>(), n, c->debug_b.as<uint32_t>());
+    hipLaunchKernelGGL(k_debug_sobol, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->debug_a.as<uint32_t>(), n, c->debug_b.as<uint32_t>(), c->sobol_tables.as<uint32_t>());
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(out_uint4, c->debug_b.ptr, size_t(n) * 16, hipMemcpyDeviceToHost));
     return HIPR_OK;

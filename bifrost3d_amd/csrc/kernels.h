@@ -42,6 +42,7 @@ struct DeviceScene {
     const HiprTexture* textures;
     const uint8_t* texels;
     const float4* sample_offsets;
+    const uint32_t* sobol_tables;   // SOBOL_TABLE_WORDS words, see sobol4ui_tables
     DeviceTables tables;
     uint32_t node_count, triangle_count, light_count;
     float env_tint[3];
@@ -109,6 +110,7 @@ HD void camera_ray(const HiprCameraState& cam, uint32_t x, uint32_t y, uint32_t 
     direction = normalize(mk3(r[0] * v.x + r[1] * v.y + r[2] * v.z, r[3] * v.x + r[4] * v.y + r[5] * v.z, r[6] * v.x + r[7] * v.y + r[8] * v.z));
 }
 
+#ifndef HIPR_SHADE_TU
 __global__ __launch_bounds__(256) void k_generate(FrameInfo frame, HiprCameraState cam, PathState out, float4* radiance, uint32_t n_paths) {
     uint32_t p = blockIdx.x * 256u + threadIdx.x;
     if (p >= n_paths) return;
@@ -126,6 +128,8 @@ __global__ __launch_bounds__(256) void k_generate(FrameInfo frame, HiprCameraSta
     out.meta[p] = make_uint4(valid ? p : HIPR_DEAD_SLOT, HIPR_NO_TRIANGLE, pixel_hash, accumulation);
     radiance[p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
+
+#endif // HIPR_SHADE_TU
 
 // ---------------------------------------------------------------------------------------------
 // BVH2 traversal shared by K2 and K4 (DESIGN.md "Traversal order" is the specification both this
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(DeviceScene sc, P
 // ---------------------------------------------------------------------------------------------
 // Textures and materials (software samplers; OR/Renderer.cpp:703-751, OR/Types.h:389-414)
 // ---------------------------------------------------------------------------------------------
-HD float srgb_to_linear(float c) { return c <= 0.04045f ? c / 12.92f : powf((c + 0.055f) / 1.055f, 2.4f); }
+HD float srgb_to_linear(float c) { return c <= 0.04045f ? c / 12.92f : pow_((c + 0.055f) / 1.055f, 2.4f); }
 
 HD f4 fetch_texel(const DeviceScene& sc, const HiprTexture& tex, int x, int y) {
     const uint8_t* base = sc.texels + tex.texel_offset;
@@ -584,240 +588,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_persistent(DeviceScene sc
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// K3: shade + next event estimation + BSDF sampling + stream compaction
-// ---------------------------------------------------------------------------------------------
-HD f3 fix_backfacing_shading_normal(f3 w, f3 n, float target) {
-    float c = dot(w, n);
-    return c < target ? normalize(n - (c - target) * w) : n;
-}
-
-HD f3 offset_ray_origin(f3 p, f3 n) {
-    const float origin = 1.0f / 32.0f, float_scale = 1.0f / 65536.0f, int_scale = 256.0f;
-    int ox = int(int_scale * n.x), oy = int(int_scale * n.y), oz = int(int_scale * n.z);
-    f3 pi = {__int_as_float(__float_as_int(p.x) + (p.x < 0 ? -ox : ox)), __int_as_float(__float_as_int(p.y) + (p.y < 0 ? -oy : oy)),
-             __int_as_float(__float_as_int(p.z) + (p.z < 0 ? -oz : oz))};
-    return {fabsf(p.x) < origin ? p.x + float_scale * n.x : pi.x, fabsf(p.y) < origin ? p.y + float_scale * n.y : pi.y,
-            fabsf(p.z) < origin ? p.z + float_scale * n.z : pi.z};
-}
-HD f3 offset_ray_origin(f3 p, f3 direction, f3 geometric_normal) {
-    return offset_ray_origin(p, dot(geometric_normal, direction) >= 0 ? geometric_normal : -geometric_normal);
-}
-
-struct ShadeOutput {
-    bool continues;      // the path goes on (next bounce or retrace)
-    bool shadow;         // a shadow ray was emitted
-    bool shaded;         // an accepted surface hit
-    f3 o, d; float tmin, bsdf_pdf; f3 throughput; uint32_t bounces, last_triangle;
-    f3 so, sd; float stmax; f3 sradiance;
-    f3 add_radiance;
-};
-
-HD void shade_path(const DeviceScene& sc, const HiprCameraState& cam, f3 ro, f3 rd, float bsdf_pdf, f3 throughput, uint32_t bounces,
-                   uint32_t last_triangle, uint32_t pixel_hash, uint32_t accumulation, float4 hit, ShadeOutput& out) {
-    out.continues = out.shadow = out.shaded = false;
-    out.add_radiance = mk3(0.0f);
-    const uint32_t id = __float_as_uint(hit.w);
-    if (id == HIPR_HIT_MISS) {
-        out.add_radiance = throughput * mk3(sc.env_tint[0], sc.env_tint[1], sc.env_tint[2]);
-        return;
-    }
-    if (id & HIPR_HIT_LIGHT) {
-        f3 L = light_evaluate_intersection(sc.lights[id & ~HIPR_HIT_LIGHT], ro, rd, bsdf_pdf);
-        out.add_radiance = min3(throughput, mk3(4.0f)) * L;
-        return;
-    }
-
-    // --- attributes of the accepted closest hit only (TriangleAttributes.cu:35-84) -------------
-    const float4* tp = sc.triangles + 3 * size_t(id);
-    const float4 ta = tp[0], tb = tp[1], tc = tp[2];
-    const f3 p0 = {ta.x, ta.y, ta.z}, p1 = {ta.w, tb.x, tb.y}, p2 = {tb.z, tb.w, tc.x};
-    const HiprInstance& inst = sc.instances[__float_as_uint(tc.y)];
-    const uint32_t prim = __float_as_uint(tc.z);
-    const HiprMaterial mp = sc.materials[inst.material_index];
-    const float u = hit.y, v = hit.z, w = 1.0f - u - v;
-    const uint32_t* idx = sc.indices + 3 * size_t(inst.index_offset + prim);
-    const uint32_t i0 = idx[0], i1 = idx[1], i2 = idx[2];
-
-    f3 geometric_normal = normalize(cross(p1 - p0, p2 - p0));
-    const f2 texcoord = triangle_texcoord(sc, inst, prim, u, v);
-
-    const bool thin_walled = (mp.flags & (HIPR_MATERIAL_CUTOUT | HIPR_MATERIAL_THIN_WALLED)) != 0;
-    const bool transmissive = mp.shading_model == HIPR_SHADING_TRANSMISSIVE;
-    const bool hit_from_front = dot(geometric_normal, rd) < 0.0f;
-    const bool backside_cull = !hit_from_front && !thin_walled && !transmissive;
-
-    const f4 bsdf_u = sobol4f(accumulation, pixel_hash, 8u * bounces + 2u);   // BSDF dimension, always drawn
-    const float coverage = material_coverage(sc, mp, texcoord);
-    if (backside_cull || coverage < bsdf_u.w) {
-        // rejected hit: same ray, tmin bumped past it, counters untouched (MonteCarlo.cu:159-164)
-        out.continues = true;
-        out.o = ro; out.d = rd; out.tmin = nextafterf(hit.x, __builtin_inff()); out.bsdf_pdf = bsdf_pdf;
-        out.throughput = throughput; out.bounces = bounces; out.last_triangle = last_triangle;
-        return;
-    }
-    out.shaded = true;
-
-    const f3 position = p1 * u + p2 * v + p0 * w;
-    f3 shading_normal = geometric_normal;
-    if (inst.mesh_flags & HIPR_MESH_NORMALS) {
-        const float4* g = sc.geometry + inst.vertex_offset;
-        f3 n = decode_octahedral(g[i1].w) * u + decode_octahedral(g[i2].w) * v + decode_octahedral(g[i0].w) * w;
-        n = normalize(n);
-        const float* M = inst.object_to_world;
-        shading_normal = normalize(mk3(M[0] * n.x + M[1] * n.y + M[2] * n.z, M[4] * n.x + M[5] * n.y + M[6] * n.z, M[8] * n.x + M[9] * n.y + M[10] * n.z));
-    }
-    f4 tint_scale = {1, 1, 1, 1};
-    if (inst.mesh_flags & HIPR_MESH_TINTS) {
-        const uint32_t* tints = sc.tints + inst.vertex_offset;
-        const uint32_t t0 = tints[i0], t1 = tints[i1], t2 = tints[i2];
-        const float s = 1.0f / 255.0f;
-        auto ch = [](uint32_t p, int c) { return float((p >> (8 * c)) & 0xFFu); };
-        tint_scale = {(ch(t1, 0) * u + ch(t2, 0) * v + ch(t0, 0) * w) * s, (ch(t1, 1) * u + ch(t2, 1) * v + ch(t0, 1) * w) * s,
-                      (ch(t1, 2) * u + ch(t2, 2) * v + ch(t0, 2) * w) * s, (ch(t1, 3) * u + ch(t2, 3) * v + ch(t0, 3) * w) * s};
-    }
-    f3 emission = {1, 1, 1};
-    if (inst.mesh_flags & HIPR_MESH_EMISSIVE) {
-        const float* e = sc.emissions + 3 * size_t(inst.vertex_offset);
-        auto em = [&](uint32_t i) { return mk3(e[3 * i], e[3 * i + 1], e[3 * i + 2]); };
-        emission = em(i1) * u + em(i2) * v + em(i0) * w;
-    }
-
-    geometric_normal = hit_from_front ? geometric_normal : -geometric_normal;
-    shading_normal = hit_from_front ? shading_normal : -shading_normal;
-    shading_normal = fix_backfacing_shading_normal(-rd, shading_normal, 0.002f);
-    const Frame tbn = make_frame(shading_normal);
-    const f3 wo = to_local(tbn, -rd);
-    const float cos_theta = (hit_from_front || thin_walled) ? wo.z : -wo.z;
-
-    // --- material ---------------------------------------------------------------------------------
-    f4 tr = {mp.tint[0], mp.tint[1], mp.tint[2], mp.roughness};
-    if (mp.tint_roughness_texture_ID) tr = tr * sample_texture(sc, mp.tint_roughness_texture_ID, texcoord);
-    if (mp.roughness_texture_ID) tr.w *= sample_texture(sc, mp.roughness_texture_ID, texcoord).x;
-    tr = tr * tint_scale;
-    MaterialInputs in;
-    in.tint = {tr.x, tr.y, tr.z};
-    in.roughness = tr.w;
-    in.specularity = mp.specularity;
-    in.metallic = mp.metallic_texture_ID ? mp.metallic * sample_texture(sc, mp.metallic_texture_ID, texcoord).x : mp.metallic;
-    in.coat = mp.coat / 65535.0f;
-    in.coat_roughness = mp.coat_roughness / 65535.0f;
-    const float max_PDF_hint = bsdf_pdf * cam.path_regularization_PDF_scale;
-    Shading shading;
-    if (mp.shading_model == HIPR_SHADING_DIFFUSE) shading = make_diffuse(in.tint, in.roughness);
-    else if (transmissive) shading = make_transmissive(sc.tables, in, cos_theta, max_PDF_hint);
-    else shading = make_default(sc.tables, in, cos_theta, max_PDF_hint);
-
-    out.add_radiance = throughput * emission * mk3(mp.emission[0], mp.emission[1], mp.emission[2]);
-
-    // --- next event estimation: streaming RIS over the light candidates (MonteCarlo.cu:91-123) ------
-    LightSample kept = light_sample_none();
-    if (sc.light_count != 0) {
-        const f4 base = sobol4f(accumulation, pixel_hash, 8u * bounces + 1u);
-        const int n = sc.next_event_sample_count;
-        for (int s = 0; s < n; ++s) {
-            const float4 off = sc.sample_offsets[s];
-            f4 r = {base.x + off.x, base.y + off.y, base.z + off.z, base.w + off.w};
-            r = {r.x - floorf(r.x), r.y - floorf(r.y), r.z - floorf(r.z), r.w - floorf(r.w)};
-            const int light_count = int(sc.light_count);
-            int li = int(r.z * light_count);
-            li = li > light_count - 1 ? light_count - 1 : li;
-            LightSample c = light_sample_radiance(sc.lights[li], position, mk2(r.x, r.y));
-            c.radiance *= float(light_count);
-            c.radiance *= fabsf(dot(tbn.n, c.dir)) / pdf_value(c.pdf);
-            Response f = shading_evaluate_with_PDF(shading, wo, to_local(tbn, c.dir));
-            if (!pdf_is_delta(c.pdf)) c.radiance *= balance_heuristic(pdf_value(c.pdf), pdf_value(f.pdf));
-            else f.f = min3(f.f, mk3(32.0f));
-            c.radiance *= f.f;
-            const float w_old = sum(kept.radiance), w_new = sum(c.radiance);
-            const float p_new = w_new / (w_old + w_new);
-            if (r.w < p_new) { kept = c; kept.radiance /= p_new; }
-            else kept.radiance /= 1.0f - p_new;
-        }
-        kept.radiance /= float(n);
-    }
-    const f3 light_origin = offset_ray_origin(position, kept.dir, geometric_normal);
-    kept.radiance *= throughput;
-    if (kept.radiance.x > 0 || kept.radiance.y > 0 || kept.radiance.z > 0) {
-        out.shadow = true;
-        out.so = light_origin; out.sd = kept.dir; out.stmax = kept.distance; out.sradiance = kept.radiance;
-    }
-
-    // --- BSDF sampling (MonteCarlo.cu:204-232) ---------------------------------------------------
-    const Sample bs = shading_sample(shading, wo, mk3(bsdf_u.x, bsdf_u.y, bsdf_u.z));
-    const bool is_reflection = bs.dir.z >= 0;
-    f3 direction = to_world(tbn, bs.dir);
-    float new_pdf = bs.pdf;
-    if (pdf_is_valid(bs.pdf)) throughput *= (bs.f * fabsf(bs.dir.z)) / pdf_value(bs.pdf);
-    else throughput = mk3(0.0f);
-    const float cos_geometric = dot(direction, geometric_normal);
-    if (is_reflection ? cos_geometric < 0.0f : cos_geometric >= 0.0f)
-        direction = reflect(direction, geometric_normal);
-    if (!pdf_is_valid(kept.pdf)) new_pdf = pdf_disable_MIS(new_pdf);
-    bounces += 1u;
-
-    out.o = offset_ray_origin(position, direction, geometric_normal);
-    out.d = direction; out.tmin = 0.0f; out.bsdf_pdf = new_pdf; out.throughput = throughput; out.bounces = bounces; out.last_triangle = id;
-    out.continues = bounces <= cam.max_bounce_count && !is_black(throughput);
-}
-
-__global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DeviceScene sc, HiprCameraState cam, PathState in, const float4* hits, PathState out,
-                                                        ShadowQueue shadows, float4* radiance, const uint32_t* count_ptr, uint32_t* next_count,
-                                                        uint32_t* shadow_count, DeviceCounters* counters) {
-    __shared__ uint32_t s_cont[SHADE_BLOCK / 64], s_shad[SHADE_BLOCK / 64], s_base[2];
-    const uint32_t n = *count_ptr;
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    uint32_t shaded_total = 0;
-    for (uint32_t base = blockIdx.x * SHADE_BLOCK; base < n; base += gridDim.x * SHADE_BLOCK) {
-        const uint32_t i = base + threadIdx.x;
-        ShadeOutput so;
-        so.continues = so.shadow = so.shaded = false;
-        uint32_t slot = HIPR_DEAD_SLOT, pixel_hash = 0, accumulation = 0;
-        if (i < n) {
-            const uint4 meta = in.meta[i];
-            slot = meta.x; pixel_hash = meta.z; accumulation = meta.w;
-            if (slot != HIPR_DEAD_SLOT) {
-                const float4 o = in.o_tmin[i], d = in.d_pdf[i], t = in.thr_bounces[i];
-                shade_path(sc, cam, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), d.w, mk3(t.x, t.y, t.z), __float_as_uint(t.w), meta.y, pixel_hash,
-                           accumulation, hits[i], so);
-                if (so.add_radiance.x != 0.0f || so.add_radiance.y != 0.0f || so.add_radiance.z != 0.0f) {
-                    float4 acc = radiance[slot];
-                    acc.x += so.add_radiance.x; acc.y += so.add_radiance.y; acc.z += so.add_radiance.z;
-                    radiance[slot] = acc;
-                }
-            }
-        }
-        // ---- compaction: ballot + prefix popcount in the wave, LDS scan over the block's waves, one atomic per queue
-        const unsigned long long cont_mask = __ballot(so.continues), shad_mask = __ballot(so.shadow);
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        if (lane == 0) { s_cont[wave] = __popcll(cont_mask); s_shad[wave] = __popcll(shad_mask); }
-        shaded_total += so.shaded ? 1u : 0u;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t c = 0, s = 0;
-            for (int wv = 0; wv < SHADE_BLOCK / 64; ++wv) { uint32_t t = s_cont[wv]; s_cont[wv] = c; c += t; t = s_shad[wv]; s_shad[wv] = s; s += t; }
-            s_base[0] = c ? atomicAdd(next_count, c) : 0u;
-            s_base[1] = s ? atomicAdd(shadow_count, s) : 0u;
-        }
-        __syncthreads();
-        if (so.continues) {
-            const uint32_t j = s_base[0] + s_cont[wave] + __popcll(cont_mask & lt);
-            out.o_tmin[j] = make_float4(so.o.x, so.o.y, so.o.z, so.tmin);
-            out.d_pdf[j] = make_float4(so.d.x, so.d.y, so.d.z, so.bsdf_pdf);
-            out.thr_bounces[j] = make_float4(so.throughput.x, so.throughput.y, so.throughput.z, __uint_as_float(so.bounces));
-            out.meta[j] = make_uint4(slot, so.last_triangle, pixel_hash, accumulation);
-        }
-        if (so.shadow) {
-            const uint32_t j = s_base[1] + s_shad[wave] + __popcll(shad_mask & lt);
-            shadows.o_tmax[j] = make_float4(so.so.x, so.so.y, so.so.z, so.stmax);
-            shadows.d_slot[j] = make_float4(so.sd.x, so.sd.y, so.sd.z, __uint_as_float(slot));
-            shadows.radiance[j] = make_float4(so.sradiance.x, so.sradiance.y, so.sradiance.z, 0.0f);
-        }
-        __syncthreads();
-    }
-    wave_add(&counters->shaded_hits, shaded_total);
-}
-
+#ifndef HIPR_SHADE_TU
 // ---------------------------------------------------------------------------------------------
 // K6: f64 running mean + half4 output
 // ---------------------------------------------------------------------------------------------
@@ -867,11 +638,20 @@ __global__ __launch_bounds__(256) void k_scatter_tiles(const ushort4* compact, u
 }
 
 // Debug / parity helpers -------------------------------------------------------------------------
-__global__ void k_debug_sobol(const uint32_t* triples, uint32_t n, uint32_t* out) {
+// Evaluates BOTH forms of the sampler (the XOR loop used by k_generate and the LDS-table form used by k_shade) and
+// poisons the output when they disagree, so the bit-exact test against the oracle covers the two.
+__global__ void k_debug_sobol(const uint32_t* triples, uint32_t n, uint32_t* out, const uint32_t* sobol_tables) {
+    __shared__ uint32_t s_sobol[SOBOL_TABLE_WORDS];
+    for (uint32_t w = threadIdx.x; w < SOBOL_TABLE_WORDS; w += blockDim.x) s_sobol[w] = sobol_tables[w];
+    __syncthreads();
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u4 s = sobol4ui(triples[3 * i], triples[3 * i + 1], triples[3 * i + 2]);
+    u4 t = sobol4ui_tables(triples[3 * i], triples[3 * i + 1], triples[3 * i + 2], s_sobol);
+    if (s.x != t.x || s.y != t.y || s.z != t.z || s.w != t.w) s.x = s.y = s.z = s.w = 0xDEADBEEFu;
     out[4 * i] = s.x; out[4 * i + 1] = s.y; out[4 * i + 2] = s.z; out[4 * i + 3] = s.w;
 }
+
+#endif // HIPR_SHADE_TU
 
 } // namespace hipr

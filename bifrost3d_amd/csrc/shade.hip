@@ -1,0 +1,30 @@
+// shade.hip -- translation unit of the shade kernel (see shade_kernel.h for why it is separate).
+#define HIPR_SHADE_TU 1
+#ifndef HIPR_FAST_MATH
+#define HIPR_FAST_MATH 1
+#endif
+#include "shade_kernel.h"
+#include "launch.h"
+
+namespace hipr {
+
+template <int MODELS>
+static void launch_models(const ShadeLaunch& a) {
+    hipLaunchKernelGGL(k_shade<MODELS>, dim3(a.grid), dim3(SHADE_BLOCK), 0, a.stream, a.scene, a.camera, a.in, a.hits, a.out, a.shadows, a.radiance, a.in_count,
+                       a.out_count, a.shadow_count, a.counters);
+}
+
+// The kernel is instantiated per set of shading models the uploaded scene uses (bit 0 Default, 1 Diffuse, 2 Transmissive).
+void launch_shade(int shading_models, const ShadeLaunch& a) {
+    switch (shading_models) {
+    case 1: launch_models<1>(a); break;
+    case 2: launch_models<2>(a); break;
+    case 4: launch_models<4>(a); break;
+    case 3: launch_models<3>(a); break;
+    case 5: launch_models<5>(a); break;
+    case 6: launch_models<6>(a); break;
+    default: launch_models<7>(a); break;
+    }
+}
+
+} // namespace hipr
