@@ -13,7 +13,7 @@ from pathlib import Path
 PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = PKG_DIR / "csrc" / "libhiprenderer.so"
 HOST_LIB_PATH = PKG_DIR / "host" / "libhiprenderer_host.so"
-TABLES_PATH = PKG_DIR / "data" / "shading_tables.bin"
+TABLES_PATH = PKG_DIR / "data" / "HIPRenderer" / "shading_tables.bin"
 
 HIPR_OK = 0
 
@@ -99,6 +99,7 @@ class HiprCounters(C.Structure):
                 ("iterations", c_u64)]
 
 
+ENTRY_PATH_TRACING, ENTRY_DEPTH, ENTRY_ALBEDO, ENTRY_TINT, ENTRY_ROUGHNESS, ENTRY_SHADING_NORMAL, ENTRY_PRIMITIVE_ID = 0, 3, 4, 5, 6, 7, 8
 HIPR_KERNEL_NAMES = ("generate", "trace_closest", "shade", "trace_shadow", "accumulate")
 
 
@@ -112,7 +113,8 @@ assert C.sizeof(HiprTriangle) == 48 and C.sizeof(HiprBvhNode) == 64 and C.sizeof
 # Every symbol include/hiprenderer_c.h declares; tests check the library exports all of them.
 C_ABI_SYMBOLS = (
     "hipr_create", "hipr_destroy", "hipr_last_error", "hipr_device_count", "hipr_set_stream",
-    "hipr_upload_tables", "hipr_upload_scene", "hipr_set_scene_state", "hipr_set_frame", "hipr_owned_pixel_count",
+    "hipr_upload_tables", "hipr_upload_scene", "hipr_set_scene_state", "hipr_set_entry_point", "hipr_use_scratch_accumulation",
+    "hipr_set_frame", "hipr_owned_pixel_count",
     "hipr_render_pass", "hipr_read_accumulation", "hipr_scatter_tiles", "hipr_synchronize", "hipr_get_counters",
     "hipr_reset_counters", "hipr_set_instrumentation", "hipr_reset_timers", "hipr_get_kernel_times",
     "hipr_debug_generate", "hipr_debug_sobol", "hipr_debug_trace_closest", "hipr_debug_trace_shadow",
@@ -150,6 +152,8 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.hipr_upload_tables.argtypes = [vp, C.POINTER(HiprTables)]
     lib.hipr_upload_scene.argtypes = [vp, C.POINTER(HiprSceneDesc)]
     lib.hipr_set_scene_state.argtypes = [vp, C.POINTER(HiprSceneState)]
+    lib.hipr_set_entry_point.argtypes = [vp, C.c_int]
+    lib.hipr_use_scratch_accumulation.argtypes = [vp, C.c_int]
     lib.hipr_set_frame.argtypes = [vp, C.POINTER(HiprFrameDesc)]
     lib.hipr_owned_pixel_count.argtypes = [vp, C.POINTER(c_u32)]
     lib.hipr_render_pass.argtypes = [vp, C.POINTER(HiprCameraState), vp, c_u32, C.c_int]
@@ -177,7 +181,7 @@ def check(lib: C.CDLL, status: int, what: str = "") -> None:
 
 
 def load_tables():
-    """Returns the five f32 tables of data/shading_tables.bin as numpy arrays (base, full, light, dense, alpha)."""
+    """Returns the five f32 tables of data/HIPRenderer/shading_tables.bin as numpy arrays (base, full, light, dense, alpha)."""
     import numpy as np
     raw = TABLES_PATH.read_bytes()
     if raw[:8] != b"HIPRTBL1":

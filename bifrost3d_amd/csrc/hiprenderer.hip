@@ -85,7 +85,10 @@ struct HiprContext {
     FrameInfo frame = {};
     bool frame_ready = false;
     uint32_t n_slots = 0;   // owned_tiles * 64 * samples_per_pass
-    DeviceBuffer path[2][4], hits, shadow[3], radiance, accumulation, queue_counts, counters, work_counters;
+    DeviceBuffer path[2][4], hits, shadow[3], radiance, accumulation, scratch_accumulation, queue_counts, counters, work_counters;
+    bool use_scratch = false;
+    int entry = HIPR_ENTRY_PATH_TRACING;
+    DeviceBuffer& active_accumulation() { return use_scratch ? scratch_accumulation : accumulation; }
     uint32_t work_index = 0;            // next unused persistent-kernel work counter (zeroed 256 at a time)
     int trace_variant = -1;             // 1: persistent kernels, 0: one ray per lane, -1: pick by BVH size (HIPR_TRACE_VARIANT)
     bool use_persistent() const { return trace_variant < 0 ? scene.node_count > 64 : trace_variant == 1; }
@@ -221,7 +224,7 @@ void launch_trace_shadow(HiprContext* c, const uint32_t* count_ptr, uint32_t upp
 }
 
 void launch_shade(HiprContext* c, const HiprCameraState& camera, int cur, uint32_t alive, const uint32_t* in_count, uint32_t* out_count, uint32_t* shadow_count) {
-    ShadeLaunch a = {grid_for(alive, SHADE_BLOCK, 256u * 8u), c->stream, c->scene, camera, c->path_state(cur), c->hits.as<float4>(), c->path_state(1 - cur),
+    ShadeLaunch a = {grid_for(alive, SHADE_BLOCK, 256u * 8u), c->stream, c->scene, camera, c->entry, c->path_state(cur), c->hits.as<float4>(), c->path_state(1 - cur),
                      c->shadow_queue(), c->radiance.as<float4>(), in_count, out_count, shadow_count, c->counters.as<DeviceCounters>()};
     hipr::launch_shade(c->shading_models, a);
 }
@@ -314,7 +317,7 @@ int hipr_destroy(HiprContext* c) {
     (void)hipDeviceSynchronize();
     DeviceBuffer* all[] = {&c->nodes, &c->triangles, &c->instances, &c->indices, &c->geometry, &c->texcoords, &c->tints, &c->emissions, &c->materials,
                            &c->lights, &c->textures, &c->texels, &c->ggx_rho, &c->dielectric_rho, &c->alpha, &c->sample_offsets, &c->sobol_tables, &c->hits, &c->radiance,
-                           &c->accumulation, &c->queue_counts, &c->counters, &c->work_counters, &c->debug_a, &c->debug_b, &c->debug_c, &c->shadow[0], &c->shadow[1], &c->shadow[2]};
+                           &c->accumulation, &c->scratch_accumulation, &c->queue_counts, &c->counters, &c->work_counters, &c->debug_a, &c->debug_b, &c->debug_c, &c->shadow[0], &c->shadow[1], &c->shadow[2]};
     for (DeviceBuffer* b : all) b->release();
     for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) c->path[i][j].release();
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
@@ -444,11 +447,40 @@ int hipr_set_frame(HiprContext* c, const HiprFrameDesc* f) {
     r |= c->radiance.resize(slots * 16);
     const size_t acc_bytes = size_t(fi.owned_tiles) * 64 * sizeof(double4);
     c->accumulation.release();
+    c->scratch_accumulation.release();
+    c->use_scratch = false;
     r |= c->accumulation.resize(acc_bytes);
     if (r) return HIPR_ERROR_OUT_OF_MEMORY;
     HIP_TRY(hipMemsetAsync(c->accumulation.ptr, 0, acc_bytes, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->frame_ready = true;
+    return HIPR_OK;
+}
+
+int hipr_set_entry_point(HiprContext* c, int entry) {
+    if (!c) return fail(HIPR_ERROR_INVALID_ARGUMENT, "null context");
+    switch (entry) {
+    case HIPR_ENTRY_PATH_TRACING: case HIPR_ENTRY_DEPTH: case HIPR_ENTRY_ALBEDO: case HIPR_ENTRY_TINT: case HIPR_ENTRY_ROUGHNESS:
+    case HIPR_ENTRY_SHADING_NORMAL: case HIPR_ENTRY_PRIMITIVE_ID:
+        c->entry = entry;
+        return HIPR_OK;
+    case 1: case 2:
+        return fail(HIPR_ERROR_UNSUPPORTED, "entry point %d wraps the NVIDIA DL denoiser and has no equivalent here", entry);
+    }
+    return fail(HIPR_ERROR_INVALID_ARGUMENT, "unknown entry point %d", entry);
+}
+
+int hipr_use_scratch_accumulation(HiprContext* c, int enable) {
+    if (int s = check_context(c)) return s;
+    if (!c->frame_ready) return fail(HIPR_ERROR_NOT_READY, "no frame set");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->collect_times();
+    if (enable) {
+        const size_t bytes = size_t(c->frame.owned_tiles) * 64 * sizeof(double4);
+        if (int s = c->scratch_accumulation.resize(bytes)) return s;
+        HIP_TRY(hipMemset(c->scratch_accumulation.ptr, 0, bytes));
+    }
+    c->use_scratch = enable != 0;
     return HIPR_OK;
 }
 
@@ -531,8 +563,15 @@ int hipr_render_pass(HiprContext* c, const HiprCameraState* camera, void* out_ha
     }
 
     c->begin_timed(HIPR_KERNEL_ACCUMULATE);
+    float depth_normalizer = 0.0f;
+    if (c->entry == HIPR_ENTRY_DEPTH) {   // max depth = distance between the near and far plane centres (SimpleRGPs.cu:247-255)
+        const float* ip = camera->inverse_projection_matrix;
+        const float near_z = (ip[8] * 0.0f + ip[9] * 0.0f + ip[10] * -1.0f + ip[11]) / (ip[12] * 0.0f + ip[13] * 0.0f + ip[14] * -1.0f + ip[15]);
+        const float far_z = (ip[8] * 0.0f + ip[9] * 0.0f + ip[10] * 1.0f + ip[11]) / (ip[12] * 0.0f + ip[13] * 0.0f + ip[14] * 1.0f + ip[15]);
+        depth_normalizer = far_z - near_z;
+    }
     hipLaunchKernelGGL(k_accumulate, dim3((f.owned_tiles * 64 + 255) / 256), dim3(256), 0, c->stream, f, camera->accumulations, c->radiance.as<float4>(),
-                       c->accumulation.as<double4>(), static_cast<ushort4*>(out_half4_device), out_pitch_pixels);
+                       c->active_accumulation().as<double4>(), static_cast<ushort4*>(out_half4_device), out_pitch_pixels, depth_normalizer);
     c->end_timed();
     HIP_TRY(hipGetLastError());
 
@@ -612,11 +651,11 @@ int hipr_read_accumulation(HiprContext* c, double* out_rgba, uint64_t capacity_p
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->collect_times();
     if (f.tile_stride != 1) {
-        HIP_TRY(hipMemcpy(out_rgba, c->accumulation.ptr, owned * 32, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out_rgba, c->active_accumulation().ptr, owned * 32, hipMemcpyDeviceToHost));
         return HIPR_OK;
     }
     std::vector<double> compact(owned * 4);
-    HIP_TRY(hipMemcpy(compact.data(), c->accumulation.ptr, owned * 32, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(compact.data(), c->active_accumulation().ptr, owned * 32, hipMemcpyDeviceToHost));
     for (uint32_t y = 0; y < f.height; ++y)
         for (uint32_t x = 0; x < f.width; ++x) {
             const uint64_t k = (uint64_t(y >> 3) * f.tiles_x + (x >> 3)) * 64 + ((x & 7) + ((y & 7) << 3));

@@ -600,7 +600,7 @@ HD unsigned short float_to_half_bits(float v) {
 }
 
 __global__ __launch_bounds__(256) void k_accumulate(FrameInfo frame, uint32_t first_accumulation, const float4* radiance, double4* accumulation,
-                                                     ushort4* out, uint32_t out_pitch) {
+                                                     ushort4* out, uint32_t out_pitch, float depth_normalizer) {
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
     const uint32_t per_sample = frame.owned_tiles * 64u;
     if (k >= per_sample) return;
@@ -621,7 +621,11 @@ __global__ __launch_bounds__(256) void k_accumulate(FrameInfo frame, uint32_t fi
     accumulation[k] = acc;
     if (out) {
         const size_t dst = frame.tile_stride == 1 ? size_t(x) + size_t(y) * out_pitch : size_t(k);
-        out[dst] = make_ushort4(float_to_half_bits(float(acc.x)), float_to_half_bits(float(acc.y)), float_to_half_bits(float(acc.z)), float_to_half_bits(1.0f));
+        if (depth_normalizer != 0.0f) {   // depth_RPG: output depth / max_depth (SimpleRGPs.cu:241-258)
+            const unsigned short d = float_to_half_bits(float(acc.x) / depth_normalizer);
+            out[dst] = make_ushort4(d, d, d, float_to_half_bits(1.0f));
+        } else
+            out[dst] = make_ushort4(float_to_half_bits(float(acc.x)), float_to_half_bits(float(acc.y)), float_to_half_bits(float(acc.z)), float_to_half_bits(1.0f));
     }
 }
 

@@ -10,6 +10,7 @@ struct ShadeLaunch {
     hipStream_t stream;
     DeviceScene scene;
     HiprCameraState camera;
+    int entry;                 // HIPR_ENTRY_*
     PathState in;
     const float4* hits;
     PathState out;

@@ -37,17 +37,25 @@ struct ShadeOutput {
     f3 add_radiance;
 };
 
-template <int MODELS>
-HD void shade_path(const DeviceScene& sc, const HiprCameraState& cam, const uint32_t* sobol_lds, f3 ro, f3 rd, float bsdf_pdf, f3 throughput, uint32_t bounces,
+template <int MODELS, bool AOV>
+HD void shade_path(const DeviceScene& sc, const HiprCameraState& cam, int entry, const uint32_t* sobol_lds, f3 ro, f3 rd, float bsdf_pdf, f3 throughput, uint32_t bounces,
                    uint32_t last_triangle, uint32_t pixel_hash, uint32_t accumulation, float4 hit, ShadeOutput& out) {
     out.continues = out.shadow = out.shaded = false;
     out.add_radiance = mk3(0.0f);
     const uint32_t id = __float_as_uint(hit.w);
     if (id == HIPR_HIT_MISS) {
+        if (AOV) {   // material_index stays 0 -> black; the depth entry adds |origin - 1e30 * direction| (SimpleRGPs.cu:227-239, 349-362)
+            if (entry == HIPR_ENTRY_DEPTH) out.add_radiance = mk3(length(ro - 1e30f * rd));
+            return;
+        }
         out.add_radiance = throughput * mk3(sc.env_tint[0], sc.env_tint[1], sc.env_tint[2]);
         return;
     }
     if (id & HIPR_HIT_LIGHT) {
+        if (AOV) {
+            if (entry == HIPR_ENTRY_DEPTH) out.add_radiance = mk3(length(ro - (rd * hit.x + ro)));
+            return;
+        }
         f3 L = light_evaluate_intersection(sc.lights[id & ~HIPR_HIT_LIGHT], ro, rd, bsdf_pdf);
         out.add_radiance = min3(throughput, mk3(4.0f)) * L;
         return;
@@ -134,6 +142,53 @@ HD void shade_path(const DeviceScene& sc, const HiprCameraState& cam, const uint
     else if (HIPR_HAS_DEFAULT(MODELS)) shading = make_default(sc.tables, in, cos_theta, max_PDF_hint);
     else shading = make_diffuse(in.tint, in.roughness);
 
+    if (AOV && entry != HIPR_ENTRY_DEPTH) {
+        // First accepted hit of the AOV entry points (SimpleRGPs.cu:265-340). The vertex tint scale takes the
+        // float_to_unorm8 round trip of the payload (MonteCarlo.cu:170) before it is used.
+        auto q8 = [](float v) { return float((unsigned char)(saturate(v) * 255.0f + 0.5f)) * (1.0f / 255.0f); };
+        const f4 qscale = {q8(tint_scale.x), q8(tint_scale.y), q8(tint_scale.z), q8(tint_scale.w)};
+        f4 base = {mp.tint[0], mp.tint[1], mp.tint[2], mp.roughness};
+        if (mp.tint_roughness_texture_ID) base = base * sample_texture(sc, mp.tint_roughness_texture_ID, texcoord);
+        if (mp.roughness_texture_ID) base.w *= sample_texture(sc, mp.roughness_texture_ID, texcoord).x;
+        f3 value = {0, 0, 0};
+        if (entry == HIPR_ENTRY_TINT) value = mk3(base.x, base.y, base.z) * mk3(qscale.x, qscale.y, qscale.z);
+        else if (entry == HIPR_ENTRY_ROUGHNESS) value = mk3(base.w * qscale.w);
+        else if (entry == HIPR_ENTRY_SHADING_NORMAL) value = shading_normal * 0.5f + 0.5f;
+        else if (entry == HIPR_ENTRY_PRIMITIVE_ID) {
+            const uint32_t instance_encoding = uint32_t(inst.instance_id) & 0x3FFFFFFu;
+            const uint32_t primitive_encoding = __brev(prim + 1u) >> 2;
+            const uint32_t code = instance_encoding ^ primitive_encoding;
+            auto compact_by_2 = [](uint32_t v) {
+                v &= 0x09249249u; v = (v ^ (v >> 2)) & 0x030c30c3u; v = (v ^ (v >> 4)) & 0x0300f00fu; v = (v ^ (v >> 8)) & 0xff0000ffu; v = (v ^ (v >> 16)) & 0x000003ffu;
+                return v;
+            };
+            value = mk3(float(compact_by_2(code >> 2)), float(compact_by_2(code >> 1)), float(compact_by_2(code))) / 1023.0f;
+        } else if (entry == HIPR_ENTRY_ALBEDO) {
+            const float abs_cos = fabsf(dot(rd, shading_normal));
+            const f4 trq = base * qscale;
+            MaterialInputs ai = in;
+            ai.tint = {trq.x, trq.y, trq.z};
+            ai.roughness = trq.w;
+            if (mp.shading_model == HIPR_SHADING_DIFFUSE) value = ai.tint;
+            else if (transmissive) {
+                const Shading t = make_transmissive(sc.tables, ai, abs_cos, -1.0f);
+                const f2 rho = fetch_dielectric_rho(sc.tables, abs_cos, sqrtf(t.s1), t.s2);
+                const float reflection = rho.y / rho.x;
+                value = reflection + (1 - reflection) * t.a;
+            } else {
+                const Shading d = make_default(sc.tables, ai, abs_cos, -1.0f);
+                const f2 rho = fetch_specular_rho(sc.tables, abs_cos, d.s0);
+                value = d.a + mk3(lerp(rho.x, rho.y, d.b.x), lerp(rho.x, rho.y, d.b.y), lerp(rho.x, rho.y, d.b.z)) * d.s1;
+                if (d.s2 > 0.0f) {
+                    const f2 crho = fetch_specular_rho(sc.tables, abs_cos, sqrtf(d.s3));
+                    value = value + lerp(crho.x, crho.y, HIPR_COAT_SPECULARITY) * d.s2;
+                }
+            }
+        }
+        out.add_radiance = value;
+        return;
+    }
+
     out.add_radiance = throughput * emission * mk3(mp.emission[0], mp.emission[1], mp.emission[2]);
 
     // --- next event estimation: streaming RIS over the light candidates (MonteCarlo.cu:91-123) ------
@@ -185,10 +240,14 @@ HD void shade_path(const DeviceScene& sc, const HiprCameraState& cam, const uint
     out.o = offset_ray_origin(position, direction, geometric_normal);
     out.d = direction; out.tmin = 0.0f; out.bsdf_pdf = new_pdf; out.throughput = throughput; out.bounces = bounces; out.last_triangle = id;
     out.continues = bounces <= cam.max_bounce_count && !is_black(throughput);
+    if (AOV) {   // depth entry: distance from the ray origin to the offset origin of the next ray (SimpleRGPs.cu:232-236)
+        out.add_radiance = mk3(length(ro - out.o));
+        out.continues = out.shadow = false;
+    }
 }
 
-template <int MODELS>
-__global__ __launch_bounds__(SHADE_BLOCK, 3) void k_shade(DeviceScene sc, HiprCameraState cam, PathState in, const float4* hits, PathState out,
+template <int MODELS, bool AOV>
+__global__ __launch_bounds__(SHADE_BLOCK, 3) void k_shade(DeviceScene sc, HiprCameraState cam, int entry, PathState in, const float4* hits, PathState out,
                                                         ShadowQueue shadows, float4* radiance, const uint32_t* count_ptr, uint32_t* next_count,
                                                         uint32_t* shadow_count, DeviceCounters* counters) {
     __shared__ uint32_t s_cont[SHADE_BLOCK / 64], s_shad[SHADE_BLOCK / 64], s_base[2];
@@ -208,7 +267,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, 3) void k_shade(DeviceScene sc, HiprCa
             slot = meta.x; pixel_hash = meta.z; accumulation = meta.w;
             if (slot != HIPR_DEAD_SLOT) {
                 const float4 o = in.o_tmin[i], d = in.d_pdf[i], t = in.thr_bounces[i];
-                shade_path<MODELS>(sc, cam, s_sobol, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), d.w, mk3(t.x, t.y, t.z), __float_as_uint(t.w), meta.y, pixel_hash,
+                shade_path<MODELS, AOV>(sc, cam, entry, s_sobol, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), d.w, mk3(t.x, t.y, t.z), __float_as_uint(t.w), meta.y, pixel_hash,
                            accumulation, hits[i], so);
                 if (so.add_radiance.x != 0.0f || so.add_radiance.y != 0.0f || so.add_radiance.z != 0.0f) {
                     float4 acc = radiance[slot];

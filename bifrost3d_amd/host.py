@@ -1,4 +1,4 @@
-"""ctypes wrapper of host/libhiprenderer_host.so (scene construction, BVH build). No GPU needed."""
+"""ctypes wrapper of host/libhiprenderer_host.so (scene construction, BVH build). These entry points need no GPU."""
 from __future__ import annotations
 
 import ctypes as C
@@ -16,6 +16,7 @@ def load_host_library() -> C.CDLL:
         return _lib
     if not capi.HOST_LIB_PATH.exists():
         raise capi.HiprError(f"{capi.HOST_LIB_PATH} is missing: run __graft_entry__.build()")
+    capi.load_library()   # the host library links libhiprenderer.so (HIPRenderer::Renderer drives the C-ABI); keeps the torch-first load order
     lib = C.CDLL(str(capi.HOST_LIB_PATH))
     vp = C.c_void_p
     lib.hiprh_scene_create.argtypes = [C.c_char_p, C.c_uint, C.c_uint, C.c_uint]

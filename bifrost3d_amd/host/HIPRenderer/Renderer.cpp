@@ -1,0 +1,495 @@
+// HIPRenderer/Renderer.cpp -- host side of the MI355X path tracer: scene mirroring + launch.
+//
+// Follows the behaviour of extensions/OptiXRenderer/OptiXRenderer/Renderer.cpp ("OR/Renderer.cpp"):
+//   handle_updates           OR/Renderer.cpp:578-1205  (pull-based scene sync, accumulation reset rules)
+//   prepare_camera_state     OR/Renderer.cpp:1207-1248
+//   render                   OR/Renderer.cpp:1250-1265
+//   request_auxiliary_buffers OR/Renderer.cpp:1267-1358
+//   settings accessors       OR/Renderer.cpp:1389-1461
+// Where the reference edits an OptiX scene graph incrementally, this host rebuilds the flat HiprSceneDesc
+// (world-space triangles + BVH2) whenever geometry, materials or lights changed -- scenes are static between
+// edits, and the rebuild is off the render path.
+#include "Renderer.h"
+
+#include "../SceneBuilder.h"
+#include "../../../include/hiprenderer_c.h"
+
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <memory>
+
+using namespace Bifrost;
+using namespace Bifrost::Assets;
+using namespace Bifrost::Math;
+using namespace Bifrost::Scene;
+
+namespace HIPRenderer {
+
+static const int MAX_RNG_SAMPLE_OFFSETS = 256;   // OR/Renderer.cpp:46
+
+static int entry_of(Backend backend) {
+    switch (backend) {
+    case Backend::PathTracing: return HIPR_ENTRY_PATH_TRACING;
+    case Backend::DepthVisualization: return HIPR_ENTRY_DEPTH;
+    case Backend::AlbedoVisualization: return HIPR_ENTRY_ALBEDO;
+    case Backend::TintVisualization: return HIPR_ENTRY_TINT;
+    case Backend::RoughnessVisualization: return HIPR_ENTRY_ROUGHNESS;
+    case Backend::ShadingNormalVisualization: return HIPR_ENTRY_SHADING_NORMAL;
+    case Backend::PrimitiveIdVisualization: return HIPR_ENTRY_PRIMITIVE_ID;
+    default: return -1;
+    }
+}
+
+// ---- scene flattening: Bifrost managers -> SceneBuilder -> HiprSceneDesc --------------------------------------------
+static HiprMaterial upload_material(MaterialID material_ID) {   // OR/Renderer.cpp:754-812
+    HiprMaterial m = {};
+    if (material_ID == MaterialID::invalid_UID()) return m;
+    Assets::Material host = material_ID;
+    m.flags = uint16_t(host.get_flags().raw());
+    m.shading_model = uint16_t(host.get_shading_model());
+    RGB tint = host.get_tint();
+    m.tint[0] = tint.r; m.tint[1] = tint.g; m.tint[2] = tint.b;
+    m.tint_roughness_texture_ID = host.has_tint_texture() ? int(host.get_tint_roughness_texture_ID().get_index()) : 0;
+    m.roughness = host.get_roughness();
+    m.roughness_texture_ID = (m.tint_roughness_texture_ID == 0 && host.has_roughness_texture()) ? int(host.get_tint_roughness_texture_ID().get_index()) : 0;
+    m.specularity = host.get_specularity();
+    m.metallic = host.get_metallic();
+    m.metallic_texture_ID = int(host.get_metallic_texture_ID().get_index());
+    m.coat = SceneBuilder::unorm16(host.get_coat());
+    m.coat_roughness = SceneBuilder::unorm16(host.get_coat_roughness());
+    m.coverage = host.is_cutout() ? host.get_cutout_threshold() : host.get_coverage();
+    m.coverage_texture_ID = int(host.get_coverage_texture_ID().get_index());
+    RGB e = host.get_emission();
+    m.emission[0] = e.r; m.emission[1] = e.g; m.emission[2] = e.b;
+    return m;
+}
+
+static ImageData convert_image(ImageID image_ID) {   // OR/Renderer.cpp:650-701: RGB24 is expanded to RGBA, alpha 255
+    ImageData out;
+    out.width = Images::get_width(image_ID);
+    out.height = Images::get_height(image_ID);
+    out.is_sRGB = Images::is_sRGB(image_ID);
+    const size_t n = size_t(out.width) * out.height;
+    const uint8_t* src = static_cast<const uint8_t*>(Images::get_pixels(image_ID));
+    switch (Images::get_pixel_format(image_ID)) {
+    case PixelFormat::Alpha8: case PixelFormat::Intensity8: out.format = HIPR_TEXEL_R8; out.pixels.assign(src, src + n); break;
+    case PixelFormat::RGB24:
+        out.format = HIPR_TEXEL_RGBA8;
+        out.pixels.resize(4 * n);
+        for (size_t i = 0; i < n; ++i) { out.pixels[4 * i] = src[3 * i]; out.pixels[4 * i + 1] = src[3 * i + 1]; out.pixels[4 * i + 2] = src[3 * i + 2]; out.pixels[4 * i + 3] = 255; }
+        break;
+    case PixelFormat::RGBA32: out.format = HIPR_TEXEL_RGBA8; out.pixels.assign(src, src + 4 * n); break;
+    case PixelFormat::Intensity_Float: out.format = HIPR_TEXEL_R32F; out.pixels.assign(src, src + 4 * n); break;
+    case PixelFormat::RGB_Float: {
+        out.format = HIPR_TEXEL_RGBA32F;
+        out.pixels.resize(16 * n);
+        const float* s = reinterpret_cast<const float*>(src);
+        float* d = reinterpret_cast<float*>(out.pixels.data());
+        for (size_t i = 0; i < n; ++i) { d[4 * i] = s[3 * i]; d[4 * i + 1] = s[3 * i + 1]; d[4 * i + 2] = s[3 * i + 2]; d[4 * i + 3] = 1.0f; }
+        break;
+    }
+    case PixelFormat::RGBA_Float: out.format = HIPR_TEXEL_RGBA32F; out.pixels.assign(src, src + 16 * n); break;
+    default: out.format = HIPR_TEXEL_R8; out.width = out.height = 1; out.pixels.assign(1, 255); break;
+    }
+    return out;
+}
+
+void flatten_bifrost_scene(SceneBuilder& sb) {
+
+    // Textures and materials keep their Bifrost indices (slot 0 = invalid), like the reference's per-ID arrays.
+    for (unsigned int t = 1; t < Textures::capacity(); ++t) {
+        TextureID id(t);
+        ImageData image;
+        bool alive = Textures::get_image_ID(id) != ImageID::invalid_UID();
+        if (alive) image = convert_image(Textures::get_image_ID(id));
+        else { image.width = image.height = 1; image.format = HIPR_TEXEL_R8; image.pixels.assign(1, 255); }
+        sb.add_texture(image, Textures::get_wrapmode_U(id) == WrapMode::Repeat, Textures::get_wrapmode_V(id) == WrapMode::Repeat,
+                       Textures::get_magnification_filter(id) == MagnificationFilter::Linear, Textures::get_minification_filter(id) != MinificationFilter::None);
+    }
+    std::vector<bool> material_alive(Materials::capacity(), false);
+    for (MaterialID id : Materials::get_iterable()) material_alive[id] = true;
+    for (unsigned int m = 1; m < Materials::capacity(); ++m) sb.add_material(material_alive[m] ? upload_material(MaterialID(m)) : HiprMaterial{});
+
+    // Meshes are added once and shared by the models that reference them (load_mesh, OR/Renderer.cpp:92-136).
+    std::map<unsigned int, uint32_t> mesh_index;
+    for (MeshModelID model_ID : MeshModels::get_iterable()) {
+        MeshModel model = model_ID;
+        Mesh mesh = model.get_mesh();
+        auto it = mesh_index.find(mesh.get_ID());
+        if (it == mesh_index.end()) {
+            MeshData data;
+            const unsigned int vertex_count = mesh.get_vertex_count(), primitive_count = mesh.get_primitive_count();
+            data.positions.assign(mesh.get_positions(), mesh.get_positions() + vertex_count);
+            if (mesh.get_normals()) data.normals.assign(mesh.get_normals(), mesh.get_normals() + vertex_count);
+            if (mesh.get_texcoords()) data.texcoords.assign(mesh.get_texcoords(), mesh.get_texcoords() + vertex_count);
+            if (mesh.get_tint_and_roughness()) {
+                data.tints.resize(vertex_count);
+                std::memcpy(data.tints.data(), mesh.get_tint_and_roughness(), vertex_count * 4);
+            }
+            if (mesh.get_emission()) data.emission.assign(mesh.get_emission(), mesh.get_emission() + vertex_count);
+            data.primitives.assign(mesh.get_primitives(), mesh.get_primitives() + primitive_count);
+            it = mesh_index.emplace(mesh.get_ID(), sb.add_mesh(std::move(data))).first;
+        }
+        // create_model: InstanceID = (MeshModel << 30) | model index, material_index = MaterialID index (OR/Renderer.cpp:138-159)
+        sb.add_model(it->second, model.get_material().get_ID().get_index(), model.get_scene_node().get_global_transform(), model_ID.get_index());
+    }
+
+    // Dense light array in ID order (light_creation, OR/Renderer.cpp:855-902).
+    for (LightSourceID light_ID : LightSources::get_iterable()) {
+        Transform t = SceneNodes::get_global_transform(LightSources::get_node_ID(light_ID));
+        RGB power = LightSources::get_power(light_ID);
+        switch (LightSources::get_type(light_ID)) {
+        case LightSources::Type::Sphere: sb.add_light(SceneBuilder::sphere_light(t.translation, power, LightSources::get_radius(light_ID))); break;
+        case LightSources::Type::Spot:
+            sb.add_light(SceneBuilder::spot_light(t.translation, t.rotation.forward(), power, LightSources::get_radius(light_ID), LightSources::get_cos_angle(light_ID)));
+            break;
+        case LightSources::Type::Directional: sb.add_light(SceneBuilder::directional_light(t.rotation.forward(), power)); break;
+        }
+    }
+    sb.finalize();
+}
+
+
+struct Renderer::Implementation {
+    int device_ID = -1;
+    Core::RendererID owning_renderer_ID;
+    std::vector<float> tables[5];
+
+    struct CameraState {
+        HiprContext* context = nullptr;   // one C-ABI context (accumulation buffer + queues) per camera
+        Vector2i frame_size = {0, 0};
+        bool initialized = false;
+        unsigned int accumulations = 0, max_accumulation_count = UINT_MAX, max_bounce_count = 4;   // OR/Renderer.cpp:211-221
+        Matrix4x4f inverse_view_projection_matrix = Matrix4x4f::identity();
+        Backend backend = Backend::None;
+        bool scene_uploaded = false;
+    };
+    std::vector<CameraState> per_camera_state = std::vector<CameraState>(1);
+    AIDenoiserFlags AI_denoiser_flags = AIDenoiserFlag::Default;
+    PathRegularizationSettings path_regularization = {0.5f, 0.0f};   // OR/Renderer.cpp:482-483
+    HiprSceneState scene_state = {{0, 0, 0}, 3};                     // next_event_sample_count = 3, OR/Renderer.cpp:479
+    std::unique_ptr<SceneBuilder> scene;
+
+    bool is_valid() const { return device_ID >= 0; }
+
+    ~Implementation() {
+        for (CameraState& c : per_camera_state)
+            if (c.context) hipr_destroy(c.context);
+    }
+
+    bool conditional_per_camera_state_resize(unsigned int camera_ID) {
+        if (per_camera_state.size() <= camera_ID) { per_camera_state.resize(std::max<size_t>(Cameras::capacity(), camera_ID + 1)); return true; }
+        return false;
+    }
+
+    bool load_tables(const std::filesystem::path& data_directory) {
+        std::ifstream f(data_directory / "HIPRenderer" / "shading_tables.bin", std::ios::binary);
+        if (!f) return false;
+        char magic[8];
+        uint32_t counts[5];
+        f.read(magic, 8);
+        f.read(reinterpret_cast<char*>(counts), sizeof(counts));
+        if (!f || std::memcmp(magic, "HIPRTBL1", 8) != 0) return false;
+        const uint32_t expected[5] = {1024, 1024, 8192, 8192, 1024};
+        for (int i = 0; i < 5; ++i) {
+            if (counts[i] != expected[i]) return false;
+            tables[i].resize(counts[i]);
+            f.read(reinterpret_cast<char*>(tables[i].data()), counts[i] * sizeof(float));
+        }
+        return bool(f);
+    }
+
+    HiprContext* create_context() {
+        HiprContext* ctx = nullptr;
+        if (hipr_create(device_ID, &ctx) != HIPR_OK) return nullptr;
+        HiprTables t = {tables[0].data(), tables[1].data(), tables[2].data(), tables[3].data(), tables[4].data()};
+        if (hipr_upload_tables(ctx, &t) != HIPR_OK) { hipr_destroy(ctx); return nullptr; }
+        return ctx;
+    }
+
+    void rebuild_scene() {
+        scene.reset(new SceneBuilder());
+        flatten_bifrost_scene(*scene);
+        for (CameraState& c : per_camera_state) c.scene_uploaded = false;
+    }
+
+    bool upload_scene_to(CameraState& c) {
+        if (!scene) rebuild_scene();
+        if (hipr_upload_scene(c.context, &scene->desc()) != HIPR_OK) return false;
+        c.scene_uploaded = true;
+        return true;
+    }
+
+    // ---- handle_updates -----------------------------------------------------------------------------------------------
+    void handle_updates() {
+        bool should_reset_accumulations = false, scene_dirty = false;
+
+        for (CameraID cam_ID : Cameras::get_changed_cameras()) {   // OR/Renderer.cpp:581-619
+            auto changes = Cameras::get_changes(cam_ID);
+            if (changes.contains(Cameras::Change::Destroyed)) {
+                if (cam_ID < per_camera_state.size()) {
+                    if (per_camera_state[cam_ID].context) hipr_destroy(per_camera_state[cam_ID].context);
+                    per_camera_state[cam_ID] = CameraState();
+                }
+                continue;
+            }
+            bool camera_initialized = per_camera_state.size() > cam_ID && per_camera_state[cam_ID].initialized;
+            bool uses_this_renderer = owning_renderer_ID == Cameras::get_renderer_ID(cam_ID);
+            bool create = uses_this_renderer && changes.is_set(Cameras::Change::Created);
+            bool switch_to = uses_this_renderer && changes.is_set(Cameras::Change::Renderer);
+            if (!camera_initialized && (create || switch_to)) {
+                conditional_per_camera_state_resize(cam_ID);
+                CameraState& state = per_camera_state[cam_ID];
+                state.initialized = true;
+                state.accumulations = 0;
+                state.frame_size = {0, 0};
+                if (state.backend == Backend::None) state.backend = Backend::PathTracing;   // preserve a backend set before handle_updates
+            }
+        }
+
+        for (MeshID mesh_ID : Meshes::get_changed_meshes())
+            if (Meshes::get_changes(mesh_ID).any_set(Meshes::Change::Created, Meshes::Change::Destroyed)) scene_dirty = true;
+        if (!Images::get_changed_images().is_empty() || !Textures::get_changed_textures().is_empty()) scene_dirty = true;
+
+        for (MaterialID material_ID : Materials::get_changed_materials()) {   // OR/Renderer.cpp:753-850
+            auto changes = Materials::get_changes(material_ID);
+            if (changes.any_set(Materials::Change::Created, Materials::Change::Updated, Materials::Change::ShadingModel)) { scene_dirty = true; should_reset_accumulations = true; }
+        }
+        if (!LightSources::get_changed_lights().is_empty()) { scene_dirty = true; should_reset_accumulations = true; }   // :852-1008
+
+        for (SceneNodeID node_ID : SceneNodes::get_changed_nodes()) {   // :1010-1041, only nodes that carry renderables or lights matter
+            if (!SceneNodes::get_changes(node_ID).contains(SceneNodes::Change::Transform)) continue;
+            bool used = false;
+            for (MeshModelID m : MeshModels::get_iterable()) used |= MeshModels::get_scene_node_ID(m) == node_ID;
+            for (LightSourceID l : LightSources::get_iterable()) used |= LightSources::get_node_ID(l) == node_ID;
+            if (used) { scene_dirty = true; should_reset_accumulations = true; }
+        }
+        for (MeshModelID model_ID : MeshModels::get_changed_models())   // :1043-1110
+            if (MeshModels::get_changes(model_ID).any_set(MeshModels::Change::Created, MeshModels::Change::Destroyed, MeshModels::Change::Material)) {
+                scene_dirty = true;
+                should_reset_accumulations = true;
+            }
+
+        for (SceneRootID scene_ID : SceneRoots::get_changed_scenes()) {   // :1112-1200
+            auto changes = SceneRoots::get_changes(scene_ID);
+            if (changes.contains(SceneRoots::Change::Destroyed)) {
+                scene_state.environment_tint[0] = scene_state.environment_tint[1] = scene_state.environment_tint[2] = 0.0f;
+                should_reset_accumulations = true;
+                continue;
+            }
+            if (changes.any_set(SceneRoots::Change::EnvironmentTint, SceneRoots::Change::Created)) {
+                RGB tint = SceneRoots::get_environment_tint(scene_ID);
+                scene_state.environment_tint[0] = tint.r; scene_state.environment_tint[1] = tint.g; scene_state.environment_tint[2] = tint.b;
+                should_reset_accumulations = true;
+            }
+        }
+
+        if (scene_dirty) scene.reset();   // rebuilt lazily by the next render
+        if (scene_dirty)
+            for (CameraState& c : per_camera_state) c.scene_uploaded = false;
+        if (should_reset_accumulations)
+            for (CameraState& c : per_camera_state) c.accumulations = 0;
+    }
+
+    // ---- render -------------------------------------------------------------------------------------------------------
+    bool prepare_camera_state(CameraID camera_ID, Vector2i frame_size, HiprCameraState& out) {   // OR/Renderer.cpp:1207-1248
+        CameraState& state = per_camera_state[camera_ID];
+        if (!state.context) {
+            state.context = create_context();
+            if (!state.context) return false;
+        }
+        if (!state.scene_uploaded && !upload_scene_to(state)) return false;
+        if (frame_size.x != state.frame_size.x || frame_size.y != state.frame_size.y) {
+            HiprFrameDesc frame = {uint32_t(frame_size.x), uint32_t(frame_size.y), 0, 1, 1};
+            if (hipr_set_frame(state.context, &frame) != HIPR_OK) return false;
+            state.frame_size = frame_size;
+            state.accumulations = 0;
+        }
+        Matrix4x4f inverse_projection = Cameras::get_inverse_projection_matrix(camera_ID);
+        Matrix4x4f inverse_view_projection = Cameras::get_inverse_view_projection_matrix(camera_ID);
+        if (state.inverse_view_projection_matrix != inverse_view_projection) state.accumulations = 0;
+        state.inverse_view_projection_matrix = inverse_view_projection;
+
+        out = {};
+        std::memcpy(out.inverse_projection_matrix, inverse_projection.begin(), sizeof(out.inverse_projection_matrix));
+        std::memcpy(out.inverse_view_projection_matrix, inverse_view_projection.begin(), sizeof(out.inverse_view_projection_matrix));
+        Matrix3x3f rotation = to_matrix3x3(Cameras::get_inverse_view_transform(camera_ID).rotation);   // holds view -> world (OR/Renderer.cpp:1238-1239)
+        std::memcpy(out.view_to_world_rotation, rotation.begin(), sizeof(out.view_to_world_rotation));
+        out.accumulations = state.accumulations;
+        out.max_bounce_count = state.max_bounce_count;
+        out.path_regularization_PDF_scale = path_regularization.PDF_scale_at_accumulation(int(state.accumulations));
+        return true;
+    }
+
+    unsigned int render(CameraID camera_ID, void* buffer, unsigned int pitch, Vector2i frame_size) {   // OR/Renderer.cpp:1250-1265
+        conditional_per_camera_state_resize(camera_ID);
+        HiprCameraState camera;
+        if (!prepare_camera_state(camera_ID, frame_size, camera)) return 0;
+        CameraState& state = per_camera_state[camera_ID];
+        if (state.accumulations >= state.max_accumulation_count) return state.accumulations;
+        hipr_set_scene_state(state.context, &scene_state);
+        int entry = entry_of(state.backend);
+        hipr_set_entry_point(state.context, entry < 0 ? HIPR_ENTRY_PATH_TRACING : entry);
+        if (hipr_render_pass(state.context, &camera, buffer, pitch, 1) != HIPR_OK) return state.accumulations;   // launch is blocking in the reference
+        ++state.accumulations;
+        return state.accumulations;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Renderer
+// ------------------------------------------------------------------------------------------------------------------------
+Renderer* Renderer::initialize(int device_ID, const std::filesystem::path& data_directory) {
+    Renderer* r = new Renderer(device_ID, data_directory);
+    if (r->m_impl->is_valid()) return r;
+    delete r;
+    return nullptr;
+}
+
+Renderer::Renderer(int device_ID, const std::filesystem::path& data_directory)
+    : m_renderer_ID(Core::Renderers::create("HIPRenderer")), m_impl(new Implementation()) {
+    m_impl->owning_renderer_ID = m_renderer_ID;
+    if (hipr_device_count() == 0) { fprintf(stderr, "HIPRenderer: no HIP device available.\n"); return; }   // OR/Renderer.cpp:280-281
+    if (!m_impl->load_tables(data_directory)) { fprintf(stderr, "HIPRenderer failed to initialize: cannot read %s/HIPRenderer/shading_tables.bin\n", data_directory.c_str()); return; }
+    m_impl->device_ID = device_ID;
+    HiprContext* probe = m_impl->create_context();   // fail here, like the OptiX context creation would
+    if (!probe) { fprintf(stderr, "HIPRenderer failed to initialize:\n%s\n", hipr_last_error()); m_impl->device_ID = -1; return; }
+    hipr_destroy(probe);
+    printf("HIPRenderer using HIP device %d.\n", device_ID);
+}
+
+Renderer::~Renderer() {
+    Core::Renderers::destroy(m_renderer_ID);
+    delete m_impl;
+}
+
+int Renderer::get_next_event_sample_count(SceneRootID) const { return m_impl->scene_state.next_event_sample_count; }
+void Renderer::set_next_event_sample_count(SceneRootID, int sample_count) {
+    m_impl->scene_state.next_event_sample_count = std::min(sample_count, MAX_RNG_SAMPLE_OFFSETS);   // OR/Renderer.cpp:1390-1392
+}
+
+unsigned int Renderer::get_max_bounce_count(CameraID camera_ID) const { m_impl->conditional_per_camera_state_resize(camera_ID); return m_impl->per_camera_state[camera_ID].max_bounce_count; }
+void Renderer::set_max_bounce_count(CameraID camera_ID, unsigned int bounce_count) { m_impl->conditional_per_camera_state_resize(camera_ID); m_impl->per_camera_state[camera_ID].max_bounce_count = bounce_count; }
+
+unsigned int Renderer::get_max_accumulation_count(CameraID camera_ID) const { m_impl->conditional_per_camera_state_resize(camera_ID); return m_impl->per_camera_state[camera_ID].max_accumulation_count; }
+void Renderer::set_max_accumulation_count(CameraID camera_ID, unsigned int count) { m_impl->conditional_per_camera_state_resize(camera_ID); m_impl->per_camera_state[camera_ID].max_accumulation_count = count; }
+
+Backend Renderer::get_backend(CameraID camera_ID) const { m_impl->conditional_per_camera_state_resize(camera_ID); return m_impl->per_camera_state[camera_ID].backend; }
+
+void Renderer::set_backend(CameraID camera_ID, Backend backend) {   // OR/Renderer.cpp:1417-1455
+    if (backend == Backend::None) return;
+    m_impl->conditional_per_camera_state_resize(camera_ID);
+    auto& state = m_impl->per_camera_state[camera_ID];
+    if (backend == Backend::AIDenoisedPathTracing)
+        printf("HIPRenderer: the AI denoised backend wraps NVIDIA's DL denoiser and is not available; rendering plain path tracing.\n");
+    else if (entry_of(backend) < 0) {
+        printf("HIPRenderer: Backend %u not supported.\n", unsigned(backend));
+        backend = Backend::AlbedoVisualization;
+    }
+    state.backend = backend;
+    state.accumulations = 0u;
+}
+
+PathRegularizationSettings Renderer::get_path_regularization_settings() const { return m_impl->path_regularization; }
+void Renderer::set_path_regularization_settings(PathRegularizationSettings settings) { m_impl->path_regularization = settings; }
+AIDenoiserFlags Renderer::get_AI_denoiser_flags() const { return m_impl->AI_denoiser_flags; }
+void Renderer::set_AI_denoiser_flags(AIDenoiserFlags flags) { m_impl->AI_denoiser_flags = flags; }
+
+void Renderer::handle_updates() { m_impl->handle_updates(); }
+
+unsigned int Renderer::render(CameraID camera_ID, void* half4_device_buffer, unsigned int buffer_pitch, Vector2i frame_size) {
+    return m_impl->render(camera_ID, half4_device_buffer, buffer_pitch, frame_size);
+}
+
+bool Renderer::read_accumulation(std::vector<double>& out_rgba) const {
+    for (auto& state : m_impl->per_camera_state)
+        if (state.context && state.frame_size.x > 0) {
+            out_rgba.resize(size_t(state.frame_size.x) * state.frame_size.y * 4);
+            return hipr_read_accumulation(state.context, out_rgba.data(), out_rgba.size() / 4) == HIPR_OK;
+        }
+    return false;
+}
+
+static float round_through_half(float v) {
+    // The reference reads AOV screenshots back from the half4 output buffer (OR/Renderer.cpp:1317-1329):
+    // round to binary16 (nearest even) and back. Values here are colours in [0, 1] or small positives.
+    uint32_t bits;
+    std::memcpy(&bits, &v, 4);
+    const uint32_t sign = bits & 0x80000000u;
+    bits &= 0x7FFFFFFFu;
+    if (bits >= 0x47800000u) bits = bits > 0x7F800000u ? 0x7FC00000u : 0x7F800000u;   // >= 65536 (or inf / nan) -> inf / nan
+    else if (bits < 0x38800000u) {                                                       // half subnormal: quantum 2^-24
+        float a; std::memcpy(&a, &bits, 4);
+        a = std::nearbyintf(a * 16777216.0f) * (1.0f / 16777216.0f);
+        std::memcpy(&bits, &a, 4);
+    } else {
+        const uint32_t lsb = (bits >> 13) & 1u;
+        bits = (bits + 0x0FFFu + lsb) & ~0x1FFFu;
+        if (bits >= 0x47800000u) bits = 0x7F800000u;
+    }
+    bits |= sign;
+    float out;
+    std::memcpy(&out, &bits, 4);
+    return out;
+}
+
+std::vector<Screenshot> Renderer::request_auxiliary_buffers(CameraID camera_ID, Cameras::ScreenshotContent content_requested, Vector2i frame_size) {
+    typedef Screenshot::Content Content;
+    std::vector<Screenshot> screenshots;
+    const unsigned int supported = unsigned(Content::Depth) | unsigned(Content::Albedo) | unsigned(Content::Tint) | unsigned(Content::Roughness);
+    if ((content_requested.raw() & supported) == 0) return screenshots;
+
+    m_impl->conditional_per_camera_state_resize(camera_ID);
+    HiprCameraState camera;
+    if (!m_impl->prepare_camera_state(camera_ID, frame_size, camera)) return screenshots;
+    auto& state = m_impl->per_camera_state[camera_ID];
+    const unsigned int accumulation_count = std::max(1u, state.accumulations);
+    const int pixel_count = frame_size.x * frame_size.y;
+    hipr_set_scene_state(state.context, &m_impl->scene_state);
+
+    auto render_auxiliary_feature = [&](int entry, std::vector<double>& accumulation) -> bool {
+        if (hipr_use_scratch_accumulation(state.context, 1) != HIPR_OK) return false;
+        hipr_set_entry_point(state.context, entry);
+        bool ok = true;
+        for (camera.accumulations = 0; ok && camera.accumulations < accumulation_count; ++camera.accumulations)
+            ok = hipr_render_pass(state.context, &camera, nullptr, 0, 1) == HIPR_OK;
+        accumulation.resize(size_t(pixel_count) * 4);
+        ok = ok && hipr_read_accumulation(state.context, accumulation.data(), pixel_count) == HIPR_OK;
+        hipr_use_scratch_accumulation(state.context, 0);
+        return ok;
+    };
+    auto unorm8 = [](float v) { v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); return (unsigned char)(v * 255.0f + 0.5f); };
+
+    std::vector<double> acc;
+    if (content_requested.is_set(Content::Depth) && render_auxiliary_feature(HIPR_ENTRY_DEPTH, acc)) {
+        float* pixels = new float[pixel_count];
+        for (int i = 0; i < pixel_count; ++i) pixels[i] = float(acc[4 * i]);
+        Screenshot s; s.width = frame_size.x; s.height = frame_size.y; s.content = Content::Depth; s.format = PixelFormat::Intensity_Float; s.pixels = pixels;
+        screenshots.push_back(s);
+    }
+    auto rgb24_screenshot = [&](Content content, int entry) {
+        if (!content_requested.is_set(content) || !render_auxiliary_feature(entry, acc)) return;
+        unsigned char* pixels = new unsigned char[3 * pixel_count];
+        for (int i = 0; i < pixel_count; ++i)
+            for (int c = 0; c < 3; ++c) pixels[3 * i + c] = unorm8(round_through_half(float(acc[4 * i + c])));
+        Screenshot s; s.width = frame_size.x; s.height = frame_size.y; s.content = content; s.format = PixelFormat::RGB24; s.pixels = pixels;
+        screenshots.push_back(s);
+    };
+    rgb24_screenshot(Content::Albedo, HIPR_ENTRY_ALBEDO);
+    rgb24_screenshot(Content::Tint, HIPR_ENTRY_TINT);
+    if (content_requested.is_set(Content::Roughness) && render_auxiliary_feature(HIPR_ENTRY_ROUGHNESS, acc)) {
+        unsigned char* pixels = new unsigned char[pixel_count];
+        for (int i = 0; i < pixel_count; ++i) pixels[i] = unorm8(round_through_half(float(acc[4 * i])));
+        Screenshot s; s.width = frame_size.x; s.height = frame_size.y; s.content = Content::Roughness; s.format = PixelFormat::Intensity8; s.pixels = pixels;
+        screenshots.push_back(s);
+    }
+    int entry = entry_of(state.backend);
+    hipr_set_entry_point(state.context, entry < 0 ? HIPR_ENTRY_PATH_TRACING : entry);
+    return screenshots;
+}
+
+} // namespace HIPRenderer

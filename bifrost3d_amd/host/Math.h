@@ -16,7 +16,7 @@ namespace Math {
 template <typename T> constexpr T PI() { return T(3.14159265358979323846); }
 
 struct Vector2f { float x, y; };
-struct Vector2i { int x, y; };
+struct Vector2i { int x, y; Vector2i() = default; constexpr Vector2i(int x, int y) : x(x), y(y) {} };
 struct Vector2s { short x, y; };
 struct Vector3ui { unsigned int x, y, z; };
 

@@ -113,7 +113,7 @@ uint32_t SceneBuilder::add_texture(const ImageData& image, bool repeat_u, bool r
     return uint32_t(m_textures.size() - 1);
 }
 
-uint32_t SceneBuilder::add_model(uint32_t mesh, uint32_t material, const Transform& transform) {
+uint32_t SceneBuilder::add_model(uint32_t mesh, uint32_t material, const Transform& transform, uint32_t explicit_model_index) {
     // create_model + transformable_model, OptiXRenderer/Renderer.cpp:138-182
     const MeshRecord& r = m_meshes[mesh];
     HiprInstance inst = {};
@@ -121,7 +121,7 @@ uint32_t SceneBuilder::add_model(uint32_t mesh, uint32_t material, const Transfo
     std::memcpy(inst.object_to_world, m.begin(), sizeof(inst.object_to_world));
     inst.index_offset = r.index_offset;
     inst.vertex_offset = r.vertex_offset;
-    const uint32_t model_index = uint32_t(m_instances.size()) + 1;        // UID index, 0 is invalid
+    const uint32_t model_index = explicit_model_index ? explicit_model_index : uint32_t(m_instances.size()) + 1;   // UID index, 0 is invalid
     inst.instance_id = int32_t((1u << 30) | model_index);                 // InstanceID::make(MeshModel, index)
     inst.material_index = int32_t(material);
     inst.mesh_flags = r.flags;

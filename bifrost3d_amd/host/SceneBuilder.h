@@ -48,7 +48,8 @@ public:
     uint32_t add_mesh(MeshData mesh);                                   // returns mesh index
     uint32_t add_material(const HiprMaterial& material);                // returns material index (0 is the invalid material)
     uint32_t add_texture(const ImageData& image, bool repeat_u, bool repeat_v, bool linear_magnification, bool linear_minification);
-    uint32_t add_model(uint32_t mesh, uint32_t material, const Transform& transform);   // returns mesh model index
+    // model_index: the MeshModel UID index used for InstanceID; 0 = next sequential index. Returns the index used.
+    uint32_t add_model(uint32_t mesh, uint32_t material, const Transform& transform, uint32_t model_index = 0);
     void add_light(const HiprLight& light);
 
     static HiprLight sphere_light(Vector3f position, RGB power, float radius);

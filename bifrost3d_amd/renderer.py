@@ -49,6 +49,12 @@ class Context:
         self._check(self.lib.hipr_set_frame(self.handle, C.byref(f)), "hipr_set_frame")
         self.frame = f
 
+    def set_entry_point(self, entry: int):
+        self._check(self.lib.hipr_set_entry_point(self.handle, entry), "hipr_set_entry_point")
+
+    def use_scratch_accumulation(self, on: bool):
+        self._check(self.lib.hipr_use_scratch_accumulation(self.handle, int(on)), "hipr_use_scratch_accumulation")
+
     def owned_pixel_count(self) -> int:
         n = C.c_uint32()
         self._check(self.lib.hipr_owned_pixel_count(self.handle, C.byref(n)), "hipr_owned_pixel_count")

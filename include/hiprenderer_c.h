@@ -238,6 +238,16 @@ int hipr_upload_tables(HiprContext* context, const HiprTables* tables);
 int hipr_upload_scene(HiprContext* context, const HiprSceneDesc* scene);
 int hipr_set_scene_state(HiprContext* context, const HiprSceneState* state);
 
+/* Entry points, numbered like OR/Types.h:33-44. set_backend() of the host renderer maps Backend values onto them
+ * (OR/Renderer.cpp:1417-1455). The two AI denoiser entries (1, 2) wrap NVIDIA's proprietary DL denoiser and are not
+ * provided: hipr_set_entry_point returns HIPR_ERROR_UNSUPPORTED for them. */
+enum { HIPR_ENTRY_PATH_TRACING = 0, HIPR_ENTRY_DEPTH = 3, HIPR_ENTRY_ALBEDO = 4, HIPR_ENTRY_TINT = 5, HIPR_ENTRY_ROUGHNESS = 6,
+       HIPR_ENTRY_SHADING_NORMAL = 7, HIPR_ENTRY_PRIMITIVE_ID = 8 };
+int hipr_set_entry_point(HiprContext* context, int entry);
+/* request_auxiliary_buffers (OR/Renderer.cpp:1267-1358) renders AOVs into scratch buffers so the camera's accumulation
+ * survives: enable != 0 redirects hipr_render_pass / hipr_read_accumulation to a zeroed scratch accumulation buffer. */
+int hipr_use_scratch_accumulation(HiprContext* context, int enable);
+
 /* (Re)allocates the f64 accumulation buffer and the wavefront queues for the owned tiles;
  * resets nothing else. Replaces accumulation_buffer->setSize (OR/Renderer.cpp:1215-1219). */
 int hipr_set_frame(HiprContext* context, const HiprFrameDesc* frame);

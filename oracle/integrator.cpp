@@ -405,6 +405,12 @@ struct Payload {
     LightSample light_sample = LightSample::none();
     float3 light_sample_origin = {0, 0, 0};
     uint32_t pixel_hash = 0, accumulation = 0;
+    // recorded at the accepted hit for the AOV entry points (MonteCarlo.cu:166-179)
+    int material_index = 0;
+    float2 texcoord = {0, 0};
+    float4 tint_and_roughness_scale = {1, 1, 1, 1};   // after the float_to_unorm8 round trip
+    float3 shading_normal = {0, 0, 0};
+    int instance_id = 0, primitive_index = 0;
     float4 sample4f(uint32_t d) const { return rng::sample4f(accumulation, pixel_hash, 8u * bounces + d); }
 };
 
@@ -504,11 +510,21 @@ static bool closest_hit_program(const HiprSceneDesc& scene, const HiprSceneState
     }
 
     payload.last_triangle = hit.id;
+    payload.material_index = inst.material_index;
+    payload.texcoord = a.texcoord;
+    {
+        auto q8 = [](float v) { return float((unsigned char)(saturate(v) * 255.0f + 0.5f)) * (1.0f / 255.0f); };
+        const float4 t = a.tint_and_roughness_scale;
+        payload.tint_and_roughness_scale = {q8(t.x), q8(t.y), q8(t.z), q8(t.w)};
+    }
+    payload.instance_id = inst.instance_id;
+    payload.primitive_index = int(tri.primitive_index);
     // float_to_unorm8 round trip of the vertex tint scale (MonteCarlo.cu:170 stores it, AOVs read it);
     // the shading model itself receives the unquantised attribute (MonteCarlo.cu:242,252,264).
     geometric_normal = hit_from_front ? geometric_normal : -geometric_normal;
     float3 shading_normal = hit_from_front ? a.shading_normal : -a.shading_normal;
     shading_normal = fix_backfacing_shading_normal(-ray_direction, shading_normal, 0.002f);
+    payload.shading_normal = shading_normal;
     const TBN tbn(shading_normal);
     float3 wo = tbn.to_local(-ray_direction);
     float cos_theta = (hit_from_front || thin_walled) ? wo.z : -wo.z;
@@ -582,6 +598,72 @@ float3 path_trace_pixel(const HiprSceneDesc& scene, const HiprSceneState& state,
     } while (payload.bounces <= cam.max_bounce_count && !is_black(payload.throughput));
 
     return payload.radiance;
+}
+
+// ---------------------------------------------------------------------------------------------
+// AOV entry points: depth_RPG and process_material_intersection (ORS/SimpleRGPs.cu:227-340).
+// ---------------------------------------------------------------------------------------------
+static inline uint32_t compact_by_2(uint32_t v) {
+    v &= 0x09249249u;
+    v = (v ^ (v >> 2)) & 0x030c30c3u;
+    v = (v ^ (v >> 4)) & 0x0300f00fu;
+    v = (v ^ (v >> 8)) & 0xff0000ffu;
+    v = (v ^ (v >> 16)) & 0x000003ffu;
+    return v;
+}
+
+float3 aov_pixel(const HiprSceneDesc& scene, const HiprSceneState& state, const HiprCameraState& cam, const float4* offsets, int x, int y,
+                 int width, int height, uint32_t accumulation, int entry, const RenderSettings& settings) {
+    Payload payload;
+    payload.pixel_hash = rng::pcg2d(uint32_t(x), uint32_t(y)).x;
+    payload.accumulation = accumulation;
+    generate_camera_ray(cam, x, y, width, height, accumulation, payload.position, payload.direction);
+    float depth = 0.0f;
+    float3 last_ray_direction = payload.direction;
+    do {
+        last_ray_direction = payload.direction;
+        float3 last_position = payload.position;
+        Ray ray = {payload.position, payload.ray_min_t, payload.direction, INFINITY};
+        Hit hit = settings.use_bvh ? closest_hit_bvh(scene, ray, payload.last_triangle, nullptr) : closest_hit_bruteforce(scene, ray, payload.last_triangle);
+        intersect_lights(scene, ray, hit);
+        if (hit.id == HIT_MISS) {
+            payload.throughput = {0, 0, 0};
+            payload.position = 1e30f * payload.direction;
+        } else if (hit.id & HIT_LIGHT_BIT) {
+            payload.throughput = {0, 0, 0};
+            payload.position = ray.direction * hit.t + ray.origin;
+        } else
+            closest_hit_program(scene, state, cam, offsets, payload, hit, ray.direction);
+        depth += length(last_position - payload.position);
+    } while (payload.material_index == 0 && !is_black(payload.throughput));
+
+    if (entry == HIPR_ENTRY_DEPTH)
+        return make_float3(depth);
+    if (payload.material_index == 0)
+        return {0, 0, 0};
+    const HiprMaterial& mp = scene.materials[payload.material_index];
+    const float4 scale = payload.tint_and_roughness_scale;
+    const float4 tr = material_tint_roughness(scene, mp, payload.texcoord);
+    switch (entry) {
+    case HIPR_ENTRY_TINT: return make_float3(tr) * make_float3(scale);
+    case HIPR_ENTRY_ROUGHNESS: return make_float3(tr.w * scale.w);
+    case HIPR_ENTRY_SHADING_NORMAL: return payload.shading_normal * 0.5f + 0.5f;
+    case HIPR_ENTRY_PRIMITIVE_ID: {
+        uint32_t instance_encoding = uint32_t(payload.instance_id) & 0x3FFFFFFu;
+        uint32_t primitive_encoding = rng::reverse_bits(uint32_t(payload.primitive_index) + 1u) >> 2;
+        uint32_t code = instance_encoding ^ primitive_encoding;
+        return make_float3(float(compact_by_2(code >> 2)), float(compact_by_2(code >> 1)), float(compact_by_2(code))) / 1023.0f;
+    }
+    case HIPR_ENTRY_ALBEDO: {
+        float abs_cos_theta = fabsf(dot(last_ray_direction, payload.shading_normal));
+        float4 trq = tr * scale;
+        MaterialInputs in = {make_float3(trq), trq.w, mp.specularity, material_metallic(scene, mp, payload.texcoord), unorm16(mp.coat), unorm16(mp.coat_roughness)};
+        if (mp.shading_model == HIPR_SHADING_DIFFUSE) return in.tint;
+        if (mp.shading_model == HIPR_SHADING_TRANSMISSIVE) return TransmissiveShading(in, abs_cos_theta).rho(abs_cos_theta);
+        return DefaultShading(in, abs_cos_theta).rho(abs_cos_theta);
+    }
+    }
+    return {0, 0, 0};
 }
 
 } // namespace oracle

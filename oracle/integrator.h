@@ -64,4 +64,8 @@ float3 path_trace_pixel(const HiprSceneDesc& scene, const HiprSceneState& state,
                         const float4* sample_offsets, int x, int y, int width, int height, uint32_t accumulation,
                         const RenderSettings& settings, RenderCounters* counters);
 
+// One pixel-sample of an AOV entry point (HIPR_ENTRY_DEPTH ... HIPR_ENTRY_PRIMITIVE_ID), ORS/SimpleRGPs.cu:227-340.
+float3 aov_pixel(const HiprSceneDesc& scene, const HiprSceneState& state, const HiprCameraState& cam, const float4* sample_offsets, int x, int y,
+                 int width, int height, uint32_t accumulation, int entry, const RenderSettings& settings);
+
 } // namespace oracle

@@ -309,8 +309,8 @@ void oracle_trace_shadow(const HiprSceneDesc* scene, const float* rays, uint32_t
 // Renders `accumulation_count` accumulations starting at cam->accumulations into accum_rgba (double4 per
 // pixel, row-major, row 0 = bottom), running mean exactly as accumulate<> (ORS/SimpleRGPs.cu:74-107).
 // counters9 follows HiprCounters (iterations unused). Returns elapsed seconds.
-double oracle_render(const HiprSceneDesc* scene, const HiprSceneState* state, const HiprCameraState* cam, int width, int height,
-                     uint32_t accumulation_count, int use_bvh, double* accum_rgba, uint64_t* counters9) {
+double oracle_render_entry(const HiprSceneDesc* scene, const HiprSceneState* state, const HiprCameraState* cam, int width, int height,
+                           uint32_t accumulation_count, int use_bvh, int entry, double* accum_rgba, uint64_t* counters9) {
     std::vector<float4> offsets(256);
     for (int i = 0; i < 256; ++i) offsets[i] = rng::sample_offset(i);
     RenderSettings settings;
@@ -327,7 +327,8 @@ double oracle_render(const HiprSceneDesc* scene, const HiprSceneState* state, co
 #pragma omp for schedule(dynamic, 4)
             for (int y = 0; y < height; ++y)
                 for (int x = 0; x < width; ++x) {
-                    float3 r = path_trace_pixel(*scene, *state, *cam, offsets.data(), x, y, width, height, accumulation, settings, &local);
+                    float3 r = entry == HIPR_ENTRY_PATH_TRACING ? path_trace_pixel(*scene, *state, *cam, offsets.data(), x, y, width, height, accumulation, settings, &local)
+                                                                : aov_pixel(*scene, *state, *cam, offsets.data(), x, y, width, height, accumulation, entry, settings);
                     double* px = accum_rgba + 4 * (size_t(y) * width + x);
                     if (accumulation != 0) {
                         double t = 1.0 / (accumulation + 1.0);
@@ -357,6 +358,11 @@ double oracle_render(const HiprSceneDesc* scene, const HiprSceneState* state, co
 #else
     return 0.0;
 #endif
+}
+
+double oracle_render(const HiprSceneDesc* scene, const HiprSceneState* state, const HiprCameraState* cam, int width, int height,
+                     uint32_t accumulation_count, int use_bvh, double* accum_rgba, uint64_t* counters9) {
+    return oracle_render_entry(scene, state, cam, width, height, accumulation_count, use_bvh, HIPR_ENTRY_PATH_TRACING, accum_rgba, counters9);
 }
 
 int oracle_max_threads(void) {

@@ -1,0 +1,451 @@
+// RendererTest.cpp -- HIPRenderer::Renderer tests, written against the Bifrost mirror the way the reference's
+// renderer tests are written against Bifrost (extensions/OptiXRenderer/tests/OptiXRendererTests/RendererTest.h):
+// same fixture helpers, same three test cases with the same tolerances, plus cases for the accumulation
+// rules of OptiXRenderer/Renderer.cpp:1207-1265 and the scene flattening.
+//
+// Built by bifrost3d_amd/Makefile into tests/native/renderer_test; run by tests/test_native_renderer.py
+// (`--cpu` here in the build container, `--gpu` on the MI355X box).
+#include "MiniTest.h"
+
+#include "../../bifrost3d_amd/host/HIPRenderer/Renderer.h"
+#include "../../bifrost3d_amd/host/SceneBuilder.h"
+#include "../../bifrost3d_amd/host/Scenes.h"
+#include "../../include/hiprenderer_c.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstdlib>
+#include <filesystem>
+
+using namespace Bifrost;
+
+namespace HIPRenderer {
+
+struct half4 { _Float16 r, g, b, a; };
+
+static std::filesystem::path get_data_directory() {   // <repo>/bifrost3d_amd/data, found from the location of this executable
+    if (const char* dir = std::getenv("HIPR_DATA_DIRECTORY")) return dir;
+    std::error_code error;
+    std::filesystem::path executable = std::filesystem::read_symlink("/proc/self/exe", error);
+    return executable.parent_path() / ".." / ".." / "bifrost3d_amd" / "data";
+}
+
+class RendererFixture {
+public:
+    Renderer* renderer = nullptr;
+    bool usable() const { return renderer != nullptr; }
+
+    void SetUp() {
+        deallocate_all();
+        renderer = Renderer::initialize(0, get_data_directory());
+    }
+    void TearDown() {
+        delete renderer;
+        renderer = nullptr;
+        deallocate_all();
+    }
+
+    Scene::CameraID create_ortho_camera(Math::Vector2i size, Math::RGB environment_tint = Math::RGB(1, 1, 1)) {
+        Scene::SceneRoot scene = Scene::SceneRoot("Test", environment_tint);
+        float depth = 1000;
+        Math::Matrix4x4f orthographic_matrix, inverse_orthographic_matrix;
+        Scene::CameraUtils::compute_orthographic_projection(float(size.x), float(size.y), depth, orthographic_matrix, inverse_orthographic_matrix);
+        Scene::CameraID camera_ID = Scene::Cameras::create("Test", scene.get_ID(), orthographic_matrix, inverse_orthographic_matrix);
+        if (renderer) Scene::Cameras::set_renderer_ID(camera_ID, renderer->get_renderer_ID());
+        return camera_ID;
+    }
+
+    // An orthographic camera and a quad that fully covers it; vertex tints encode the position in the frame.
+    Scene::CameraID create_ortho_camera_with_quad_scene(Math::Vector2i size, Math::RGB environment_tint = Math::RGB(1, 1, 1)) {
+        using namespace Bifrost::Assets;
+        using namespace Bifrost::Scene;
+
+        CameraID camera_ID = create_ortho_camera(size, environment_tint);
+        SceneRoot root = Cameras::get_scene_ID(camera_ID);
+
+        Mesh mesh = Mesh("Triangle", 2, 4, {MeshFlag::Position, MeshFlag::TintAndRoughness});
+        mesh.get_primitives()[0] = {0, 1, 2};
+        mesh.get_primitives()[1] = {1, 2, 3};
+        mesh.get_positions()[0] = {-0.5f * size.x, -0.5f * size.y, 1.0f};
+        mesh.get_positions()[1] = {-0.5f * size.x, 0.5f * size.y, 1.0f};
+        mesh.get_positions()[2] = {0.5f * size.x, -0.5f * size.y, 1.0f};
+        mesh.get_positions()[3] = {0.5f * size.x, 0.5f * size.y, 1.0f};
+        mesh.get_tint_and_roughness()[0] = {0, 0, 255, 0};
+        mesh.get_tint_and_roughness()[1] = {0, 255, 255, 0};
+        mesh.get_tint_and_roughness()[2] = {255, 0, 255, 0};
+        mesh.get_tint_and_roughness()[3] = {255, 255, 255, 0};
+
+        auto material = Material::create_dielectric("Material", Math::RGB::white(), 0.0f);
+        material.set_flags(MaterialFlag::ThinWalled);
+        material.set_shading_model(ShadingModel::Diffuse);
+
+        SceneNode node = SceneNode("Node");
+        node.set_parent(root.get_root_node());
+        MeshModel(node, mesh, material);
+        return camera_ID;
+    }
+
+    // The render target the presentation layer would own: half4 pixels in device memory.
+    struct RenderTarget {
+        half4* device = nullptr;
+        Math::Vector2i size;
+        RenderTarget(Math::Vector2i size) : size(size) {
+            if (hipMalloc(reinterpret_cast<void**>(&device), size_t(size.x) * size.y * sizeof(half4)) != hipSuccess) device = nullptr;
+        }
+        ~RenderTarget() { if (device) (void)hipFree(device); }
+        std::vector<half4> map() const {
+            std::vector<half4> pixels(size_t(size.x) * size.y);
+            (void)hipMemcpy(pixels.data(), device, pixels.size() * sizeof(half4), hipMemcpyDeviceToHost);
+            return pixels;
+        }
+    };
+
+    void render(Scene::CameraID camera_ID, Math::Vector2i size, Backend backend, std::function<void(half4*)> render_callback) {
+        renderer->set_backend(camera_ID, backend);
+        renderer->handle_updates();
+        RenderTarget render_target(size);
+        renderer->render(camera_ID, render_target.device, size.x, size);
+        std::vector<half4> frame = render_target.map();
+        render_callback(frame.data());
+    }
+
+    void render(Scene::CameraID camera_ID, Math::Vector2i size, std::function<void(half4*)> render_callback) {
+        render(camera_ID, size, Backend::PathTracing, render_callback);
+    }
+
+    Scene::Screenshot render_auxiliary(Scene::CameraID camera_ID, Scene::Screenshot::Content content, Math::Vector2i size) {
+        renderer->handle_updates();
+        auto images = renderer->request_auxiliary_buffers(camera_ID, content, size);
+        return images.empty() ? Scene::Screenshot() : images[0];
+    }
+};
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The reference's three renderer tests (RendererTest.h:147-201)
+// ------------------------------------------------------------------------------------------------------------------------
+GPU_TEST_F(RendererFixture, render_background_color) {
+    Math::RGB background_color = {0.1f, 0.5f, 2.0f};
+    auto frame_size = Math::Vector2i(16, 12);
+    auto camera_ID = create_ortho_camera(frame_size, background_color);
+
+    render(camera_ID, frame_size, [=](half4* pixels) {
+        for (int i = 0; i < frame_size.x * frame_size.y; ++i) {
+            EXPECT_FLOAT_EQ_EPS(background_color.r, float(pixels[i].r), 1e-4f);
+            EXPECT_FLOAT_EQ_EPS(background_color.g, float(pixels[i].g), 1e-4f);
+            EXPECT_FLOAT_EQ_EPS(background_color.b, float(pixels[i].b), 1e-4f);
+        }
+    });
+}
+
+GPU_TEST_F(RendererFixture, render_tint) {
+    auto frame_size = Math::Vector2i(4, 3);
+    auto camera_ID = create_ortho_camera_with_quad_scene(frame_size);
+
+    render(camera_ID, frame_size, Backend::TintVisualization, [=](half4* pixels) {
+        for (int y = 0; y < frame_size.y; ++y) {
+            float green_tint = (0.5f + y) / frame_size.y;
+            for (int x = 0; x < frame_size.x; ++x) {
+                float red_tint = (0.5f + x) / frame_size.x;
+                half4 pixel = pixels[x + y * frame_size.x];
+                EXPECT_FLOAT_EQ_EPS(red_tint, float(pixel.r), 0.003f);
+                EXPECT_FLOAT_EQ_EPS(green_tint, float(pixel.g), 0.003f);
+            }
+        }
+    });
+}
+
+GPU_TEST_F(RendererFixture, render_auxiliary_tint) {
+    auto frame_size = Math::Vector2i(4, 3);
+    auto camera_ID = create_ortho_camera_with_quad_scene(frame_size);
+
+    auto tint_image = render_auxiliary(camera_ID, Scene::Screenshot::Content::Tint, frame_size);
+    EXPECT_TRUE(tint_image.pixels != nullptr);
+    if (!tint_image.pixels) return;
+    EXPECT_TRUE(tint_image.format == Assets::PixelFormat::RGB24);
+    const unsigned char* rgb = static_cast<const unsigned char*>(tint_image.pixels);
+
+    float unorm8_eps = (1.0f / 255.0f) * 1.001f;   // UNorm8::max_precision() * 1.001f
+    for (int y = 0; y < frame_size.y; ++y) {
+        float green_tint = (0.5f + y) / frame_size.y;
+        for (int x = 0; x < frame_size.x; ++x) {
+            float red_tint = (0.5f + x) / frame_size.x;
+            const unsigned char* pixel = rgb + 3 * (x + y * frame_size.x);
+            EXPECT_FLOAT_EQ_EPS(red_tint, pixel[0] / 255.0f, unorm8_eps);
+            EXPECT_FLOAT_EQ_EPS(green_tint, pixel[1] / 255.0f, unorm8_eps);
+        }
+    }
+    delete[] static_cast<unsigned char*>(tint_image.pixels);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Accumulation rules (OptiXRenderer/Renderer.cpp:1207-1265, 753-850, 1112-1200)
+// ------------------------------------------------------------------------------------------------------------------------
+GPU_TEST_F(RendererFixture, render_returns_the_iteration_count) {
+    auto frame_size = Math::Vector2i(8, 8);
+    auto camera_ID = create_ortho_camera_with_quad_scene(frame_size);
+    renderer->handle_updates();
+    reset_all_change_notifications();
+    RenderTarget target(frame_size);
+    EXPECT_EQ(1u, renderer->render(camera_ID, target.device, frame_size.x, frame_size));
+    EXPECT_EQ(2u, renderer->render(camera_ID, target.device, frame_size.x, frame_size));
+    EXPECT_EQ(3u, renderer->render(camera_ID, target.device, frame_size.x, frame_size));
+
+    // The accumulation cap stops rendering (Renderer.cpp:1256-1257).
+    renderer->set_max_accumulation_count(camera_ID, 3);
+    EXPECT_EQ(3u, renderer->render(camera_ID, target.device, frame_size.x, frame_size));
+    renderer->set_max_accumulation_count(camera_ID, 100);
+
+    // A frame size change restarts (Renderer.cpp:1215-1222), and so does switching the backend (:1417-1455).
+    auto smaller = Math::Vector2i(4, 4);
+    EXPECT_EQ(1u, renderer->render(camera_ID, target.device, frame_size.x, smaller));
+    EXPECT_EQ(2u, renderer->render(camera_ID, target.device, frame_size.x, smaller));
+    renderer->set_backend(camera_ID, Backend::AlbedoVisualization);
+    EXPECT_EQ(1u, renderer->render(camera_ID, target.device, frame_size.x, smaller));
+}
+
+GPU_TEST_F(RendererFixture, scene_changes_restart_accumulation) {
+    auto frame_size = Math::Vector2i(8, 8);
+    auto camera_ID = create_ortho_camera_with_quad_scene(frame_size);
+    Scene::SceneRoot scene = Scene::Cameras::get_scene_ID(camera_ID);
+    RenderTarget target(frame_size);
+    auto tick = [&]() {   // what the engine does per frame: renderers pull, render, then the change sets are cleared
+        renderer->handle_updates();
+        unsigned int iteration = renderer->render(camera_ID, target.device, frame_size.x, frame_size);
+        reset_all_change_notifications();
+        return iteration;
+    };
+    EXPECT_EQ(1u, tick());
+    EXPECT_EQ(2u, tick());
+
+    scene.set_environment_tint(Math::RGB(0.5f, 0.25f, 0.125f));
+    EXPECT_EQ(1u, tick());
+    EXPECT_EQ(2u, tick());
+
+    Assets::Material material = *Assets::Materials::get_iterable().begin();
+    material.set_tint(Math::RGB(0.5f));
+    EXPECT_EQ(1u, tick());
+    EXPECT_EQ(2u, tick());
+
+    // Moving the camera restarts too (the inverse view-projection matrix is compared, Renderer.cpp:1226-1229).
+    Scene::Cameras::set_transform(camera_ID, Math::Transform(Math::Vector3f(0.25f, 0.0f, 0.0f)));
+    EXPECT_EQ(1u, tick());
+
+    // The tinted material shows up in the tint AOV after the rebuild.
+    render(camera_ID, frame_size, Backend::TintVisualization, [=](half4* pixels) {
+        half4 top_right = pixels[frame_size.x * frame_size.y - 1];
+        EXPECT_FLOAT_EQ_EPS(0.5f * (0.5f + 7 + 0.25f) / 8, float(top_right.r), 0.004f);
+    });
+}
+
+GPU_TEST_F(RendererFixture, render_target_pitch_is_respected) {
+    // The adaptor's buffer may be wider than the frame (Adaptor.cpp:141-153): rows land `pitch` pixels apart.
+    auto frame_size = Math::Vector2i(5, 3);
+    const int pitch = 8;
+    Math::RGB background = {0.25f, 0.5f, 0.75f};
+    auto camera_ID = create_ortho_camera(frame_size, background);
+    renderer->handle_updates();
+    RenderTarget target(Math::Vector2i(pitch, frame_size.y));
+    (void)hipMemset(target.device, 0, size_t(pitch) * frame_size.y * sizeof(half4));
+    renderer->render(camera_ID, target.device, pitch, frame_size);
+    auto pixels = target.map();
+    for (int y = 0; y < frame_size.y; ++y)
+        for (int x = 0; x < pitch; ++x) {
+            float expected = x < frame_size.x ? background.g : 0.0f;
+            EXPECT_FLOAT_EQ_EPS(expected, float(pixels[x + y * pitch].g), 1e-3f);
+        }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Scene flattening: the Bifrost managers and the SceneBuilder route give the same HiprSceneDesc.
+// ------------------------------------------------------------------------------------------------------------------------
+static const Math::RGB iron_tint = Math::RGB(0.560f, 0.570f, 0.580f), copper_tint = Math::RGB(0.955f, 0.637f, 0.538f);
+
+// The SimpleViewer Cornell box (apps/SimpleViewer/Scenes/CornellBox.h:22-122) through the Bifrost mirror.
+static void create_cornell_box(Scene::CameraID camera_ID, Scene::SceneNode root_node) {
+    using namespace Bifrost::Assets;
+    using namespace Bifrost::Math;
+    using namespace Bifrost::Scene;
+
+    auto thin_dielectric = [](const char* name, RGB tint) {
+        Materials::Data data = Materials::Data::create_dielectric(tint, 1.0f, 0.02f);
+        data.flags = MaterialFlag::ThinWalled;
+        return Material(Materials::create(name, data));
+    };
+    Material white = thin_dielectric("White", RGB(0.98f));
+    Material red = thin_dielectric("Red", RGB(0.98f, 0.02f, 0.02f));
+    Material green = thin_dielectric("Green", RGB(0.02f, 0.98f, 0.02f));
+    Material iron = Material::create_metal("Iron", iron_tint, 0.4f);
+    Material copper = Material::create_metal("Copper", copper_tint, 0.02f);
+
+    Transform camera_transform = Cameras::get_transform(camera_ID);
+    camera_transform.translation = Vector3f(0, 0.0f, -1.5f);
+    Cameras::set_transform(camera_ID, camera_transform);
+
+    SceneNode light_node = SceneNode("Light", Transform(Vector3f(0.0f, 0.45f, 0.0f)));
+    light_node.set_parent(root_node);
+    LightSources::create_sphere_light(light_node.get_ID(), RGB(2.0f), 0.05f);
+
+    const float half_pi = PI<float>() * 0.5f;
+    struct Wall { const char* name; Material material; Transform transform; };
+    const Wall walls[] = {
+        {"Floor", white, Transform(Vector3f(0.0f, -0.5f, 0.0f))},
+        {"Roof", white, Transform(Vector3f(0.0f, 0.5f, 0.0f), Quaternionf::from_angle_axis(PI<float>(), Vector3f::forward()))},
+        {"Back", white, Transform(Vector3f(0.0f, 0.0f, 0.5f), Quaternionf::from_angle_axis(-half_pi, Vector3f::right()))},
+        {"Left", red, Transform(Vector3f(-0.5f, 0.0f, 0.0f), Quaternionf::from_angle_axis(-half_pi, Vector3f::forward()))},
+        {"Right", green, Transform(Vector3f(0.5f, 0.0f, 0.0f), Quaternionf::from_angle_axis(half_pi, Vector3f::forward()))},
+    };
+    Mesh plane_mesh = MeshCreation::plane(1, MeshFlag::GeometryBuffers);
+    for (const Wall& wall : walls) {
+        SceneNode node = SceneNode(wall.name, wall.transform);
+        MeshModel(node, plane_mesh, wall.material);
+        node.set_parent(root_node);
+    }
+
+    struct Box { const char* name; Material material; float y_stretch; Transform transform; };
+    const Box boxes[] = {
+        {"Small box", iron, 1.0f, Transform(Vector3f(0.2f, -0.35f, -0.2f), Quaternionf::from_angle_axis(PI<float>() / 6.0f, Vector3f::up()), 0.3f)},
+        {"Big box", copper, 2.0f, Transform(Vector3f(-0.2f, -0.2f, 0.2f), Quaternionf::from_angle_axis(-PI<float>() / 6.0f, Vector3f::up()), 0.3f)},
+    };
+    for (const Box& box : boxes) {
+        Mesh mesh = MeshCreation::box(1);
+        for (unsigned int v = 0; v < mesh.get_vertex_count(); ++v) mesh.get_positions()[v].y *= box.y_stretch;
+        SceneNode node = SceneNode(box.name, box.transform);
+        MeshModel(node, mesh, box.material);
+        node.set_parent(root_node);
+    }
+}
+
+template <typename T>
+static bool same_bytes(const T* a, const T* b, size_t count) { return (a == nullptr && b == nullptr) || (a && b && std::memcmp(a, b, count * sizeof(T)) == 0); }
+
+static void expect_same_scene(const HiprSceneDesc& a, const HiprSceneDesc& b) {
+    const int failures_before = minitest::failure_count();
+    EXPECT_EQ(a.triangle_count, b.triangle_count);
+    EXPECT_EQ(a.node_count, b.node_count);
+    EXPECT_EQ(a.instance_count, b.instance_count);
+    EXPECT_EQ(a.vertex_count, b.vertex_count);
+    EXPECT_EQ(a.index_count, b.index_count);
+    EXPECT_EQ(a.material_count, b.material_count);
+    EXPECT_EQ(a.light_count, b.light_count);
+    EXPECT_EQ(a.bvh_max_depth, b.bvh_max_depth);
+    if (minitest::failure_count() != failures_before) return;
+    EXPECT_TRUE(same_bytes(a.triangles, b.triangles, a.triangle_count));
+    EXPECT_TRUE(same_bytes(a.nodes, b.nodes, a.node_count));
+    EXPECT_TRUE(same_bytes(a.instances, b.instances, a.instance_count));
+    EXPECT_TRUE(same_bytes(a.geometry, b.geometry, a.vertex_count));
+    EXPECT_TRUE(same_bytes(a.indices, b.indices, a.index_count));
+    EXPECT_TRUE(same_bytes(a.materials, b.materials, a.material_count));
+    EXPECT_TRUE(same_bytes(a.lights, b.lights, a.light_count));
+    EXPECT_TRUE(same_bytes(a.tints, b.tints, a.vertex_count));
+}
+
+CPU_TEST_F(RendererFixture, flattened_cornell_box_matches_the_scene_builder) {
+    Scene::SceneRoot scene = Scene::SceneRoot("Cornell", Math::RGB(0.68f, 0.92f, 1.0f));
+    Math::Matrix4x4f projection, inverse_projection;
+    Scene::CameraUtils::compute_perspective_projection(0.1f, 100.0f, Math::PI<float>() / 4.0f, 16.0f / 9.0f, projection, inverse_projection);
+    Scene::CameraID camera_ID = Scene::Cameras::create("Camera", scene.get_ID(), projection, inverse_projection);
+    create_cornell_box(camera_ID, scene.get_root_node());
+
+    SceneBuilder from_managers;
+    flatten_bifrost_scene(from_managers);
+
+    SceneBuilder direct;
+    Scenes::create_cornell_box(direct);
+    direct.finalize();
+
+    EXPECT_EQ(34u, from_managers.desc().triangle_count);   // 5 walls * 2 + 2 boxes * 12
+    expect_same_scene(from_managers.desc(), direct.desc());
+}
+
+CPU_TEST_F(RendererFixture, change_sets_follow_the_engine_tick) {
+    // Created / Updated flags live until reset_all_change_notifications(), like Bifrost's managers
+    // (core/Bifrost/Bifrost/Core/ChangeSet.h, apps/SimpleViewer/main.cpp:298-308).
+    Assets::Material material = Assets::Material::create_dielectric("M", Math::RGB(0.5f), 0.5f);
+    EXPECT_TRUE(material.get_changes().is_set(Assets::Materials::Change::Created));
+    EXPECT_FALSE(Assets::Materials::get_changed_materials().is_empty());
+    reset_all_change_notifications();
+    EXPECT_TRUE(Assets::Materials::get_changed_materials().is_empty());
+    material.set_roughness(0.25f);
+    EXPECT_TRUE(material.get_changes().is_set(Assets::Materials::Change::Updated));
+    EXPECT_FALSE(material.get_changes().is_set(Assets::Materials::Change::ShadingModel));
+    material.set_shading_model(Assets::ShadingModel::Diffuse);
+    EXPECT_TRUE(material.get_changes().is_set(Assets::Materials::Change::ShadingModel));
+
+    // Children follow their parent's global transform.
+    Scene::SceneNode parent = Scene::SceneNode("parent"), child = Scene::SceneNode("child", Math::Transform(Math::Vector3f(1, 0, 0)));
+    child.set_parent(parent);
+    parent.set_global_transform(Math::Transform(Math::Vector3f(0, 2, 0)));
+    EXPECT_FLOAT_EQ_EPS(1.0f, child.get_global_transform().translation.x, 1e-6f);
+    EXPECT_FLOAT_EQ_EPS(2.0f, child.get_global_transform().translation.y, 1e-6f);
+}
+
+CPU_TEST_F(RendererFixture, initialize_fails_without_a_device_or_data) {
+    // Renderer::initialize returns nullptr instead of throwing (OptiXRenderer/Renderer.cpp:1365-1378).
+    if (hipr_device_count() == 0) EXPECT_TRUE(renderer == nullptr);
+    Renderer* broken = Renderer::initialize(0, "/nonexistent/data/directory");
+    EXPECT_TRUE(broken == nullptr);
+    delete broken;
+}
+
+GPU_TEST_F(RendererFixture, cornell_box_through_the_renderer_matches_the_c_abi) {
+    // The same scene rendered through HIPRenderer::Renderer (managers -> handle_updates -> render) and directly
+    // through the C-ABI from the SceneBuilder route must accumulate identical radiance.
+    auto frame_size = Math::Vector2i(64, 36);
+    Scene::SceneRoot scene = Scene::SceneRoot("Cornell", Math::RGB(0.68f, 0.92f, 1.0f));
+    SceneBuilder direct;
+    Scenes::create_cornell_box(direct);
+    direct.finalize();
+
+    Math::Matrix4x4f projection, inverse_projection;
+    Scene::CameraUtils::compute_perspective_projection(direct.camera.near_plane, direct.camera.far_plane, direct.camera.field_of_view,
+                                                       float(frame_size.x) / frame_size.y, projection, inverse_projection);
+    Scene::CameraID camera_ID = Scene::Cameras::create("Camera", scene.get_ID(), projection, inverse_projection);
+    Scene::Cameras::set_renderer_ID(camera_ID, renderer->get_renderer_ID());
+    create_cornell_box(camera_ID, scene.get_root_node());
+    renderer->set_max_bounce_count(camera_ID, direct.camera.max_bounce_count);
+
+    renderer->handle_updates();
+    RenderTarget target(frame_size);
+    for (int i = 0; i < 3; ++i) renderer->render(camera_ID, target.device, frame_size.x, frame_size);
+    std::vector<double> through_renderer;
+    EXPECT_TRUE(renderer->read_accumulation(through_renderer));
+
+    // Direct route.
+    HiprContext* context = nullptr;
+    EXPECT_EQ(int(HIPR_OK), int(hipr_create(0, &context)));
+    std::vector<float> tables[5];
+    {
+        FILE* f = fopen((get_data_directory() / "HIPRenderer" / "shading_tables.bin").c_str(), "rb");
+        EXPECT_TRUE(f != nullptr);
+        if (!f) return;
+        char magic[8]; uint32_t counts[5];
+        EXPECT_EQ(size_t(8), fread(magic, 1, 8, f));
+        EXPECT_EQ(size_t(5), fread(counts, 4, 5, f));
+        for (int i = 0; i < 5; ++i) { tables[i].resize(counts[i]); EXPECT_EQ(size_t(counts[i]), fread(tables[i].data(), 4, counts[i], f)); }
+        fclose(f);
+    }
+    HiprTables t = {tables[0].data(), tables[1].data(), tables[2].data(), tables[3].data(), tables[4].data()};
+    EXPECT_EQ(int(HIPR_OK), int(hipr_upload_tables(context, &t)));
+    EXPECT_EQ(int(HIPR_OK), int(hipr_upload_scene(context, &direct.desc())));
+    hipr_set_scene_state(context, &direct.state());
+    HiprFrameDesc frame = {uint32_t(frame_size.x), uint32_t(frame_size.y), 0, 1, 1};
+    EXPECT_EQ(int(HIPR_OK), int(hipr_set_frame(context, &frame)));
+    for (uint32_t i = 0; i < 3; ++i) {
+        HiprCameraState camera = make_camera_state(direct.camera, float(frame_size.x) / frame_size.y, i, 0.5f);
+        EXPECT_EQ(int(HIPR_OK), int(hipr_render_pass(context, &camera, nullptr, 0, 1)));
+    }
+    std::vector<double> through_c_abi(size_t(frame_size.x) * frame_size.y * 4);
+    EXPECT_EQ(int(HIPR_OK), int(hipr_read_accumulation(context, through_c_abi.data(), through_c_abi.size() / 4)));
+    hipr_destroy(context);
+
+    EXPECT_EQ(through_c_abi.size(), through_renderer.size());
+    size_t mismatches = 0;
+    double sum = 0;
+    for (size_t i = 0; i < through_c_abi.size() && i < through_renderer.size(); ++i) { mismatches += through_c_abi[i] != through_renderer[i]; sum += through_c_abi[i]; }
+    EXPECT_EQ(size_t(0), mismatches);
+    EXPECT_TRUE(sum > 0.0);
+}
+
+} // namespace HIPRenderer
+
+int main(int argc, char** argv) { return minitest::run_all(argc, argv); }

@@ -76,6 +76,8 @@ class Oracle:
         lib.oracle_trace_shadow.argtypes = [SP, _fp, u32, i, _fp, C.POINTER(C.c_uint64)]
         lib.oracle_render.argtypes = [SP, C.POINTER(capi.HiprSceneState), CP, i, i, u32, i, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
         lib.oracle_render.restype = C.c_double
+        lib.oracle_render_entry.argtypes = [SP, C.POINTER(capi.HiprSceneState), CP, i, i, u32, i, i, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+        lib.oracle_render_entry.restype = C.c_double
         lib.oracle_max_threads.restype = i
         lib.oracle_set_threads.argtypes = [i]
         lib.oracle_smallpt_accumulate.argtypes = [i, i, _fp, C.POINTER(i)]
@@ -189,12 +191,12 @@ class Oracle:
         self.lib.oracle_trace_shadow(C.byref(scene), fptr(rays), len(rays), int(use_bvh), fptr(out), counters)
         return out, (counters[0], counters[1])
 
-    def render(self, scene, state, cam, width, height, accumulation_count, use_bvh=True, accum=None):
+    def render(self, scene, state, cam, width, height, accumulation_count, use_bvh=True, accum=None, entry=0):
         if accum is None:
             accum = np.zeros((height, width, 4), np.float64)
         counters = (C.c_uint64 * 9)()
-        seconds = self.lib.oracle_render(C.byref(scene), C.byref(state), C.byref(cam), width, height, accumulation_count, int(use_bvh),
-                                         accum.ctypes.data_as(C.POINTER(C.c_double)), counters)
+        seconds = self.lib.oracle_render_entry(C.byref(scene), C.byref(state), C.byref(cam), width, height, accumulation_count, int(use_bvh), entry,
+                                               accum.ctypes.data_as(C.POINTER(C.c_double)), counters)
         names = [f[0] for f in capi.HiprCounters._fields_]
         return accum, dict(zip(names, list(counters))), seconds
 

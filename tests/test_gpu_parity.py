@@ -238,3 +238,51 @@ def test_errors_are_reported_not_swallowed(ctx):
     assert b"null scene" in lib.hipr_last_error()
     bad = capi.HiprFrameDesc(0, 0, 0, 1, 1)
     assert lib.hipr_set_frame(ctx.handle, C.byref(bad)) == -1
+
+
+AOV_ENTRIES = [("depth", capi.ENTRY_DEPTH), ("albedo", capi.ENTRY_ALBEDO), ("tint", capi.ENTRY_TINT), ("roughness", capi.ENTRY_ROUGHNESS),
+               ("shading_normal", capi.ENTRY_SHADING_NORMAL), ("primitive_id", capi.ENTRY_PRIMITIVE_ID)]
+
+
+@pytest.mark.parametrize("name,entry", AOV_ENTRIES)
+@pytest.mark.parametrize("scene_name", ["cornell", "atrium"])
+def test_aov_entry_points_match_oracle(ctx, oracle_q, cornell, atrium, scene_name, name, entry):
+    """The visualisation backends (SimpleRGPs.cu:227-340): depth, tint, roughness, normals and primitive ids are one
+    closest hit + attribute fetch (tolerance 1e-5 absolute: the camera ray and hit are bit-exact, the colour is a few
+    f32 operations); albedo goes through the rho tables and pow (tolerance 2e-3)."""
+    scene = cornell if scene_name == "cornell" else atrium
+    w, h, spp = 48, 27, 2
+    ctx.set_entry_point(entry)
+    try:
+        gpu, _ = render_gpu(ctx, scene, w, h, spp, 4)
+    finally:
+        ctx.set_entry_point(capi.ENTRY_PATH_TRACING)
+    cpu, _, _ = oracle_q.render(scene.desc, scene.state, scene.camera(w, h, max_bounce_count=4), w, h, spp, entry=entry)
+    tol = 2e-3 if name == "albedo" else 1e-5
+    if name == "depth":   # world units, scaled by the scene size on both sides
+        tol = 1e-5 * max(1.0, float(np.nanmax(np.where(np.isfinite(cpu[..., 0]), cpu[..., 0], 0.0))))
+    g, c = gpu[..., :3], cpu[..., :3]
+    if name == "depth":
+        # A miss adds |origin - 1e30 * direction|, which overflows f32 to +inf (as in the reference), and the running mean
+        # of inf is NaN from the second accumulation on: the non-finite pixels must be the same set on both sides.
+        assert np.array_equal(np.isfinite(g), np.isfinite(c))
+        assert 0.05 < np.isfinite(c).mean()
+        g, c = np.where(np.isfinite(g), g, 0.0), np.where(np.isfinite(c), c, 0.0)
+    err = np.abs(g - c).max(axis=-1)
+    assert (err <= tol).mean() >= 0.999, (name, float(err.max()), float((err <= tol).mean()))
+    assert np.isfinite(g).all()
+
+
+def test_tint_quad_G10(ctx):
+    """RendererFixture.render_tint, RendererTest.h:155-172: 4x3 ortho quad, red = (x+.5)/4, green = (y+.5)/3, +-0.003."""
+    w, h = 4, 3
+    scene = Scene("quad", param0=w, param1=h)
+    ctx.set_entry_point(capi.ENTRY_TINT)
+    try:
+        gpu, _ = render_gpu(ctx, scene, w, h, 1, 4)
+    finally:
+        ctx.set_entry_point(capi.ENTRY_PATH_TRACING)
+    xs = (np.arange(w) + 0.5) / w
+    ys = (np.arange(h) + 0.5) / h
+    assert np.abs(gpu[..., 0] - xs[None, :]).max() <= 0.003
+    assert np.abs(gpu[..., 1] - ys[:, None]).max() <= 0.003

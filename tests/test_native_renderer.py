@@ -1,0 +1,29 @@
+"""Runs tests/native/renderer_test: the C++ HIPRenderer::Renderer tests that mirror the reference's
+RendererFixture (extensions/OptiXRenderer/tests/OptiXRendererTests/RendererTest.h). The binary is built by
+bifrost3d_amd/Makefile (see __graft_entry__.build)."""
+import subprocess
+from pathlib import Path
+
+import pytest
+
+BINARY = Path(__file__).resolve().parent / "native" / "renderer_test"
+
+
+def run(flag):
+    assert BINARY.exists(), f"{BINARY} is missing: run __graft_entry__.build()"
+    p = subprocess.run([str(BINARY), flag], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-4000:] + p.stderr[-4000:]
+    return p.stdout
+
+
+def test_host_side_renderer_cases():
+    out = run("--cpu")
+    assert "flattened_cornell_box_matches_the_scene_builder" in out and " 0 failed." in out
+
+
+@pytest.mark.gpu
+def test_reference_renderer_cases_on_gpu():
+    out = run("--gpu")
+    for name in ("render_background_color", "render_tint", "render_auxiliary_tint", "render_returns_the_iteration_count",
+                 "scene_changes_restart_accumulation", "render_target_pitch_is_respected", "cornell_box_through_the_renderer_matches_the_c_abi"):
+        assert f"[       OK ] RendererFixture.{name}" in out, out[-4000:]
