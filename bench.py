@@ -14,7 +14,8 @@ accumulations of the frame, so every GPU keeps the same 2 073 600 paths per step
 no data-path collective). The timed region ends with the RCCL gather of the half4 tiles to rank 0 plus the
 scatter kernel that assembles the frame.
 
-Prints ONE JSON line on rank 0 with the contract keys plus `roofline` (dominant kernel = trace_closest) and
+Prints ONE JSON line on rank 0 with the contract keys plus `roofline` (the kernel with the largest total time in the
+timed region; every kernel's figures are under `roofline_by_kernel`) and
 `cpu_baseline` (SmallPT restatement on the host cores, N = 1 only).
 """
 from __future__ import annotations
@@ -55,6 +56,24 @@ def make_scene(args):
     if args.scene == "cornell":
         return Scene("cornell"), "SimpleViewer Cornell box (34 triangles, 1 sphere light), reference materials"
     return Scene("atrium", param0=args.atrium_triangles, param1=1), f"procedural atrium ({args.atrium_triangles} triangles target), DefaultShading"
+
+
+def load_measured_traffic(args):
+    """HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in
+    separate runs of this same command; bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024, the gfx950 correction of
+    MI355X_MICROARCH.md "HBM"). Only used when the recorded command matches this run's workload; otherwise traffic is null."""
+    path = ROOT / "profiles" / "pmc_traffic.json"
+    if not path.exists():
+        return {}
+    try:
+        table = json.loads(path.read_text())
+    except ValueError:
+        return {}
+    key = f"{args.scene}:{args.width}x{args.height}:spp{args.spp_per_pass}:bounces{args.bounces}"
+    if args.scene == "atrium":
+        key += f":tris{args.atrium_triangles}"
+    entry = table.get(key, {})
+    return {k: v["traffic_bytes_per_launch"] for k, v in entry.get("kernels", {}).items()}
 
 
 def cpu_baseline(seconds: float):
@@ -179,14 +198,38 @@ def main():
 
     if rank == 0:
         ok = bool(torch.isfinite(frame.float()).all().item()) and float(frame[..., :3].float().mean()) > 0
-        # Roofline of the dominant kernel (rank 0's launches): algorithmic bytes per closest-hit ray =
-        # 48 B path state read (origin+tmin, direction+pdf, meta) + 16 B hit record written + 64 B per BVH node
-        # visited + 48 B per triangle tested (DESIGN.md "Kernels").
-        k = times["trace_closest"]
-        bytes_per_ray = 48 + 16 + 64 * nodes_per_ray + 48 * tris_per_ray
-        kernel_bytes = counters["closest_rays"] * bytes_per_ray
-        launches = max(1, k["launches"])
-        achieved = kernel_bytes / (k["ms"] * 1e-3) / 1e9 if k["ms"] > 0 else 0.0
+        # Rooflines (rank 0's launches). Algorithmic HBM bytes per unit of work, DESIGN.md "Kernels" / SURVEY.md 8d:
+        #   generate       80 B per path        (64 B path state + 16 B radiance slot written)
+        #   trace_closest  48 B path state read + 16 B hit written per ray, + 64 B per BVH node visited + 48 B per triangle tested
+        #   shade          80 B per queued ray (hit + path state) + 408 B per shaded hit (triangle 48, instance 80, material 64,
+        #                  indices 12, 3 vertices 48, 3 tints 12, 3 RIS light candidates 144) + 64 B per continued path
+        #                  + 48 B per shadow ray queued + 32 B radiance read-modify-write per queued ray
+        #   trace_shadow   48 B record + 32 B radiance rmw per shadow ray, + 64 B per node + 48 B per triangle
+        #   accumulate     16 B radiance per sample + 64 B f64 accumulation rmw + 8 B half4 per owned pixel
+        n_closest, n_shadow, n_camera, n_hits = (counters[k] for k in ("closest_rays", "shadow_rays", "camera_rays", "shaded_hits"))
+        kernel_bytes = {
+            "generate": 80.0 * n_camera,
+            "trace_closest": n_closest * (48 + 16 + 64 * nodes_per_ray + 48 * tris_per_ray),
+            "shade": 80.0 * n_closest + 408.0 * n_hits + 64.0 * max(0, n_closest - n_camera) + 48.0 * n_shadow + 32.0 * n_closest,
+            "trace_shadow": n_shadow * (48 + 32 + 64 * shadow_nodes_per_ray + 48 * shadow_tris_per_ray),
+            "accumulate": 16.0 * n_camera + (64.0 + 8.0) * n_camera / max(1, S),
+        }
+        kernel_names = {"generate": "k_generate", "trace_closest": "k_trace_closest / k_trace_persistent<closest>", "shade": "k_shade",
+                        "trace_shadow": "k_trace_shadow / k_trace_persistent<shadow>", "accumulate": "k_accumulate"}
+        measured_traffic = load_measured_traffic(args)
+        rooflines = {}
+        for name, nbytes in kernel_bytes.items():
+            t = times.get(name)
+            if not t or t["ms"] <= 0 or t["launches"] == 0:
+                continue
+            gbs = nbytes / (t["ms"] * 1e-3) / 1e9
+            rooflines[name] = {"bound": "hbm", "kernel": kernel_names[name], "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                               "traffic": measured_traffic.get(name), "avg_launch_ms": t["ms"] / t["launches"], "launches": t["launches"],
+                               "algorithmic_bytes_per_launch": nbytes / t["launches"], "total_ms": t["ms"]}
+        dominant = max(rooflines, key=lambda n: rooflines[n]["total_ms"])
+        roofline = dict(rooflines[dominant])
+        roofline.update({"nodes_per_ray": nodes_per_ray, "triangles_per_ray": tris_per_ray, "shadow_nodes_per_ray": shadow_nodes_per_ray,
+                         "shadow_triangles_per_ray": shadow_tris_per_ray, "selection": "kernel with the largest total time in the timed region"})
         out = {
             "metric": "Mrays/sec + ms/frame at 1080p/256spp; per-pixel RMSE vs OptiXRenderer",
             "value": total_rays / elapsed / 1e6,
@@ -211,14 +254,8 @@ def main():
                 "frame_finite_and_lit": ok,
                 "rmse_note": "per-pixel RMSE vs the CPU oracle is asserted in tests/test_gpu_parity.py; no OptiX image exists (DESIGN.md)",
             },
-            "roofline": {
-                "bound": "hbm", "kernel": "k_trace_closest", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "avg_launch_ms": k["ms"] / launches, "launches": launches,
-                "algorithmic_bytes_per_launch": kernel_bytes / launches, "bytes_per_ray": bytes_per_ray,
-                "nodes_per_ray": nodes_per_ray, "triangles_per_ray": tris_per_ray,
-                "shadow_nodes_per_ray": shadow_nodes_per_ray, "shadow_triangles_per_ray": shadow_tris_per_ray,
-            },
+            "roofline": roofline,
+            "roofline_by_kernel": rooflines,
             "kernel_ms_per_step": {name: v["ms"] / args.steps for name, v in times.items()},
         }
         if world == 1 and not args.no_cpu_baseline:

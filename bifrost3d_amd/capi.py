@@ -116,6 +116,7 @@ C_ABI_SYMBOLS = (
     "hipr_upload_tables", "hipr_upload_scene", "hipr_set_scene_state", "hipr_set_entry_point", "hipr_use_scratch_accumulation",
     "hipr_set_frame", "hipr_owned_pixel_count",
     "hipr_render_pass", "hipr_read_accumulation", "hipr_scatter_tiles", "hipr_synchronize", "hipr_get_counters",
+    "hipr_device_malloc", "hipr_device_free", "hipr_copy_to_host", "hipr_present_flipped",
     "hipr_reset_counters", "hipr_set_instrumentation", "hipr_reset_timers", "hipr_get_kernel_times",
     "hipr_debug_generate", "hipr_debug_sobol", "hipr_debug_trace_closest", "hipr_debug_trace_shadow",
 )

@@ -674,6 +674,41 @@ int hipr_scatter_tiles(HiprContext* c, const void* compact, uint64_t rank_stride
     return HIPR_OK;
 }
 
+// ------------------------------------------------------------------------------------------- presentation side
+int hipr_device_malloc(HiprContext* c, uint64_t bytes, void** out_device_pointer) {
+    if (int s = check_context(c)) return s;
+    if (!out_device_pointer || bytes == 0) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_device_malloc: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMalloc(out_device_pointer, bytes));
+    return HIPR_OK;
+}
+
+int hipr_device_free(HiprContext* c, void* device_pointer) {
+    if (int s = check_context(c)) return s;
+    if (!device_pointer) return HIPR_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipFree(device_pointer));
+    return HIPR_OK;
+}
+
+int hipr_copy_to_host(HiprContext* c, void* host, const void* device_pointer, uint64_t bytes) {
+    if (int s = check_context(c)) return s;
+    if (!host || !device_pointer) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_copy_to_host: bad argument");
+    HIP_TRY(hipMemcpyAsync(host, device_pointer, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return HIPR_OK;
+}
+
+int hipr_present_flipped(HiprContext* c, const void* pixels, uint32_t pitch, uint32_t width, uint32_t height, void* backbuffer, uint32_t backbuffer_pitch) {
+    if (int s = check_context(c)) return s;
+    if (!pixels || !backbuffer || pitch < width || backbuffer_pitch < width) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_present_flipped: bad argument");
+    if (width == 0 || height == 0) return HIPR_OK;
+    hipLaunchKernelGGL(k_present_flipped, dim3((width + 63) / 64, (height + 3) / 4), dim3(256), 0, c->stream, static_cast<const ushort4*>(pixels), pitch, width,
+                       height, static_cast<ushort4*>(backbuffer), backbuffer_pitch);
+    HIP_TRY(hipGetLastError());
+    return HIPR_OK;
+}
+
 // ------------------------------------------------------------------------------------------- debug / parity entry points
 int hipr_debug_generate(HiprContext* c, const HiprCameraState* camera, uint32_t accumulation, float* out_origin_tmin, float* out_direction, uint32_t* out_pixel) {
     if (int s = check_context(c)) return s;

@@ -641,6 +641,15 @@ __global__ __launch_bounds__(256) void k_scatter_tiles(const ushort4* compact, u
     out[size_t(x) + size_t(y) * out_pitch] = compact[size_t(rank) * rank_stride + size_t(local_tile) * 64u + lane];
 }
 
+// The presentation blit of the adaptor (DX11OptiXAdaptor/Adaptor.cpp:96-100 pixel shader): the renderer writes row 0 at
+// the bottom, the back buffer has row 0 at the top.
+__global__ __launch_bounds__(256) void k_present_flipped(const ushort4* pixels, uint32_t pitch, uint32_t width, uint32_t height, ushort4* backbuffer,
+                                                          uint32_t backbuffer_pitch) {
+    const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u), y = blockIdx.y * 4u + (threadIdx.x >> 6);
+    if (x >= width || y >= height) return;
+    backbuffer[size_t(x) + size_t(y) * backbuffer_pitch] = pixels[size_t(x) + size_t(height - y - 1u) * pitch];
+}
+
 // Debug / parity helpers -------------------------------------------------------------------------
 // Evaluates BOTH forms of the sampler (the XOR loop used by k_generate and the LDS-table form used by k_shade) and
 // poisons the output when they disagree, so the bit-exact test against the oracle covers the two.

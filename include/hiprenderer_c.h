@@ -275,6 +275,21 @@ int hipr_scatter_tiles(HiprContext* context, const void* compact_half4_device, u
                        uint32_t rank_count, uint32_t width, uint32_t height,
                        void* out_half4_device, uint32_t out_pitch_pixels);
 
+/* ------------------------------------------------------------------------------------------- */
+/* Presentation side: what DX11OptiXAdaptor::Adaptor does around Renderer::render                */
+/* (extensions/DX11OptiXAdapter/DX11OptiXAdaptor/Adaptor.cpp:141-247), so that the host library   */
+/* above this ABI links no GPU runtime.                                                          */
+/* ------------------------------------------------------------------------------------------- */
+/* The render target / back buffer the adaptor owns (Adaptor.cpp:227-247 resize_render_target). */
+int hipr_device_malloc(HiprContext* context, uint64_t bytes, void** out_device_pointer);
+int hipr_device_free(HiprContext* context, void* device_pointer);   /* waits for the context stream first */
+/* optix::Buffer::map() of the non-interop path (Adaptor.cpp:159-166). Blocking. */
+int hipr_copy_to_host(HiprContext* context, void* host, const void* device_pointer, uint64_t bytes);
+/* The adaptor's full-screen blit (Adaptor.cpp:96-100): backbuffer[x + y * backbuffer_pitch] =
+ * pixels[x + (height - y - 1) * pitch] for the width x height viewport. Runs on the context stream. */
+int hipr_present_flipped(HiprContext* context, const void* pixels_half4_device, uint32_t pitch_pixels, uint32_t width, uint32_t height,
+                         void* backbuffer_half4_device, uint32_t backbuffer_pitch_pixels);
+
 int hipr_synchronize(HiprContext* context);
 int hipr_get_counters(HiprContext* context, HiprCounters* out);
 int hipr_reset_counters(HiprContext* context);

@@ -7,6 +7,7 @@
 // (`--cpu` here in the build container, `--gpu` on the MI355X box).
 #include "MiniTest.h"
 
+#include "../../bifrost3d_amd/host/HIPRenderer/Adaptor.h"
 #include "../../bifrost3d_amd/host/HIPRenderer/Renderer.h"
 #include "../../bifrost3d_amd/host/SceneBuilder.h"
 #include "../../bifrost3d_amd/host/Scenes.h"
@@ -444,6 +445,66 @@ GPU_TEST_F(RendererFixture, cornell_box_through_the_renderer_matches_the_c_abi) 
     for (size_t i = 0; i < through_c_abi.size() && i < through_renderer.size(); ++i) { mismatches += through_c_abi[i] != through_renderer[i]; sum += through_c_abi[i]; }
     EXPECT_EQ(size_t(0), mismatches);
     EXPECT_TRUE(sum > 0.0);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The compositor-facing adaptor (DX11OptiXAdaptor/Adaptor.cpp:141-247)
+// ------------------------------------------------------------------------------------------------------------------------
+static float half_bits_to_float(unsigned short bits) { _Float16 h; std::memcpy(&h, &bits, 2); return float(h); }
+
+GPU_TEST_F(RendererFixture, adaptor_presents_the_flipped_viewport) {
+    delete renderer;   // the adaptor owns its own renderer, like the compositor's unique_ptr<IRenderer>
+    renderer = nullptr;
+    deallocate_all();
+    IRenderer* adaptor = HeadlessAdaptor::initialize(0, get_data_directory());
+    EXPECT_TRUE(adaptor != nullptr);
+    if (!adaptor) return;
+    renderer = static_cast<HeadlessAdaptor*>(adaptor)->get_renderer();
+    EXPECT_TRUE(adaptor->get_ID() == renderer->get_renderer_ID());
+
+    auto frame_size = Math::Vector2i(8, 6);
+    auto camera_ID = create_ortho_camera_with_quad_scene(frame_size);
+    renderer->set_backend(camera_ID, Backend::TintVisualization);
+    adaptor->handle_updates();
+
+    RenderedFrame frame = adaptor->render(camera_ID, frame_size);
+    EXPECT_EQ(1u, frame.iteration_count);
+    EXPECT_EQ(8, frame.frame_viewport.width);
+    EXPECT_EQ(6, frame.frame_viewport.height);
+    std::vector<unsigned short> pixels;
+    EXPECT_TRUE(static_cast<HeadlessAdaptor*>(adaptor)->read_back_buffer(frame, pixels));
+    for (int y = 0; y < frame_size.y && !pixels.empty(); ++y)
+        for (int x = 0; x < frame_size.x; ++x) {
+            // Row 0 of the back buffer is the TOP of the image: green runs from 1 down to 0.
+            float red_tint = (0.5f + x) / frame_size.x, green_tint = (0.5f + (frame_size.y - 1 - y)) / frame_size.y;
+            EXPECT_FLOAT_EQ_EPS(red_tint, half_bits_to_float(pixels[4 * (x + y * frame_size.x)]), 0.003f);
+            EXPECT_FLOAT_EQ_EPS(green_tint, half_bits_to_float(pixels[4 * (x + y * frame_size.x) + 1]), 0.003f);
+        }
+
+    // A smaller frame afterwards keeps the larger buffers (pitch stays 8) and restarts the accumulation.
+    auto smaller = Math::Vector2i(4, 3);
+    RenderedFrame small_frame = adaptor->render(camera_ID, smaller);
+    EXPECT_EQ(8u, small_frame.frame_pitch);
+    EXPECT_EQ(4, small_frame.frame_viewport.width);
+    EXPECT_EQ(1u, small_frame.iteration_count);
+    EXPECT_EQ(2u, adaptor->render(camera_ID, smaller).iteration_count);
+    EXPECT_TRUE(static_cast<HeadlessAdaptor*>(adaptor)->read_back_buffer(small_frame, pixels));
+    EXPECT_EQ(size_t(4 * 3 * 4), pixels.size());
+
+    // Screenshots go straight through to the renderer.
+    auto images = adaptor->request_auxiliary_buffers(camera_ID, Scene::Screenshot::Content::Roughness, smaller);
+    EXPECT_EQ(size_t(1), images.size());
+    for (auto& image : images) { EXPECT_TRUE(image.format == Assets::PixelFormat::Intensity8); delete[] static_cast<unsigned char*>(image.pixels); }
+
+    renderer = nullptr;   // owned by the adaptor
+    delete adaptor;
+}
+
+CPU_TEST_F(RendererFixture, adaptor_initialize_fails_like_the_renderer) {
+    IRenderer* adaptor = HeadlessAdaptor::initialize(0, "/nonexistent/data/directory");
+    EXPECT_TRUE(adaptor == nullptr);
+    RendererCreator creator = HeadlessAdaptor::initialize;   // the compositor registers renderers through this signature
+    EXPECT_TRUE(creator != nullptr);
 }
 
 } // namespace HIPRenderer

@@ -25,5 +25,5 @@ def test_host_side_renderer_cases():
 def test_reference_renderer_cases_on_gpu():
     out = run("--gpu")
     for name in ("render_background_color", "render_tint", "render_auxiliary_tint", "render_returns_the_iteration_count",
-                 "scene_changes_restart_accumulation", "render_target_pitch_is_respected", "cornell_box_through_the_renderer_matches_the_c_abi"):
+                 "scene_changes_restart_accumulation", "render_target_pitch_is_respected", "cornell_box_through_the_renderer_matches_the_c_abi", "adaptor_presents_the_flipped_viewport"):
         assert f"[       OK ] RendererFixture.{name}" in out, out[-4000:]
