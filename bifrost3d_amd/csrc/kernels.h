@@ -161,6 +161,20 @@ HD bool intersect_triangle(f3 v0, f3 v1, f3 v2, f3 o, f3 d, float& t, float& u, 
     return true;
 }
 
+// The same arithmetic without early outs (every lane of a wave runs the whole test anyway): identical t, u, v and verdict.
+HD bool intersect_triangle_full(f3 v0, f3 v1, f3 v2, f3 o, f3 d, float& t, float& u, float& v) {
+    const f3 e1 = v1 - v0, e2 = v2 - v0;
+    const f3 p = cross_fma(d, e2);
+    const float det = dot_fma(e1, p);
+    const float inv = 1.0f / det;
+    const f3 tv = o - v0;
+    u = dot_fma(tv, p) * inv;
+    const f3 q = cross_fma(tv, e1);
+    v = dot_fma(d, q) * inv;
+    t = dot_fma(e2, q) * inv;
+    return (det != 0.0f) & (u >= 0.0f) & (u <= 1.0f) & (v >= 0.0f) & (u + v <= 1.0f);
+}
+
 // `stack` points at this lane's column of the LDS stack; entry k is stack[k * STRIDE].
 template <int STRIDE, typename LeafFn>
 HD void traverse(const DeviceScene& sc, f3 o, f3 d, float tmin, const float& tmax, int* stack, uint32_t& nodes_visited, LeafFn&& leaf) {
@@ -433,15 +447,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_persistent(DeviceScene sc
     uint32_t tri_cur = 0, tri_end = 0;
     uint32_t nodes = 0, tris = 0;
 
-    auto set_item = [&](int item) {
-        if (item >= 0) { cur = item; tri_cur = tri_end = 0; }
-        else { const uint32_t leaf = uint32_t(~item); tri_cur = leaf >> 3; tri_end = tri_cur + (leaf & 7u) + 1u; }
-    };
-    auto pop_next = [&]() {
-        if (sp == 0) { active = false; finished = true; return; }
-        --sp;
-        set_item(stack[sp * TRACE_BLOCK]);
-    };
+    // Work item encoding: >= 0 inner node index, < 0 leaf ~((first << 3) | (count - 1)), TRACE_DONE = nothing left.
+    constexpr int TRACE_DONE = 0x7FFFFFFF;
 
     for (;;) {
         // ---- retire finished lanes (converged: every lane of the wave is here) --------------------------------------
@@ -529,54 +536,72 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_persistent(DeviceScene sc
         // ---- traverse. Every iteration runs ONE of the two blocks -- the one more lanes are waiting for -- so the
         // ---- 64 lanes are not serialised through both; a lane's own visiting order is unchanged.
         do {
-            const bool tri_mode = active && tri_cur < tri_end;
-            const bool node_mode = active && !tri_mode;
+            const bool tri_mode = active & (tri_cur < tri_end);
+            const bool node_mode = active & !tri_mode;
             const unsigned long long tmask = __ballot(tri_mode), nmask = __ballot(node_mode);
+            int next_item = TRACE_DONE;     // the item this lane continues with; selects only, no divergent state updates
+            bool take_next = false, need_pop = false;
             if (__popcll(tmask) > __popcll(nmask)) {
                 if (tri_mode) {
-                    const uint32_t i = tri_cur++;
+                    const uint32_t i = tri_cur;
+                    tri_cur = i + 1u;
                     ++tris;
                     const float4* tp = sc.triangles + 3 * size_t(i);
                     const float4 a = tp[0], b = tp[1], c = tp[2];
                     float t, u, v;
-                    bool stop = false;
-                    if ((SHADOW || i != skip) && intersect_triangle(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), o, d, t, u, v)) {
-                        if constexpr (SHADOW) {
-                            if (t > tmin && t < tmax) {
-                                float coverage = 1.0f;
-                                if (!(__float_as_uint(c.w) & HIPR_TRIANGLE_OPAQUE)) {
-                                    const HiprInstance& inst = sc.instances[__float_as_uint(c.y)];
-                                    coverage = material_coverage(sc, sc.materials[inst.material_index], triangle_texcoord(sc, inst, __float_as_uint(c.z), u, v));
-                                }
-                                rad *= 1.0f - coverage;
-                                if (rad.x < 0.0000001f && rad.y < 0.0000001f && rad.z < 0.0000001f) { rad = mk3(0.0f); stop = true; }
+                    const bool hit = intersect_triangle_full(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), o, d, t, u, v);
+                    need_pop = tri_cur == tri_end;
+                    if constexpr (SHADOW) {
+                        if (hit && t > tmin && t < tmax) {
+                            float coverage = 1.0f;
+                            if (!(__float_as_uint(c.w) & HIPR_TRIANGLE_OPAQUE)) {
+                                const HiprInstance& inst = sc.instances[__float_as_uint(c.y)];
+                                coverage = material_coverage(sc, sc.materials[inst.material_index], triangle_texcoord(sc, inst, __float_as_uint(c.z), u, v));
                             }
-                        } else {
-                            if (t > tmin && (t < tmax || (t == tmax && i < best_id))) { tmax = t; best_u = u; best_v = v; best_id = i; }
+                            rad *= 1.0f - coverage;
+                            if (rad.x < 0.0000001f && rad.y < 0.0000001f && rad.z < 0.0000001f) {   // fully shadowed: the ray is done
+                                rad = mk3(0.0f);
+                                need_pop = false; take_next = true; next_item = TRACE_DONE;
+                            }
                         }
+                    } else {
+                        const bool closer = hit & (i != skip) & (t > tmin) & ((t < tmax) | ((t == tmax) & (i < best_id)));
+                        tmax = closer ? t : tmax; best_u = closer ? u : best_u; best_v = closer ? v : best_v; best_id = closer ? i : best_id;
                     }
-                    if (stop) { active = false; finished = true; }
-                    else if (tri_cur == tri_end) pop_next();
                 }
             } else if (node_mode) {
                 const float4* np = sc.nodes + 4 * size_t(cur);
                 const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
                 ++nodes;
                 float t0, t1;
-                bool h0 = slab(inv, ood, n0.x, n0.y, n0.z, n0.w, n2.x, n2.y, tmin, tmax, t0);
-                bool h1 = slab(inv, ood, n1.x, n1.y, n1.z, n1.w, n2.z, n2.w, tmin, tmax, t1);
-                int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
-                if (h0 && h1 && t1 < t0) { const int tmp = c0; c0 = c1; c1 = tmp; }
-                if (!h0 && h1) { c0 = c1; h0 = true; h1 = false; }
-                if (h0 && h1) {
-                    // Visiting order of the specification: a leaf child is intersected before descending into an inner sibling.
-                    int first = c0, second = c1;
-                    if (c0 >= 0 && c1 < 0) { first = c1; second = c0; }
-                    stack[sp * TRACE_BLOCK] = second;
-                    ++sp;
-                    set_item(first);
-                } else if (h0) set_item(c0);
-                else pop_next();
+                const bool h0 = slab(inv, ood, n0.x, n0.y, n0.z, n0.w, n2.x, n2.y, tmin, tmax, t0);
+                const bool h1 = slab(inv, ood, n1.x, n1.y, n1.z, n1.w, n2.z, n2.w, tmin, tmax, t1);
+                const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+                const bool both = h0 & h1;
+                // near child first; with both hit, a leaf child is intersected before an inner sibling is descended (the specification)
+                const bool swap = both ? ((t1 < t0) ? !((c1 >= 0) & (c0 < 0)) : ((c0 >= 0) & (c1 < 0))) : !h0;
+                const int first = swap ? c1 : c0, second = swap ? c0 : c1;
+                if (both) stack[sp * TRACE_BLOCK] = second;
+                sp += both ? 1 : 0;
+                take_next = h0 | h1;
+                next_item = first;
+                need_pop = !take_next;
+            }
+            if (need_pop) {
+                const int below = sp > 0 ? sp - 1 : 0;
+                const int popped = stack[below * TRACE_BLOCK];
+                next_item = sp > 0 ? popped : TRACE_DONE;
+                sp = below;
+                take_next = true;
+            }
+            if (take_next) {
+                const bool done = next_item == TRACE_DONE, leaf = next_item < 0;
+                const uint32_t code = uint32_t(~next_item), first_triangle = code >> 3;
+                tri_cur = leaf ? first_triangle : 0u;
+                tri_end = leaf ? first_triangle + (code & 7u) + 1u : 0u;
+                cur = (leaf | done) ? cur : next_item;
+                active = !done;
+                finished = done;
             }
             busy = __ballot(active);
         } while (busy && (exhausted || __popcll(busy) >= refill_below));
