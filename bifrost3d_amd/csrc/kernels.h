@@ -418,7 +418,7 @@ constexpr uint32_t TRACE_CHUNK_MAX = 512; // rays a wave claims per global atomi
 // The ray range of a launch is cut into TRACE_SHARDS contiguous shards, each with its own claim counter on its
 // own 64 B line: 64 x the atomic throughput of a single word (one word saturates near 88 atomics/us), and blocks
 // that start on the same shard work on neighbouring rays. A wave that drains its shard steals from the next.
-constexpr uint32_t TRACE_SHARDS = 64;
+constexpr uint32_t TRACE_SHARDS = 64;   // == wave size: a drained wave probes all of them with one load per lane
 constexpr uint32_t TRACE_SHARD_STRIDE = 16;   // uint32 words between shard counters
 
 template <int STACK, bool SHADOW, bool INSTRUMENT>
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_persistent(DeviceScene sc
     const unsigned long long lt = (1ull << lane) - 1ull;
 
     uint32_t chunk_next = 0, chunk_end = 0;   // wave uniform
-    uint32_t shard = blockIdx.x % TRACE_SHARDS, shards_drained = 0;
+    uint32_t shard = blockIdx.x % TRACE_SHARDS;
     bool exhausted = false;
 
     bool active = false, finished = false;    // finished: traversal done, result still in registers
@@ -478,17 +478,20 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_persistent(DeviceScene sc
                 const uint32_t shard_begin = uint32_t((unsigned long long)n * shard / TRACE_SHARDS);
                 const uint32_t shard_end = uint32_t((unsigned long long)n * (shard + 1u) / TRACE_SHARDS);
                 uint32_t base = 0;
-                if (lane == 0) {
-                    uint32_t* counter = work_counter + shard * TRACE_SHARD_STRIDE;
-                    // probe with a plain L2 load first: at the end of a launch every wave walks the drained shards
-                    base = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (base < shard_end - shard_begin) base = atomicAdd(counter, chunk_size);
-                }
+                if (lane == 0) base = atomicAdd(work_counter + shard * TRACE_SHARD_STRIDE, chunk_size);
                 base = __shfl(base, 0);
                 if (base < shard_end - shard_begin) { chunk_next = shard_begin + base; chunk_end = min(chunk_next + chunk_size, shard_end); }
                 else {
-                    shard = (shard + 1u) % TRACE_SHARDS;
-                    if (++shards_drained >= TRACE_SHARDS) exhausted = true;
+                    // This shard is drained: look at all 64 claim counters at once (lane k probes shard k; TRACE_SHARDS == wave size)
+                    // and move to the next one that still has rays, instead of walking the shards one dependent load at a time.
+                    const uint32_t my_size = uint32_t((unsigned long long)n * (lane + 1u) / TRACE_SHARDS) - uint32_t((unsigned long long)n * lane / TRACE_SHARDS);
+                    const uint32_t claimed = __hip_atomic_load(work_counter + lane * TRACE_SHARD_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long open = __ballot(claimed < my_size);
+                    if (!open) exhausted = true;
+                    else {
+                        const unsigned long long rotated = shard ? ((open >> shard) | (open << (64u - shard))) : open;
+                        shard = (shard + uint32_t(__builtin_ctzll(rotated))) % TRACE_SHARDS;
+                    }
                 }
             }
             if (chunk_next < chunk_end) {
