@@ -214,12 +214,17 @@ def main():
             "trace_shadow": n_shadow * (48 + 32 + 64 * shadow_nodes_per_ray + 48 * shadow_tris_per_ray),
             "accumulate": 16.0 * n_camera + (64.0 + 8.0) * n_camera / max(1, S),
         }
-        kernel_names = {"generate": "k_generate", "trace_closest": "k_trace_closest / k_trace_persistent<closest>", "shade": "k_shade",
-                        "trace_shadow": "k_trace_shadow / k_trace_persistent<shadow>", "accumulate": "k_accumulate"}
+        kernel_names = {"generate": "k_generate", "trace_closest": "k_trace_closest", "shade": "k_shade", "trace_shadow": "k_trace_shadow",
+                        "accumulate": "k_accumulate", "trace": "k_trace_persistent<TRACE_FUSED> (closest-hit rays of bounce k + shadow rays of bounce k-1)"}
+        kernel_times = dict(times)
+        if ctx.trace_is_fused():   # one launch serves both ray kinds: bytes and time of the two are reported together
+            kernel_bytes["trace"] = kernel_bytes.pop("trace_closest") + kernel_bytes.pop("trace_shadow")
+            a, b = kernel_times.pop("trace_closest"), kernel_times.pop("trace_shadow")
+            kernel_times["trace"] = {"ms": a["ms"] + b["ms"], "launches": a["launches"] + b["launches"]}
         measured_traffic = load_measured_traffic(args)
         rooflines = {}
         for name, nbytes in kernel_bytes.items():
-            t = times.get(name)
+            t = kernel_times.get(name)
             if not t or t["ms"] <= 0 or t["launches"] == 0:
                 continue
             gbs = nbytes / (t["ms"] * 1e-3) / 1e9
@@ -256,7 +261,7 @@ def main():
             },
             "roofline": roofline,
             "roofline_by_kernel": rooflines,
-            "kernel_ms_per_step": {name: v["ms"] / args.steps for name, v in times.items()},
+            "kernel_ms_per_step": {name: v["ms"] / args.steps for name, v in kernel_times.items()},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_seconds)

@@ -71,7 +71,7 @@ struct TimedLaunch { int kernel; hipEvent_t start, stop; };
 struct HiprContext {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr, copy_stream = nullptr;
-    hipEvent_t shade_done = nullptr;
+    hipEvent_t shade_done[2] = {nullptr, nullptr}, counts_copied[2] = {nullptr, nullptr};   // by bounce parity: two bounces are in flight
 
     // scene
     DeviceBuffer nodes, triangles, instances, indices, geometry, texcoords, tints, emissions, materials, lights, textures, texels;
@@ -94,12 +94,14 @@ struct HiprContext {
     bool use_persistent() const { return trace_variant < 0 ? scene.node_count > 64 : trace_variant == 1; }
     int cu_count = 256;
     int refill_below = 40;              // persistent kernels refill a wave once fewer lanes than this are busy (HIPR_REFILL_BELOW)
-    int persistent_blocks_per_cu[2][3] = {{0, 0, 0}, {0, 0, 0}};   // [shadow][stack bucket]
-    uint32_t* host_counts = nullptr;   // pinned: next, shadow
+    int persistent_blocks_per_cu[3][3] = {{0, 0, 0}, {0, 0, 0}};   // [shadow][stack bucket]
+    uint32_t* host_counts = nullptr;   // pinned: {continuing paths, shadow rays} per bounce parity, [4] staging word
 
     // bookkeeping
     HiprCounters total = {};   // since hipr_reset_counters
     bool instrument = false;
+    bool trace_log = false;
+    DeviceCounters trace_log_previous = {};
     bool timing = true;
     std::vector<hipEvent_t> event_pool;
     size_t events_used = 0;
@@ -167,30 +169,28 @@ uint32_t* next_work_counter(HiprContext* c) {
     return c->work_counters.as<uint32_t>() + size_t(c->work_index++) * WORK_SET_WORDS;
 }
 
-template <int STACK, bool SHADOW, bool INSTRUMENT>
-void launch_persistent(HiprContext* c, const PathState& in, float4* hits, const uint32_t* count_ptr, uint32_t upper_bound, int bucket) {
-    int& per_cu = c->persistent_blocks_per_cu[SHADOW ? 1 : 0][bucket];
+// One persistent launch over the path queue (closest_count != nullptr), the shadow queue (shadow_count != nullptr) or both.
+template <int STACK, int MODE, bool INSTRUMENT>
+void launch_persistent(HiprContext* c, const PathState& in, const uint32_t* closest_count, const uint32_t* shadow_count, uint32_t upper_bound, int bucket) {
+    int& per_cu = c->persistent_blocks_per_cu[MODE][bucket];
     if (per_cu == 0) {
         int blocks = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_trace_persistent<STACK, SHADOW, INSTRUMENT>, TRACE_BLOCK, 0) != hipSuccess || blocks <= 0) blocks = 4;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_trace_persistent<STACK, MODE, INSTRUMENT>, TRACE_BLOCK, 0) != hipSuccess || blocks <= 0) blocks = 4;
         per_cu = blocks;
     }
     const uint32_t waves_per_block = TRACE_BLOCK / 64;
     uint32_t grid = uint32_t(c->cu_count) * uint32_t(per_cu);
     grid = std::max(1u, std::min(grid, (upper_bound + 63u) / 64u / waves_per_block + 1u));
-    // every wave should get several chunks so the tail balances; small launches fall back to one wave-load per claim
-    uint32_t chunk = upper_bound / (grid * waves_per_block * 2u);
-    chunk = std::min(TRACE_CHUNK_MAX, std::max(64u, chunk & ~63u));
-    hipLaunchKernelGGL((k_trace_persistent<STACK, SHADOW, INSTRUMENT>), dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->scene, in, hits, c->shadow_queue(),
-                       c->radiance.as<float4>(), count_ptr, next_work_counter(c), chunk, c->refill_below, c->counters.as<DeviceCounters>());
+    hipLaunchKernelGGL((k_trace_persistent<STACK, MODE, INSTRUMENT>), dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->scene, in, c->hits.as<float4>(), c->shadow_queue(),
+                       c->radiance.as<float4>(), closest_count, shadow_count, next_work_counter(c), c->refill_below, c->counters.as<DeviceCounters>());
 }
 
-template <bool SHADOW, bool INSTRUMENT>
-void launch_persistent_for_stack(HiprContext* c, const PathState& in, float4* hits, const uint32_t* count_ptr, uint32_t upper_bound) {
+template <int MODE, bool INSTRUMENT>
+void launch_persistent_for_stack(HiprContext* c, const PathState& in, const uint32_t* closest_count, const uint32_t* shadow_count, uint32_t upper_bound) {
     switch (c->stack_size) {
-    case 16: launch_persistent<16, SHADOW, INSTRUMENT>(c, in, hits, count_ptr, upper_bound, 0); break;
-    case 32: launch_persistent<32, SHADOW, INSTRUMENT>(c, in, hits, count_ptr, upper_bound, 1); break;
-    default: launch_persistent<64, SHADOW, INSTRUMENT>(c, in, hits, count_ptr, upper_bound, 2); break;
+    case 16: launch_persistent<16, MODE, INSTRUMENT>(c, in, closest_count, shadow_count, upper_bound, 0); break;
+    case 32: launch_persistent<32, MODE, INSTRUMENT>(c, in, closest_count, shadow_count, upper_bound, 1); break;
+    default: launch_persistent<64, MODE, INSTRUMENT>(c, in, closest_count, shadow_count, upper_bound, 2); break;
     }
 }
 
@@ -199,7 +199,7 @@ void launch_trace_closest(HiprContext* c, const PathState& in, const uint32_t* c
     float4* hits = c->hits.as<float4>();
     // Scenes whose whole BVH sits in the L1 / scalar cache (a few dozen nodes) are VALU-issue bound and run fastest with
     // the plain one-ray-per-lane kernel; everything larger wants the persistent kernel (measured: profiles/).
-    if (c->use_persistent()) { launch_persistent_for_stack<false, INSTRUMENT>(c, in, hits, count_ptr, upper_bound); return; }
+    if (c->use_persistent()) { launch_persistent_for_stack<TRACE_CLOSEST, INSTRUMENT>(c, in, count_ptr, nullptr, upper_bound); return; }
     const uint32_t grid = grid_for(upper_bound, TRACE_BLOCK, 256u * 16u);
     DeviceCounters* dc = c->counters.as<DeviceCounters>();
     switch (c->stack_size) {
@@ -211,7 +211,7 @@ void launch_trace_closest(HiprContext* c, const PathState& in, const uint32_t* c
 
 template <bool INSTRUMENT>
 void launch_trace_shadow(HiprContext* c, const uint32_t* count_ptr, uint32_t upper_bound) {
-    if (c->use_persistent()) { launch_persistent_for_stack<true, INSTRUMENT>(c, PathState{}, nullptr, count_ptr, upper_bound); return; }
+    if (c->use_persistent()) { launch_persistent_for_stack<TRACE_SHADOW, INSTRUMENT>(c, PathState{}, nullptr, count_ptr, upper_bound); return; }
     const uint32_t grid = grid_for(upper_bound, TRACE_BLOCK, 256u * 16u);
     DeviceCounters* dc = c->counters.as<DeviceCounters>();
     float4* rad = c->radiance.as<float4>();
@@ -221,6 +221,12 @@ void launch_trace_shadow(HiprContext* c, const uint32_t* count_ptr, uint32_t upp
     case 32: hipLaunchKernelGGL((k_trace_shadow<32, INSTRUMENT>), dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->scene, q, rad, count_ptr, dc); break;
     default: hipLaunchKernelGGL((k_trace_shadow<64, INSTRUMENT>), dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->scene, q, rad, count_ptr, dc); break;
     }
+}
+
+// The closest-hit rays of this bounce and the shadow rays the previous bounce queued, as one persistent launch.
+template <bool INSTRUMENT>
+void launch_trace_fused(HiprContext* c, const PathState& in, const uint32_t* closest_count, const uint32_t* shadow_count, uint32_t upper_bound) {
+    launch_persistent_for_stack<TRACE_FUSED, INSTRUMENT>(c, in, closest_count, shadow_count, upper_bound);
 }
 
 void launch_shade(HiprContext* c, const HiprCameraState& camera, int cur, uint32_t alive, const uint32_t* in_count, uint32_t* out_count, uint32_t* shadow_count) {
@@ -271,7 +277,9 @@ int hipr_create(int device_id, HiprContext** out_context) {
     HiprContext* c = new HiprContext();
     c->device = device_id;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&c->shade_done, hipEventDisableTiming) != hipSuccess || hipHostMalloc((void**)&c->host_counts, 4 * sizeof(uint32_t)) != hipSuccess) {
+        hipEventCreateWithFlags(&c->shade_done[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->shade_done[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->counts_copied[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->counts_copied[1], hipEventDisableTiming) != hipSuccess ||
+        hipHostMalloc((void**)&c->host_counts, 8 * sizeof(uint32_t)) != hipSuccess) {
         delete c;
         return fail(HIPR_ERROR_HIP, "stream / event / pinned allocation failed");
     }
@@ -285,6 +293,7 @@ int hipr_create(int device_id, HiprContext** out_context) {
     if (hipGetDeviceProperties(&props, device_id) == hipSuccess && props.multiProcessorCount > 0) c->cu_count = props.multiProcessorCount;
     if (const char* v = getenv("HIPR_TRACE_VARIANT")) c->trace_variant = atoi(v);
     if (const char* v = getenv("HIPR_REFILL_BELOW")) c->refill_below = atoi(v);
+    if (const char* v = getenv("HIPR_TRACE_LOG")) c->trace_log = atoi(v) != 0;
     HIP_TRY(hipMemsetAsync(c->counters.ptr, 0, sizeof(DeviceCounters), c->stream));
 
     float offsets[256 * 4];
@@ -321,7 +330,8 @@ int hipr_destroy(HiprContext* c) {
     for (DeviceBuffer* b : all) b->release();
     for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) c->path[i][j].release();
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
-    if (c->shade_done) (void)hipEventDestroy(c->shade_done);
+    for (hipEvent_t e : c->shade_done) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->counts_copied) if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->host_counts) (void)hipHostFree(c->host_counts);
@@ -516,50 +526,86 @@ int hipr_render_pass(HiprContext* c, const HiprCameraState* camera, void* out_ha
     }
     pass.camera_rays = valid_pixels * f.samples_per_pass;
 
-    c->host_counts[2] = n;   // pinned staging word, rewritten only after the syncs of the next pass
-    HIP_TRY(hipMemcpyAsync(counts + 0, c->host_counts + 2, 4, hipMemcpyHostToDevice, c->stream));
+    c->host_counts[4] = n;   // pinned staging word, rewritten only after the syncs of the next pass
+    HIP_TRY(hipMemcpyAsync(counts + 0, c->host_counts + 4, 4, hipMemcpyHostToDevice, c->stream));
 
     c->begin_timed(HIPR_KERNEL_GENERATE);
     hipLaunchKernelGGL(k_generate, dim3((n + 255) / 256), dim3(256), 0, c->stream, f, *camera, c->path_state(0), c->radiance.as<float4>(), n);
     c->end_timed();
 
-    int cur = 0;
-    uint32_t alive = n;
-    uint32_t first_dead = n - uint32_t(std::min<uint64_t>(n, pass.camera_rays));   // dead lanes of partial tiles are never traced
-    while (alive > 0) {
-        uint32_t* in_count = counts + cur;
-        uint32_t* out_count = counts + (1 - cur);
+    // Bounce k = trace stage + shade(k). The trace stage serves the closest-hit rays of bounce k AND the shadow rays shade(k - 1)
+    // queued (they are independent; radiance slots are still updated in the order shade(0), shadow(0), shade(1), ...): one fused
+    // persistent launch for big scenes, two plain launches otherwise. All queue sizes stay on the device; the host only needs
+    // them to stop, so it enqueues bounce k + 1 (sized by the known upper bound: the rays of bounce k) BEFORE it waits for the
+    // sizes bounce k produced -- the GPU never idles on the read-back.
+    const bool fused = c->use_persistent();
+    auto enqueue_bounce = [&](uint32_t k, uint32_t bound) -> int {
+        const int parity = int(k & 1u);
+        uint32_t* in_count = counts + parity;
+        uint32_t* out_count = counts + (1 - parity);
+        uint32_t* shadow_in = counts + 2 + (1 - parity);   // written by shade(k - 1)
+        uint32_t* shadow_out = counts + 2 + parity;
+        const size_t first_timed = c->timed.size();
         HIP_TRY(hipMemsetAsync(out_count, 0, 4, c->stream));
-        HIP_TRY(hipMemsetAsync(counts + 2, 0, 4, c->stream));
+        HIP_TRY(hipMemsetAsync(shadow_out, 0, 4, c->stream));
 
         c->begin_timed(HIPR_KERNEL_TRACE_CLOSEST);
-        if (c->instrument) launch_trace_closest<true>(c, c->path_state(cur), in_count, alive);
-        else launch_trace_closest<false>(c, c->path_state(cur), in_count, alive);
+        if (k > 0 && fused) {
+            if (c->instrument) launch_trace_fused<true>(c, c->path_state(parity), in_count, shadow_in, 2u * bound);
+            else launch_trace_fused<false>(c, c->path_state(parity), in_count, shadow_in, 2u * bound);
+        } else {
+            if (c->instrument) launch_trace_closest<true>(c, c->path_state(parity), in_count, bound);
+            else launch_trace_closest<false>(c, c->path_state(parity), in_count, bound);
+        }
         c->end_timed();
+        if (k > 0 && !fused) {
+            c->begin_timed(HIPR_KERNEL_TRACE_SHADOW);
+            if (c->instrument) launch_trace_shadow<true>(c, shadow_in, bound);
+            else launch_trace_shadow<false>(c, shadow_in, bound);
+            c->end_timed();
+        }
 
         c->begin_timed(HIPR_KERNEL_SHADE);
-        launch_shade(c, *camera, cur, alive, in_count, out_count, counts + 2);
+        launch_shade(c, *camera, parity, bound, in_count, out_count, shadow_out);
         c->end_timed();
-        HIP_TRY(hipEventRecord(c->shade_done, c->stream));
+        HIP_TRY(hipEventRecord(c->shade_done[parity], c->stream));
+        HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->shade_done[parity], 0));
+        HIP_TRY(hipMemcpyAsync(c->host_counts + 2 * parity, out_count, 4, hipMemcpyDeviceToHost, c->copy_stream));
+        HIP_TRY(hipMemcpyAsync(c->host_counts + 2 * parity + 1, shadow_out, 4, hipMemcpyDeviceToHost, c->copy_stream));
+        HIP_TRY(hipEventRecord(c->counts_copied[parity], c->copy_stream));
 
-        // The shadow kernel reads its count on the device; it is launched for the upper bound so the
-        // host can fetch the queue sizes (on the copy stream) while it runs.
-        c->begin_timed(HIPR_KERNEL_TRACE_SHADOW);
-        if (c->instrument) launch_trace_shadow<true>(c, counts + 2, alive);
-        else launch_trace_shadow<false>(c, counts + 2, alive);
-        c->end_timed();
+        if (c->instrument && c->trace_log) {   // diagnostic (HIPR_TRACE_LOG=1): per-bounce counters and kernel times; serialises the pass
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            HIP_TRY(hipStreamSynchronize(c->copy_stream));
+            DeviceCounters dc;
+            HIP_TRY(hipMemcpy(&dc, c->counters.ptr, sizeof(dc), hipMemcpyDeviceToHost));
+            const DeviceCounters& p = c->trace_log_previous;
+            fprintf(stderr, "[hipr] bounce %u: <= %u closest rays: nodes %llu tris %llu | shadow rays of the previous bounce: nodes %llu tris %llu | kernels", k, bound,
+                    dc.closest_nodes - p.closest_nodes, dc.closest_triangles - p.closest_triangles, dc.shadow_nodes - p.shadow_nodes, dc.shadow_triangles - p.shadow_triangles);
+            for (size_t i = first_timed; i < c->timed.size(); ++i) {
+                float ms = 0;
+                (void)hipEventElapsedTime(&ms, c->timed[i].start, c->timed[i].stop);
+                fprintf(stderr, " %s %.1f us", c->timed[i].kernel == HIPR_KERNEL_SHADE ? "shade" : (c->timed[i].kernel == HIPR_KERNEL_TRACE_SHADOW ? "shadow" : "trace"), ms * 1e3f);
+            }
+            fprintf(stderr, " -> %u paths continue, %u shadow rays\n", c->host_counts[2 * parity], c->host_counts[2 * parity + 1]);
+            c->trace_log_previous = dc;
+        }
+        return HIPR_OK;
+    };
 
-        HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->shade_done, 0));
-        HIP_TRY(hipMemcpyAsync(c->host_counts, out_count, 4, hipMemcpyDeviceToHost, c->copy_stream));
-        HIP_TRY(hipMemcpyAsync(c->host_counts + 1, counts + 2, 4, hipMemcpyDeviceToHost, c->copy_stream));
-        HIP_TRY(hipStreamSynchronize(c->copy_stream));
-
-        pass.closest_rays += alive - (pass.iterations == 0 ? first_dead : 0);
-        pass.shadow_rays += c->host_counts[1];
+    const uint32_t first_dead = n - uint32_t(std::min<uint64_t>(n, pass.camera_rays));   // dead lanes of partial tiles are never traced
+    uint32_t alive = n;   // rays of bounce k
+    if (int s = enqueue_bounce(0, alive)) return s;
+    for (uint32_t k = 0;; ++k) {
+        if (int s = enqueue_bounce(k + 1, alive)) return s;   // speculative: at most `alive` paths continue
+        HIP_TRY(hipEventSynchronize(c->counts_copied[k & 1u]));
+        pass.closest_rays += alive - (k == 0 ? first_dead : 0);
+        pass.shadow_rays += c->host_counts[2 * (k & 1u) + 1];
         pass.iterations += 1;
-        alive = c->host_counts[0];
-        cur = 1 - cur;
-        if (pass.iterations > 4096) return fail(HIPR_ERROR_HIP, "wavefront loop did not terminate");
+        alive = c->host_counts[2 * (k & 1u)];
+        // Nothing continues: bounce k + 1 (already queued) traces the shadow rays of bounce k and shades nothing.
+        if (alive == 0) break;
+        if (k > 4096) return fail(HIPR_ERROR_HIP, "wavefront loop did not terminate");
     }
 
     c->begin_timed(HIPR_KERNEL_ACCUMULATE);
@@ -615,6 +661,13 @@ int hipr_reset_counters(HiprContext* c) {
     c->collect_times();
     HIP_TRY(hipMemset(c->counters.ptr, 0, sizeof(DeviceCounters)));
     c->total = {};
+    c->trace_log_previous = {};
+    return HIPR_OK;
+}
+
+int hipr_trace_is_fused(HiprContext* c, int* out_fused) {
+    if (!c || !out_fused) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_trace_is_fused: null argument");
+    *out_fused = c->scene_ready && c->use_persistent() ? 1 : 0;
     return HIPR_OK;
 }
 

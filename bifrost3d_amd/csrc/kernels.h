@@ -421,31 +421,44 @@ constexpr uint32_t TRACE_CHUNK_MAX = 512; // rays a wave claims per global atomi
 constexpr uint32_t TRACE_SHARDS = 64;   // == wave size: a drained wave probes all of them with one load per lane
 constexpr uint32_t TRACE_SHARD_STRIDE = 16;   // uint32 words between shard counters
 
-template <int STACK, bool SHADOW, bool INSTRUMENT>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_persistent(DeviceScene sc, PathState in, float4* hits, ShadowQueue q, float4* radiance,
-                                                                  const uint32_t* count_ptr, uint32_t* work_counter, uint32_t chunk_size,
+// MODE: which rays one launch serves.
+//   TRACE_CLOSEST  the path queue (closest hit)                       -- bounce 0 and the stage-level parity entry point
+//   TRACE_SHADOW   the shadow queue (any hit, transmittance)          -- the shadow rays of the last bounce
+//   TRACE_FUSED    both: the closest-hit rays of bounce k and the shadow rays of bounce k - 1 are independent, so one launch
+//                  takes them as one index space [0, n_closest + n_shadow). Every lane carries its own kind, waves refill
+//                  from whatever is left, and the long-ray tail of one kind is filled with work of the other.
+enum { TRACE_CLOSEST = 0, TRACE_SHADOW = 1, TRACE_FUSED = 2 };
+
+template <int STACK, int MODE, bool INSTRUMENT>
+__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) void k_trace_persistent(DeviceScene sc, PathState in, float4* hits, ShadowQueue q, float4* radiance,
+                                                                  const uint32_t* closest_count_ptr, const uint32_t* shadow_count_ptr, uint32_t* work_counter,
                                                                   int refill_below, DeviceCounters* counters) {
     __shared__ int s_stack[STACK * TRACE_BLOCK];
     int* stack = s_stack + threadIdx.x;
-    const uint32_t n = *count_ptr;
+    const uint32_t n_closest = MODE != TRACE_SHADOW ? *closest_count_ptr : 0u;
+    const uint32_t n = n_closest + (MODE != TRACE_CLOSEST ? *shadow_count_ptr : 0u);
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lt = (1ull << lane) - 1ull;
+    // every wave should get several chunks so the tail balances; small launches fall back to one wave-load per claim
+    const uint32_t chunk_size = min(TRACE_CHUNK_MAX, max(64u, (n / (gridDim.x * (TRACE_BLOCK / 64u) * 2u)) & ~63u));
 
     uint32_t chunk_next = 0, chunk_end = 0;   // wave uniform
     uint32_t shard = blockIdx.x % TRACE_SHARDS;
     bool exhausted = false;
 
     bool active = false, finished = false;    // finished: traversal done, result still in registers
+    bool is_shadow = MODE == TRACE_SHADOW;     // per lane in the fused mode
     uint32_t ray_index = 0;
     f3 o = {0, 0, 0}, d = {0, 0, 1}, inv = {0, 0, 0}, ood = {0, 0, 0};
-    float tmin = 0.0f, tmax = 0.0f;                       // tmax: best distance so far (closest) or the ray extent (shadow)
-    float best_u = 0.0f, best_v = 0.0f;
-    uint32_t best_id = HIPR_HIT_MISS, skip = HIPR_NO_TRIANGLE;
-    f3 rad = {0, 0, 0};
-    uint32_t slot = 0;
+    float tmin = 0.0f, tmax = 0.0f;            // tmax: best distance so far (closest) or the ray extent (shadow)
+    // Four registers with a meaning per ray kind (a lane is one or the other, never both):
+    //   closest: pay_x, pay_y = barycentrics of the best hit, pay_z = bits of its id, pay_k = the triangle the ray left from
+    //   shadow : pay_x, pay_y, pay_z = radiance carried by the ray,                  pay_k = radiance slot of the path
+    float pay_x = 0.0f, pay_y = 0.0f, pay_z = __uint_as_float(HIPR_HIT_MISS);
+    uint32_t pay_k = HIPR_NO_TRIANGLE;
     int cur = 0, sp = 0;
     uint32_t tri_cur = 0, tri_end = 0;
-    uint32_t nodes = 0, tris = 0;
+    uint32_t nodes = 0, tris = 0, shadow_nodes = 0, shadow_tris = 0;
 
     // Work item encoding: >= 0 inner node index, < 0 leaf ~((first << 3) | (count - 1)), TRACE_DONE = nothing left.
     constexpr int TRACE_DONE = 0x7FFFFFFF;
@@ -453,11 +466,13 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_persistent(DeviceScene sc
     for (;;) {
         // ---- retire finished lanes (converged: every lane of the wave is here) --------------------------------------
         if (finished) {
-            if constexpr (SHADOW) {
-                float4 acc = radiance[slot];
-                acc.x += rad.x; acc.y += rad.y; acc.z += rad.z;
-                radiance[slot] = acc;
-            } else {
+            if (is_shadow) {
+                if constexpr (MODE != TRACE_CLOSEST) {
+                    float4 acc = radiance[pay_k];
+                    acc.x += pay_x; acc.y += pay_y; acc.z += pay_z;
+                    radiance[pay_k] = acc;
+                }
+            } else if constexpr (MODE != TRACE_SHADOW) {
                 for (uint32_t li = 0; li < sc.light_count; ++li) {   // analytic area lights, LightSources.cu:31-70
                     const HiprLight& l = sc.lights[li];
                     const uint32_t type = l.flags & HIPR_LIGHT_TYPE_MASK;
@@ -465,9 +480,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_persistent(DeviceScene sc
                     if (type == HIPR_LIGHT_SPHERE) { if (!(l.data[6] > 0.0f)) continue; t = ray_sphere(o, d, L3(l, 3), l.data[6]); }
                     else if (type == HIPR_LIGHT_SPOT) { if (!(l.data[6] > 0.0f)) continue; t = ray_disk(o, d, L3(l, 3), L3(l, 7), l.data[6]); }
                     else continue;
-                    if (t > tmin && t < tmax) { tmax = t; best_u = 0; best_v = 0; best_id = HIPR_HIT_LIGHT | li; }
+                    if (t > tmin && t < tmax) { tmax = t; pay_x = 0; pay_y = 0; pay_z = __uint_as_float(HIPR_HIT_LIGHT | li); }
                 }
-                hits[ray_index] = make_float4(tmax, best_u, best_v, __uint_as_float(best_id));
+                hits[ray_index] = make_float4(tmax, pay_x, pay_y, pay_z);
             }
             finished = false;
         }
@@ -497,22 +512,27 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_persistent(DeviceScene sc
             if (chunk_next < chunk_end) {
                 const uint32_t idx = chunk_next + __popcll(idle & lt);
                 if (!active && idx < chunk_end) {
-                    ray_index = idx;
                     bool dead = false;
                     float4 ro, rdv;
-                    if constexpr (SHADOW) {
-                        ro = q.o_tmax[idx]; rdv = q.d_slot[idx];
-                        const float4 rr = q.radiance[idx];
-                        rad = mk3(rr.x, rr.y, rr.z);
-                        slot = __float_as_uint(rdv.w);
-                        tmin = 0.0f; tmax = ro.w;
-                    } else {
+                    if (MODE == TRACE_FUSED) is_shadow = idx >= n_closest;
+                    if (is_shadow) {
+                        if constexpr (MODE != TRACE_CLOSEST) {
+                            const uint32_t si = idx - n_closest;
+                            ray_index = si;
+                            ro = q.o_tmax[si]; rdv = q.d_slot[si];
+                            const float4 rr = q.radiance[si];
+                            pay_x = rr.x; pay_y = rr.y; pay_z = rr.z;
+                            pay_k = __float_as_uint(rdv.w);
+                            tmin = 0.0f; tmax = ro.w;
+                        }
+                    } else if constexpr (MODE != TRACE_SHADOW) {
+                        ray_index = idx;
                         const uint4 meta = in.meta[idx];
                         dead = meta.x == HIPR_DEAD_SLOT;
-                        skip = meta.y;
+                        pay_k = meta.y;
                         ro = in.o_tmin[idx]; rdv = in.d_pdf[idx];
                         tmin = ro.w; tmax = __builtin_inff();
-                        best_u = best_v = 0.0f; best_id = HIPR_HIT_MISS;
+                        pay_x = pay_y = 0.0f; pay_z = __uint_as_float(HIPR_HIT_MISS);
                     }
                     if (dead) hits[idx] = make_float4(0, 0, 0, __uint_as_float(HIPR_HIT_MISS));
                     else {
@@ -548,34 +568,35 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_persistent(DeviceScene sc
                 if (tri_mode) {
                     const uint32_t i = tri_cur;
                     tri_cur = i + 1u;
-                    ++tris;
+                    if (INSTRUMENT) { tris += is_shadow ? 0u : 1u; shadow_tris += is_shadow ? 1u : 0u; }
                     const float4* tp = sc.triangles + 3 * size_t(i);
                     const float4 a = tp[0], b = tp[1], c = tp[2];
                     float t, u, v;
                     const bool hit = intersect_triangle_full(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), o, d, t, u, v);
                     need_pop = tri_cur == tri_end;
-                    if constexpr (SHADOW) {
-                        if (hit && t > tmin && t < tmax) {
+                    if constexpr (MODE != TRACE_CLOSEST) {
+                        if (is_shadow && hit && t > tmin && t < tmax) {
                             float coverage = 1.0f;
                             if (!(__float_as_uint(c.w) & HIPR_TRIANGLE_OPAQUE)) {
                                 const HiprInstance& inst = sc.instances[__float_as_uint(c.y)];
                                 coverage = material_coverage(sc, sc.materials[inst.material_index], triangle_texcoord(sc, inst, __float_as_uint(c.z), u, v));
                             }
-                            rad *= 1.0f - coverage;
-                            if (rad.x < 0.0000001f && rad.y < 0.0000001f && rad.z < 0.0000001f) {   // fully shadowed: the ray is done
-                                rad = mk3(0.0f);
+                            pay_x *= 1.0f - coverage; pay_y *= 1.0f - coverage; pay_z *= 1.0f - coverage;
+                            if (pay_x < 0.0000001f && pay_y < 0.0000001f && pay_z < 0.0000001f) {   // fully shadowed: the ray is done
+                                pay_x = pay_y = pay_z = 0.0f;
                                 need_pop = false; take_next = true; next_item = TRACE_DONE;
                             }
                         }
-                    } else {
-                        const bool closer = hit & (i != skip) & (t > tmin) & ((t < tmax) | ((t == tmax) & (i < best_id)));
-                        tmax = closer ? t : tmax; best_u = closer ? u : best_u; best_v = closer ? v : best_v; best_id = closer ? i : best_id;
+                    }
+                    if constexpr (MODE != TRACE_SHADOW) {
+                        const bool closer = !is_shadow & hit & (i != pay_k) & (t > tmin) & ((t < tmax) | ((t == tmax) & (i < __float_as_uint(pay_z))));
+                        tmax = closer ? t : tmax; pay_x = closer ? u : pay_x; pay_y = closer ? v : pay_y; pay_z = closer ? __uint_as_float(i) : pay_z;
                     }
                 }
             } else if (node_mode) {
                 const float4* np = sc.nodes + 4 * size_t(cur);
                 const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-                ++nodes;
+                if (INSTRUMENT) { nodes += is_shadow ? 0u : 1u; shadow_nodes += is_shadow ? 1u : 0u; }
                 float t0, t1;
                 const bool h0 = slab(inv, ood, n0.x, n0.y, n0.z, n0.w, n2.x, n2.y, tmin, tmax, t0);
                 const bool h1 = slab(inv, ood, n1.x, n1.y, n1.z, n1.w, n2.z, n2.w, tmin, tmax, t1);
@@ -611,8 +632,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_persistent(DeviceScene sc
     }
 
     if (INSTRUMENT) {
-        wave_add(SHADOW ? &counters->shadow_nodes : &counters->closest_nodes, nodes);
-        wave_add(SHADOW ? &counters->shadow_triangles : &counters->closest_triangles, tris);
+        if (MODE != TRACE_SHADOW) { wave_add(&counters->closest_nodes, nodes); wave_add(&counters->closest_triangles, tris); }
+        if (MODE != TRACE_CLOSEST) { wave_add(&counters->shadow_nodes, shadow_nodes); wave_add(&counters->shadow_triangles, shadow_tris); }
     }
 }
 

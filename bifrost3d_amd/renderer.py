@@ -89,6 +89,11 @@ class Context:
     def reset_timers(self):
         self._check(self.lib.hipr_reset_timers(self.handle), "hipr_reset_timers")
 
+    def trace_is_fused(self) -> bool:
+        v = C.c_int(0)
+        self._check(self.lib.hipr_trace_is_fused(self.handle, C.byref(v)), "hipr_trace_is_fused")
+        return bool(v.value)
+
     def kernel_times(self) -> dict:
         t = capi.HiprKernelTimes()
         self._check(self.lib.hipr_get_kernel_times(self.handle, C.byref(t)), "hipr_get_kernel_times")

@@ -294,6 +294,9 @@ int hipr_synchronize(HiprContext* context);
 int hipr_get_counters(HiprContext* context, HiprCounters* out);
 int hipr_reset_counters(HiprContext* context);
 /* Enables per-ray node / triangle visit counting in the trace kernels (slower, off by default). */
+/* 1 when the uploaded scene is traced by the fused persistent kernel (closest-hit rays of bounce k and shadow rays of bounce
+ * k - 1 in one launch, timed under HIPR_KERNEL_TRACE_CLOSEST); 0 when closest and shadow rays are separate launches. */
+int hipr_trace_is_fused(HiprContext* context, int* out_fused);
 int hipr_set_instrumentation(HiprContext* context, int count_traversal_steps);
 int hipr_reset_timers(HiprContext* context);
 int hipr_get_kernel_times(HiprContext* context, HiprKernelTimes* out);
