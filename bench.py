@@ -201,8 +201,8 @@ def main():
         # Rooflines (rank 0's launches). Algorithmic HBM bytes per unit of work, DESIGN.md "Kernels" / SURVEY.md 8d:
         #   generate       80 B per path        (64 B path state + 16 B radiance slot written)
         #   trace_closest  48 B path state read + 16 B hit written per ray, + 64 B per BVH node visited + 48 B per triangle tested
-        #   shade          80 B per queued ray (hit + path state) + 408 B per shaded hit (triangle 48, instance 80, material 64,
-        #                  indices 12, 3 vertices 48, 3 tints 12, 3 RIS light candidates 144) + 64 B per continued path
+        #   shade          80 B per queued ray (hit + path state) + 352 B per shaded hit (triangle 48, shading record 96, material 64,
+        #                  3 RIS light candidates 144) + 64 B per continued path
         #                  + 48 B per shadow ray queued + 32 B radiance read-modify-write per queued ray
         #   trace_shadow   48 B record + 32 B radiance rmw per shadow ray, + 64 B per node + 48 B per triangle
         #   accumulate     16 B radiance per sample + 64 B f64 accumulation rmw + 8 B half4 per owned pixel
@@ -210,7 +210,7 @@ def main():
         kernel_bytes = {
             "generate": 80.0 * n_camera,
             "trace_closest": n_closest * (48 + 16 + 64 * nodes_per_ray + 48 * tris_per_ray),
-            "shade": 80.0 * n_closest + 408.0 * n_hits + 64.0 * max(0, n_closest - n_camera) + 48.0 * n_shadow + 32.0 * n_closest,
+            "shade": 80.0 * n_closest + 352.0 * n_hits + 64.0 * max(0, n_closest - n_camera) + 48.0 * n_shadow + 32.0 * n_closest,
             "trace_shadow": n_shadow * (48 + 32 + 64 * shadow_nodes_per_ray + 48 * shadow_tris_per_ray),
             "accumulate": 16.0 * n_camera + (64.0 + 8.0) * n_camera / max(1, S),
         }

@@ -11,7 +11,7 @@ import os
 from pathlib import Path
 
 PKG_DIR = Path(__file__).resolve().parent
-LIB_PATH = PKG_DIR / "csrc" / "libhiprenderer.so"
+LIB_PATH = Path(os.environ.get("HIPR_LIBRARY", PKG_DIR / "csrc" / "libhiprenderer.so"))   # HIPR_LIBRARY: A/B builds of the kernels
 HOST_LIB_PATH = PKG_DIR / "host" / "libhiprenderer_host.so"
 TABLES_PATH = PKG_DIR / "data" / "HIPRenderer" / "shading_tables.bin"
 
@@ -117,7 +117,7 @@ C_ABI_SYMBOLS = (
     "hipr_set_frame", "hipr_owned_pixel_count",
     "hipr_render_pass", "hipr_read_accumulation", "hipr_scatter_tiles", "hipr_synchronize", "hipr_get_counters",
     "hipr_device_malloc", "hipr_device_free", "hipr_copy_to_host", "hipr_present_flipped",
-    "hipr_reset_counters", "hipr_trace_is_fused", "hipr_set_instrumentation", "hipr_reset_timers", "hipr_get_kernel_times",
+    "hipr_reset_counters", "hipr_set_wavefront_count", "hipr_trace_is_fused", "hipr_set_instrumentation", "hipr_reset_timers", "hipr_get_kernel_times",
     "hipr_debug_generate", "hipr_debug_sobol", "hipr_debug_trace_closest", "hipr_debug_trace_shadow",
 )
 

@@ -66,14 +66,48 @@ struct DeviceBuffer {
 
 struct TimedLaunch { int kernel; hipEvent_t start, stop; };
 
+// One independent wavefront of paths: its own queues, queue sizes and stream. A pass splits its path slots over the
+// context's wavefronts; they advance through their bounces independently, so while one of them shades (few resident
+// waves, waiting on gathers) the other one traces (many waves, latency bound) on the same CUs.
+struct Wavefront {
+    hipStream_t stream = nullptr;       // wavefront 0 runs on the context stream, the others on their own
+    hipStream_t own_stream = nullptr;
+    hipEvent_t shade_done[2] = {nullptr, nullptr}, counts_copied[2] = {nullptr, nullptr}, finished = nullptr;   // by bounce parity: two bounces are in flight
+    DeviceBuffer path[2][4], hits, shadow[3], queue_counts;
+    uint32_t* host_counts = nullptr;    // pinned: {continuing paths, shadow rays} per bounce parity, [4] staging word
+    uint32_t first_slot = 0, n_slots = 0;
+
+    PathState path_state(int which) const {
+        return {path[which][0].as<float4>(), path[which][1].as<float4>(), path[which][2].as<float4>(), path[which][3].as<uint4>()};
+    }
+    ShadowQueue shadow_queue() const { return {shadow[0].as<float4>(), shadow[1].as<float4>(), shadow[2].as<float4>()}; }
+    void release() {
+        for (auto& buffers : path) for (DeviceBuffer& b : buffers) b.release();
+        hits.release(); queue_counts.release();
+        for (DeviceBuffer& b : shadow) b.release();
+        for (hipEvent_t e : shade_done) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : counts_copied) if (e) (void)hipEventDestroy(e);
+        if (finished) (void)hipEventDestroy(finished);
+        if (own_stream) (void)hipStreamDestroy(own_stream);
+        if (host_counts) (void)hipHostFree(host_counts);
+        *this = Wavefront();
+    }
+};
+constexpr int MAX_WAVEFRONTS = 2;
+constexpr int COUNT_PAIR_STRIDE = 16;   // uint32 words between the two queue-size pairs of a wavefront (one 64 B line each)
+
 } // namespace
 
 struct HiprContext {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr, copy_stream = nullptr;
-    hipEvent_t shade_done[2] = {nullptr, nullptr}, counts_copied[2] = {nullptr, nullptr};   // by bounce parity: two bounces are in flight
+    hipEvent_t pass_start = nullptr;
+    Wavefront wavefronts[MAX_WAVEFRONTS];
+    int wavefront_limit = 1;                // hipr_set_wavefront_count / HIPR_WAVEFRONTS: 2 overlaps one half-frame's shading with the other's tracing
+    int wavefront_count = 1;                // set by hipr_set_frame: small frames run as one wavefront
 
     // scene
+    DeviceBuffer shade_triangles;
     DeviceBuffer nodes, triangles, instances, indices, geometry, texcoords, tints, emissions, materials, lights, textures, texels;
     DeviceBuffer ggx_rho, dielectric_rho, alpha, sample_offsets, sobol_tables;
     DeviceScene scene = {};
@@ -85,7 +119,7 @@ struct HiprContext {
     FrameInfo frame = {};
     bool frame_ready = false;
     uint32_t n_slots = 0;   // owned_tiles * 64 * samples_per_pass
-    DeviceBuffer path[2][4], hits, shadow[3], radiance, accumulation, scratch_accumulation, queue_counts, counters, work_counters;
+    DeviceBuffer radiance, accumulation, scratch_accumulation, counters, work_counters;
     bool use_scratch = false;
     int entry = HIPR_ENTRY_PATH_TRACING;
     DeviceBuffer& active_accumulation() { return use_scratch ? scratch_accumulation : accumulation; }
@@ -93,9 +127,9 @@ struct HiprContext {
     int trace_variant = -1;             // 1: persistent kernels, 0: one ray per lane, -1: pick by BVH size (HIPR_TRACE_VARIANT)
     bool use_persistent() const { return trace_variant < 0 ? scene.node_count > 64 : trace_variant == 1; }
     int cu_count = 256;
+    int blocks_per_cu_override = 0;     // HIPR_BLOCKS_PER_CU
     int refill_below = 40;              // persistent kernels refill a wave once fewer lanes than this are busy (HIPR_REFILL_BELOW)
     int persistent_blocks_per_cu[3][3] = {{0, 0, 0}, {0, 0, 0}};   // [shadow][stack bucket]
-    uint32_t* host_counts = nullptr;   // pinned: {continuing paths, shadow rays} per bounce parity, [4] staging word
 
     // bookkeeping
     HiprCounters total = {};   // since hipr_reset_counters
@@ -110,11 +144,6 @@ struct HiprContext {
 
     DeviceBuffer debug_a, debug_b, debug_c;
 
-    PathState path_state(int which) const {
-        return {path[which][0].as<float4>(), path[which][1].as<float4>(), path[which][2].as<float4>(), path[which][3].as<uint4>()};
-    }
-    ShadowQueue shadow_queue() const { return {shadow[0].as<float4>(), shadow[1].as<float4>(), shadow[2].as<float4>()}; }
-
     hipEvent_t next_event() {
         if (events_used == event_pool.size()) {
             hipEvent_t e;
@@ -123,16 +152,16 @@ struct HiprContext {
         }
         return event_pool[events_used++];
     }
-    void begin_timed(int kernel) {
+    void begin_timed(int kernel, hipStream_t on) {
         if (!timing) return;
         TimedLaunch t = {kernel, next_event(), next_event()};
         if (!t.start || !t.stop) return;
-        (void)hipEventRecord(t.start, stream);
+        (void)hipEventRecord(t.start, on);
         timed.push_back(t);
     }
-    void end_timed() {
+    void end_timed(hipStream_t on) {
         if (!timing || timed.empty()) return;
-        (void)hipEventRecord(timed.back().stop, stream);
+        (void)hipEventRecord(timed.back().stop, on);
     }
     // Requires the stream to be idle (called after a synchronize).
     void collect_times() {
@@ -162,8 +191,10 @@ constexpr uint32_t WORK_COUNTERS = WORK_SETS * WORK_SET_WORDS;
 
 // Hands out a zeroed work counter for one persistent launch; re-zeroes the ring when it wraps (stream ordered).
 uint32_t* next_work_counter(HiprContext* c) {
-    if (c->work_index >= WORK_SETS) {
+    if (c->work_index >= WORK_SETS) {   // out of sets inside a pass (the used prefix is re-zeroed at every pass start): drain and re-zero
+        for (int g = 0; g < MAX_WAVEFRONTS; ++g) if (c->wavefronts[g].stream) (void)hipStreamSynchronize(c->wavefronts[g].stream);
         (void)hipMemsetAsync(c->work_counters.ptr, 0, WORK_COUNTERS * sizeof(uint32_t), c->stream);
+        (void)hipStreamSynchronize(c->stream);
         c->work_index = 0;
     }
     return c->work_counters.as<uint32_t>() + size_t(c->work_index++) * WORK_SET_WORDS;
@@ -171,67 +202,70 @@ uint32_t* next_work_counter(HiprContext* c) {
 
 // One persistent launch over the path queue (closest_count != nullptr), the shadow queue (shadow_count != nullptr) or both.
 template <int STACK, int MODE, bool INSTRUMENT>
-void launch_persistent(HiprContext* c, const PathState& in, const uint32_t* closest_count, const uint32_t* shadow_count, uint32_t upper_bound, int bucket) {
+void launch_persistent(HiprContext* c, const Wavefront& w, const PathState& in, const uint32_t* closest_count, const uint32_t* shadow_count, uint32_t upper_bound, int bucket) {
     int& per_cu = c->persistent_blocks_per_cu[MODE][bucket];
     if (per_cu == 0) {
         int blocks = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_trace_persistent<STACK, MODE, INSTRUMENT>, TRACE_BLOCK, 0) != hipSuccess || blocks <= 0) blocks = 4;
+        if (c->trace_log) fprintf(stderr, "[hipr] k_trace_persistent<%d, %d>: occupancy query says %d blocks of %d threads per CU\n", STACK, MODE, blocks, TRACE_BLOCK);
+        if (c->blocks_per_cu_override > 0) blocks = c->blocks_per_cu_override;
         per_cu = blocks;
     }
     const uint32_t waves_per_block = TRACE_BLOCK / 64;
     uint32_t grid = uint32_t(c->cu_count) * uint32_t(per_cu);
     grid = std::max(1u, std::min(grid, (upper_bound + 63u) / 64u / waves_per_block + 1u));
-    hipLaunchKernelGGL((k_trace_persistent<STACK, MODE, INSTRUMENT>), dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->scene, in, c->hits.as<float4>(), c->shadow_queue(),
+    hipLaunchKernelGGL((k_trace_persistent<STACK, MODE, INSTRUMENT>), dim3(grid), dim3(TRACE_BLOCK), 0, w.stream, c->scene, in, w.hits.as<float4>(), w.shadow_queue(),
                        c->radiance.as<float4>(), closest_count, shadow_count, next_work_counter(c), c->refill_below, c->counters.as<DeviceCounters>());
 }
 
 template <int MODE, bool INSTRUMENT>
-void launch_persistent_for_stack(HiprContext* c, const PathState& in, const uint32_t* closest_count, const uint32_t* shadow_count, uint32_t upper_bound) {
+void launch_persistent_for_stack(HiprContext* c, const Wavefront& w, const PathState& in, const uint32_t* closest_count, const uint32_t* shadow_count, uint32_t upper_bound) {
     switch (c->stack_size) {
-    case 16: launch_persistent<16, MODE, INSTRUMENT>(c, in, closest_count, shadow_count, upper_bound, 0); break;
-    case 32: launch_persistent<32, MODE, INSTRUMENT>(c, in, closest_count, shadow_count, upper_bound, 1); break;
-    default: launch_persistent<64, MODE, INSTRUMENT>(c, in, closest_count, shadow_count, upper_bound, 2); break;
+    case 16: launch_persistent<16, MODE, INSTRUMENT>(c, w, in, closest_count, shadow_count, upper_bound, 0); break;
+    case 32: launch_persistent<32, MODE, INSTRUMENT>(c, w, in, closest_count, shadow_count, upper_bound, 1); break;
+    default: launch_persistent<64, MODE, INSTRUMENT>(c, w, in, closest_count, shadow_count, upper_bound, 2); break;
     }
 }
 
 template <bool INSTRUMENT>
-void launch_trace_closest(HiprContext* c, const PathState& in, const uint32_t* count_ptr, uint32_t upper_bound) {
-    float4* hits = c->hits.as<float4>();
+void launch_trace_closest(HiprContext* c, const Wavefront& w, const PathState& in, const uint32_t* count_ptr, uint32_t upper_bound) {
+    float4* hits = w.hits.as<float4>();
     // Scenes whose whole BVH sits in the L1 / scalar cache (a few dozen nodes) are VALU-issue bound and run fastest with
     // the plain one-ray-per-lane kernel; everything larger wants the persistent kernel (measured: profiles/).
-    if (c->use_persistent()) { launch_persistent_for_stack<TRACE_CLOSEST, INSTRUMENT>(c, in, count_ptr, nullptr, upper_bound); return; }
+    if (c->use_persistent()) { launch_persistent_for_stack<TRACE_CLOSEST, INSTRUMENT>(c, w, in, count_ptr, nullptr, upper_bound); return; }
     const uint32_t grid = grid_for(upper_bound, TRACE_BLOCK, 256u * 16u);
     DeviceCounters* dc = c->counters.as<DeviceCounters>();
     switch (c->stack_size) {
-    case 16: hipLaunchKernelGGL((k_trace_closest<16, INSTRUMENT>), dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->scene, in, hits, count_ptr, dc); break;
-    case 32: hipLaunchKernelGGL((k_trace_closest<32, INSTRUMENT>), dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->scene, in, hits, count_ptr, dc); break;
-    default: hipLaunchKernelGGL((k_trace_closest<64, INSTRUMENT>), dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->scene, in, hits, count_ptr, dc); break;
+    case 16: hipLaunchKernelGGL((k_trace_closest<16, INSTRUMENT>), dim3(grid), dim3(TRACE_BLOCK), 0, w.stream, c->scene, in, hits, count_ptr, dc); break;
+    case 32: hipLaunchKernelGGL((k_trace_closest<32, INSTRUMENT>), dim3(grid), dim3(TRACE_BLOCK), 0, w.stream, c->scene, in, hits, count_ptr, dc); break;
+    default: hipLaunchKernelGGL((k_trace_closest<64, INSTRUMENT>), dim3(grid), dim3(TRACE_BLOCK), 0, w.stream, c->scene, in, hits, count_ptr, dc); break;
     }
 }
 
 template <bool INSTRUMENT>
-void launch_trace_shadow(HiprContext* c, const uint32_t* count_ptr, uint32_t upper_bound) {
-    if (c->use_persistent()) { launch_persistent_for_stack<TRACE_SHADOW, INSTRUMENT>(c, PathState{}, nullptr, count_ptr, upper_bound); return; }
+void launch_trace_shadow(HiprContext* c, const Wavefront& w, const uint32_t* count_ptr, uint32_t upper_bound) {
+    if (c->use_persistent()) { launch_persistent_for_stack<TRACE_SHADOW, INSTRUMENT>(c, w, PathState{}, nullptr, count_ptr, upper_bound); return; }
     const uint32_t grid = grid_for(upper_bound, TRACE_BLOCK, 256u * 16u);
     DeviceCounters* dc = c->counters.as<DeviceCounters>();
     float4* rad = c->radiance.as<float4>();
-    ShadowQueue q = c->shadow_queue();
+    ShadowQueue q = w.shadow_queue();
     switch (c->stack_size) {
-    case 16: hipLaunchKernelGGL((k_trace_shadow<16, INSTRUMENT>), dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->scene, q, rad, count_ptr, dc); break;
-    case 32: hipLaunchKernelGGL((k_trace_shadow<32, INSTRUMENT>), dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->scene, q, rad, count_ptr, dc); break;
-    default: hipLaunchKernelGGL((k_trace_shadow<64, INSTRUMENT>), dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->scene, q, rad, count_ptr, dc); break;
+    case 16: hipLaunchKernelGGL((k_trace_shadow<16, INSTRUMENT>), dim3(grid), dim3(TRACE_BLOCK), 0, w.stream, c->scene, q, rad, count_ptr, dc); break;
+    case 32: hipLaunchKernelGGL((k_trace_shadow<32, INSTRUMENT>), dim3(grid), dim3(TRACE_BLOCK), 0, w.stream, c->scene, q, rad, count_ptr, dc); break;
+    default: hipLaunchKernelGGL((k_trace_shadow<64, INSTRUMENT>), dim3(grid), dim3(TRACE_BLOCK), 0, w.stream, c->scene, q, rad, count_ptr, dc); break;
     }
 }
 
 // The closest-hit rays of this bounce and the shadow rays the previous bounce queued, as one persistent launch.
 template <bool INSTRUMENT>
-void launch_trace_fused(HiprContext* c, const PathState& in, const uint32_t* closest_count, const uint32_t* shadow_count, uint32_t upper_bound) {
-    launch_persistent_for_stack<TRACE_FUSED, INSTRUMENT>(c, in, closest_count, shadow_count, upper_bound);
+void launch_trace_fused(HiprContext* c, const Wavefront& w, const PathState& in, const uint32_t* closest_count, const uint32_t* shadow_count, uint32_t upper_bound) {
+    launch_persistent_for_stack<TRACE_FUSED, INSTRUMENT>(c, w, in, closest_count, shadow_count, upper_bound);
 }
 
-void launch_shade(HiprContext* c, const HiprCameraState& camera, int cur, uint32_t alive, const uint32_t* in_count, uint32_t* out_count, uint32_t* shadow_count) {
-    ShadeLaunch a = {grid_for(alive, SHADE_BLOCK, 256u * 8u), c->stream, c->scene, camera, c->entry, c->path_state(cur), c->hits.as<float4>(), c->path_state(1 - cur),
-                     c->shadow_queue(), c->radiance.as<float4>(), in_count, out_count, shadow_count, c->counters.as<DeviceCounters>()};
+void launch_shade(HiprContext* c, const Wavefront& w, const HiprCameraState& camera, int cur, uint32_t alive, const uint32_t* in_count, uint32_t* out_counts) {
+    // persistent blocks: two per CU stay resident (2 waves per SIMD), each walks the queue with a grid stride
+    ShadeLaunch a = {grid_for(alive, SHADE_BLOCK, uint32_t(c->cu_count) * 2u), w.stream, c->scene, camera, c->entry, w.path_state(cur), w.hits.as<float4>(), w.path_state(1 - cur),
+                     w.shadow_queue(), c->radiance.as<float4>(), in_count, reinterpret_cast<unsigned long long*>(out_counts), c->counters.as<DeviceCounters>()};
     hipr::launch_shade(c->shading_models, a);
 }
 
@@ -276,16 +310,24 @@ int hipr_create(int device_id, HiprContext** out_context) {
     HIP_TRY(hipSetDevice(device_id));
     HiprContext* c = new HiprContext();
     c->device = device_id;
-    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&c->shade_done[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->shade_done[1], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->counts_copied[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->counts_copied[1], hipEventDisableTiming) != hipSuccess ||
-        hipHostMalloc((void**)&c->host_counts, 8 * sizeof(uint32_t)) != hipSuccess) {
-        delete c;
+    bool ok = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&c->pass_start, hipEventDisableTiming) == hipSuccess;
+    c->stream = c->own_stream;
+    for (int g = 0; ok && g < MAX_WAVEFRONTS; ++g) {
+        Wavefront& w = c->wavefronts[g];
+        if (g > 0) ok = ok && hipStreamCreateWithFlags(&w.own_stream, hipStreamNonBlocking) == hipSuccess;
+        w.stream = g == 0 ? c->stream : w.own_stream;
+        for (int i = 0; i < 2; ++i)
+            ok = ok && hipEventCreateWithFlags(&w.shade_done[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&w.counts_copied[i], hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&w.finished, hipEventDisableTiming) == hipSuccess && hipHostMalloc((void**)&w.host_counts, 8 * sizeof(uint32_t)) == hipSuccess &&
+             w.queue_counts.resize(2 * COUNT_PAIR_STRIDE * sizeof(uint32_t)) == 0;
+    }
+    if (!ok) {
+        hipr_destroy(c);
         return fail(HIPR_ERROR_HIP, "stream / event / pinned allocation failed");
     }
-    c->stream = c->own_stream;
-    if (c->queue_counts.resize(4 * sizeof(uint32_t)) || c->counters.resize(sizeof(DeviceCounters)) || c->work_counters.resize(WORK_COUNTERS * sizeof(uint32_t))) {
-        delete c;
+    if (c->counters.resize(sizeof(DeviceCounters)) || c->work_counters.resize(WORK_COUNTERS * sizeof(uint32_t))) {
+        hipr_destroy(c);
         return HIPR_ERROR_OUT_OF_MEMORY;
     }
     c->work_index = WORK_SETS;   // forces the first launch to zero the ring
@@ -293,6 +335,8 @@ int hipr_create(int device_id, HiprContext** out_context) {
     if (hipGetDeviceProperties(&props, device_id) == hipSuccess && props.multiProcessorCount > 0) c->cu_count = props.multiProcessorCount;
     if (const char* v = getenv("HIPR_TRACE_VARIANT")) c->trace_variant = atoi(v);
     if (const char* v = getenv("HIPR_REFILL_BELOW")) c->refill_below = atoi(v);
+    if (const char* v = getenv("HIPR_BLOCKS_PER_CU")) c->blocks_per_cu_override = atoi(v);
+    if (const char* v = getenv("HIPR_WAVEFRONTS")) c->wavefront_limit = std::max(1, std::min(MAX_WAVEFRONTS, atoi(v)));
     if (const char* v = getenv("HIPR_TRACE_LOG")) c->trace_log = atoi(v) != 0;
     HIP_TRY(hipMemsetAsync(c->counters.ptr, 0, sizeof(DeviceCounters), c->stream));
 
@@ -324,17 +368,15 @@ int hipr_destroy(HiprContext* c) {
     if (!c) return HIPR_OK;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    DeviceBuffer* all[] = {&c->nodes, &c->triangles, &c->instances, &c->indices, &c->geometry, &c->texcoords, &c->tints, &c->emissions, &c->materials,
-                           &c->lights, &c->textures, &c->texels, &c->ggx_rho, &c->dielectric_rho, &c->alpha, &c->sample_offsets, &c->sobol_tables, &c->hits, &c->radiance,
-                           &c->accumulation, &c->scratch_accumulation, &c->queue_counts, &c->counters, &c->work_counters, &c->debug_a, &c->debug_b, &c->debug_c, &c->shadow[0], &c->shadow[1], &c->shadow[2]};
+    DeviceBuffer* all[] = {&c->shade_triangles, &c->nodes, &c->triangles, &c->instances, &c->indices, &c->geometry, &c->texcoords, &c->tints, &c->emissions, &c->materials,
+                           &c->lights, &c->textures, &c->texels, &c->ggx_rho, &c->dielectric_rho, &c->alpha, &c->sample_offsets, &c->sobol_tables, &c->radiance,
+                           &c->accumulation, &c->scratch_accumulation, &c->counters, &c->work_counters, &c->debug_a, &c->debug_b, &c->debug_c};
     for (DeviceBuffer* b : all) b->release();
-    for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) c->path[i][j].release();
+    for (Wavefront& w : c->wavefronts) w.release();
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
-    for (hipEvent_t e : c->shade_done) if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : c->counts_copied) if (e) (void)hipEventDestroy(e);
+    if (c->pass_start) (void)hipEventDestroy(c->pass_start);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
-    if (c->host_counts) (void)hipHostFree(c->host_counts);
     delete c;
     return HIPR_OK;
 }
@@ -344,6 +386,7 @@ int hipr_set_stream(HiprContext* c, void* hip_stream) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->collect_times();
     c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    c->wavefronts[0].stream = c->stream;
     return HIPR_OK;
 }
 
@@ -414,6 +457,13 @@ int hipr_upload_scene(HiprContext* c, const HiprSceneDesc* s) {
     d.node_count = s->node_count;
     d.triangle_count = s->triangle_count;
     d.light_count = s->light_count;
+    if (s->triangle_count) {   // flatten the per-hit attribute chain into one record per triangle
+        if (c->shade_triangles.resize(size_t(s->triangle_count) * SHADE_TRIANGLE_QUADS * sizeof(float4))) return HIPR_ERROR_OUT_OF_MEMORY;
+        d.shade_triangles = c->shade_triangles.as<float4>();
+        hipLaunchKernelGGL(k_build_shade_triangles, dim3((s->triangle_count + 255) / 256), dim3(256), 0, st, d, c->shade_triangles.as<float4>());
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(st));
+    }
     c->stack_size = s->bvh_max_depth <= 16 ? 16 : (s->bvh_max_depth <= 32 ? 32 : 64);
     int models = 0;
     for (uint32_t i = 0; i < s->instance_count; ++i) {
@@ -451,9 +501,19 @@ int hipr_set_frame(HiprContext* c, const HiprFrameDesc* f) {
     c->frame = fi;
     c->n_slots = uint32_t(slots);
     int r = 0;
-    for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) r |= c->path[i][j].resize(slots * 16);
-    r |= c->hits.resize(slots * 16);
-    for (int j = 0; j < 3; ++j) r |= c->shadow[j].resize(slots * 16);
+    // Split the slots over the wavefronts on a tile (= wave) boundary; small frames stay one wavefront.
+    c->wavefront_count = (c->wavefront_limit > 1 && slots >= 2u * 65536u) ? 2 : 1;
+    const uint64_t first_share = c->wavefront_count == 1 ? slots : ((slots / 2 + 63) / 64) * 64;
+    for (int g = 0; g < MAX_WAVEFRONTS; ++g) {
+        Wavefront& w = c->wavefronts[g];
+        w.first_slot = g == 0 ? 0u : uint32_t(first_share);
+        w.n_slots = g >= c->wavefront_count ? 0u : uint32_t(g == 0 ? first_share : slots - first_share);
+        const size_t bytes = size_t(std::max(w.n_slots, 64u)) * 16;
+        if (g >= c->wavefront_count) continue;
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) r |= w.path[i][j].resize(bytes);
+        r |= w.hits.resize(bytes);
+        for (int j = 0; j < 3; ++j) r |= w.shadow[j].resize(bytes);
+    }
     r |= c->radiance.resize(slots * 16);
     const size_t acc_bytes = size_t(fi.owned_tiles) * 64 * sizeof(double4);
     c->accumulation.release();
@@ -509,106 +569,133 @@ int hipr_render_pass(HiprContext* c, const HiprCameraState* camera, void* out_ha
 
     const FrameInfo& f = c->frame;
     const uint32_t n = c->n_slots;
-    uint32_t* counts = c->queue_counts.as<uint32_t>();
     HiprCounters pass = {};
 
     // valid pixel-samples (edge tiles may hang over the frame)
     uint64_t valid_pixels = 0;
     if (f.tile_stride == 1) valid_pixels = uint64_t(f.width) * f.height;
     else {
-        const uint32_t tiles_y = (f.height + 7) / 8;
         for (uint32_t t = f.tile_phase; t < f.tiles_total; t += f.tile_stride) {
             uint32_t tx = t % f.tiles_x, ty = t / f.tiles_x;
             uint32_t w = std::min(8u, f.width - tx * 8), h = std::min(8u, f.height - ty * 8);
-            (void)tiles_y;
             valid_pixels += uint64_t(w) * h;
         }
     }
     pass.camera_rays = valid_pixels * f.samples_per_pass;
 
-    c->host_counts[4] = n;   // pinned staging word, rewritten only after the syncs of the next pass
-    HIP_TRY(hipMemcpyAsync(counts + 0, c->host_counts + 4, 4, hipMemcpyHostToDevice, c->stream));
+    if (c->work_index > 0) {   // claim counters used by the previous pass (every wavefront stream is ordered behind pass_start)
+        HIP_TRY(hipMemsetAsync(c->work_counters.ptr, 0, size_t(std::min(c->work_index, WORK_SETS)) * WORK_SET_WORDS * sizeof(uint32_t), c->stream));
+        c->work_index = 0;
+    }
+    HIP_TRY(hipEventRecord(c->pass_start, c->stream));
 
-    c->begin_timed(HIPR_KERNEL_GENERATE);
-    hipLaunchKernelGGL(k_generate, dim3((n + 255) / 256), dim3(256), 0, c->stream, f, *camera, c->path_state(0), c->radiance.as<float4>(), n);
-    c->end_timed();
-
-    // Bounce k = trace stage + shade(k). The trace stage serves the closest-hit rays of bounce k AND the shadow rays shade(k - 1)
-    // queued (they are independent; radiance slots are still updated in the order shade(0), shadow(0), shade(1), ...): one fused
-    // persistent launch for big scenes, two plain launches otherwise. All queue sizes stay on the device; the host only needs
-    // them to stop, so it enqueues bounce k + 1 (sized by the known upper bound: the rays of bounce k) BEFORE it waits for the
-    // sizes bounce k produced -- the GPU never idles on the read-back.
+    // Bounce k of a wavefront = trace stage + shade(k). The trace stage serves the closest-hit rays of bounce k AND the shadow rays
+    // shade(k - 1) queued (they are independent; radiance slots are still updated in the order shade(0), shadow(0), shade(1), ...):
+    // one fused persistent launch for big scenes, two plain launches otherwise. All queue sizes stay on the device; the host only
+    // needs them to stop, so it enqueues bounce k + 1 (sized by the known upper bound: the rays of bounce k) BEFORE it waits for
+    // the sizes bounce k produced -- the GPU never idles on the read-back.
     const bool fused = c->use_persistent();
-    auto enqueue_bounce = [&](uint32_t k, uint32_t bound) -> int {
+    auto enqueue_bounce = [&](Wavefront& w, uint32_t k, uint32_t bound) -> int {
+        // Queue sizes live in two 8-byte pairs, 64 B apart: pair[k & 1] = {paths of bounce k, shadow rays shade(k - 1) queued}.
+        // shade(k) fills pair[(k + 1) & 1] with one 64-bit atomic per block.
+        uint32_t* counts = w.queue_counts.as<uint32_t>();
         const int parity = int(k & 1u);
-        uint32_t* in_count = counts + parity;
-        uint32_t* out_count = counts + (1 - parity);
-        uint32_t* shadow_in = counts + 2 + (1 - parity);   // written by shade(k - 1)
-        uint32_t* shadow_out = counts + 2 + parity;
+        uint32_t* in_count = counts + COUNT_PAIR_STRIDE * parity;
+        uint32_t* shadow_in = in_count + 1;
+        uint32_t* out_count = counts + COUNT_PAIR_STRIDE * (1 - parity);
+        uint32_t* shadow_out = out_count + 1;
         const size_t first_timed = c->timed.size();
-        HIP_TRY(hipMemsetAsync(out_count, 0, 4, c->stream));
-        HIP_TRY(hipMemsetAsync(shadow_out, 0, 4, c->stream));
+        HIP_TRY(hipMemsetAsync(out_count, 0, 8, w.stream));
 
-        c->begin_timed(HIPR_KERNEL_TRACE_CLOSEST);
+        c->begin_timed(HIPR_KERNEL_TRACE_CLOSEST, w.stream);
         if (k > 0 && fused) {
-            if (c->instrument) launch_trace_fused<true>(c, c->path_state(parity), in_count, shadow_in, 2u * bound);
-            else launch_trace_fused<false>(c, c->path_state(parity), in_count, shadow_in, 2u * bound);
+            if (c->instrument) launch_trace_fused<true>(c, w, w.path_state(parity), in_count, shadow_in, 2u * bound);
+            else launch_trace_fused<false>(c, w, w.path_state(parity), in_count, shadow_in, 2u * bound);
         } else {
-            if (c->instrument) launch_trace_closest<true>(c, c->path_state(parity), in_count, bound);
-            else launch_trace_closest<false>(c, c->path_state(parity), in_count, bound);
+            if (c->instrument) launch_trace_closest<true>(c, w, w.path_state(parity), in_count, bound);
+            else launch_trace_closest<false>(c, w, w.path_state(parity), in_count, bound);
         }
-        c->end_timed();
+        c->end_timed(w.stream);
         if (k > 0 && !fused) {
-            c->begin_timed(HIPR_KERNEL_TRACE_SHADOW);
-            if (c->instrument) launch_trace_shadow<true>(c, shadow_in, bound);
-            else launch_trace_shadow<false>(c, shadow_in, bound);
-            c->end_timed();
+            c->begin_timed(HIPR_KERNEL_TRACE_SHADOW, w.stream);
+            if (c->instrument) launch_trace_shadow<true>(c, w, shadow_in, bound);
+            else launch_trace_shadow<false>(c, w, shadow_in, bound);
+            c->end_timed(w.stream);
         }
 
-        c->begin_timed(HIPR_KERNEL_SHADE);
-        launch_shade(c, *camera, parity, bound, in_count, out_count, shadow_out);
-        c->end_timed();
-        HIP_TRY(hipEventRecord(c->shade_done[parity], c->stream));
-        HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->shade_done[parity], 0));
-        HIP_TRY(hipMemcpyAsync(c->host_counts + 2 * parity, out_count, 4, hipMemcpyDeviceToHost, c->copy_stream));
-        HIP_TRY(hipMemcpyAsync(c->host_counts + 2 * parity + 1, shadow_out, 4, hipMemcpyDeviceToHost, c->copy_stream));
-        HIP_TRY(hipEventRecord(c->counts_copied[parity], c->copy_stream));
+        c->begin_timed(HIPR_KERNEL_SHADE, w.stream);
+        launch_shade(c, w, *camera, parity, bound, in_count, out_count);
+        c->end_timed(w.stream);
+        HIP_TRY(hipEventRecord(w.shade_done[parity], w.stream));
+        HIP_TRY(hipStreamWaitEvent(c->copy_stream, w.shade_done[parity], 0));
+        HIP_TRY(hipMemcpyAsync(w.host_counts + 2 * parity, out_count, 4, hipMemcpyDeviceToHost, c->copy_stream));
+        HIP_TRY(hipMemcpyAsync(w.host_counts + 2 * parity + 1, shadow_out, 4, hipMemcpyDeviceToHost, c->copy_stream));
+        HIP_TRY(hipEventRecord(w.counts_copied[parity], c->copy_stream));
 
         if (c->instrument && c->trace_log) {   // diagnostic (HIPR_TRACE_LOG=1): per-bounce counters and kernel times; serialises the pass
-            HIP_TRY(hipStreamSynchronize(c->stream));
+            HIP_TRY(hipStreamSynchronize(w.stream));
             HIP_TRY(hipStreamSynchronize(c->copy_stream));
             DeviceCounters dc;
             HIP_TRY(hipMemcpy(&dc, c->counters.ptr, sizeof(dc), hipMemcpyDeviceToHost));
             const DeviceCounters& p = c->trace_log_previous;
-            fprintf(stderr, "[hipr] bounce %u: <= %u closest rays: nodes %llu tris %llu | shadow rays of the previous bounce: nodes %llu tris %llu | kernels", k, bound,
-                    dc.closest_nodes - p.closest_nodes, dc.closest_triangles - p.closest_triangles, dc.shadow_nodes - p.shadow_nodes, dc.shadow_triangles - p.shadow_triangles);
+            fprintf(stderr, "[hipr] wavefront %d bounce %u: <= %u closest rays: nodes %llu tris %llu | shadow rays of the previous bounce: nodes %llu tris %llu | kernels",
+                    int(&w - c->wavefronts), k, bound, dc.closest_nodes - p.closest_nodes, dc.closest_triangles - p.closest_triangles, dc.shadow_nodes - p.shadow_nodes,
+                    dc.shadow_triangles - p.shadow_triangles);
             for (size_t i = first_timed; i < c->timed.size(); ++i) {
                 float ms = 0;
                 (void)hipEventElapsedTime(&ms, c->timed[i].start, c->timed[i].stop);
                 fprintf(stderr, " %s %.1f us", c->timed[i].kernel == HIPR_KERNEL_SHADE ? "shade" : (c->timed[i].kernel == HIPR_KERNEL_TRACE_SHADOW ? "shadow" : "trace"), ms * 1e3f);
             }
-            fprintf(stderr, " -> %u paths continue, %u shadow rays\n", c->host_counts[2 * parity], c->host_counts[2 * parity + 1]);
+            fprintf(stderr, " -> %u paths continue, %u shadow rays\n", w.host_counts[2 * parity], w.host_counts[2 * parity + 1]);
             c->trace_log_previous = dc;
         }
         return HIPR_OK;
     };
 
-    const uint32_t first_dead = n - uint32_t(std::min<uint64_t>(n, pass.camera_rays));   // dead lanes of partial tiles are never traced
-    uint32_t alive = n;   // rays of bounce k
-    if (int s = enqueue_bounce(0, alive)) return s;
-    for (uint32_t k = 0;; ++k) {
-        if (int s = enqueue_bounce(k + 1, alive)) return s;   // speculative: at most `alive` paths continue
-        HIP_TRY(hipEventSynchronize(c->counts_copied[k & 1u]));
-        pass.closest_rays += alive - (k == 0 ? first_dead : 0);
-        pass.shadow_rays += c->host_counts[2 * (k & 1u) + 1];
-        pass.iterations += 1;
-        alive = c->host_counts[2 * (k & 1u)];
-        // Nothing continues: bounce k + 1 (already queued) traces the shadow rays of bounce k and shades nothing.
-        if (alive == 0) break;
-        if (k > 4096) return fail(HIPR_ERROR_HIP, "wavefront loop did not terminate");
+    // Start every wavefront: camera rays + bounce 0.
+    uint32_t alive[MAX_WAVEFRONTS] = {0, 0}, bounce[MAX_WAVEFRONTS] = {0, 0};
+    bool running[MAX_WAVEFRONTS] = {false, false};
+    for (int g = 0; g < c->wavefront_count; ++g) {
+        Wavefront& w = c->wavefronts[g];
+        if (g > 0) HIP_TRY(hipStreamWaitEvent(w.stream, c->pass_start, 0));
+        w.host_counts[4] = w.n_slots;   // pinned staging pair {paths, 0 shadow rays}, rewritten only after the syncs of the next pass
+        w.host_counts[5] = 0;
+        HIP_TRY(hipMemcpyAsync(w.queue_counts.as<uint32_t>(), w.host_counts + 4, 8, hipMemcpyHostToDevice, w.stream));
+        c->begin_timed(HIPR_KERNEL_GENERATE, w.stream);
+        hipLaunchKernelGGL(k_generate, dim3((w.n_slots + 255) / 256), dim3(256), 0, w.stream, f, *camera, w.path_state(0), c->radiance.as<float4>(), w.first_slot, w.n_slots);
+        c->end_timed(w.stream);
+        alive[g] = w.n_slots;
+        running[g] = true;
+        if (int s = enqueue_bounce(w, 0, alive[g])) return s;
+    }
+    // Round robin over the wavefronts: queue the next bounce speculatively (at most `alive` paths continue), then read the sizes
+    // the current one produced. A wavefront whose paths all ended has, with that last speculative bounce, also traced its last shadow rays.
+    pass.closest_rays -= n - uint32_t(std::min<uint64_t>(n, pass.camera_rays));   // dead lanes of partial tiles are queued but never traced
+    for (int remaining = c->wavefront_count; remaining > 0;) {
+        for (int g = 0; g < c->wavefront_count; ++g) {
+            if (!running[g]) continue;
+            Wavefront& w = c->wavefronts[g];
+            const uint32_t k = bounce[g];
+            if (int s = enqueue_bounce(w, k + 1, alive[g])) return s;
+            HIP_TRY(hipEventSynchronize(w.counts_copied[k & 1u]));
+            pass.closest_rays += alive[g];
+            pass.shadow_rays += w.host_counts[2 * (k & 1u) + 1];
+            pass.iterations += 1;
+            alive[g] = w.host_counts[2 * (k & 1u)];
+            bounce[g] = k + 1;
+            if (alive[g] == 0) {
+                running[g] = false;
+                --remaining;
+                if (g > 0) {
+                    HIP_TRY(hipEventRecord(w.finished, w.stream));
+                    HIP_TRY(hipStreamWaitEvent(c->stream, w.finished, 0));
+                }
+            }
+            if (k > 4096) return fail(HIPR_ERROR_HIP, "wavefront loop did not terminate");
+        }
     }
 
-    c->begin_timed(HIPR_KERNEL_ACCUMULATE);
+    c->begin_timed(HIPR_KERNEL_ACCUMULATE, c->stream);
     float depth_normalizer = 0.0f;
     if (c->entry == HIPR_ENTRY_DEPTH) {   // max depth = distance between the near and far plane centres (SimpleRGPs.cu:247-255)
         const float* ip = camera->inverse_projection_matrix;
@@ -618,7 +705,7 @@ int hipr_render_pass(HiprContext* c, const HiprCameraState* camera, void* out_ha
     }
     hipLaunchKernelGGL(k_accumulate, dim3((f.owned_tiles * 64 + 255) / 256), dim3(256), 0, c->stream, f, camera->accumulations, c->radiance.as<float4>(),
                        c->active_accumulation().as<double4>(), static_cast<ushort4*>(out_half4_device), out_pitch_pixels, depth_normalizer);
-    c->end_timed();
+    c->end_timed(c->stream);
     HIP_TRY(hipGetLastError());
 
     c->total.camera_rays += pass.camera_rays;
@@ -662,6 +749,13 @@ int hipr_reset_counters(HiprContext* c) {
     HIP_TRY(hipMemset(c->counters.ptr, 0, sizeof(DeviceCounters)));
     c->total = {};
     c->trace_log_previous = {};
+    return HIPR_OK;
+}
+
+int hipr_set_wavefront_count(HiprContext* c, int count) {
+    if (!c) return fail(HIPR_ERROR_INVALID_ARGUMENT, "null context");
+    if (count < 1 || count > MAX_WAVEFRONTS) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_set_wavefront_count: %d is outside [1, %d]", count, MAX_WAVEFRONTS);
+    c->wavefront_limit = count;   // takes effect with the next hipr_set_frame
     return HIPR_OK;
 }
 
@@ -771,10 +865,14 @@ int hipr_debug_generate(HiprContext* c, const HiprCameraState* camera, uint32_t 
     const uint32_t n = f.owned_tiles * 64;
     HiprCameraState cam = *camera;
     cam.accumulations = accumulation;
-    hipLaunchKernelGGL(k_generate, dim3((n + 255) / 256), dim3(256), 0, c->stream, f, cam, c->path_state(0), c->radiance.as<float4>(), n);
+    DeviceBuffer bo, bd, bt, bm, br;
+    if (bo.resize(size_t(n) * 16) | bd.resize(size_t(n) * 16) | bt.resize(size_t(n) * 16) | bm.resize(size_t(n) * 16) | br.resize(size_t(n) * 16)) return HIPR_ERROR_OUT_OF_MEMORY;
+    const PathState out = {bo.as<float4>(), bd.as<float4>(), bt.as<float4>(), bm.as<uint4>()};
+    hipLaunchKernelGGL(k_generate, dim3((n + 255) / 256), dim3(256), 0, c->stream, f, cam, out, br.as<float4>(), 0u, n);
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (out_origin_tmin) HIP_TRY(hipMemcpy(out_origin_tmin, c->path[0][0].ptr, size_t(n) * 16, hipMemcpyDeviceToHost));
-    if (out_direction) HIP_TRY(hipMemcpy(out_direction, c->path[0][1].ptr, size_t(n) * 16, hipMemcpyDeviceToHost));
+    if (out_origin_tmin) HIP_TRY(hipMemcpy(out_origin_tmin, bo.ptr, size_t(n) * 16, hipMemcpyDeviceToHost));
+    if (out_direction) HIP_TRY(hipMemcpy(out_direction, bd.ptr, size_t(n) * 16, hipMemcpyDeviceToHost));
+    bo.release(); bd.release(); bt.release(); bm.release(); br.release();
     if (out_pixel) {
         for (uint32_t k = 0; k < n; ++k) {
             uint32_t tile = (k >> 6) * f.tile_stride + f.tile_phase, lane = k & 63;
@@ -822,11 +920,11 @@ int hipr_debug_trace_closest(HiprContext* c, const float* rays, const uint32_t* 
     if (r) return HIPR_ERROR_OUT_OF_MEMORY;
     HIP_TRY(hipMemsetAsync(c->counters.ptr, 0, sizeof(DeviceCounters), c->stream));
     PathState in = {bo.as<float4>(), bd.as<float4>(), nullptr, bm.as<uint4>()};
-    DeviceBuffer saved_hits = c->hits;
-    c->hits = bh;
-    if (c->instrument) launch_trace_closest<true>(c, in, bc.as<uint32_t>(), n);
-    else launch_trace_closest<false>(c, in, bc.as<uint32_t>(), n);
-    c->hits = saved_hits;
+    Wavefront w;   // borrows the buffers above; never released
+    w.stream = c->stream;
+    w.hits = bh;
+    if (c->instrument) launch_trace_closest<true>(c, w, in, bc.as<uint32_t>(), n);
+    else launch_trace_closest<false>(c, w, in, bc.as<uint32_t>(), n);
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(out_hits, bh.ptr, size_t(n) * 16, hipMemcpyDeviceToHost));
     c->total = {};
@@ -852,11 +950,14 @@ int hipr_debug_trace_shadow(HiprContext* c, const float* rays, uint32_t n, float
             bacc.upload(rad.data(), rad.size() * 4, c->stream) | bc.upload(&n, 4, c->stream);
     if (r) return HIPR_ERROR_OUT_OF_MEMORY;
     HIP_TRY(hipMemsetAsync(c->counters.ptr, 0, sizeof(DeviceCounters), c->stream));
-    DeviceBuffer s0 = c->shadow[0], s1 = c->shadow[1], s2 = c->shadow[2], sr = c->radiance;
-    c->shadow[0] = bo; c->shadow[1] = bd; c->shadow[2] = br; c->radiance = bacc;
-    if (c->instrument) launch_trace_shadow<true>(c, bc.as<uint32_t>(), n);
-    else launch_trace_shadow<false>(c, bc.as<uint32_t>(), n);
-    c->shadow[0] = s0; c->shadow[1] = s1; c->shadow[2] = s2; c->radiance = sr;
+    Wavefront w;   // borrows the buffers above; never released
+    w.stream = c->stream;
+    w.shadow[0] = bo; w.shadow[1] = bd; w.shadow[2] = br;
+    const DeviceBuffer saved_radiance = c->radiance;
+    c->radiance = bacc;
+    if (c->instrument) launch_trace_shadow<true>(c, w, bc.as<uint32_t>(), n);
+    else launch_trace_shadow<false>(c, w, bc.as<uint32_t>(), n);
+    c->radiance = saved_radiance;
     HIP_TRY(hipStreamSynchronize(c->stream));
     std::vector<float> result(size_t(n) * 4);
     HIP_TRY(hipMemcpy(result.data(), bacc.ptr, result.size() * 4, hipMemcpyDeviceToHost));

@@ -27,10 +27,12 @@ namespace hipr {
 
 constexpr int TRACE_BLOCK = 128;   // 2 waves; LDS stack = STACK * 128 * 4 B
 constexpr int SHADE_BLOCK = 256;
+constexpr int SHADE_TRIANGLE_QUADS = 6;   // float4 per shading record (96 B), see k_build_shade_triangles
 
 struct DeviceScene {
     const float4* nodes;
     const float4* triangles;
+    const float4* shade_triangles;   // SHADE_TRIANGLE_QUADS float4 per triangle, built on upload (k_build_shade_triangles)
     const HiprInstance* instances;
     const uint32_t* indices;
     const float4* geometry;
@@ -111,9 +113,11 @@ HD void camera_ray(const HiprCameraState& cam, uint32_t x, uint32_t y, uint32_t 
 }
 
 #ifndef HIPR_SHADE_TU
-__global__ __launch_bounds__(256) void k_generate(FrameInfo frame, HiprCameraState cam, PathState out, float4* radiance, uint32_t n_paths) {
-    uint32_t p = blockIdx.x * 256u + threadIdx.x;
-    if (p >= n_paths) return;
+// Camera rays of the path slots [first_slot, first_slot + n_paths) of the pass into queue entries [0, n_paths) of one wavefront.
+__global__ __launch_bounds__(256) void k_generate(FrameInfo frame, HiprCameraState cam, PathState out, float4* radiance, uint32_t first_slot, uint32_t n_paths) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_paths) return;
+    const uint32_t p = first_slot + i;
     uint32_t per_sample = frame.owned_tiles * 64u;
     uint32_t s = p / per_sample, k = p - s * per_sample;
     uint32_t x, y;
@@ -122,10 +126,10 @@ __global__ __launch_bounds__(256) void k_generate(FrameInfo frame, HiprCameraSta
     uint32_t pixel_hash = pcg2d_x(x, y);
     f3 o = {0, 0, 0}, d = {0, 0, 1};
     if (valid) camera_ray(cam, x, y, frame.width, frame.height, accumulation, pixel_hash, o, d);
-    out.o_tmin[p] = make_float4(o.x, o.y, o.z, 0.0f);
-    out.d_pdf[p] = make_float4(d.x, d.y, d.z, -1.0f);           // bsdf_PDF = delta_dirac(1)
-    out.thr_bounces[p] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(0u));
-    out.meta[p] = make_uint4(valid ? p : HIPR_DEAD_SLOT, HIPR_NO_TRIANGLE, pixel_hash, accumulation);
+    out.o_tmin[i] = make_float4(o.x, o.y, o.z, 0.0f);
+    out.d_pdf[i] = make_float4(d.x, d.y, d.z, -1.0f);           // bsdf_PDF = delta_dirac(1)
+    out.thr_bounces[i] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(0u));
+    out.meta[i] = make_uint4(valid ? p : HIPR_DEAD_SLOT, HIPR_NO_TRIANGLE, pixel_hash, accumulation);
     radiance[p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
@@ -638,6 +642,43 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(5))
 }
 
 #ifndef HIPR_SHADE_TU
+// ---------------------------------------------------------------------------------------------
+// Shading records. The reference resolves a hit through instance -> mesh buffers -> index -> vertex (TriangleAttributes.cu:35-84,
+// four dependent fetches); here everything the shade kernel interpolates is flattened per world-space triangle when the scene
+// is uploaded, so a hit costs ONE dependent fetch of 96 B next to the 48 B of positions:
+//   quad 0..2: object-to-world transformed vertex normal i (not normalised: sum(w_i * M n_i) = M sum(w_i * n_i), so the
+//              interpolated normal is the one the per-hit transform gives), .w = bits(material index | instance id | mesh flags)
+//   quad 3   : uv0.xy, uv1.xy       quad 4: uv2.xy, bits(tint0), bits(tint1)       quad 5: bits(tint2), 0, 0, 0
+// Per-vertex emission (rare) still goes through the instance.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_build_shade_triangles(DeviceScene sc, float4* out) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= sc.triangle_count) return;
+    const float4 tc = sc.triangles[3 * size_t(t) + 2];
+    const HiprInstance inst = sc.instances[__float_as_uint(tc.y)];
+    const uint32_t prim = __float_as_uint(tc.z);
+    const uint32_t* idx = sc.indices + 3 * size_t(inst.index_offset + prim);
+    const uint32_t i[3] = {idx[0], idx[1], idx[2]};
+    const float* M = inst.object_to_world;
+    const uint32_t words[3] = {uint32_t(inst.material_index), uint32_t(inst.instance_id), inst.mesh_flags};
+    float4* q = out + SHADE_TRIANGLE_QUADS * size_t(t);
+    for (int k = 0; k < 3; ++k) {
+        f3 n = {0, 0, 0};
+        if (inst.mesh_flags & HIPR_MESH_NORMALS) {
+            const f3 o = decode_octahedral(sc.geometry[inst.vertex_offset + i[k]].w);
+            n = mk3(M[0] * o.x + M[1] * o.y + M[2] * o.z, M[4] * o.x + M[5] * o.y + M[6] * o.z, M[8] * o.x + M[9] * o.y + M[10] * o.z);
+        }
+        q[k] = make_float4(n.x, n.y, n.z, __uint_as_float(words[k]));
+    }
+    float2 uv[3] = {{0, 0}, {0, 0}, {0, 0}};
+    if (inst.mesh_flags & HIPR_MESH_TEXCOORDS) for (int k = 0; k < 3; ++k) uv[k] = sc.texcoords[inst.vertex_offset + i[k]];
+    uint32_t tint[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    if (inst.mesh_flags & HIPR_MESH_TINTS) for (int k = 0; k < 3; ++k) tint[k] = sc.tints[inst.vertex_offset + i[k]];
+    q[3] = make_float4(uv[0].x, uv[0].y, uv[1].x, uv[1].y);
+    q[4] = make_float4(uv[2].x, uv[2].y, __uint_as_float(tint[0]), __uint_as_float(tint[1]));
+    q[5] = make_float4(__uint_as_float(tint[2]), 0.0f, 0.0f, 0.0f);
+}
+
 // ---------------------------------------------------------------------------------------------
 // K6: f64 running mean + half4 output
 // ---------------------------------------------------------------------------------------------

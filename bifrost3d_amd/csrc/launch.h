@@ -17,8 +17,7 @@ struct ShadeLaunch {
     ShadowQueue shadows;
     float4* radiance;
     const uint32_t* in_count;
-    uint32_t* out_count;
-    uint32_t* shadow_count;
+    unsigned long long* out_counts;   // {paths that continue, shadow rays queued}: one 8-byte word so that a block reserves both with one atomic
     DeviceCounters* counters;
 };
 

@@ -37,9 +37,15 @@ struct ShadeOutput {
     f3 add_radiance;
 };
 
+// What shade_path reads of the hit triangle, fetched one loop iteration ahead by k_shade.
+struct ShadeGeometry {
+    float4 ta, tb, tc;                 // world-space positions + ids (the 48 B traversal triangle)
+    float4 s0, s1, s2, s3, s4, s5;     // shading record (k_build_shade_triangles)
+};
+
 template <int MODELS, bool AOV>
 HD void shade_path(const DeviceScene& sc, const HiprCameraState& cam, int entry, const uint32_t* sobol_lds, f3 ro, f3 rd, float bsdf_pdf, f3 throughput, uint32_t bounces,
-                   uint32_t last_triangle, uint32_t pixel_hash, uint32_t accumulation, float4 hit, ShadeOutput& out) {
+                   uint32_t last_triangle, uint32_t pixel_hash, uint32_t accumulation, float4 hit, const ShadeGeometry& geo, const HiprMaterial& mp, ShadeOutput& out) {
     out.continues = out.shadow = out.shaded = false;
     out.add_radiance = mk3(0.0f);
     const uint32_t id = __float_as_uint(hit.w);
@@ -61,19 +67,17 @@ HD void shade_path(const DeviceScene& sc, const HiprCameraState& cam, int entry,
         return;
     }
 
-    // --- attributes of the accepted closest hit only (TriangleAttributes.cu:35-84) -------------
-    const float4* tp = sc.triangles + 3 * size_t(id);
-    const float4 ta = tp[0], tb = tp[1], tc = tp[2];
+    // --- attributes of the accepted closest hit only (TriangleAttributes.cu:35-84), from the flattened shading record ---------
+    const float4 ta = geo.ta, tb = geo.tb, tc = geo.tc;
+    const float4 s0 = geo.s0, s1 = geo.s1, s2 = geo.s2, s3 = geo.s3, s4 = geo.s4, s5 = geo.s5;
     const f3 p0 = {ta.x, ta.y, ta.z}, p1 = {ta.w, tb.x, tb.y}, p2 = {tb.z, tb.w, tc.x};
-    const HiprInstance& inst = sc.instances[__float_as_uint(tc.y)];
     const uint32_t prim = __float_as_uint(tc.z);
-    const HiprMaterial mp = sc.materials[inst.material_index];
+    const uint32_t mesh_flags = __float_as_uint(s2.w);
+    const int32_t instance_id = int32_t(__float_as_uint(s1.w));
     const float u = hit.y, v = hit.z, w = 1.0f - u - v;
-    const uint32_t* idx = sc.indices + 3 * size_t(inst.index_offset + prim);
-    const uint32_t i0 = idx[0], i1 = idx[1], i2 = idx[2];
 
     f3 geometric_normal = normalize(cross(p1 - p0, p2 - p0));
-    const f2 texcoord = triangle_texcoord(sc, inst, prim, u, v);
+    const f2 texcoord = (mesh_flags & HIPR_MESH_TEXCOORDS) ? mk2(s3.z, s3.w) * u + mk2(s4.x, s4.y) * v + mk2(s3.x, s3.y) * w : mk2(0.0f, 0.0f);
 
     const bool thin_walled = (mp.flags & (HIPR_MATERIAL_CUTOUT | HIPR_MATERIAL_THIN_WALLED)) != 0;
     const bool transmissive = mp.shading_model == HIPR_SHADING_TRANSMISSIVE;
@@ -93,24 +97,20 @@ HD void shade_path(const DeviceScene& sc, const HiprCameraState& cam, int entry,
 
     const f3 position = p1 * u + p2 * v + p0 * w;
     f3 shading_normal = geometric_normal;
-    if (inst.mesh_flags & HIPR_MESH_NORMALS) {
-        const float4* g = sc.geometry + inst.vertex_offset;
-        f3 n = decode_octahedral(g[i1].w) * u + decode_octahedral(g[i2].w) * v + decode_octahedral(g[i0].w) * w;
-        n = normalize(n);
-        const float* M = inst.object_to_world;
-        shading_normal = normalize(mk3(M[0] * n.x + M[1] * n.y + M[2] * n.z, M[4] * n.x + M[5] * n.y + M[6] * n.z, M[8] * n.x + M[9] * n.y + M[10] * n.z));
-    }
+    if (mesh_flags & HIPR_MESH_NORMALS) shading_normal = normalize(mk3(s1.x, s1.y, s1.z) * u + mk3(s2.x, s2.y, s2.z) * v + mk3(s0.x, s0.y, s0.z) * w);
     f4 tint_scale = {1, 1, 1, 1};
-    if (inst.mesh_flags & HIPR_MESH_TINTS) {
-        const uint32_t* tints = sc.tints + inst.vertex_offset;
-        const uint32_t t0 = tints[i0], t1 = tints[i1], t2 = tints[i2];
+    if (mesh_flags & HIPR_MESH_TINTS) {
+        const uint32_t t0 = __float_as_uint(s4.z), t1 = __float_as_uint(s4.w), t2 = __float_as_uint(s5.x);
         const float s = 1.0f / 255.0f;
         auto ch = [](uint32_t p, int c) { return float((p >> (8 * c)) & 0xFFu); };
         tint_scale = {(ch(t1, 0) * u + ch(t2, 0) * v + ch(t0, 0) * w) * s, (ch(t1, 1) * u + ch(t2, 1) * v + ch(t0, 1) * w) * s,
                       (ch(t1, 2) * u + ch(t2, 2) * v + ch(t0, 2) * w) * s, (ch(t1, 3) * u + ch(t2, 3) * v + ch(t0, 3) * w) * s};
     }
     f3 emission = {1, 1, 1};
-    if (inst.mesh_flags & HIPR_MESH_EMISSIVE) {
+    if (mesh_flags & HIPR_MESH_EMISSIVE) {   // rare: per-vertex emission stays behind the instance
+        const HiprInstance& inst = sc.instances[__float_as_uint(tc.y)];
+        const uint32_t* idx = sc.indices + 3 * size_t(inst.index_offset + prim);
+        const uint32_t i0 = idx[0], i1 = idx[1], i2 = idx[2];
         const float* e = sc.emissions + 3 * size_t(inst.vertex_offset);
         auto em = [&](uint32_t i) { return mk3(e[3 * i], e[3 * i + 1], e[3 * i + 2]); };
         emission = em(i1) * u + em(i2) * v + em(i0) * w;
@@ -155,7 +155,7 @@ HD void shade_path(const DeviceScene& sc, const HiprCameraState& cam, int entry,
         else if (entry == HIPR_ENTRY_ROUGHNESS) value = mk3(base.w * qscale.w);
         else if (entry == HIPR_ENTRY_SHADING_NORMAL) value = shading_normal * 0.5f + 0.5f;
         else if (entry == HIPR_ENTRY_PRIMITIVE_ID) {
-            const uint32_t instance_encoding = uint32_t(inst.instance_id) & 0x3FFFFFFu;
+            const uint32_t instance_encoding = uint32_t(instance_id) & 0x3FFFFFFu;
             const uint32_t primitive_encoding = __brev(prim + 1u) >> 2;
             const uint32_t code = instance_encoding ^ primitive_encoding;
             auto compact_by_2 = [](uint32_t v) {
@@ -246,37 +246,83 @@ HD void shade_path(const DeviceScene& sc, const HiprCameraState& cam, int entry,
     }
 }
 
+// Persistent blocks (the launch sizes the grid to what is resident) walk the queue with a grid stride and run one iteration
+// AHEAD on their inputs: while a batch of 256 paths is shaded, the path state and hit of the next batch are in flight; its
+// triangle, shading record and material are requested once the hit id has arrived, behind the compaction barriers. The four
+// dependent gathers of a hit (path state -> hit -> triangle / record -> material) are thereby off the critical path.
+struct ShadeInputs {
+    uint4 meta;            // slot, last accepted triangle, pixel hash, accumulation
+    float4 o, d, t, hit;   // origin + tmin, direction + pdf, throughput + bounces, (t, u, v, id)
+};
+
+HD ShadeInputs shade_fetch_inputs(const PathState& in, const float4* hits, uint32_t i, uint32_t n) {
+    ShadeInputs r;
+    r.meta = make_uint4(HIPR_DEAD_SLOT, 0u, 0u, 0u);
+    r.o = r.d = r.t = make_float4(0, 0, 0, 0);
+    r.hit = make_float4(0, 0, 0, __uint_as_float(HIPR_HIT_MISS));
+    if (i < n) { r.meta = in.meta[i]; r.o = in.o_tmin[i]; r.d = in.d_pdf[i]; r.t = in.thr_bounces[i]; r.hit = hits[i]; }
+    return r;
+}
+HD bool shade_hits_triangle(const ShadeInputs& in) {
+    const uint32_t id = __float_as_uint(in.hit.w);
+    return in.meta.x != HIPR_DEAD_SLOT && id != HIPR_HIT_MISS && !(id & HIPR_HIT_LIGHT);
+}
+HD ShadeGeometry shade_fetch_geometry(const DeviceScene& sc, const ShadeInputs& in) {
+    ShadeGeometry g;
+    g.ta = g.tb = g.tc = g.s0 = g.s1 = g.s2 = g.s3 = g.s4 = g.s5 = make_float4(0, 0, 0, 0);
+    if (shade_hits_triangle(in)) {
+        const uint32_t id = __float_as_uint(in.hit.w);
+        const float4* tp = sc.triangles + 3 * size_t(id);
+        const float4* sp = sc.shade_triangles + SHADE_TRIANGLE_QUADS * size_t(id);
+        g.ta = tp[0]; g.tb = tp[1]; g.tc = tp[2];
+        g.s0 = sp[0]; g.s1 = sp[1]; g.s2 = sp[2]; g.s3 = sp[3]; g.s4 = sp[4]; g.s5 = sp[5];
+    }
+    return g;
+}
+HD HiprMaterial shade_fetch_material(const DeviceScene& sc, const ShadeInputs& in, const ShadeGeometry& g) {
+    return sc.materials[shade_hits_triangle(in) ? __float_as_uint(g.s0.w) : 0u];   // slot 0 is the invalid material: always readable
+}
+
+#ifndef HIPR_SHADE_WAVES
+#define HIPR_SHADE_WAVES 2
+#endif
 template <int MODELS, bool AOV>
-__global__ __launch_bounds__(SHADE_BLOCK, 3) void k_shade(DeviceScene sc, HiprCameraState cam, int entry, PathState in, const float4* hits, PathState out,
-                                                        ShadowQueue shadows, float4* radiance, const uint32_t* count_ptr, uint32_t* next_count,
-                                                        uint32_t* shadow_count, DeviceCounters* counters) {
+__global__ __launch_bounds__(SHADE_BLOCK, HIPR_SHADE_WAVES) void k_shade(DeviceScene sc, HiprCameraState cam, int entry, PathState in, const float4* hits, PathState out,
+                                                        ShadowQueue shadows, float4* radiance, const uint32_t* count_ptr, unsigned long long* out_counts,
+                                                        DeviceCounters* counters) {
     __shared__ uint32_t s_cont[SHADE_BLOCK / 64], s_shad[SHADE_BLOCK / 64], s_base[2];
     __shared__ uint32_t s_sobol[SOBOL_TABLE_WORDS];
-    for (uint32_t w = threadIdx.x; w < SOBOL_TABLE_WORDS; w += SHADE_BLOCK) s_sobol[w] = sc.sobol_tables[w];
-    __syncthreads();
     const uint32_t n = *count_ptr;
+    if (blockIdx.x * SHADE_BLOCK >= n) return;
+    const uint32_t stride = gridDim.x * SHADE_BLOCK;
+    uint32_t base = blockIdx.x * SHADE_BLOCK;
+    ShadeInputs cur = shade_fetch_inputs(in, hits, base + threadIdx.x, n);
+    for (uint32_t w = threadIdx.x; w < SOBOL_TABLE_WORDS; w += SHADE_BLOCK) s_sobol[w] = sc.sobol_tables[w];
+    ShadeGeometry geo = shade_fetch_geometry(sc, cur);
+    HiprMaterial mat = shade_fetch_material(sc, cur, geo);
+    __syncthreads();
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     uint32_t shaded_total = 0;
-    for (uint32_t base = blockIdx.x * SHADE_BLOCK; base < n; base += gridDim.x * SHADE_BLOCK) {
-        const uint32_t i = base + threadIdx.x;
+    for (; base < n; base += stride) {
+        // inputs of the next batch: issued now, first used after this batch has been shaded
+        const ShadeInputs next = shade_fetch_inputs(in, hits, base + stride + threadIdx.x, n);
+
         ShadeOutput so;
         so.continues = so.shadow = so.shaded = false;
-        uint32_t slot = HIPR_DEAD_SLOT, pixel_hash = 0, accumulation = 0;
-        if (i < n) {
-            const uint4 meta = in.meta[i];
-            slot = meta.x; pixel_hash = meta.z; accumulation = meta.w;
-            if (slot != HIPR_DEAD_SLOT) {
-                const float4 o = in.o_tmin[i], d = in.d_pdf[i], t = in.thr_bounces[i];
-                shade_path<MODELS, AOV>(sc, cam, entry, s_sobol, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), d.w, mk3(t.x, t.y, t.z), __float_as_uint(t.w), meta.y, pixel_hash,
-                           accumulation, hits[i], so);
-                if (so.add_radiance.x != 0.0f || so.add_radiance.y != 0.0f || so.add_radiance.z != 0.0f) {
-                    float4 acc = radiance[slot];
-                    acc.x += so.add_radiance.x; acc.y += so.add_radiance.y; acc.z += so.add_radiance.z;
-                    radiance[slot] = acc;
-                }
+        const uint32_t slot = cur.meta.x, pixel_hash = cur.meta.z, accumulation = cur.meta.w;
+        if (slot != HIPR_DEAD_SLOT) {
+            shade_path<MODELS, AOV>(sc, cam, entry, s_sobol, mk3(cur.o.x, cur.o.y, cur.o.z), mk3(cur.d.x, cur.d.y, cur.d.z), cur.d.w, mk3(cur.t.x, cur.t.y, cur.t.z),
+                                    __float_as_uint(cur.t.w), cur.meta.y, pixel_hash, accumulation, cur.hit, geo, mat, so);
+            if (so.add_radiance.x != 0.0f || so.add_radiance.y != 0.0f || so.add_radiance.z != 0.0f) {
+                float4 acc = radiance[slot];
+                acc.x += so.add_radiance.x; acc.y += so.add_radiance.y; acc.z += so.add_radiance.z;
+                radiance[slot] = acc;
             }
         }
-        // ---- compaction: ballot + prefix popcount in the wave, LDS scan over the block's waves, one atomic per queue
+        // the hit id of the next batch has arrived by now: request its triangle and shading record
+        geo = shade_fetch_geometry(sc, next);
+
+        // ---- compaction: ballot + prefix popcount in the wave, LDS scan over the block's waves, one atomic for both queues
         const unsigned long long cont_mask = __ballot(so.continues), shad_mask = __ballot(so.shadow);
         const unsigned long long lt = (1ull << lane) - 1ull;
         if (lane == 0) { s_cont[wave] = __popcll(cont_mask); s_shad[wave] = __popcll(shad_mask); }
@@ -285,9 +331,12 @@ __global__ __launch_bounds__(SHADE_BLOCK, 3) void k_shade(DeviceScene sc, HiprCa
         if (threadIdx.x == 0) {
             uint32_t c = 0, s = 0;
             for (int wv = 0; wv < SHADE_BLOCK / 64; ++wv) { uint32_t t = s_cont[wv]; s_cont[wv] = c; c += t; t = s_shad[wv]; s_shad[wv] = s; s += t; }
-            s_base[0] = c ? atomicAdd(next_count, c) : 0u;
-            s_base[1] = s ? atomicAdd(shadow_count, s) : 0u;
+            // one 64-bit atomic reserves space in both queues: low word = paths that continue, high word = shadow rays
+            const unsigned long long before = (c | s) ? atomicAdd(out_counts, ((unsigned long long)s << 32) | c) : 0ull;
+            s_base[0] = uint32_t(before);
+            s_base[1] = uint32_t(before >> 32);
         }
+        mat = shade_fetch_material(sc, next, geo);
         __syncthreads();
         if (so.continues) {
             const uint32_t j = s_base[0] + s_cont[wave] + __popcll(cont_mask & lt);
@@ -302,6 +351,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, 3) void k_shade(DeviceScene sc, HiprCa
             shadows.d_slot[j] = make_float4(so.sd.x, so.sd.y, so.sd.z, __uint_as_float(slot));
             shadows.radiance[j] = make_float4(so.sradiance.x, so.sradiance.y, so.sradiance.z, 0.0f);
         }
+        cur = next;
         __syncthreads();
     }
     wave_add(&counters->shaded_hits, shaded_total);

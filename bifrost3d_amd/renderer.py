@@ -89,6 +89,9 @@ class Context:
     def reset_timers(self):
         self._check(self.lib.hipr_reset_timers(self.handle), "hipr_reset_timers")
 
+    def set_wavefront_count(self, count: int):
+        self._check(self.lib.hipr_set_wavefront_count(self.handle, count), "hipr_set_wavefront_count")
+
     def trace_is_fused(self) -> bool:
         v = C.c_int(0)
         self._check(self.lib.hipr_trace_is_fused(self.handle, C.byref(v)), "hipr_trace_is_fused")

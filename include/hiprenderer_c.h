@@ -294,6 +294,10 @@ int hipr_synchronize(HiprContext* context);
 int hipr_get_counters(HiprContext* context, HiprCounters* out);
 int hipr_reset_counters(HiprContext* context);
 /* Enables per-ray node / triangle visit counting in the trace kernels (slower, off by default). */
+/* Number of independent wavefronts a pass is split into (1 or 2; default 1, or HIPR_WAVEFRONTS). With 2, each half of the path
+ * slots runs its bounces on its own stream, so one half shades while the other traces; results are bit-identical. Applies to
+ * the next hipr_set_frame. Kernel timers then overlap (their sum exceeds the wall time). */
+int hipr_set_wavefront_count(HiprContext* context, int count);
 /* 1 when the uploaded scene is traced by the fused persistent kernel (closest-hit rays of bounce k and shadow rays of bounce
  * k - 1 in one launch, timed under HIPR_KERNEL_TRACE_CLOSEST); 0 when closest and shadow rays are separate launches. */
 int hipr_trace_is_fused(HiprContext* context, int* out_fused);

@@ -286,3 +286,21 @@ def test_tint_quad_G10(ctx):
     ys = (np.arange(h) + 0.5) / h
     assert np.abs(gpu[..., 0] - xs[None, :]).max() <= 0.003
     assert np.abs(gpu[..., 1] - ys[:, None]).max() <= 0.003
+
+
+@pytest.mark.parametrize("scene_name", ["cornell", "atrium"])
+def test_two_wavefronts_are_bit_identical(ctx, cornell, atrium, scene_name):
+    """hipr_set_wavefront_count(2) splits a pass into two half-frame wavefronts on two streams (one shades while the other
+    traces). Every path still owns its radiance slot and sees the same kernel order, so the accumulation must not change."""
+    scene = cornell if scene_name == "cornell" else atrium
+    w, h, spp = 512, 300, 2          # 153 600 pixels: above the 131 072-slot threshold below which a frame stays one wavefront
+    one, c1 = render_gpu(ctx, scene, w, h, spp, 4)
+    ctx.set_wavefront_count(2)
+    try:
+        two, c2 = render_gpu(ctx, scene, w, h, spp, 4)
+    finally:
+        ctx.set_wavefront_count(1)
+        ctx.set_frame(w, h)
+    assert np.array_equal(one, two)
+    for key in ("camera_rays", "closest_rays", "shadow_rays"):
+        assert c1[key] == c2[key], key
