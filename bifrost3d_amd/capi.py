@@ -59,6 +59,10 @@ class HiprTexture(C.Structure):
                 ("wrap_u", c_u8), ("wrap_v", c_u8), ("filter", c_u8), ("is_sRGB", c_u8), ("_pad", c_u8 * 3)]
 
 
+class HiprWideNode(C.Structure):
+    _fields_ = [("origin", c_f * 3), ("exponents", c_u32), ("qlo", c_u32 * 3), ("qhi", c_u32 * 3), ("_pad", c_u32 * 2), ("child", c_i32 * 4)]
+
+
 class HiprSceneDesc(C.Structure):
     _fields_ = [("nodes", C.POINTER(HiprBvhNode)), ("node_count", c_u32),
                 ("triangles", C.POINTER(HiprTriangle)), ("triangle_count", c_u32),
@@ -70,7 +74,8 @@ class HiprSceneDesc(C.Structure):
                 ("lights", C.POINTER(HiprLight)), ("light_count", c_u32),
                 ("textures", C.POINTER(HiprTexture)), ("texture_count", c_u32),
                 ("texels", C.POINTER(c_u8)), ("texel_bytes", c_u32),
-                ("bvh_max_depth", c_u32)]
+                ("bvh_max_depth", c_u32),
+                ("wide_nodes", C.POINTER(HiprWideNode)), ("wide_node_count", c_u32), ("wide_stack_entries", c_u32)]
 
 
 class HiprSceneState(C.Structure):

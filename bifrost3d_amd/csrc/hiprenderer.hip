@@ -107,7 +107,7 @@ struct HiprContext {
     int wavefront_count = 1;                // set by hipr_set_frame: small frames run as one wavefront
 
     // scene
-    DeviceBuffer shade_triangles;
+    DeviceBuffer shade_triangles, wide_nodes;
     DeviceBuffer nodes, triangles, instances, indices, geometry, texcoords, tints, emissions, materials, lights, textures, texels;
     DeviceBuffer ggx_rho, dielectric_rho, alpha, sample_offsets, sobol_tables;
     DeviceScene scene = {};
@@ -125,7 +125,9 @@ struct HiprContext {
     DeviceBuffer& active_accumulation() { return use_scratch ? scratch_accumulation : accumulation; }
     uint32_t work_index = 0;            // next unused persistent-kernel work counter (zeroed 256 at a time)
     int trace_variant = -1;             // 1: persistent kernels, 0: one ray per lane, -1: pick by BVH size (HIPR_TRACE_VARIANT)
-    bool use_persistent() const { return trace_variant < 0 ? scene.node_count > 64 : trace_variant == 1; }
+    uint32_t wide_stack_entries = 0;
+    // persistent kernels walk the compressed 4-wide BVH; without one (HiprSceneDesc::wide_nodes == NULL) the plain BVH2 kernels serve every scene
+    bool use_persistent() const { return scene.wide_node_count > 0 && (trace_variant < 0 ? scene.node_count > 64 : trace_variant == 1); }
     int cu_count = 256;
     int blocks_per_cu_override = 0;     // HIPR_BLOCKS_PER_CU
     int refill_below = 40;              // persistent kernels refill a wave once fewer lanes than this are busy (HIPR_REFILL_BELOW)
@@ -201,12 +203,12 @@ uint32_t* next_work_counter(HiprContext* c) {
 }
 
 // One persistent launch over the path queue (closest_count != nullptr), the shadow queue (shadow_count != nullptr) or both.
-template <int STACK, int MODE, bool INSTRUMENT>
+template <int STACK, int MODE, bool INSTRUMENT, bool OVERFLOW>
 void launch_persistent(HiprContext* c, const Wavefront& w, const PathState& in, const uint32_t* closest_count, const uint32_t* shadow_count, uint32_t upper_bound, int bucket) {
     int& per_cu = c->persistent_blocks_per_cu[MODE][bucket];
     if (per_cu == 0) {
         int blocks = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_trace_persistent<STACK, MODE, INSTRUMENT>, TRACE_BLOCK, 0) != hipSuccess || blocks <= 0) blocks = 4;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_trace_persistent<STACK, MODE, INSTRUMENT, OVERFLOW>, TRACE_BLOCK, 0) != hipSuccess || blocks <= 0) blocks = 4;
         if (c->trace_log) fprintf(stderr, "[hipr] k_trace_persistent<%d, %d>: occupancy query says %d blocks of %d threads per CU\n", STACK, MODE, blocks, TRACE_BLOCK);
         if (c->blocks_per_cu_override > 0) blocks = c->blocks_per_cu_override;
         per_cu = blocks;
@@ -214,17 +216,16 @@ void launch_persistent(HiprContext* c, const Wavefront& w, const PathState& in, 
     const uint32_t waves_per_block = TRACE_BLOCK / 64;
     uint32_t grid = uint32_t(c->cu_count) * uint32_t(per_cu);
     grid = std::max(1u, std::min(grid, (upper_bound + 63u) / 64u / waves_per_block + 1u));
-    hipLaunchKernelGGL((k_trace_persistent<STACK, MODE, INSTRUMENT>), dim3(grid), dim3(TRACE_BLOCK), 0, w.stream, c->scene, in, w.hits.as<float4>(), w.shadow_queue(),
+    hipLaunchKernelGGL((k_trace_persistent<STACK, MODE, INSTRUMENT, OVERFLOW>), dim3(grid), dim3(TRACE_BLOCK), 0, w.stream, c->scene, in, w.hits.as<float4>(), w.shadow_queue(),
                        c->radiance.as<float4>(), closest_count, shadow_count, next_work_counter(c), c->refill_below, c->counters.as<DeviceCounters>());
 }
 
 template <int MODE, bool INSTRUMENT>
 void launch_persistent_for_stack(HiprContext* c, const Wavefront& w, const PathState& in, const uint32_t* closest_count, const uint32_t* shadow_count, uint32_t upper_bound) {
-    switch (c->stack_size) {
-    case 16: launch_persistent<16, MODE, INSTRUMENT>(c, w, in, closest_count, shadow_count, upper_bound, 0); break;
-    case 32: launch_persistent<32, MODE, INSTRUMENT>(c, w, in, closest_count, shadow_count, upper_bound, 1); break;
-    default: launch_persistent<64, MODE, INSTRUMENT>(c, w, in, closest_count, shadow_count, upper_bound, 2); break;
-    }
+    // LDS stack entries by the worst case of the wide tree; beyond 32 the LDS stack is backed by a scratch array
+    if (c->wide_stack_entries <= 16) launch_persistent<16, MODE, INSTRUMENT, false>(c, w, in, closest_count, shadow_count, upper_bound, 0);
+    else if (c->wide_stack_entries <= 32) launch_persistent<32, MODE, INSTRUMENT, false>(c, w, in, closest_count, shadow_count, upper_bound, 1);
+    else launch_persistent<32, MODE, INSTRUMENT, true>(c, w, in, closest_count, shadow_count, upper_bound, 2);
 }
 
 template <bool INSTRUMENT>
@@ -368,7 +369,7 @@ int hipr_destroy(HiprContext* c) {
     if (!c) return HIPR_OK;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    DeviceBuffer* all[] = {&c->shade_triangles, &c->nodes, &c->triangles, &c->instances, &c->indices, &c->geometry, &c->texcoords, &c->tints, &c->emissions, &c->materials,
+    DeviceBuffer* all[] = {&c->shade_triangles, &c->wide_nodes, &c->nodes, &c->triangles, &c->instances, &c->indices, &c->geometry, &c->texcoords, &c->tints, &c->emissions, &c->materials,
                            &c->lights, &c->textures, &c->texels, &c->ggx_rho, &c->dielectric_rho, &c->alpha, &c->sample_offsets, &c->sobol_tables, &c->radiance,
                            &c->accumulation, &c->scratch_accumulation, &c->counters, &c->work_counters, &c->debug_a, &c->debug_b, &c->debug_c};
     for (DeviceBuffer* b : all) b->release();
@@ -420,6 +421,8 @@ int hipr_upload_scene(HiprContext* c, const HiprSceneDesc* s) {
     if (s->triangle_count && (!s->nodes || !s->triangles || !s->instances || !s->indices || !s->geometry || !s->materials))
         return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_upload_scene: missing geometry arrays");
     if (s->bvh_max_depth > 64) return fail(HIPR_ERROR_UNSUPPORTED, "BVH depth %u exceeds the 64 entry LDS stack", s->bvh_max_depth);
+    if (s->wide_nodes && s->wide_stack_entries > 32u + uint32_t(TRACE_SPILL_ENTRIES))
+        return fail(HIPR_ERROR_UNSUPPORTED, "the wide BVH needs %u stack entries, more than the %u the traversal kernels provide", s->wide_stack_entries, 32u + uint32_t(TRACE_SPILL_ENTRIES));
     for (uint32_t i = 0; i < s->instance_count; ++i)
         if ((s->instances[i].mesh_flags & HIPR_MESH_TEXCOORDS && !s->texcoords) || (s->instances[i].mesh_flags & HIPR_MESH_TINTS && !s->tints) ||
             (s->instances[i].mesh_flags & HIPR_MESH_EMISSIVE && !s->emissions))
@@ -428,6 +431,7 @@ int hipr_upload_scene(HiprContext* c, const HiprSceneDesc* s) {
     hipStream_t st = c->stream;
     int r = 0;
     r |= c->nodes.upload(s->nodes, size_t(s->node_count) * sizeof(HiprBvhNode), st);
+    if (s->wide_nodes && s->wide_node_count) r |= c->wide_nodes.upload(s->wide_nodes, size_t(s->wide_node_count) * sizeof(HiprWideNode), st);
     r |= c->triangles.upload(s->triangles, size_t(s->triangle_count) * sizeof(HiprTriangle), st);
     r |= c->instances.upload(s->instances, size_t(s->instance_count) * sizeof(HiprInstance), st);
     r |= c->indices.upload(s->indices, size_t(s->index_count) * 4, st);
@@ -443,6 +447,9 @@ int hipr_upload_scene(HiprContext* c, const HiprSceneDesc* s) {
     HIP_TRY(hipStreamSynchronize(st));
     DeviceScene& d = c->scene;
     d.nodes = c->nodes.as<float4>();
+    d.wide_nodes = s->wide_nodes && s->wide_node_count ? c->wide_nodes.as<uint4>() : nullptr;
+    d.wide_node_count = s->wide_nodes ? s->wide_node_count : 0u;
+    c->wide_stack_entries = s->wide_stack_entries;
     d.triangles = c->triangles.as<float4>();
     d.instances = c->instances.as<HiprInstance>();
     d.indices = c->indices.as<uint32_t>();

@@ -31,6 +31,7 @@ constexpr int SHADE_TRIANGLE_QUADS = 6;   // float4 per shading record (96 B), s
 
 struct DeviceScene {
     const float4* nodes;
+    const uint4* wide_nodes;         // HiprWideNode, 4 x uint4 each: what the persistent kernels traverse
     const float4* triangles;
     const float4* shade_triangles;   // SHADE_TRIANGLE_QUADS float4 per triangle, built on upload (k_build_shade_triangles)
     const HiprInstance* instances;
@@ -46,7 +47,7 @@ struct DeviceScene {
     const float4* sample_offsets;
     const uint32_t* sobol_tables;   // SOBOL_TABLE_WORDS words, see sobol4ui_tables
     DeviceTables tables;
-    uint32_t node_count, triangle_count, light_count;
+    uint32_t node_count, wide_node_count, triangle_count, light_count;
     float env_tint[3];
     int next_event_sample_count;
 };
@@ -424,6 +425,7 @@ constexpr uint32_t TRACE_CHUNK_MAX = 512; // rays a wave claims per global atomi
 // that start on the same shard work on neighbouring rays. A wave that drains its shard steals from the next.
 constexpr uint32_t TRACE_SHARDS = 64;   // == wave size: a drained wave probes all of them with one load per lane
 constexpr uint32_t TRACE_SHARD_STRIDE = 16;   // uint32 words between shard counters
+constexpr int TRACE_SPILL_ENTRIES = 96;       // stack entries beyond the LDS stack, in scratch memory (OVERFLOW kernels only)
 
 // MODE: which rays one launch serves.
 //   TRACE_CLOSEST  the path queue (closest hit)                       -- bounce 0 and the stage-level parity entry point
@@ -433,12 +435,15 @@ constexpr uint32_t TRACE_SHARD_STRIDE = 16;   // uint32 words between shard coun
 //                  from whatever is left, and the long-ray tail of one kind is filled with work of the other.
 enum { TRACE_CLOSEST = 0, TRACE_SHADOW = 1, TRACE_FUSED = 2 };
 
-template <int STACK, int MODE, bool INSTRUMENT>
+template <int STACK, int MODE, bool INSTRUMENT, bool OVERFLOW>
 __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) void k_trace_persistent(DeviceScene sc, PathState in, float4* hits, ShadowQueue q, float4* radiance,
                                                                   const uint32_t* closest_count_ptr, const uint32_t* shadow_count_ptr, uint32_t* work_counter,
                                                                   int refill_below, DeviceCounters* counters) {
     __shared__ int s_stack[STACK * TRACE_BLOCK];
     int* stack = s_stack + threadIdx.x;
+    // Entries beyond the LDS stack (only trees whose worst case needs more than STACK entries are compiled with OVERFLOW) go
+    // to a per-lane array in scratch memory; traversals rarely get that deep.
+    int spill[OVERFLOW ? TRACE_SPILL_ENTRIES : 1];
     const uint32_t n_closest = MODE != TRACE_SHADOW ? *closest_count_ptr : 0u;
     const uint32_t n = n_closest + (MODE != TRACE_CLOSEST ? *shadow_count_ptr : 0u);
     const uint32_t lane = threadIdx.x & 63u;
@@ -546,7 +551,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(5))
                         inv = {1.0f / sd.x, 1.0f / sd.y, 1.0f / sd.z};
                         ood = o * inv;
                         sp = 0; cur = 0; tri_cur = tri_end = 0;
-                        if (sc.node_count == 0) finished = true;
+                        if (sc.wide_node_count == 0) finished = true;
                         else active = true;
                     }
                 }
@@ -598,26 +603,54 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(5))
                     }
                 }
             } else if (node_mode) {
-                const float4* np = sc.nodes + 4 * size_t(cur);
-                const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+                // One compressed 4-wide node (HiprWideNode): 4 gathers of 16 B serve what ~2.1 BVH2 nodes (8.4 gathers) did.
+                const uint4* np = sc.wide_nodes + 4 * size_t(cur);
+                const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
                 if (INSTRUMENT) { nodes += is_shadow ? 0u : 1u; shadow_nodes += is_shadow ? 1u : 0u; }
-                float t0, t1;
-                const bool h0 = slab(inv, ood, n0.x, n0.y, n0.z, n0.w, n2.x, n2.y, tmin, tmax, t0);
-                const bool h1 = slab(inv, ood, n1.x, n1.y, n1.z, n1.w, n2.z, n2.w, tmin, tmax, t1);
-                const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
-                const bool both = h0 & h1;
-                // near child first; with both hit, a leaf child is intersected before an inner sibling is descended (the specification)
-                const bool swap = both ? ((t1 < t0) ? !((c1 >= 0) & (c0 < 0)) : ((c0 >= 0) & (c1 < 0))) : !h0;
-                const int first = swap ? c1 : c0, second = swap ? c0 : c1;
-                if (both) stack[sp * TRACE_BLOCK] = second;
-                sp += both ? 1 : 0;
-                take_next = h0 | h1;
-                next_item = first;
+                // slab distances of a quantised bound q: fma(float(q), A, B) with A = 2^(e - 127) * inv_d, B = fma(origin, inv_d, -ood)
+                const float ax = __uint_as_float((w0.w & 0xFFu) << 23) * inv.x, ay = __uint_as_float(((w0.w >> 8) & 0xFFu) << 23) * inv.y,
+                            az = __uint_as_float(((w0.w >> 16) & 0xFFu) << 23) * inv.z;
+                const float bx = fmaf(__uint_as_float(w0.x), inv.x, -ood.x), by = fmaf(__uint_as_float(w0.y), inv.y, -ood.y), bz = fmaf(__uint_as_float(w0.z), inv.z, -ood.z);
+                uint32_t key[4];
+                int child[4] = {int(w3.x), int(w3.y), int(w3.z), int(w3.w)};
+                // fma(q, A, B) is monotone in q with the sign of A, and qlo <= qhi: the entry bound of an axis is the low one where the
+                // ray travels in +axis (A >= 0) and the high one otherwise -- the same values min / max of the pair would give.
+                const uint32_t nx = ax >= 0.0f ? w1.x : w1.w, fx = ax >= 0.0f ? w1.w : w1.x;
+                const uint32_t ny = ay >= 0.0f ? w1.y : w2.x, fy = ay >= 0.0f ? w2.x : w1.y;
+                const uint32_t nz = az >= 0.0f ? w1.z : w2.y, fz = az >= 0.0f ? w2.y : w1.z;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float x0 = fmaf(float((nx >> (8 * k)) & 0xFFu), ax, bx), x1 = fmaf(float((fx >> (8 * k)) & 0xFFu), ax, bx);
+                    const float y0 = fmaf(float((ny >> (8 * k)) & 0xFFu), ay, by), y1 = fmaf(float((fy >> (8 * k)) & 0xFFu), ay, by);
+                    const float z0 = fmaf(float((nz >> (8 * k)) & 0xFFu), az, bz), z1 = fmaf(float((fz >> (8 * k)) & 0xFFu), az, bz);
+                    const float tnear = fmaxf(fmaxf(x0, y0), fmaxf(z0, tmin));
+                    float tfar = fminf(fminf(x1, y1), z1);
+                    tfar = fminf(tfar, tmax) * 1.0000004f;
+                    const bool hit = (child[k] != HIPR_WIDE_EMPTY) & (tnear <= tfar);
+                    key[k] = hit ? ((__float_as_uint(tnear) & 0x7FFFFFFCu) | uint32_t(k)) : 0xFFFFFFFFu;   // distinct keys: a total order
+                }
+                // sorting network, nearest first
+#define HIPR_ORDER(i, j) { const bool s_ = key[j] < key[i]; const uint32_t lo_ = min(key[i], key[j]), hi_ = max(key[i], key[j]); \
+                           const int ci_ = s_ ? child[j] : child[i], cj_ = s_ ? child[i] : child[j]; key[i] = lo_; key[j] = hi_; child[i] = ci_; child[j] = cj_; }
+                HIPR_ORDER(0, 1) HIPR_ORDER(2, 3) HIPR_ORDER(0, 2) HIPR_ORDER(1, 3) HIPR_ORDER(1, 2)
+#undef HIPR_ORDER
+                // the nearest hit child is next; the others wait on the stack, farthest first
+#pragma unroll
+                for (int k = 3; k >= 1; --k) {
+                    if (key[k] != 0xFFFFFFFFu) {
+                        if (!OVERFLOW || sp < STACK) stack[sp * TRACE_BLOCK] = child[k];
+                        else spill[sp - STACK] = child[k];
+                        ++sp;
+                    }
+                }
+                take_next = key[0] != 0xFFFFFFFFu;
+                next_item = child[0];
                 need_pop = !take_next;
             }
             if (need_pop) {
                 const int below = sp > 0 ? sp - 1 : 0;
-                const int popped = stack[below * TRACE_BLOCK];
+                int popped = stack[(OVERFLOW && below >= STACK ? 0 : below) * TRACE_BLOCK];
+                if (OVERFLOW && below >= STACK) popped = spill[below - STACK];
                 next_item = sp > 0 ? popped : TRACE_DONE;
                 sp = below;
                 take_next = true;

@@ -32,6 +32,9 @@ def load_host_library() -> C.CDLL:
     lib.hiprh_bvh_max_depth.argtypes = [vp]; lib.hiprh_bvh_max_depth.restype = C.c_uint
     lib.hiprh_bvh_nodes.argtypes = [vp]; lib.hiprh_bvh_nodes.restype = C.POINTER(capi.HiprBvhNode)
     lib.hiprh_bvh_order.argtypes = [vp]; lib.hiprh_bvh_order.restype = C.POINTER(C.c_uint)
+    lib.hiprh_bvh_wide_node_count.argtypes = [vp]; lib.hiprh_bvh_wide_node_count.restype = C.c_uint
+    lib.hiprh_bvh_wide_stack_entries.argtypes = [vp]; lib.hiprh_bvh_wide_stack_entries.restype = C.c_uint
+    lib.hiprh_bvh_wide_nodes.argtypes = [vp]; lib.hiprh_bvh_wide_nodes.restype = C.POINTER(capi.HiprWideNode)
     lib.hiprh_bvh_destroy.argtypes = [vp]
     lib.hiprh_encode_octahedral.argtypes = [C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_short)]
     _lib = lib

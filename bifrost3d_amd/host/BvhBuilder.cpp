@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <cstdlib>
 #include <cmath>
 
 namespace HIPRenderer {
@@ -30,7 +31,13 @@ struct Box {
 };
 
 constexpr int BIN_COUNT = 16;
-constexpr uint32_t LEAF_MAX = 4;
+// Triangles per leaf. The traversal kernels spend one loop iteration per node AND per triangle, so a leaf is worth splitting
+// as long as the split culls triangles; HIPR_BVH_LEAF_SIZE overrides for experiments.
+static uint32_t leaf_max() {
+    static const uint32_t value = [] { const char* v = std::getenv("HIPR_BVH_LEAF_SIZE"); int n = v ? std::atoi(v) : 4; return uint32_t(n < 1 ? 1 : (n > 8 ? 8 : n)); }();
+    return value;
+}
+#define LEAF_MAX leaf_max()
 
 struct Builder {
     const std::vector<HiprTriangle>& tris;
@@ -156,6 +163,82 @@ struct Builder {
     }
 };
 
+// ---------------------------------------------------------------------------------------------
+// Collapse to compressed 4-wide nodes: a node adopts the children of its largest inner child until it has four, then the
+// child boxes are quantised to 8 bits per bound on the node's own grid, rounding outwards.
+// ---------------------------------------------------------------------------------------------
+struct WideCollapse {
+    const std::vector<HiprBvhNode>& nodes;
+    std::vector<HiprWideNode> wide;
+
+    struct Child { Box box; int32_t ref; };
+
+    static Child child_of(const HiprBvhNode& n, int c) {
+        Child r;
+        const float* xy = c == 0 ? n.c0xy : n.c1xy;
+        r.box.lo[0] = xy[0]; r.box.hi[0] = xy[1]; r.box.lo[1] = xy[2]; r.box.hi[1] = xy[3];
+        r.box.lo[2] = n.cz[2 * c]; r.box.hi[2] = n.cz[2 * c + 1];
+        r.ref = n.child[c];
+        return r;
+    }
+
+    // Returns the wide node index and, through `stack_need`, the worst case number of stack entries below it.
+    uint32_t collapse(uint32_t node_index, uint32_t& stack_need) {
+        std::vector<Child> children = {child_of(nodes[node_index], 0), child_of(nodes[node_index], 1)};
+        if (children[0].ref == children[1].ref && children[0].ref < 0) children.pop_back();   // the single-leaf root references its leaf twice
+        while (children.size() < 4) {
+            int widest = -1;
+            float widest_area = -1.0f;
+            for (size_t i = 0; i < children.size(); ++i)
+                if (children[i].ref >= 0 && children[i].box.half_area() > widest_area) { widest = int(i); widest_area = children[i].box.half_area(); }
+            if (widest < 0) break;
+            const HiprBvhNode& inner = nodes[children[widest].ref];
+            children[widest] = child_of(inner, 0);
+            children.insert(children.begin() + widest + 1, child_of(inner, 1));
+        }
+
+        const uint32_t index = uint32_t(wide.size());
+        wide.emplace_back();
+        HiprWideNode w = {};
+        Box all; all.reset();
+        for (const Child& ch : children) all.grow(ch.box);
+        uint32_t q[2][3] = {{0, 0, 0}, {0, 0, 0}};
+        for (int a = 0; a < 3; ++a) {
+            w.origin[a] = all.lo[a];
+            const double origin = all.lo[a], extent = double(all.hi[a]) - origin;
+            int e = extent > 0.0 ? int(std::ceil(std::log2(extent / 255.0))) : -126;
+            e = std::max(e, -126);
+            for (;; ++e) {   // grow the grid until every bound fits in [0, 255] after rounding outwards
+                const double scale = std::ldexp(1.0, e);
+                bool fits = true;
+                uint32_t qa[2] = {0, 0};
+                for (size_t k = 0; k < children.size() && fits; ++k) {
+                    double lo = std::floor((double(children[k].box.lo[a]) - origin) / scale), hi = std::ceil((double(children[k].box.hi[a]) - origin) / scale);
+                    while (lo > 0.0 && origin + lo * scale > double(children[k].box.lo[a])) lo -= 1.0;
+                    while (origin + hi * scale < double(children[k].box.hi[a])) hi += 1.0;
+                    lo = std::max(lo, 0.0);
+                    if (hi > 255.0) { fits = false; break; }
+                    qa[0] |= uint32_t(lo) << (8 * k);
+                    qa[1] |= uint32_t(hi) << (8 * k);
+                }
+                if (fits) { q[0][a] = qa[0]; q[1][a] = qa[1]; break; }
+            }
+            w.exponents |= uint32_t(e + 127) << (8 * a);
+        }
+        for (int a = 0; a < 3; ++a) { w.qlo[a] = q[0][a]; w.qhi[a] = q[1][a]; }
+
+        stack_need = 0;
+        for (int k = 0; k < 4; ++k) w.child[k] = HIPR_WIDE_EMPTY;
+        for (size_t k = 0; k < children.size(); ++k) {
+            uint32_t below = 0;
+            w.child[k] = children[k].ref >= 0 ? int32_t(collapse(uint32_t(children[k].ref), below)) : children[k].ref;
+            stack_need = std::max(stack_need, uint32_t(children.size() - 1) + below);
+        }
+        wide[index] = w;
+        return index;
+    }
+};
+
 } // namespace
 
 BvhBuildResult build_bvh(const std::vector<HiprTriangle>& triangles, uint32_t max_depth) {
@@ -192,6 +275,10 @@ BvhBuildResult build_bvh(const std::vector<HiprTriangle>& triangles, uint32_t ma
 
     result.nodes = std::move(b.nodes);
     result.order = std::move(b.order);
+    WideCollapse collapse{result.nodes, {}};
+    collapse.wide.reserve(result.nodes.size() / 2 + 1);
+    collapse.collapse(0, result.wide_stack_entries);
+    result.wide_nodes = std::move(collapse.wide);
     result.max_depth = b.deepest + 1;   // stack entries needed is bounded by the node depth; keep one spare
     return result;
 }

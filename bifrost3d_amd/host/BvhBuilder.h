@@ -12,6 +12,9 @@ struct BvhBuildResult {
     std::vector<HiprBvhNode> nodes;   // node 0 is the root; empty for an empty scene
     std::vector<uint32_t> order;      // order[k] = index of the input triangle stored at leaf slot k
     uint32_t max_depth = 0;           // upper bound of the traversal stack entries the tree needs
+    // The same tree collapsed to compressed 4-wide nodes (HiprWideNode); empty when the scene is empty.
+    std::vector<HiprWideNode> wide_nodes;
+    uint32_t wide_stack_entries = 0;  // most entries a traversal of wide_nodes can have on its stack
 };
 
 // `max_depth`: the deepest leaf the builder may produce (root = 1). 62 fits the 64 entry LDS stack.

@@ -186,6 +186,8 @@ void SceneBuilder::finalize(uint32_t bvh_max_depth) {
     d.textures = m_textures.data(); d.texture_count = uint32_t(m_textures.size());
     d.texels = m_texels.data(); d.texel_bytes = uint32_t(m_texels.size());
     d.bvh_max_depth = m_bvh.max_depth;
+    d.wide_nodes = m_bvh.wide_nodes.data(); d.wide_node_count = uint32_t(m_bvh.wide_nodes.size());
+    d.wide_stack_entries = m_bvh.wide_stack_entries;
 }
 
 HiprCameraState make_camera_state(const CameraDescription& camera, float aspect_ratio, uint32_t accumulations, float path_regularization_PDF_scale) {

@@ -59,6 +59,9 @@ unsigned hiprh_bvh_node_count(void* h) { return unsigned(static_cast<BvhHandle*>
 unsigned hiprh_bvh_max_depth(void* h) { return static_cast<BvhHandle*>(h)->result.max_depth; }
 const HiprBvhNode* hiprh_bvh_nodes(void* h) { return static_cast<BvhHandle*>(h)->result.nodes.data(); }
 const unsigned* hiprh_bvh_order(void* h) { return static_cast<BvhHandle*>(h)->result.order.data(); }
+unsigned hiprh_bvh_wide_node_count(void* h) { return unsigned(static_cast<BvhHandle*>(h)->result.wide_nodes.size()); }
+unsigned hiprh_bvh_wide_stack_entries(void* h) { return static_cast<BvhHandle*>(h)->result.wide_stack_entries; }
+const HiprWideNode* hiprh_bvh_wide_nodes(void* h) { return static_cast<BvhHandle*>(h)->result.wide_nodes.data(); }
 void hiprh_bvh_destroy(void* h) { delete static_cast<BvhHandle*>(h); }
 
 void hiprh_encode_octahedral(const float* normals_n3, int n, short* out_n2) {

@@ -129,6 +129,23 @@ typedef struct HiprBvhNode {
     uint32_t _pad[2];
 } HiprBvhNode;
 
+/* Compressed 4-wide BVH node, 64 bytes: what the persistent traversal kernels walk in scenes with more than 64 BVH2 nodes.
+ * (The traversal is bound by the number of 16-byte gathers it issues, not by arithmetic: one of these replaces ~2.1 BVH2
+ * nodes of 64 bytes each.) Built by collapsing the BVH2 (host/BvhBuilder.cpp); child boxes are quantised to 8 bits per bound
+ * relative to the node's own box, conservatively (decoded boxes contain the exact ones):
+ *   lo_a[k] = origin[a] + qlo_a[k] * 2^(exponent_a - 127),  hi_a[k] = origin[a] + qhi_a[k] * 2^(exponent_a - 127)
+ * exponents = ex | ey << 8 | ez << 16 (biased like an IEEE exponent field); byte k of qlo/qhi word a = child k.
+ * child[k]: >= 0 inner wide node, < 0 leaf (same encoding as HiprBvhNode), HIPR_WIDE_EMPTY = unused slot. */
+typedef struct HiprWideNode {
+    float origin[3];
+    uint32_t exponents;
+    uint32_t qlo[3];
+    uint32_t qhi[3];
+    uint32_t _pad[2];
+    int32_t child[4];
+} HiprWideNode;
+#define HIPR_WIDE_EMPTY 0x7FFFFFFF
+
 /* Software replacement for the reference's texture samplers (OR/Renderer.cpp:703-751).
  * Texels live in HiprSceneDesc::texels at `texel_offset` (bytes). */
 typedef struct HiprTexture {
@@ -158,6 +175,8 @@ typedef struct HiprSceneDesc {
     const HiprTexture* textures;         uint32_t texture_count;    /* slot 0 = none */
     const uint8_t* texels;               uint32_t texel_bytes;
     uint32_t bvh_max_depth;              /* deepest leaf, root = 1; selects the LDS stack size */
+    const HiprWideNode* wide_nodes;      uint32_t wide_node_count;  /* the same tree collapsed to 4-wide nodes; may be NULL / 0 */
+    uint32_t wide_stack_entries;         /* most entries a traversal of wide_nodes can have on its stack */
 } HiprSceneDesc;
 
 /* OR/Types.h:507-523 SceneStateGPU, without OptiX buffer ids. */

@@ -144,6 +144,78 @@ static inline void traverse(const HiprSceneDesc& scene, const Ray& ray, float& t
     }
 }
 
+// Traversal of the compressed 4-wide BVH (HiprWideNode, include/hiprenderer_c.h). Specification shared with
+// k_trace_persistent (csrc/kernels.h), so that results AND node / triangle counters agree exactly:
+//   * child bounds are never reconstructed: per axis A = 2^(e - 127) * inv_d and B = fma(origin, inv_d, -ood); the slab
+//     distances of a bound q (0..255) are fma(float(q), A, B); tnear / tfar as in slab() above (same 3 ulp slack);
+//   * the hit children are visited in ascending order of key = (bits(tnear) & 0x7FFFFFFC) | slot (distinct keys: a total
+//     order); the first becomes the current item, the others go on the stack, farthest first;
+//   * a leaf is an item like a node: its triangles are tested in storage order when it is taken.
+template <typename LeafFn>
+static inline void traverse_wide(const HiprSceneDesc& scene, const Ray& ray, float& tmax, TraversalCounters* counters, LeafFn&& leaf) {
+    if (scene.wide_node_count == 0)
+        return;
+    const SlabRay sr = make_slab_ray(ray);
+    const float inv[3] = {sr.inv_d.x, sr.inv_d.y, sr.inv_d.z}, ood[3] = {sr.ood.x, sr.ood.y, sr.ood.z};
+    int32_t stack[256];
+    int sp = 0;
+    int32_t item = 0;
+    for (;;) {
+        bool descended = false;
+        if (item < 0) {
+            if (leaf(uint32_t(~item)))
+                return;
+        } else {
+            const HiprWideNode& n = scene.wide_nodes[item];
+            if (counters) counters->nodes++;
+            float A[3], B[3];
+            for (int a = 0; a < 3; ++a) {
+                A[a] = int_as_float(int32_t(((n.exponents >> (8 * a)) & 0xFFu) << 23)) * inv[a];
+                B[a] = fmaf(n.origin[a], inv[a], -ood[a]);
+            }
+            uint32_t key[4];
+            int32_t child[4];
+            for (int k = 0; k < 4; ++k) {
+                float lo[3], hi[3];
+                for (int a = 0; a < 3; ++a) {
+                    lo[a] = fmaf(float((n.qlo[a] >> (8 * k)) & 0xFFu), A[a], B[a]);
+                    hi[a] = fmaf(float((n.qhi[a] >> (8 * k)) & 0xFFu), A[a], B[a]);
+                }
+                const float tnear = fmaxf(fmaxf(fminf(lo[0], hi[0]), fminf(lo[1], hi[1])), fmaxf(fminf(lo[2], hi[2]), ray.tmin));
+                float tfar = fminf(fminf(fmaxf(lo[0], hi[0]), fmaxf(lo[1], hi[1])), fmaxf(lo[2], hi[2]));
+                tfar = fminf(tfar, tmax) * 1.0000004f;
+                const bool hit = n.child[k] != HIPR_WIDE_EMPTY && tnear <= tfar;
+                key[k] = hit ? ((uint32_t(float_as_int(tnear)) & 0x7FFFFFFCu) | uint32_t(k)) : 0xFFFFFFFFu;
+                child[k] = n.child[k];
+            }
+            auto order = [&](int i, int j) { if (key[j] < key[i]) { std::swap(key[i], key[j]); std::swap(child[i], child[j]); } };
+            order(0, 1); order(2, 3); order(0, 2); order(1, 3); order(1, 2);
+            int hits = 0;
+            while (hits < 4 && key[hits] != 0xFFFFFFFFu) ++hits;
+            for (int k = hits - 1; k >= 1; --k) stack[sp++] = child[k];
+            if (hits > 0) { item = child[0]; descended = true; }
+        }
+        if (!descended) {
+            if (sp == 0)
+                return;
+            item = stack[--sp];
+        }
+    }
+}
+
+Hit closest_hit_wide(const HiprSceneDesc& scene, const Ray& ray, uint32_t skip, TraversalCounters* counters) {
+    Hit best = {ray.tmax, 0, 0, HIT_MISS};
+    traverse_wide(scene, ray, best.t, counters, [&](uint32_t leaf) {
+        uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
+        for (uint32_t i = first; i < first + count; ++i) {
+            if (counters) counters->triangles++;
+            consider_triangle(scene, i, ray, skip, best);
+        }
+        return false;
+    });
+    return best;
+}
+
 Hit closest_hit_bvh(const HiprSceneDesc& scene, const Ray& ray, uint32_t skip, TraversalCounters* counters) {
     Hit best = {ray.tmax, 0, 0, HIT_MISS};
     traverse(scene, ray, best.t, counters, [&](uint32_t leaf) {
@@ -347,6 +419,20 @@ float3 shadow_bruteforce(const HiprSceneDesc& scene, const Ray& ray, float3 radi
     for (uint32_t i = 0; i < scene.triangle_count; ++i)
         if (shadow_triangle(scene, i, ray, radiance))
             break;
+    return radiance;
+}
+
+float3 shadow_wide(const HiprSceneDesc& scene, const Ray& ray, float3 radiance, TraversalCounters* counters) {
+    float tmax = ray.tmax;
+    traverse_wide(scene, ray, tmax, counters, [&](uint32_t leaf) {
+        uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
+        for (uint32_t i = first; i < first + count; ++i) {
+            if (counters) counters->triangles++;
+            if (shadow_triangle(scene, i, ray, radiance))
+                return true;
+        }
+        return false;
+    });
     return radiance;
 }
 
@@ -564,7 +650,8 @@ float3 path_trace_pixel(const HiprSceneDesc& scene, const HiprSceneState& state,
 
     do {
         Ray ray = {payload.position, payload.ray_min_t, payload.direction, INFINITY};
-        Hit hit = settings.use_bvh ? closest_hit_bvh(scene, ray, payload.last_triangle, counters ? &counters->closest : nullptr)
+        Hit hit = settings.use_wide ? closest_hit_wide(scene, ray, payload.last_triangle, counters ? &counters->closest : nullptr)
+                  : settings.use_bvh ? closest_hit_bvh(scene, ray, payload.last_triangle, counters ? &counters->closest : nullptr)
                                    : closest_hit_bruteforce(scene, ray, payload.last_triangle);
         intersect_lights(scene, ray, hit);
         if (counters) counters->closest_rays++;
@@ -589,7 +676,8 @@ float3 path_trace_pixel(const HiprSceneDesc& scene, const HiprSceneState& state,
         const LightSample& ls = payload.light_sample;
         if (ls.radiance.x > 0 || ls.radiance.y > 0 || ls.radiance.z > 0) {
             Ray shadow = {payload.light_sample_origin, 0.0f, ls.direction_to_light, ls.distance};
-            float3 r = settings.use_bvh ? shadow_bvh(scene, shadow, ls.radiance, counters ? &counters->shadow : nullptr)
+            float3 r = settings.use_wide ? shadow_wide(scene, shadow, ls.radiance, counters ? &counters->shadow : nullptr)
+                       : settings.use_bvh ? shadow_bvh(scene, shadow, ls.radiance, counters ? &counters->shadow : nullptr)
                                         : shadow_bruteforce(scene, shadow, ls.radiance);
             if (counters) counters->shadow_rays++;
             payload.radiance += r;
@@ -624,7 +712,8 @@ float3 aov_pixel(const HiprSceneDesc& scene, const HiprSceneState& state, const 
         last_ray_direction = payload.direction;
         float3 last_position = payload.position;
         Ray ray = {payload.position, payload.ray_min_t, payload.direction, INFINITY};
-        Hit hit = settings.use_bvh ? closest_hit_bvh(scene, ray, payload.last_triangle, nullptr) : closest_hit_bruteforce(scene, ray, payload.last_triangle);
+        Hit hit = settings.use_wide ? closest_hit_wide(scene, ray, payload.last_triangle, nullptr)
+                  : settings.use_bvh ? closest_hit_bvh(scene, ray, payload.last_triangle, nullptr) : closest_hit_bruteforce(scene, ray, payload.last_triangle);
         intersect_lights(scene, ray, hit);
         if (hit.id == HIT_MISS) {
             payload.throughput = {0, 0, 0};

@@ -40,10 +40,12 @@ void generate_camera_ray(const HiprCameraState& cam, int x, int y, int width, in
 bool intersect_triangle(const HiprTriangle& tri, float3 o, float3 d, float& t, float& u, float& v);
 Hit closest_hit_bruteforce(const HiprSceneDesc& scene, const Ray& ray, uint32_t skip_triangle);
 Hit closest_hit_bvh(const HiprSceneDesc& scene, const Ray& ray, uint32_t skip_triangle, TraversalCounters* counters);
+Hit closest_hit_wide(const HiprSceneDesc& scene, const Ray& ray, uint32_t skip_triangle, TraversalCounters* counters);   // compressed 4-wide BVH
 void intersect_lights(const HiprSceneDesc& scene, const Ray& ray, Hit& hit);
 // Shadow any-hit accumulation over all triangles in (tmin, tmax); returns the attenuated radiance.
 float3 shadow_bruteforce(const HiprSceneDesc& scene, const Ray& ray, float3 radiance);
 float3 shadow_bvh(const HiprSceneDesc& scene, const Ray& ray, float3 radiance, TraversalCounters* counters);
+float3 shadow_wide(const HiprSceneDesc& scene, const Ray& ray, float3 radiance, TraversalCounters* counters);
 
 // --- textures / materials ---------------------------------------------------------------------
 float4 sample_texture(const HiprSceneDesc& scene, int texture_ID, float2 uv);
@@ -52,6 +54,7 @@ float material_coverage(const HiprSceneDesc& scene, const HiprMaterial& m, float
 // --- integrator -------------------------------------------------------------------------------
 struct RenderSettings {
     bool use_bvh = true;          // false: brute force over all triangles (tiny scenes)
+    bool use_wide = false;        // true: the compressed 4-wide BVH (what the HIP kernels walk in scenes with more than 64 BVH2 nodes)
 };
 
 struct RenderCounters {

@@ -99,7 +99,9 @@ def test_closest_hit_bit_exact(ctx, oracle_q, cornell, atrium, scene_name):
     gpu = ctx.debug_trace_closest(rays, skip)
     counters = ctx.counters()
     ctx.set_instrumentation(False)
-    cpu, (nodes, tris) = oracle_q.trace_closest(scene.desc, rays, skip, use_bvh=True, with_lights=True)
+    # scenes with more than 64 BVH2 nodes are traced by the persistent kernels, which walk the compressed 4-wide BVH (oracle mode 2)
+    cpu, (nodes, tris) = oracle_q.trace_closest(scene.desc, rays, skip, use_bvh=2 if ctx.trace_is_fused() else 1, with_lights=True)
+    assert ctx.trace_is_fused() == (scene_name == "atrium")
     assert np.array_equal(gpu.view(np.uint32), cpu.view(np.uint32)), "t, u, v and primitive id must match bit for bit"
     assert counters["closest_nodes"] == nodes and counters["closest_triangles"] == tris
     # The BVH answer equals exhaustive search (oracle side), so traversal loses no hits. The only admissible
@@ -124,7 +126,7 @@ def test_shadow_rays_bit_exact(ctx, oracle_q, cornell, atrium, scene_name):
     gpu = ctx.debug_trace_shadow(rays)
     counters = ctx.counters()
     ctx.set_instrumentation(False)
-    cpu, (nodes, tris) = oracle_q.trace_shadow(scene.desc, rays, use_bvh=True)
+    cpu, (nodes, tris) = oracle_q.trace_shadow(scene.desc, rays, use_bvh=2 if ctx.trace_is_fused() else 1)
     assert np.array_equal(gpu, cpu)
     assert counters["shadow_nodes"] == nodes and counters["shadow_triangles"] == tris
     assert 0.05 < (gpu == 0).mean() < 0.99

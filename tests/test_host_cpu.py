@@ -1,6 +1,7 @@
 """CPU tests of the host side: C-ABI surface, scene flattening, BVH builder, camera, tiling. No GPU."""
 import ctypes as C
 import re
+import sys
 from pathlib import Path
 
 import numpy as np
@@ -198,3 +199,77 @@ def test_tile_partition_covers_every_pixel_once():
                 valid = coords[:, 0] >= 0
                 np.add.at(seen, (coords[valid, 1], coords[valid, 0]), 1)
             assert (seen == 1).all()
+
+
+def _decode_wide_child_boxes(node):
+    """Decoded child boxes of a HiprWideNode, exactly as the traversal specification reconstructs them (f64 here: exact)."""
+    boxes = []
+    for k in range(4):
+        if node.child[k] == 0x7FFFFFFF:
+            continue
+        lo, hi = [], []
+        for a in range(3):
+            scale = 2.0 ** (((node.exponents >> (8 * a)) & 0xFF) - 127)
+            lo.append(node.origin[a] + ((node.qlo[a] >> (8 * k)) & 0xFF) * scale)
+            hi.append(node.origin[a] + ((node.qhi[a] >> (8 * k)) & 0xFF) * scale)
+        boxes.append((node.child[k], np.array(lo), np.array(hi)))
+    return boxes
+
+
+@pytest.mark.parametrize("name,kw", [("cornell", {}), ("atrium", dict(param0=3000, param1=5))])
+def test_wide_bvh_is_a_conservative_partition(name, kw):
+    """The compressed 4-wide BVH: every triangle is in exactly one leaf, every decoded (8-bit quantised) child box contains
+    all the triangles below it, and the recorded stack bound holds."""
+    scene = Scene(name, **kw)
+    d = scene.desc
+    assert d.wide_node_count > 0 and d.wide_node_count <= d.node_count
+    tris = np.ctypeslib.as_array(C.cast(d.triangles, C.POINTER(C.c_float)), shape=(d.triangle_count, 12))[:, :9].reshape(-1, 3, 3)
+    seen = np.zeros(d.triangle_count, np.int32)
+    deepest_stack = 0
+
+    def visit(index, stack_entries):
+        nonlocal deepest_stack
+        node = d.wide_nodes[index]
+        children = _decode_wide_child_boxes(node)
+        assert len(children) >= 1
+        lo_all, hi_all = np.full(3, np.inf), np.full(3, -np.inf)
+        for ref, lo, hi in children:
+            if ref < 0:
+                code = ~ref & 0xFFFFFFFF
+                first, count = code >> 3, (code & 7) + 1
+                seen[first:first + count] += 1
+                tlo, thi = tris[first:first + count].min(axis=(0, 1)), tris[first:first + count].max(axis=(0, 1))
+            else:
+                tlo, thi = visit(ref, stack_entries + len(children) - 1)
+            assert np.all(lo <= tlo) and np.all(hi >= thi), (index, ref)
+            lo_all, hi_all = np.minimum(lo_all, tlo), np.maximum(hi_all, thi)
+        deepest_stack = max(deepest_stack, stack_entries + len(children) - 1)
+        return lo_all, hi_all
+
+    visit(0, 0)
+    assert np.all(seen == 1)
+    assert deepest_stack <= d.wide_stack_entries
+
+
+def test_oracle_wide_traversal_equals_bvh2_and_brute_force():
+    """oracle/integrator.cpp traverse_wide against the BVH2 traversal and exhaustive search on random rays."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    from oracle_bindings import get_oracle
+    o = get_oracle(True)
+    scene = Scene("atrium", param0=6000, param1=7)
+    rng = np.random.default_rng(5)
+    n = 6000
+    origin = rng.uniform(-12, 12, (n, 3)).astype(np.float32)
+    direction = rng.normal(size=(n, 3)).astype(np.float32)
+    direction /= np.linalg.norm(direction, axis=1, keepdims=True)
+    rays = np.concatenate([origin, np.zeros((n, 1), np.float32), direction, np.full((n, 1), np.inf, np.float32)], axis=1)
+    brute, _ = o.trace_closest(scene.desc, rays, use_bvh=0, with_lights=False)
+    two, (n2, _) = o.trace_closest(scene.desc, rays, use_bvh=1, with_lights=False)
+    wide, (nw, _) = o.trace_closest(scene.desc, rays, use_bvh=2, with_lights=False)
+    assert np.array_equal(wide.view(np.uint32), two.view(np.uint32))
+    assert (wide[:, 3].view(np.uint32) != brute[:, 3].view(np.uint32)).mean() <= 2e-3
+    assert nw < 0.75 * n2   # the point of the wide tree: far fewer node visits
+    rays[:, 7] = rng.uniform(1, 30, n)
+    sb, _ = o.trace_shadow(scene.desc, rays, use_bvh=0)
+    sw, _ = o.trace_shadow(scene.desc, rays, use_bvh=2)
+    assert np.array_equal(sb, sw)
