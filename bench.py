@@ -207,14 +207,19 @@ def main():
         #   trace_shadow   48 B record + 32 B radiance rmw per shadow ray, + 64 B per node + 48 B per triangle
         #   accumulate     16 B radiance per sample + 64 B f64 accumulation rmw + 8 B half4 per owned pixel
         n_closest, n_shadow, n_camera, n_hits = (counters[k] for k in ("closest_rays", "shadow_rays", "camera_rays", "shaded_hits"))
+        from bifrost3d_amd import capi
+        # exhaustive-search kernels (<= 64 triangles): the triangle array is read once per 64-ray wave through the scalar cache
+        tri_share = 1.0 / 64.0 if ctx.trace_variant() == capi.TRACE_EXHAUSTIVE else 1.0
         kernel_bytes = {
             "generate": 80.0 * n_camera,
-            "trace_closest": n_closest * (48 + 16 + 64 * nodes_per_ray + 48 * tris_per_ray),
+            "trace_closest": n_closest * (48 + 16 + 64 * nodes_per_ray + 48 * tris_per_ray * tri_share),
             "shade": 80.0 * n_closest + 352.0 * n_hits + 64.0 * max(0, n_closest - n_camera) + 48.0 * n_shadow + 32.0 * n_closest,
-            "trace_shadow": n_shadow * (48 + 32 + 64 * shadow_nodes_per_ray + 48 * shadow_tris_per_ray),
+            "trace_shadow": n_shadow * (48 + 32 + 64 * shadow_nodes_per_ray + 48 * shadow_tris_per_ray * tri_share),
             "accumulate": 16.0 * n_camera + (64.0 + 8.0) * n_camera / max(1, S),
         }
-        kernel_names = {"generate": "k_generate", "trace_closest": "k_trace_closest", "shade": "k_shade", "trace_shadow": "k_trace_shadow",
+        small = ctx.trace_variant() == capi.TRACE_EXHAUSTIVE
+        kernel_names = {"generate": "k_generate", "trace_closest": "k_trace_closest_small" if small else "k_trace_closest", "shade": "k_shade",
+                        "trace_shadow": "k_trace_shadow_small" if small else "k_trace_shadow",
                         "accumulate": "k_accumulate", "trace": "k_trace_persistent<TRACE_FUSED> (closest-hit rays of bounce k + shadow rays of bounce k-1)"}
         kernel_times = dict(times)
         if ctx.trace_is_fused():   # one launch serves both ray kinds: bytes and time of the two are reported together

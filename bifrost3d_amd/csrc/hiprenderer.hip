@@ -127,7 +127,10 @@ struct HiprContext {
     int trace_variant = -1;             // 1: persistent kernels, 0: one ray per lane, -1: pick by BVH size (HIPR_TRACE_VARIANT)
     uint32_t wide_stack_entries = 0;
     // persistent kernels walk the compressed 4-wide BVH; without one (HiprSceneDesc::wide_nodes == NULL) the plain BVH2 kernels serve every scene
-    bool use_persistent() const { return scene.wide_node_count > 0 && (trace_variant < 0 ? scene.node_count > 64 : trace_variant == 1); }
+    bool use_persistent() const { return scene.wide_node_count > 0 && (trace_variant < 0 ? scene.node_count > 64 : trace_variant == HIPR_TRACE_WIDE_PERSISTENT); }
+    // tiny scenes: exhaustive search over the triangles (k_trace_*_small)
+    bool use_exhaustive() const { return trace_variant < 0 ? (scene.triangle_count <= SMALL_SCENE_TRIANGLES && !use_persistent()) : trace_variant == HIPR_TRACE_EXHAUSTIVE; }
+    int active_trace_variant() const { return use_persistent() ? HIPR_TRACE_WIDE_PERSISTENT : (use_exhaustive() ? HIPR_TRACE_EXHAUSTIVE : HIPR_TRACE_BVH2); }
     int cu_count = 256;
     int blocks_per_cu_override = 0;     // HIPR_BLOCKS_PER_CU
     int refill_below = 40;              // persistent kernels refill a wave once fewer lanes than this are busy (HIPR_REFILL_BELOW)
@@ -234,8 +237,12 @@ void launch_trace_closest(HiprContext* c, const Wavefront& w, const PathState& i
     // Scenes whose whole BVH sits in the L1 / scalar cache (a few dozen nodes) are VALU-issue bound and run fastest with
     // the plain one-ray-per-lane kernel; everything larger wants the persistent kernel (measured: profiles/).
     if (c->use_persistent()) { launch_persistent_for_stack<TRACE_CLOSEST, INSTRUMENT>(c, w, in, count_ptr, nullptr, upper_bound); return; }
-    const uint32_t grid = grid_for(upper_bound, TRACE_BLOCK, 256u * 16u);
     DeviceCounters* dc = c->counters.as<DeviceCounters>();
+    if (c->use_exhaustive()) {
+        hipLaunchKernelGGL((k_trace_closest_small<INSTRUMENT>), dim3(grid_for(upper_bound, 256, 256u * 16u)), dim3(256), 0, w.stream, c->scene, in, hits, count_ptr, dc);
+        return;
+    }
+    const uint32_t grid = grid_for(upper_bound, TRACE_BLOCK, 256u * 16u);
     switch (c->stack_size) {
     case 16: hipLaunchKernelGGL((k_trace_closest<16, INSTRUMENT>), dim3(grid), dim3(TRACE_BLOCK), 0, w.stream, c->scene, in, hits, count_ptr, dc); break;
     case 32: hipLaunchKernelGGL((k_trace_closest<32, INSTRUMENT>), dim3(grid), dim3(TRACE_BLOCK), 0, w.stream, c->scene, in, hits, count_ptr, dc); break;
@@ -246,10 +253,14 @@ void launch_trace_closest(HiprContext* c, const Wavefront& w, const PathState& i
 template <bool INSTRUMENT>
 void launch_trace_shadow(HiprContext* c, const Wavefront& w, const uint32_t* count_ptr, uint32_t upper_bound) {
     if (c->use_persistent()) { launch_persistent_for_stack<TRACE_SHADOW, INSTRUMENT>(c, w, PathState{}, nullptr, count_ptr, upper_bound); return; }
-    const uint32_t grid = grid_for(upper_bound, TRACE_BLOCK, 256u * 16u);
     DeviceCounters* dc = c->counters.as<DeviceCounters>();
     float4* rad = c->radiance.as<float4>();
     ShadowQueue q = w.shadow_queue();
+    if (c->use_exhaustive()) {
+        hipLaunchKernelGGL((k_trace_shadow_small<INSTRUMENT>), dim3(grid_for(upper_bound, 256, 256u * 16u)), dim3(256), 0, w.stream, c->scene, q, rad, count_ptr, dc);
+        return;
+    }
+    const uint32_t grid = grid_for(upper_bound, TRACE_BLOCK, 256u * 16u);
     switch (c->stack_size) {
     case 16: hipLaunchKernelGGL((k_trace_shadow<16, INSTRUMENT>), dim3(grid), dim3(TRACE_BLOCK), 0, w.stream, c->scene, q, rad, count_ptr, dc); break;
     case 32: hipLaunchKernelGGL((k_trace_shadow<32, INSTRUMENT>), dim3(grid), dim3(TRACE_BLOCK), 0, w.stream, c->scene, q, rad, count_ptr, dc); break;
@@ -766,9 +777,9 @@ int hipr_set_wavefront_count(HiprContext* c, int count) {
     return HIPR_OK;
 }
 
-int hipr_trace_is_fused(HiprContext* c, int* out_fused) {
-    if (!c || !out_fused) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_trace_is_fused: null argument");
-    *out_fused = c->scene_ready && c->use_persistent() ? 1 : 0;
+int hipr_get_trace_variant(HiprContext* c, int* out_variant) {
+    if (!c || !out_variant) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_get_trace_variant: null argument");
+    *out_variant = c->scene_ready ? c->active_trace_variant() : HIPR_TRACE_BVH2;
     return HIPR_OK;
 }
 

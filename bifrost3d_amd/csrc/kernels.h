@@ -410,6 +410,84 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_shadow(DeviceScene sc, Sh
 }
 
 // ---------------------------------------------------------------------------------------------
+// K2 / K4 for scenes of at most SMALL_SCENE_TRIANGLES triangles (the Cornell box has 34): exhaustive search. Every lane tests
+// every triangle, so the loop is uniform -- no stack, no divergence, triangle data arrive through the scalar cache -- and that
+// beats a BVH whose rays diverge after two or three nodes (measured: profiles/). The result is the closest hit under the same
+// tie-break (order independent), i.e. what oracle::closest_hit_bruteforce returns; counters: 0 nodes, every triangle per ray.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t SMALL_SCENE_TRIANGLES = 64;
+
+template <bool INSTRUMENT>
+__global__ __launch_bounds__(256) void k_trace_closest_small(DeviceScene sc, PathState in, float4* hits, const uint32_t* count_ptr, DeviceCounters* counters) {
+    const uint32_t n = *count_ptr;
+    uint32_t tris = 0;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const uint4 meta = in.meta[i];
+        if (meta.x == HIPR_DEAD_SLOT) { hits[i] = make_float4(0, 0, 0, __uint_as_float(HIPR_HIT_MISS)); continue; }
+        const float4 ro = in.o_tmin[i], rd = in.d_pdf[i];
+        const f3 o = mk3(ro.x, ro.y, ro.z), d = mk3(rd.x, rd.y, rd.z);
+        const float tmin = ro.w;
+        const uint32_t skip = meta.y;
+        float best_t = __builtin_inff(), best_u = 0.0f, best_v = 0.0f;
+        uint32_t best_id = HIPR_HIT_MISS;
+        for (uint32_t t = 0; t < sc.triangle_count; ++t) {   // uniform: scalar loads of the triangle
+            const float4 a = sc.triangles[3 * t], b = sc.triangles[3 * t + 1], c = sc.triangles[3 * t + 2];
+            float tt, u, v;
+            const bool hit = intersect_triangle_full(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), o, d, tt, u, v);
+            const bool closer = hit & (t != skip) & (tt > tmin) & ((tt < best_t) | ((tt == best_t) & (t < best_id)));
+            best_t = closer ? tt : best_t; best_u = closer ? u : best_u; best_v = closer ? v : best_v; best_id = closer ? t : best_id;
+        }
+        if (INSTRUMENT) tris += sc.triangle_count;
+        for (uint32_t li = 0; li < sc.light_count; ++li) {   // analytic area lights, LightSources.cu:31-70
+            const HiprLight& l = sc.lights[li];
+            const uint32_t type = l.flags & HIPR_LIGHT_TYPE_MASK;
+            float t = -1e30f;
+            if (type == HIPR_LIGHT_SPHERE) { if (!(l.data[6] > 0.0f)) continue; t = ray_sphere(o, d, L3(l, 3), l.data[6]); }
+            else if (type == HIPR_LIGHT_SPOT) { if (!(l.data[6] > 0.0f)) continue; t = ray_disk(o, d, L3(l, 3), L3(l, 7), l.data[6]); }
+            else continue;
+            if (t > tmin && t < best_t) { best_t = t; best_u = 0; best_v = 0; best_id = HIPR_HIT_LIGHT | li; }
+        }
+        hits[i] = make_float4(best_t, best_u, best_v, __uint_as_float(best_id));
+    }
+    if (INSTRUMENT) wave_add(&counters->closest_triangles, tris);
+}
+
+// Any-hit transmittance in triangle order (oracle::shadow_bruteforce); a lane stops at full occlusion, a wave when all its lanes did.
+template <bool INSTRUMENT>
+__global__ __launch_bounds__(256) void k_trace_shadow_small(DeviceScene sc, ShadowQueue q, float4* radiance, const uint32_t* count_ptr, DeviceCounters* counters) {
+    const uint32_t n = *count_ptr;
+    uint32_t tris = 0;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const float4 ro = q.o_tmax[i], rd = q.d_slot[i], rr = q.radiance[i];
+        const f3 o = mk3(ro.x, ro.y, ro.z), d = mk3(rd.x, rd.y, rd.z);
+        const float tmax = ro.w;
+        f3 rad = mk3(rr.x, rr.y, rr.z);
+        bool blocked = false;
+        for (uint32_t t = 0; t < sc.triangle_count; ++t) {
+            if (!__any(!blocked)) break;
+            const float4 a = sc.triangles[3 * t], b = sc.triangles[3 * t + 1], c = sc.triangles[3 * t + 2];
+            if (INSTRUMENT) tris += blocked ? 0u : 1u;
+            float tt, u, v;
+            const bool hit = intersect_triangle_full(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), o, d, tt, u, v);
+            if (!blocked && hit && tt > 0.0f && tt < tmax) {
+                float coverage = 1.0f;
+                if (!(__float_as_uint(c.w) & HIPR_TRIANGLE_OPAQUE)) {
+                    const HiprInstance& inst = sc.instances[__float_as_uint(c.y)];
+                    coverage = material_coverage(sc, sc.materials[inst.material_index], triangle_texcoord(sc, inst, __float_as_uint(c.z), u, v));
+                }
+                rad *= 1.0f - coverage;
+                if (rad.x < 0.0000001f && rad.y < 0.0000001f && rad.z < 0.0000001f) { rad = mk3(0.0f); blocked = true; }
+            }
+        }
+        const uint32_t slot = __float_as_uint(rd.w);
+        float4 acc = radiance[slot];
+        acc.x += rad.x; acc.y += rad.y; acc.z += rad.z;
+        radiance[slot] = acc;
+    }
+    if (INSTRUMENT) wave_add(&counters->shadow_triangles, tris);
+}
+
+// ---------------------------------------------------------------------------------------------
 // K2 / K4, persistent form. Same per-ray visiting order as traverse() above (so results and the
 // node / triangle counters are identical), restructured for wave64 efficiency:
 //   * persistent waves: a wave claims TRACE_CHUNK consecutive rays with one global atomic and

@@ -80,7 +80,7 @@ struct BoundsEstimator {
     float scene_size() const { return magnitude(scene.size()); }
 };
 
-void create_cornell_box(SceneBuilder& sb) {
+void create_cornell_box(SceneBuilder& sb, unsigned wall_quads_per_edge) {
     const uint16_t thin = HIPR_MATERIAL_THIN_WALLED;
     const uint32_t white = sb.add_material(SceneBuilder::make_material(RGB(0.98f), 1.0f, 0.02f, 0.0f, thin));
     const uint32_t red = sb.add_material(SceneBuilder::make_material(RGB(0.98f, 0.02f, 0.02f), 1.0f, 0.02f, 0.0f, thin));
@@ -96,7 +96,7 @@ void create_cornell_box(SceneBuilder& sb) {
     const AABB box_bounds = {Vector3f(-0.5f), Vector3f(0.5f)};
     const float PI_half = PI<float>() * 0.5f;
 
-    const uint32_t plane_mesh = sb.add_mesh(plane(1, true, false));   // MeshFlag::GeometryBuffers
+    const uint32_t plane_mesh = sb.add_mesh(plane(wall_quads_per_edge ? wall_quads_per_edge : 1u, true, false));   // MeshFlag::GeometryBuffers
     auto add_wall = [&](uint32_t material, Transform t) { sb.add_model(plane_mesh, material, t); bounds.add(plane_bounds, t); };
     add_wall(white, Transform(Vector3f(0.0f, -0.5f, 0.0f)));
     add_wall(white, Transform(Vector3f(0.0f, 0.5f, 0.0f), Quaternionf::from_angle_axis(PI<float>(), Vector3f::forward())));

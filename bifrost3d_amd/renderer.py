@@ -92,10 +92,18 @@ class Context:
     def set_wavefront_count(self, count: int):
         self._check(self.lib.hipr_set_wavefront_count(self.handle, count), "hipr_set_wavefront_count")
 
-    def trace_is_fused(self) -> bool:
+    def trace_variant(self) -> int:
+        """capi.TRACE_BVH2 / TRACE_WIDE_PERSISTENT / TRACE_EXHAUSTIVE for the uploaded scene."""
         v = C.c_int(0)
-        self._check(self.lib.hipr_trace_is_fused(self.handle, C.byref(v)), "hipr_trace_is_fused")
-        return bool(v.value)
+        self._check(self.lib.hipr_get_trace_variant(self.handle, C.byref(v)), "hipr_get_trace_variant")
+        return v.value
+
+    def trace_is_fused(self) -> bool:
+        return self.trace_variant() == capi.TRACE_WIDE_PERSISTENT
+
+    def oracle_search(self) -> int:
+        """The `use_bvh` mode of the oracle that states the same search: 0 exhaustive, 1 BVH2, 2 compressed 4-wide BVH."""
+        return {capi.TRACE_BVH2: 1, capi.TRACE_WIDE_PERSISTENT: 2, capi.TRACE_EXHAUSTIVE: 0}[self.trace_variant()]
 
     def kernel_times(self) -> dict:
         t = capi.HiprKernelTimes()

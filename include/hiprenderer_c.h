@@ -317,9 +317,15 @@ int hipr_reset_counters(HiprContext* context);
  * slots runs its bounces on its own stream, so one half shades while the other traces; results are bit-identical. Applies to
  * the next hipr_set_frame. Kernel timers then overlap (their sum exceeds the wall time). */
 int hipr_set_wavefront_count(HiprContext* context, int count);
-/* 1 when the uploaded scene is traced by the fused persistent kernel (closest-hit rays of bounce k and shadow rays of bounce
- * k - 1 in one launch, timed under HIPR_KERNEL_TRACE_CLOSEST); 0 when closest and shadow rays are separate launches. */
-int hipr_trace_is_fused(HiprContext* context, int* out_fused);
+/* How the uploaded scene is traced (chosen from its size; HIPR_TRACE_VARIANT overrides for experiments):
+ *   HIPR_TRACE_BVH2             BVH2 kernels, one ray per lane (k_trace_closest / k_trace_shadow)
+ *   HIPR_TRACE_WIDE_PERSISTENT  more than 64 BVH2 nodes: persistent kernels over the compressed 4-wide BVH; from bounce 1 on the
+ *                               closest-hit rays of a bounce and the shadow rays of the previous one share one fused launch,
+ *                               timed under HIPR_KERNEL_TRACE_CLOSEST
+ *   HIPR_TRACE_EXHAUSTIVE       at most 64 triangles: every ray tests every triangle (k_trace_*_small)
+ * The CPU oracle has the same three searches; parity tests pick the matching one. */
+enum { HIPR_TRACE_BVH2 = 0, HIPR_TRACE_WIDE_PERSISTENT = 1, HIPR_TRACE_EXHAUSTIVE = 2 };
+int hipr_get_trace_variant(HiprContext* context, int* out_variant);
 int hipr_set_instrumentation(HiprContext* context, int count_traversal_steps);
 int hipr_reset_timers(HiprContext* context);
 int hipr_get_kernel_times(HiprContext* context, HiprKernelTimes* out);

@@ -79,10 +79,11 @@ static inline void consider_triangle(const HiprSceneDesc& scene, uint32_t i, con
         best = {t, u, v, i};
 }
 
-Hit closest_hit_bruteforce(const HiprSceneDesc& scene, const Ray& ray, uint32_t skip) {
+Hit closest_hit_bruteforce(const HiprSceneDesc& scene, const Ray& ray, uint32_t skip, TraversalCounters* counters) {
     Hit best = {ray.tmax, 0, 0, HIT_MISS};
     for (uint32_t i = 0; i < scene.triangle_count; ++i)
         consider_triangle(scene, i, ray, skip, best);
+    if (counters) counters->triangles += scene.triangle_count;   // the exhaustive kernels count every triangle of every ray
     return best;
 }
 
@@ -415,10 +416,12 @@ static inline bool shadow_triangle(const HiprSceneDesc& scene, uint32_t i, const
     return false;
 }
 
-float3 shadow_bruteforce(const HiprSceneDesc& scene, const Ray& ray, float3 radiance) {
-    for (uint32_t i = 0; i < scene.triangle_count; ++i)
+float3 shadow_bruteforce(const HiprSceneDesc& scene, const Ray& ray, float3 radiance, TraversalCounters* counters) {
+    for (uint32_t i = 0; i < scene.triangle_count; ++i) {
+        if (counters) counters->triangles++;
         if (shadow_triangle(scene, i, ray, radiance))
             break;
+    }
     return radiance;
 }
 
@@ -652,7 +655,7 @@ float3 path_trace_pixel(const HiprSceneDesc& scene, const HiprSceneState& state,
         Ray ray = {payload.position, payload.ray_min_t, payload.direction, INFINITY};
         Hit hit = settings.use_wide ? closest_hit_wide(scene, ray, payload.last_triangle, counters ? &counters->closest : nullptr)
                   : settings.use_bvh ? closest_hit_bvh(scene, ray, payload.last_triangle, counters ? &counters->closest : nullptr)
-                                   : closest_hit_bruteforce(scene, ray, payload.last_triangle);
+                                   : closest_hit_bruteforce(scene, ray, payload.last_triangle, counters ? &counters->closest : nullptr);
         intersect_lights(scene, ray, hit);
         if (counters) counters->closest_rays++;
 
@@ -678,7 +681,7 @@ float3 path_trace_pixel(const HiprSceneDesc& scene, const HiprSceneState& state,
             Ray shadow = {payload.light_sample_origin, 0.0f, ls.direction_to_light, ls.distance};
             float3 r = settings.use_wide ? shadow_wide(scene, shadow, ls.radiance, counters ? &counters->shadow : nullptr)
                        : settings.use_bvh ? shadow_bvh(scene, shadow, ls.radiance, counters ? &counters->shadow : nullptr)
-                                        : shadow_bruteforce(scene, shadow, ls.radiance);
+                                        : shadow_bruteforce(scene, shadow, ls.radiance, counters ? &counters->shadow : nullptr);
             if (counters) counters->shadow_rays++;
             payload.radiance += r;
         }
@@ -713,7 +716,7 @@ float3 aov_pixel(const HiprSceneDesc& scene, const HiprSceneState& state, const 
         float3 last_position = payload.position;
         Ray ray = {payload.position, payload.ray_min_t, payload.direction, INFINITY};
         Hit hit = settings.use_wide ? closest_hit_wide(scene, ray, payload.last_triangle, nullptr)
-                  : settings.use_bvh ? closest_hit_bvh(scene, ray, payload.last_triangle, nullptr) : closest_hit_bruteforce(scene, ray, payload.last_triangle);
+                  : settings.use_bvh ? closest_hit_bvh(scene, ray, payload.last_triangle, nullptr) : closest_hit_bruteforce(scene, ray, payload.last_triangle, nullptr);
         intersect_lights(scene, ray, hit);
         if (hit.id == HIT_MISS) {
             payload.throughput = {0, 0, 0};

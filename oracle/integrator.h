@@ -38,12 +38,12 @@ void generate_camera_ray(const HiprCameraState& cam, int x, int y, int width, in
 
 // --- intersection -----------------------------------------------------------------------------
 bool intersect_triangle(const HiprTriangle& tri, float3 o, float3 d, float& t, float& u, float& v);
-Hit closest_hit_bruteforce(const HiprSceneDesc& scene, const Ray& ray, uint32_t skip_triangle);
+Hit closest_hit_bruteforce(const HiprSceneDesc& scene, const Ray& ray, uint32_t skip_triangle, TraversalCounters* counters = nullptr);
 Hit closest_hit_bvh(const HiprSceneDesc& scene, const Ray& ray, uint32_t skip_triangle, TraversalCounters* counters);
 Hit closest_hit_wide(const HiprSceneDesc& scene, const Ray& ray, uint32_t skip_triangle, TraversalCounters* counters);   // compressed 4-wide BVH
 void intersect_lights(const HiprSceneDesc& scene, const Ray& ray, Hit& hit);
 // Shadow any-hit accumulation over all triangles in (tmin, tmax); returns the attenuated radiance.
-float3 shadow_bruteforce(const HiprSceneDesc& scene, const Ray& ray, float3 radiance);
+float3 shadow_bruteforce(const HiprSceneDesc& scene, const Ray& ray, float3 radiance, TraversalCounters* counters = nullptr);
 float3 shadow_bvh(const HiprSceneDesc& scene, const Ray& ray, float3 radiance, TraversalCounters* counters);
 float3 shadow_wide(const HiprSceneDesc& scene, const Ray& ray, float3 radiance, TraversalCounters* counters);
 

@@ -278,7 +278,7 @@ void oracle_trace_closest(const HiprSceneDesc* scene, const float* rays, const u
         for (int64_t i = 0; i < int64_t(n); ++i) {
             Ray ray = ray_of(rays + 8 * i);
             uint32_t sk = skip ? skip[i] : HIT_MISS;
-            Hit h = use_bvh == 2 ? closest_hit_wide(*scene, ray, sk, &local) : use_bvh ? closest_hit_bvh(*scene, ray, sk, &local) : closest_hit_bruteforce(*scene, ray, sk);
+            Hit h = use_bvh == 2 ? closest_hit_wide(*scene, ray, sk, &local) : use_bvh ? closest_hit_bvh(*scene, ray, sk, &local) : closest_hit_bruteforce(*scene, ray, sk, &local);
             if (with_lights) intersect_lights(*scene, ray, h);
             out_hits[4 * i] = h.t; out_hits[4 * i + 1] = h.u; out_hits[4 * i + 2] = h.v; out_hits[4 * i + 3] = uint_as_float(h.id);
         }
@@ -298,7 +298,7 @@ void oracle_trace_shadow(const HiprSceneDesc* scene, const float* rays, uint32_t
         for (int64_t i = 0; i < int64_t(n); ++i) {
             Ray ray = ray_of(rays + 8 * i);
             float3 r = use_bvh == 2 ? shadow_wide(*scene, ray, make_float3(1.0f), &local)
-                       : use_bvh ? shadow_bvh(*scene, ray, make_float3(1.0f), &local) : shadow_bruteforce(*scene, ray, make_float3(1.0f));
+                       : use_bvh ? shadow_bvh(*scene, ray, make_float3(1.0f), &local) : shadow_bruteforce(*scene, ray, make_float3(1.0f), &local);
             out_transmittance[i] = r.x;
         }
 #pragma omp critical

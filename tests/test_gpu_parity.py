@@ -39,6 +39,15 @@ def atrium():
     return Scene("atrium", param0=20000, param1=3)
 
 
+@pytest.fixture(scope="module")
+def cornell_tessellated():
+    """The Cornell box with every wall cut into 3 x 3 quads: 114 triangles, 35 BVH2 nodes -> the BVH2 kernels."""
+    return Scene("cornell", param0=3)
+
+
+EXPECTED_VARIANT = {"cornell": capi.TRACE_EXHAUSTIVE, "cornell_tessellated": capi.TRACE_BVH2, "atrium": capi.TRACE_WIDE_PERSISTENT}
+
+
 def random_rays(rng, n, lo, hi, tmax=np.inf):
     o = rng.uniform(lo, hi, size=(n, 3)).astype(np.float32)
     d = rng.normal(size=(n, 3)).astype(np.float32)
@@ -74,13 +83,13 @@ def test_camera_rays_bit_exact(ctx, oracle_q, cornell, size):
         assert np.array_equal(d[valid, :3].view(np.uint32), ed[:, :3].view(np.uint32))
 
 
-@pytest.mark.parametrize("scene_name", ["cornell", "atrium"])
-def test_closest_hit_bit_exact(ctx, oracle_q, cornell, atrium, scene_name):
-    scene = cornell if scene_name == "cornell" else atrium
+@pytest.mark.parametrize("scene_name", ["cornell", "cornell_tessellated", "atrium"])
+def test_closest_hit_bit_exact(ctx, oracle_q, cornell, cornell_tessellated, atrium, scene_name):
+    scene = {"cornell": cornell, "cornell_tessellated": cornell_tessellated, "atrium": atrium}[scene_name]
     ctx.upload_scene(scene)
     ctx.set_instrumentation(True)
     rng = np.random.default_rng(11)
-    lo, hi = (-0.6, 0.6) if scene_name == "cornell" else (-14.0, 14.0)
+    lo, hi = (-14.0, 14.0) if scene_name == "atrium" else (-0.6, 0.6)
     rays = random_rays(rng, 50000, lo, hi)
     if scene_name == "atrium":
         rays[:, 1] = np.abs(rays[:, 1]) * 0.7
@@ -99,9 +108,10 @@ def test_closest_hit_bit_exact(ctx, oracle_q, cornell, atrium, scene_name):
     gpu = ctx.debug_trace_closest(rays, skip)
     counters = ctx.counters()
     ctx.set_instrumentation(False)
-    # scenes with more than 64 BVH2 nodes are traced by the persistent kernels, which walk the compressed 4-wide BVH (oracle mode 2)
-    cpu, (nodes, tris) = oracle_q.trace_closest(scene.desc, rays, skip, use_bvh=2 if ctx.trace_is_fused() else 1, with_lights=True)
-    assert ctx.trace_is_fused() == (scene_name == "atrium")
+    # more than 64 BVH2 nodes: persistent kernels over the compressed 4-wide BVH (oracle mode 2); at most 64 triangles: exhaustive
+    # search (oracle mode 0). The oracle states the same search, so counters agree too.
+    cpu, (nodes, tris) = oracle_q.trace_closest(scene.desc, rays, skip, use_bvh=ctx.oracle_search(), with_lights=True)
+    assert ctx.trace_variant() == EXPECTED_VARIANT[scene_name]
     assert np.array_equal(gpu.view(np.uint32), cpu.view(np.uint32)), "t, u, v and primitive id must match bit for bit"
     assert counters["closest_nodes"] == nodes and counters["closest_triangles"] == tris
     # The BVH answer equals exhaustive search (oracle side), so traversal loses no hits. The only admissible
@@ -114,19 +124,19 @@ def test_closest_hit_bit_exact(ctx, oracle_q, cornell, atrium, scene_name):
     assert (gpu[:, 3].view(np.uint32) != 0xFFFFFFFF).mean() > 0.5
 
 
-@pytest.mark.parametrize("scene_name", ["cornell", "atrium"])
-def test_shadow_rays_bit_exact(ctx, oracle_q, cornell, atrium, scene_name):
-    scene = cornell if scene_name == "cornell" else atrium
+@pytest.mark.parametrize("scene_name", ["cornell", "cornell_tessellated", "atrium"])
+def test_shadow_rays_bit_exact(ctx, oracle_q, cornell, cornell_tessellated, atrium, scene_name):
+    scene = {"cornell": cornell, "cornell_tessellated": cornell_tessellated, "atrium": atrium}[scene_name]
     ctx.upload_scene(scene)
     ctx.set_instrumentation(True)
     rng = np.random.default_rng(13)
-    lo, hi = (-0.45, 0.45) if scene_name == "cornell" else (-12.0, 12.0)
+    lo, hi = (-12.0, 12.0) if scene_name == "atrium" else (-0.45, 0.45)
     rays = random_rays(rng, 40000, lo, hi)
-    rays[:, 7] = rng.uniform(0.05, 3.0 if scene_name == "cornell" else 30.0, len(rays)).astype(np.float32)
+    rays[:, 7] = rng.uniform(0.05, 30.0 if scene_name == "atrium" else 3.0, len(rays)).astype(np.float32)
     gpu = ctx.debug_trace_shadow(rays)
     counters = ctx.counters()
     ctx.set_instrumentation(False)
-    cpu, (nodes, tris) = oracle_q.trace_shadow(scene.desc, rays, use_bvh=2 if ctx.trace_is_fused() else 1)
+    cpu, (nodes, tris) = oracle_q.trace_shadow(scene.desc, rays, use_bvh=ctx.oracle_search())
     assert np.array_equal(gpu, cpu)
     assert counters["shadow_nodes"] == nodes and counters["shadow_triangles"] == tris
     assert 0.05 < (gpu == 0).mean() < 0.99
@@ -306,3 +316,14 @@ def test_two_wavefronts_are_bit_identical(ctx, cornell, atrium, scene_name):
     assert np.array_equal(one, two)
     for key in ("camera_rays", "closest_rays", "shadow_rays"):
         assert c1[key] == c2[key], key
+
+
+def test_tessellated_cornell_renders_the_same_image(ctx, oracle_q, cornell_tessellated):
+    """The BVH2 kernels end to end: the tessellated box is the same surface set, so the image matches the oracle's (BVH2) render
+    of it under the usual statistical bar."""
+    w, h, spp = 64, 36, 8
+    gpu, _ = render_gpu(ctx, cornell_tessellated, w, h, spp, 4)
+    cpu, _, _ = oracle_q.render(cornell_tessellated.desc, cornell_tessellated.state, cornell_tessellated.camera(w, h, max_bounce_count=4), w, h, spp)
+    rel = np.abs(gpu[..., :3] - cpu[..., :3]) / (np.abs(cpu[..., :3]) + 1e-3)
+    assert (rel.max(axis=-1) <= 1e-3).mean() >= 0.97
+    assert rmse(gpu, cpu) <= 0.03
