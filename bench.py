@@ -8,7 +8,9 @@ A "step" is one pass of the hot path over one batch of synthetic input: one accu
 of the 1920x1080 frame = 2 073 600 camera paths traced to completion (<= 5 surface interactions, next event
 estimation with 3 RIS candidates, shadow rays), folded into the f64 running mean and written as half4.
 Workload (BASELINE.json configs[1]): SimpleViewer Cornell box, every material forced to the Diffuse shading
-model, max_bounce_count 4. Inputs (scene, BVH, tables) are resident in HBM before the timed region; the output
+model, max_bounce_count 4 (34 triangles: traced by the exhaustive-search kernels; `--scene atrium` is the 251 k-triangle
+Sponza-class stand-in, traced by the fused persistent kernel over the compressed wide BVH). Inputs (scene, BVH, tables) are
+resident in HBM before the timed region; the output
 frame stays in HBM. N > 1: tiles of 8x8 pixels are dealt round-robin to the ranks and a step traces N
 accumulations of the frame, so every GPU keeps the same 2 073 600 paths per step as N grows ("weak" scaling;
 no data-path collective). The timed region ends with the RCCL gather of the half4 tiles to rank 0 plus the

@@ -227,7 +227,7 @@ template <int MODE, bool INSTRUMENT>
 void launch_persistent_for_stack(HiprContext* c, const Wavefront& w, const PathState& in, const uint32_t* closest_count, const uint32_t* shadow_count, uint32_t upper_bound) {
     // LDS stack entries by the worst case of the wide tree; beyond 32 the LDS stack is backed by a scratch array
     if (c->wide_stack_entries <= 16) launch_persistent<16, MODE, INSTRUMENT, false>(c, w, in, closest_count, shadow_count, upper_bound, 0);
-    else if (c->wide_stack_entries <= 32) launch_persistent<32, MODE, INSTRUMENT, false>(c, w, in, closest_count, shadow_count, upper_bound, 1);
+    else if (c->wide_stack_entries <= 32 || getenv("HIPR_EXPERIMENT_NO_STACK_OVERFLOW")) launch_persistent<32, MODE, INSTRUMENT, false>(c, w, in, closest_count, shadow_count, upper_bound, 1);
     else launch_persistent<32, MODE, INSTRUMENT, true>(c, w, in, closest_count, shadow_count, upper_bound, 2);
 }
 

@@ -170,6 +170,17 @@ struct Builder {
 struct WideCollapse {
     const std::vector<HiprBvhNode>& nodes;
     std::vector<HiprWideNode> wide;
+    std::vector<uint32_t> binary_need;   // stack entries the BVH2 subtree of a node needs when nothing below it is widened
+
+    uint32_t compute_binary_need(uint32_t node_index) {
+        uint32_t need = 0;
+        for (int c = 0; c < 2; ++c) {
+            const int32_t ref = nodes[node_index].child[c];
+            need = std::max(need, 1u + (ref >= 0 ? compute_binary_need(uint32_t(ref)) : 0u));
+        }
+        return binary_need[node_index] = need;
+    }
+    uint32_t need_of(int32_t ref) const { return ref >= 0 ? binary_need[ref] : 0u; }
 
     struct Child { Box box; int32_t ref; };
 
@@ -182,8 +193,10 @@ struct WideCollapse {
         return r;
     }
 
-    // Returns the wide node index and, through `stack_need`, the worst case number of stack entries below it.
-    uint32_t collapse(uint32_t node_index, uint32_t& stack_need) {
+    // Returns the wide node index and, through `stack_need`, the worst case number of stack entries below it. `budget`: the
+    // entries this subtree may need. A node with c children keeps c - 1 entries on the stack while a child is traversed, and a
+    // subtree can always fall back to binary nodes (binary_need), so a node is only widened while every child still fits.
+    uint32_t collapse(uint32_t node_index, uint32_t budget, uint32_t& stack_need) {
         std::vector<Child> children = {child_of(nodes[node_index], 0), child_of(nodes[node_index], 1)};
         if (children[0].ref == children[1].ref && children[0].ref < 0) children.pop_back();   // the single-leaf root references its leaf twice
         while (children.size() < 4) {
@@ -193,6 +206,11 @@ struct WideCollapse {
                 if (children[i].ref >= 0 && children[i].box.half_area() > widest_area) { widest = int(i); widest_area = children[i].box.half_area(); }
             if (widest < 0) break;
             const HiprBvhNode& inner = nodes[children[widest].ref];
+            const uint32_t held = uint32_t(children.size());   // entries held once this node has one more child
+            bool fits = held + std::max(need_of(inner.child[0]), need_of(inner.child[1])) <= budget;
+            for (size_t i = 0; i < children.size() && fits; ++i)
+                if (int(i) != widest) fits = held + need_of(children[i].ref) <= budget;
+            if (!fits) break;
             children[widest] = child_of(inner, 0);
             children.insert(children.begin() + widest + 1, child_of(inner, 1));
         }
@@ -231,7 +249,8 @@ struct WideCollapse {
         for (int k = 0; k < 4; ++k) w.child[k] = HIPR_WIDE_EMPTY;
         for (size_t k = 0; k < children.size(); ++k) {
             uint32_t below = 0;
-            w.child[k] = children[k].ref >= 0 ? int32_t(collapse(uint32_t(children[k].ref), below)) : children[k].ref;
+            const uint32_t held = uint32_t(children.size() - 1);
+            w.child[k] = children[k].ref >= 0 ? int32_t(collapse(uint32_t(children[k].ref), budget > held ? budget - held : 0u, below)) : children[k].ref;
             stack_need = std::max(stack_need, uint32_t(children.size() - 1) + below);
         }
         wide[index] = w;
@@ -275,9 +294,13 @@ BvhBuildResult build_bvh(const std::vector<HiprTriangle>& triangles, uint32_t ma
 
     result.nodes = std::move(b.nodes);
     result.order = std::move(b.order);
-    WideCollapse collapse{result.nodes, {}};
+    WideCollapse collapse{result.nodes, {}, {}};
     collapse.wide.reserve(result.nodes.size() / 2 + 1);
-    collapse.collapse(0, result.wide_stack_entries);
+    collapse.binary_need.assign(result.nodes.size(), 0u);
+    // Keep the worst case within the 32 entry LDS stack of the traversal kernels whenever the BVH2 itself allows it; deeper
+    // trees are collapsed freely and traversed by the kernels that back the LDS stack with scratch memory.
+    const uint32_t budget = collapse.compute_binary_need(0) <= 32u ? 32u : 0xFFFFu;
+    collapse.collapse(0, budget, result.wide_stack_entries);
     result.wide_nodes = std::move(collapse.wide);
     result.max_depth = b.deepest + 1;   // stack entries needed is bounded by the node depth; keep one spare
     return result;
