@@ -143,8 +143,11 @@ def main():
     def finish_frame():
         if world == 1:
             return
+        # The context renders on its own (non-blocking) stream, torch.distributed on torch's: order them explicitly.
+        ctx.synchronize()
         gathered = distributed.gather_to_root(compact, world, rank)
         if rank == 0:
+            torch.cuda.current_stream(device).synchronize()
             ctx.scatter_tiles(gathered.data_ptr(), n_compact, world, W, H, frame.data_ptr(), W)
 
     def barrier():

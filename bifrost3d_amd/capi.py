@@ -105,6 +105,7 @@ class HiprCounters(C.Structure):
 
 
 TRACE_BVH2, TRACE_WIDE_PERSISTENT, TRACE_EXHAUSTIVE = 0, 1, 2
+SHADING_DEFAULT, SHADING_DIFFUSE, SHADING_TRANSMISSIVE = 0, 1, 2
 ENTRY_PATH_TRACING, ENTRY_DEPTH, ENTRY_ALBEDO, ENTRY_TINT, ENTRY_ROUGHNESS, ENTRY_SHADING_NORMAL, ENTRY_PRIMITIVE_ID = 0, 3, 4, 5, 6, 7, 8
 HIPR_KERNEL_NAMES = ("generate", "trace_closest", "shade", "trace_shadow", "accumulate")
 
@@ -124,7 +125,7 @@ C_ABI_SYMBOLS = (
     "hipr_render_pass", "hipr_read_accumulation", "hipr_scatter_tiles", "hipr_synchronize", "hipr_get_counters",
     "hipr_device_malloc", "hipr_device_free", "hipr_copy_to_host", "hipr_present_flipped",
     "hipr_reset_counters", "hipr_set_wavefront_count", "hipr_get_trace_variant", "hipr_set_instrumentation", "hipr_reset_timers", "hipr_get_kernel_times",
-    "hipr_debug_generate", "hipr_debug_sobol", "hipr_debug_trace_closest", "hipr_debug_trace_shadow",
+    "hipr_debug_shading", "hipr_debug_generate", "hipr_debug_sobol", "hipr_debug_trace_closest", "hipr_debug_trace_shadow",
 )
 
 

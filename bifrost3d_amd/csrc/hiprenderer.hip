@@ -901,6 +901,22 @@ int hipr_debug_generate(HiprContext* c, const HiprCameraState* camera, uint32_t 
     return HIPR_OK;
 }
 
+int hipr_debug_shading(HiprContext* c, int shading_model, const float* params10, const float* wo_n3, const float* in_n3, uint32_t n, int mode, float* out_n7) {
+    if (int s = check_context(c)) return s;
+    if (!c->tables_ready) return fail(HIPR_ERROR_NOT_READY, "hipr_debug_shading needs the tables");
+    if (!params10 || !wo_n3 || !in_n3 || !out_n7 || shading_model < 0 || shading_model > 2 || mode < 0 || mode > 1) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_debug_shading: bad argument");
+    if (n == 0) return HIPR_OK;
+    DeviceBuffer bp, bw, bi, bo;
+    int r = bp.upload(params10, 10 * 4, c->stream) | bw.upload(wo_n3, size_t(n) * 12, c->stream) | bi.upload(in_n3, size_t(n) * 12, c->stream) | bo.resize(size_t(n) * 28);
+    if (r) return HIPR_ERROR_OUT_OF_MEMORY;
+    hipr::launch_debug_shading(c->stream, c->scene.tables, shading_model, bp.as<float>(), bw.as<float>(), bi.as<float>(), int(n), mode, bo.as<float>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out_n7, bo.ptr, size_t(n) * 28, hipMemcpyDeviceToHost));
+    bp.release(); bw.release(); bi.release(); bo.release();
+    return HIPR_OK;
+}
+
 int hipr_debug_sobol(HiprContext* c, const uint32_t* triples, uint32_t n, uint32_t* out_uint4) {
     if (int s = check_context(c)) return s;
     if (!triples || !out_uint4) return fail(HIPR_ERROR_INVALID_ARGUMENT, "null argument");

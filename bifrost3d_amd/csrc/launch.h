@@ -23,4 +23,8 @@ struct ShadeLaunch {
 
 void launch_shade(int shading_models, const ShadeLaunch& args);
 
+// All pointers are device pointers; see k_debug_shading (shade.hip).
+void launch_debug_shading(hipStream_t stream, const DeviceTables& tables, int model, const float* params10, const float* wo_n3, const float* in_n3, int n, int mode,
+                          float* out_n7);
+
 } // namespace hipr

@@ -28,4 +28,36 @@ void launch_shade(int shading_models, const ShadeLaunch& a) {
     }
 }
 
+// Stage-level parity entry point (hipr_debug_shading): the shading models exactly as the shade kernel evaluates them.
+// model: 0 Default, 1 Diffuse, 2 Transmissive. params: tint[3], roughness, specularity, metallic, coat, coat_roughness,
+// cos_theta_o (NaN: wo.z), max_PDF_hint (NaN: none). mode 0: sample(wo, u) -> f[3], pdf, direction[3]; mode 1:
+// evaluate_with_PDF(wo, wi = third input) -> f[3], pdf, 0, 0, 0.
+__global__ void k_debug_shading(DeviceTables tables, int model, const float* params, const float* wo_n3, const float* in_n3, int n, int mode, float* out_n7) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const f3 wo = {wo_n3[3 * i], wo_n3[3 * i + 1], wo_n3[3 * i + 2]}, in = {in_n3[3 * i], in_n3[3 * i + 1], in_n3[3 * i + 2]};
+    MaterialInputs m;
+    m.tint = {params[0], params[1], params[2]};
+    m.roughness = params[3]; m.specularity = params[4]; m.metallic = params[5]; m.coat = params[6]; m.coat_roughness = params[7];
+    const float cos_theta = params[8] != params[8] ? wo.z : params[8];
+    const float hint = params[9] != params[9] ? -1.0f : params[9];
+    Shading s;
+    if (model == HIPR_SHADING_DIFFUSE) s = make_diffuse(m.tint, m.roughness);
+    else if (model == HIPR_SHADING_TRANSMISSIVE) s = make_transmissive(tables, m, cos_theta, hint);
+    else s = make_default(tables, m, cos_theta, hint);
+    float* o = out_n7 + 7 * i;
+    if (mode == 0) {
+        const Sample r = shading_sample<7>(s, wo, in);
+        o[0] = r.f.x; o[1] = r.f.y; o[2] = r.f.z; o[3] = r.pdf; o[4] = r.dir.x; o[5] = r.dir.y; o[6] = r.dir.z;
+    } else {
+        const Response r = shading_evaluate_with_PDF<7>(s, wo, in);
+        o[0] = r.f.x; o[1] = r.f.y; o[2] = r.f.z; o[3] = r.pdf; o[4] = o[5] = o[6] = 0.0f;
+    }
+}
+
+void launch_debug_shading(hipStream_t stream, const DeviceTables& tables, int model, const float* params, const float* wo_n3, const float* in_n3, int n, int mode,
+                          float* out_n7) {
+    hipLaunchKernelGGL(k_debug_shading, dim3((n + 63) / 64), dim3(64), 0, stream, tables, model, params, wo_n3, in_n3, n, mode, out_n7);
+}
+
 } // namespace hipr

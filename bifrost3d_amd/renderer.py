@@ -123,6 +123,17 @@ class Context:
                     "hipr_debug_generate")
         return o, d, px
 
+    def debug_shading(self, shading_model, params10, wo, inputs, mode=0):
+        """mode 0: sample(wo, u) -> (n, 7) f, pdf, direction; mode 1: evaluate_with_PDF(wo, wi) -> (n, 7) f, pdf, 0, 0, 0."""
+        inputs = np.ascontiguousarray(inputs, np.float32).reshape(-1, 3)
+        wo = np.ascontiguousarray(np.broadcast_to(np.asarray(wo, np.float32), inputs.shape))
+        params = np.ascontiguousarray(params10, np.float32)
+        out = np.zeros((len(inputs), 7), np.float32)
+        fp = C.POINTER(C.c_float)
+        self._check(self.lib.hipr_debug_shading(self.handle, int(shading_model), params.ctypes.data_as(fp), wo.ctypes.data_as(fp), inputs.ctypes.data_as(fp), len(inputs),
+                                                int(mode), out.ctypes.data_as(fp)), "hipr_debug_shading")
+        return out
+
     def debug_sobol(self, triples):
         triples = np.ascontiguousarray(triples, np.uint32).reshape(-1, 3)
         out = np.zeros((len(triples), 4), np.uint32)

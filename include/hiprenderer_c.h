@@ -340,6 +340,13 @@ int hipr_get_kernel_times(HiprContext* context, HiprKernelTimes* out);
 int hipr_debug_generate(HiprContext* context, const HiprCameraState* camera, uint32_t accumulation,
                         float* out_origin_tmin, float* out_direction, uint32_t* out_pixel);
 /* RNG: PracticalScrambledSobol::sample4ui (OR/RNG.h:280-287) for n (accumulation, pixel_hash, dimension) triples. */
+/* The shading models as the shade kernel evaluates them (DefaultShading / DiffuseShading / TransmissiveShading of
+ * ORS/ShadingModels/), for the reference's golden vectors (ORT/ShadingModels/DefaultShadingTest.h:410-447,
+ * TransmissiveShadingTest.h:203-236). shading_model: HIPR_SHADING_*. params10: tint[3], roughness, specularity, metallic,
+ * coat, coat_roughness, cos_theta_o (NaN: wo.z), max_PDF_hint (NaN: none). mode 0: sample(wo, u = in) -> out7 = f[3], pdf,
+ * direction[3]; mode 1: evaluate_with_PDF(wo, wi = in) -> out7 = f[3], pdf, 0, 0, 0. Host pointers. */
+int hipr_debug_shading(HiprContext* context, int shading_model, const float* params10, const float* wo_n3, const float* in_n3, uint32_t n, int mode,
+                       float* out_n7);
 int hipr_debug_sobol(HiprContext* context, const uint32_t* accumulation_pixelhash_dimension, uint32_t n, uint32_t* out_uint4);
 /* K2: closest hit for n rays. rays: float4 origin_tmin + float4 direction_tmax per ray; skip: global triangle index
  * to ignore per ray (0xFFFFFFFF = none). out_hits: float4 {t, u, v, bits(tri_or_light)} per ray. */
