@@ -171,6 +171,8 @@ public:
     static unsigned get_width(ImageID id) { return m()[id].width; }
     static unsigned get_height(ImageID id) { return m()[id].height; }
     static const void* get_pixels(ImageID id) { return m()[id].pixels.data(); }
+    static void* get_mutable_pixels(ImageID id) { m().flag(id, Change::PixelsUpdated); return m()[id].pixels.data(); }
+    static bool has(ImageID id) { return m().has(id); }
     static unsigned get_pixel_count(ImageID id) { return m()[id].width * m()[id].height; }
     static const std::string& get_name(ImageID id) { return m()[id].name; }
     static void reset_change_notifications() { m().reset_change_notifications(); }
@@ -178,6 +180,32 @@ public:
 private:
     struct Record { std::string name; PixelFormat format = PixelFormat::Unknown; bool is_sRGB = false; unsigned width = 0, height = 0; std::vector<uint8_t> pixels; };
     static Core::Manager<ImageID, Record, Change>& m() { static Core::Manager<ImageID, Record, Change> s; return s; }
+};
+
+// Object wrapper (BF/Assets/Image.h), as much of it as the loaders use.
+class Image {
+public:
+    Image(ImageID id = ImageID::invalid_UID()) : m_ID(id) {}
+    static Image create2D(const std::string& name, PixelFormat format, bool is_sRGB, unsigned width, unsigned height, const void* pixels = nullptr) {
+        const size_t bytes = size_t(width) * height * bytes_per_pixel(format);
+        std::vector<uint8_t> zero;
+        if (!pixels) { zero.assign(bytes, 0); pixels = zero.data(); }
+        return Images::create2D(name, format, is_sRGB, width, height, pixels, bytes);
+    }
+    static size_t bytes_per_pixel(PixelFormat f) {
+        switch (f) { case PixelFormat::Alpha8: case PixelFormat::Intensity8: return 1; case PixelFormat::RGB24: return 3; case PixelFormat::RGBA32: return 4;
+                     case PixelFormat::Intensity_Float: return 4; case PixelFormat::RGB_Float: return 12; case PixelFormat::RGBA_Float: return 16; default: return 0; }
+    }
+    bool exists() const { return m_ID != ImageID::invalid_UID() && Images::has(m_ID); }
+    ImageID get_ID() const { return m_ID; }
+    PixelFormat get_pixel_format() const { return Images::get_pixel_format(m_ID); }
+    unsigned get_width() const { return Images::get_width(m_ID); }
+    unsigned get_height() const { return Images::get_height(m_ID); }
+    unsigned get_pixel_count() const { return Images::get_pixel_count(m_ID); }
+    const std::string& get_name() const { return Images::get_name(m_ID); }
+    template <typename T> T* get_pixels() const { return static_cast<T*>(Images::get_mutable_pixels(m_ID)); }
+private:
+    ImageID m_ID;
 };
 
 struct TexturesTag; typedef Core::UID<TexturesTag> TextureID;
@@ -249,6 +277,7 @@ public:
     static Core::Iterable<MaterialID> get_changed_materials() { return m().get_changed(); }
     static Core::Bitmask<Change> get_changes(MaterialID id) { return m().get_changes(id); }
     static const Data& get_data(MaterialID id) { return m()[id].data; }
+    static const std::string& get_name(MaterialID id) { return m()[id].name; }
     static void set_data(MaterialID id, const Data& d) {
         bool model_changed = d.shading_model != m()[id].data.shading_model;
         m()[id].data = d;
@@ -266,6 +295,9 @@ private:
 class Material {
 public:
     Material(MaterialID id = MaterialID::invalid_UID()) : m_ID(id) {}
+    Material(const std::string& name, const Materials::Data& data) : m_ID(Materials::create(name, data)) {}
+    static Material invalid() { return Material(); }
+    const std::string& get_name() const { return Materials::get_name(m_ID); }
     static Material create_dielectric(const std::string& name, RGB tint, float roughness, float specularity = 0.04f) { return Materials::create(name, Materials::Data::create_dielectric(tint, roughness, specularity)); }
     static Material create_metal(const std::string& name, RGB tint, float roughness) { return Materials::create(name, Materials::Data::create_metal(tint, roughness)); }
     MaterialID get_ID() const { return m_ID; }
@@ -331,6 +363,7 @@ public:
     static unsigned capacity() { return m().capacity(); }
     static Core::Iterable<MeshID> get_changed_meshes() { return m().get_changed(); }
     static Core::Bitmask<Change> get_changes(MeshID id) { return m().get_changes(id); }
+    static const std::string& get_name(MeshID id) { return m()[id].name; }
     static unsigned get_primitive_count(MeshID id) { return (unsigned)m()[id].primitives.size(); }
     static unsigned get_vertex_count(MeshID id) { return (unsigned)m()[id].positions.size(); }
     static Vector3ui* get_primitives(MeshID id) { return m()[id].primitives.data(); }
@@ -363,6 +396,12 @@ public:
     Vector3f* get_emission() const { return Meshes::get_emission(m_ID); }
     AABB get_bounds() const { return Meshes::get_bounds(m_ID); }
     void set_bounds(AABB b) { Meshes::set_bounds(m_ID, b); }
+    const std::string& get_name() const { return Meshes::get_name(m_ID); }
+    void compute_bounds() {   // BF/Assets/Mesh.cpp compute_bounds
+        AABB b = AABB::invalid();
+        for (unsigned v = 0; v < get_vertex_count(); ++v) b.grow_to_contain(get_positions()[v]);
+        set_bounds(b);
+    }
 private:
     MeshID m_ID;
 };
@@ -398,6 +437,8 @@ public:
     // Parenting keeps the GLOBAL transform of the child, like the reference (BF/Scene/SceneNode.cpp set_parent).
     static void set_parent(SceneNodeID id, SceneNodeID parent) { m()[id].parent = parent; }
     static SceneNodeID get_parent(SceneNodeID id) { return m()[id].parent; }
+    static const std::string& get_name(SceneNodeID id) { return m()[id].name; }
+    static bool has(SceneNodeID id) { return m().has(id); }
     static Transform get_global_transform(SceneNodeID id) { return m()[id].global_transform; }
     static void set_global_transform(SceneNodeID id, Transform t) {
         Transform delta = t * invert(m()[id].global_transform);
@@ -418,6 +459,11 @@ class SceneNode {
 public:
     SceneNode(SceneNodeID id = SceneNodeID::invalid_UID()) : m_ID(id) {}
     SceneNode(const std::string& name, Transform t = Transform::identity()) : m_ID(SceneNodes::create(name, t)) {}
+    static SceneNode invalid() { return SceneNode(); }
+    bool operator==(SceneNode rhs) const { return m_ID == rhs.m_ID; }
+    bool operator!=(SceneNode rhs) const { return !(m_ID == rhs.m_ID); }
+    const std::string& get_name() const { return SceneNodes::get_name(m_ID); }
+    SceneNode get_parent() const { return SceneNodes::get_parent(m_ID); }
     SceneNodeID get_ID() const { return m_ID; }
     void set_parent(SceneNode parent) { SceneNodes::set_parent(m_ID, parent.m_ID); }
     Transform get_global_transform() const { return SceneNodes::get_global_transform(m_ID); }

@@ -19,6 +19,8 @@ def run(flag):
 def test_host_side_renderer_cases():
     out = run("--cpu")
     assert "flattened_cornell_box_matches_the_scene_builder" in out and " 0 failed." in out
+    for name in ("obj_shapes_materials_and_nodes", "single_shape_is_its_own_root_and_missing_files_fail", "viewer_defaults_place_camera_light_and_clip_planes"):
+        assert f"[       OK ] LoaderFixture.{name}" in out, out[-4000:]
 
 
 @pytest.mark.gpu
@@ -27,3 +29,4 @@ def test_reference_renderer_cases_on_gpu():
     for name in ("render_background_color", "render_tint", "render_auxiliary_tint", "render_returns_the_iteration_count",
                  "scene_changes_restart_accumulation", "render_target_pitch_is_respected", "cornell_box_through_the_renderer_matches_the_c_abi", "adaptor_presents_the_flipped_viewport"):
         assert f"[       OK ] RendererFixture.{name}" in out, out[-4000:]
+    assert "[       OK ] LoaderFixture.loaded_obj_renders_through_the_renderer" in out, out[-4000:]
