@@ -50,6 +50,9 @@ def parse_args():
     p.add_argument("--atrium-triangles", type=int, default=260000)
     p.add_argument("--bounces", type=int, default=4)
     p.add_argument("--spp-per-pass", type=int, default=8, help="accumulations traced together per step and GPU (HiprFrameDesc::samples_per_pass)")
+    p.add_argument("--wavefronts", type=int, default=1, choices=[1, 2],
+                   help="2: each pass runs as two half-frame wavefronts on two streams (one shades while the other traces); faster, but concurrent kernels "
+                        "inflate the per-kernel timers the roofline is computed from, so the default stays 1")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     return p.parse_args()
@@ -131,6 +134,7 @@ def main():
     ctx = Context(local_rank if world > 1 else 0)
     ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
     ctx.upload_scene(scene)
+    ctx.set_wavefront_count(args.wavefronts)
     ctx.set_frame(W, H, tile_phase=rank, tile_stride=world, samples_per_pass=S)
 
     n_compact = distributed.padded_pixels_per_rank(W, H, world)
@@ -266,7 +270,7 @@ def main():
                 "workload": f"{scene_text}; {W}x{H}, {S} accumulation(s) per step ({W * H * args.spp_per_pass} paths per GPU per step), max_bounce_count {args.bounces}, "
                             f"next_event_sample_count 3, path regularisation PDF_scale 0.5; f64 accumulation + half4 output",
                 "frame": [W, H], "spp_per_step": S,
-                "parallelism": f"tiles8x8-round-robin-x{world}" if world > 1 else "single-gpu",
+                "parallelism": f"tiles8x8-round-robin-x{world}" if world > 1 else "single-gpu", "wavefronts": args.wavefronts,
                 "ms_per_256spp_frame": elapsed / (args.steps * S) * 1e3 * 256,
                 "rays_per_step": total_rays / args.steps,
                 "closest_rays": total_closest, "shadow_rays": total_shadow, "pixel_samples": total_camera,
