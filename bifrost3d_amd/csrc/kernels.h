@@ -417,6 +417,12 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_shadow(DeviceScene sc, Sh
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t SMALL_SCENE_TRIANGLES = 64;
 
+// The triangle array through the constant address space: a wave-uniform index then compiles to scalar loads (s_load_dwordx4 into
+// SGPRs) instead of 64 identical vector loads. Valid because the kernels never write the scene.
+typedef float ScalarFloat4 __attribute__((ext_vector_type(4)));
+typedef const ScalarFloat4 __attribute__((address_space(4))) * ConstantFloat4Pointer;
+HD ConstantFloat4Pointer as_constant(const float4* p) { return (ConstantFloat4Pointer)(p); }
+
 template <bool INSTRUMENT>
 __global__ __launch_bounds__(256) void k_trace_closest_small(DeviceScene sc, PathState in, float4* hits, const uint32_t* count_ptr, DeviceCounters* counters) {
     const uint32_t n = *count_ptr;
@@ -430,8 +436,9 @@ __global__ __launch_bounds__(256) void k_trace_closest_small(DeviceScene sc, Pat
         const uint32_t skip = meta.y;
         float best_t = __builtin_inff(), best_u = 0.0f, best_v = 0.0f;
         uint32_t best_id = HIPR_HIT_MISS;
+        const ConstantFloat4Pointer triangles = as_constant(sc.triangles);
         for (uint32_t t = 0; t < sc.triangle_count; ++t) {   // uniform: scalar loads of the triangle
-            const float4 a = sc.triangles[3 * t], b = sc.triangles[3 * t + 1], c = sc.triangles[3 * t + 2];
+            const ScalarFloat4 a = triangles[3 * t], b = triangles[3 * t + 1], c = triangles[3 * t + 2];
             float tt, u, v;
             const bool hit = intersect_triangle_full(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), o, d, tt, u, v);
             const bool closer = hit & (t != skip) & (tt > tmin) & ((tt < best_t) | ((tt == best_t) & (t < best_id)));
@@ -463,9 +470,10 @@ __global__ __launch_bounds__(256) void k_trace_shadow_small(DeviceScene sc, Shad
         const float tmax = ro.w;
         f3 rad = mk3(rr.x, rr.y, rr.z);
         bool blocked = false;
+        const ConstantFloat4Pointer triangles = as_constant(sc.triangles);
         for (uint32_t t = 0; t < sc.triangle_count; ++t) {
             if (!__any(!blocked)) break;
-            const float4 a = sc.triangles[3 * t], b = sc.triangles[3 * t + 1], c = sc.triangles[3 * t + 2];
+            const ScalarFloat4 a = triangles[3 * t], b = triangles[3 * t + 1], c = triangles[3 * t + 2];
             if (INSTRUMENT) tris += blocked ? 0u : 1u;
             float tt, u, v;
             const bool hit = intersect_triangle_full(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), o, d, tt, u, v);
