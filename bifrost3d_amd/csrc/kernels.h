@@ -52,6 +52,20 @@ struct DeviceScene {
     int next_event_sample_count;
 };
 
+// Wave-uniform reads of scene arrays go through the constant address space: a uniform index then compiles to scalar loads
+// (s_load_dwordx4 into SGPRs) instead of 64 identical vector loads. Valid because the kernels never write the scene.
+typedef float ScalarFloat4 __attribute__((ext_vector_type(4)));
+typedef const ScalarFloat4 __attribute__((address_space(4))) * ConstantFloat4Pointer;
+HD ConstantFloat4Pointer as_constant(const float4* p) { return (ConstantFloat4Pointer)(p); }
+HD HiprLight load_light_uniform(const HiprLight* lights, uint32_t i) {   // i must be wave uniform
+    const ConstantFloat4Pointer p = (ConstantFloat4Pointer)(lights + i);
+    const ScalarFloat4 a = p[0], b = p[1], c = p[2];
+    HiprLight l;
+    l.data[0] = a.x; l.data[1] = a.y; l.data[2] = a.z; l.data[3] = a.w; l.data[4] = b.x; l.data[5] = b.y; l.data[6] = b.z; l.data[7] = b.w;
+    l.data[8] = c.x; l.data[9] = c.y; l.data[10] = c.z; l.flags = __float_as_uint(c.w);
+    return l;
+}
+
 struct PathState {
     float4* o_tmin;       // origin.xyz, tmin
     float4* d_pdf;        // direction.xyz, bsdf pdf
@@ -251,7 +265,7 @@ HD float4 closest_hit(const DeviceScene& sc, f3 o, f3 d, float tmin, uint32_t sk
     });
     // Analytic area lights take part in closest-hit selection (LightSources.cu:31-70).
     for (uint32_t li = 0; li < sc.light_count; ++li) {
-        const HiprLight& l = sc.lights[li];
+        const HiprLight l = load_light_uniform(sc.lights, li);
         uint32_t type = l.flags & HIPR_LIGHT_TYPE_MASK;
         float t = -1e30f;
         if (type == HIPR_LIGHT_SPHERE) {
@@ -417,11 +431,6 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_shadow(DeviceScene sc, Sh
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t SMALL_SCENE_TRIANGLES = 64;
 
-// The triangle array through the constant address space: a wave-uniform index then compiles to scalar loads (s_load_dwordx4 into
-// SGPRs) instead of 64 identical vector loads. Valid because the kernels never write the scene.
-typedef float ScalarFloat4 __attribute__((ext_vector_type(4)));
-typedef const ScalarFloat4 __attribute__((address_space(4))) * ConstantFloat4Pointer;
-HD ConstantFloat4Pointer as_constant(const float4* p) { return (ConstantFloat4Pointer)(p); }
 
 template <bool INSTRUMENT>
 __global__ __launch_bounds__(256) void k_trace_closest_small(DeviceScene sc, PathState in, float4* hits, const uint32_t* count_ptr, DeviceCounters* counters) {
@@ -446,7 +455,7 @@ __global__ __launch_bounds__(256) void k_trace_closest_small(DeviceScene sc, Pat
         }
         if (INSTRUMENT) tris += sc.triangle_count;
         for (uint32_t li = 0; li < sc.light_count; ++li) {   // analytic area lights, LightSources.cu:31-70
-            const HiprLight& l = sc.lights[li];
+            const HiprLight l = load_light_uniform(sc.lights, li);
             const uint32_t type = l.flags & HIPR_LIGHT_TYPE_MASK;
             float t = -1e30f;
             if (type == HIPR_LIGHT_SPHERE) { if (!(l.data[6] > 0.0f)) continue; t = ray_sphere(o, d, L3(l, 3), l.data[6]); }
@@ -569,7 +578,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(5))
                 }
             } else if constexpr (MODE != TRACE_SHADOW) {
                 for (uint32_t li = 0; li < sc.light_count; ++li) {   // analytic area lights, LightSources.cu:31-70
-                    const HiprLight& l = sc.lights[li];
+                    const HiprLight l = load_light_uniform(sc.lights, li);
                     const uint32_t type = l.flags & HIPR_LIGHT_TYPE_MASK;
                     float t = -1e30f;
                     if (type == HIPR_LIGHT_SPHERE) { if (!(l.data[6] > 0.0f)) continue; t = ray_sphere(o, d, L3(l, 3), l.data[6]); }

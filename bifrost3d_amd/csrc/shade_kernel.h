@@ -197,7 +197,7 @@ HD void shade_path(const DeviceScene& sc, const HiprCameraState& cam, int entry,
         const f4 base = sobol4f_tables(accumulation, pixel_hash, 8u * bounces + 1u, sobol_lds);
         const int n = sc.next_event_sample_count;
         for (int s = 0; s < n; ++s) {
-            const float4 off = sc.sample_offsets[s];
+            const ScalarFloat4 off = as_constant(sc.sample_offsets)[s];   // uniform index: scalar load
             f4 r = {base.x + off.x, base.y + off.y, base.z + off.z, base.w + off.w};
             r = {r.x - floorf(r.x), r.y - floorf(r.y), r.z - floorf(r.z), r.w - floorf(r.w)};
             const int light_count = int(sc.light_count);
