@@ -34,7 +34,7 @@ constexpr int BIN_COUNT = 16;
 // Triangles per leaf. The traversal kernels spend one loop iteration per node AND per triangle, so a leaf is worth splitting
 // as long as the split culls triangles; HIPR_BVH_LEAF_SIZE overrides for experiments.
 static uint32_t leaf_max() {
-    static const uint32_t value = [] { const char* v = std::getenv("HIPR_BVH_LEAF_SIZE"); int n = v ? std::atoi(v) : 4; return uint32_t(n < 1 ? 1 : (n > 8 ? 8 : n)); }();
+    static const uint32_t value = [] { const char* v = std::getenv("HIPR_BVH_LEAF_SIZE"); int n = v ? std::atoi(v) : 3; return uint32_t(n < 1 ? 1 : (n > 8 ? 8 : n)); }();
     return value;
 }
 #define LEAF_MAX leaf_max()
