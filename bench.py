@@ -53,6 +53,9 @@ def parse_args():
     p.add_argument("--wavefronts", type=int, default=1, choices=[1, 2],
                    help="2: each pass runs as two half-frame wavefronts on two streams (one shades while the other traces); faster, but concurrent kernels "
                         "inflate the per-kernel timers the roofline is computed from, so the default stays 1")
+    p.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                   help="gloo + --share-device runs the N > 1 code path with every rank on GPU 0 (a functional test of the tiling / gather / scatter logic on a 1-GPU box; the gather then goes through host memory)")
+    p.add_argument("--share-device", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     return p.parse_args()
@@ -145,16 +148,22 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        device_index = 0 if args.share_device else local_rank
+        torch.cuda.set_device(device_index)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     else:
+        device_index = 0
         torch.cuda.set_device(0)
-    device = torch.device("cuda", local_rank if world > 1 else 0)
+    device = torch.device("cuda", device_index)
+    on_host = world > 1 and args.dist_backend == "gloo"   # gloo collectives take host tensors
 
     W, H = args.width, args.height
     S = args.spp_per_pass * world   # accumulations per step: per-GPU paths per step stay W*H*spp_per_pass for every N
     scene, scene_text = make_scene(args)
-    ctx = Context(local_rank if world > 1 else 0)
+    ctx = Context(device_index)
     ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
     ctx.upload_scene(scene)
     ctx.set_wavefront_count(args.wavefronts)
@@ -176,10 +185,13 @@ def main():
             return
         # The context renders on its own (non-blocking) stream, torch.distributed on torch's: order them explicitly.
         ctx.synchronize()
-        gathered = distributed.gather_to_root(compact, world, rank)
+        gathered = distributed.gather_to_root(compact.cpu() if on_host else compact, world, rank)
         if rank == 0:
+            if on_host:
+                gathered = gathered.to(device)
             torch.cuda.current_stream(device).synchronize()
             ctx.scatter_tiles(gathered.data_ptr(), n_compact, world, W, H, frame.data_ptr(), W)
+            ctx.synchronize()
 
     def barrier():
         if world > 1:
@@ -225,6 +237,8 @@ def main():
     stats = torch.tensor([elapsed, counters["closest_rays"], counters["shadow_rays"], counters["camera_rays"],
                           times["trace_closest"]["ms"], times["trace_closest"]["launches"]], dtype=torch.float64, device=device)
     if world > 1:
+        if on_host:
+            stats = stats.cpu()
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
