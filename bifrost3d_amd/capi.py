@@ -63,6 +63,15 @@ class HiprWideNode(C.Structure):
     _fields_ = [("origin", c_f * 3), ("exponents", c_u32), ("qlo", c_u32 * 3), ("qhi", c_u32 * 3), ("_pad", c_u32 * 2), ("child", c_i32 * 4)]
 
 
+class HiprLightSample(C.Structure):
+    _fields_ = [("radiance", c_f * 3), ("PDF", c_f), ("direction_to_light", c_f * 3), ("distance", c_f)]
+
+
+class HiprEnvironment(C.Structure):
+    _fields_ = [("environment_map_ID", c_i32), ("pdf_width", c_u32), ("pdf_height", c_u32), ("per_pixel_PDF", C.POINTER(c_f)),
+                ("samples", C.POINTER(HiprLightSample)), ("sample_count", c_u32)]
+
+
 class HiprSceneDesc(C.Structure):
     _fields_ = [("nodes", C.POINTER(HiprBvhNode)), ("node_count", c_u32),
                 ("triangles", C.POINTER(HiprTriangle)), ("triangle_count", c_u32),
@@ -75,7 +84,8 @@ class HiprSceneDesc(C.Structure):
                 ("textures", C.POINTER(HiprTexture)), ("texture_count", c_u32),
                 ("texels", C.POINTER(c_u8)), ("texel_bytes", c_u32),
                 ("bvh_max_depth", c_u32),
-                ("wide_nodes", C.POINTER(HiprWideNode)), ("wide_node_count", c_u32), ("wide_stack_entries", c_u32)]
+                ("wide_nodes", C.POINTER(HiprWideNode)), ("wide_node_count", c_u32), ("wide_stack_entries", c_u32),
+                ("environment", C.POINTER(HiprEnvironment))]
 
 
 class HiprSceneState(C.Structure):

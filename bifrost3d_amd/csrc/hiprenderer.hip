@@ -107,7 +107,7 @@ struct HiprContext {
     int wavefront_count = 1;                // set by hipr_set_frame: small frames run as one wavefront
 
     // scene
-    DeviceBuffer shade_triangles, wide_nodes;
+    DeviceBuffer shade_triangles, wide_nodes, environment_PDF, environment_samples;
     DeviceBuffer nodes, triangles, instances, indices, geometry, texcoords, tints, emissions, materials, lights, textures, texels;
     DeviceBuffer ggx_rho, dielectric_rho, alpha, sample_offsets, sobol_tables;
     DeviceScene scene = {};
@@ -380,7 +380,7 @@ int hipr_destroy(HiprContext* c) {
     if (!c) return HIPR_OK;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    DeviceBuffer* all[] = {&c->shade_triangles, &c->wide_nodes, &c->nodes, &c->triangles, &c->instances, &c->indices, &c->geometry, &c->texcoords, &c->tints, &c->emissions, &c->materials,
+    DeviceBuffer* all[] = {&c->shade_triangles, &c->wide_nodes, &c->environment_PDF, &c->environment_samples, &c->nodes, &c->triangles, &c->instances, &c->indices, &c->geometry, &c->texcoords, &c->tints, &c->emissions, &c->materials,
                            &c->lights, &c->textures, &c->texels, &c->ggx_rho, &c->dielectric_rho, &c->alpha, &c->sample_offsets, &c->sobol_tables, &c->radiance,
                            &c->accumulation, &c->scratch_accumulation, &c->counters, &c->work_counters, &c->debug_a, &c->debug_b, &c->debug_c};
     for (DeviceBuffer* b : all) b->release();
@@ -454,6 +454,17 @@ int hipr_upload_scene(HiprContext* c, const HiprSceneDesc* s) {
     r |= c->lights.upload(s->lights, size_t(s->light_count) * sizeof(HiprLight), st);
     r |= c->textures.upload(s->textures, size_t(s->texture_count) * sizeof(HiprTexture), st);
     r |= c->texels.upload(s->texels, s->texel_bytes, st);
+    const HiprEnvironment* env = s->environment;
+    if (env) {
+        if (env->environment_map_ID <= 0 || uint32_t(env->environment_map_ID) >= s->texture_count || !env->per_pixel_PDF || !env->samples || env->sample_count == 0 ||
+            env->pdf_width == 0 || env->pdf_height == 0)
+            return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_upload_scene: incomplete environment description");
+        const uint8_t format = s->textures[env->environment_map_ID].format;
+        if (format != HIPR_TEXEL_RGBA8 && format != HIPR_TEXEL_RGBA32F)
+            return fail(HIPR_ERROR_UNSUPPORTED, "only environments with 4 channels are supported (OptiXRenderer/Renderer.cpp:1141-1158)");
+        r |= c->environment_PDF.upload(env->per_pixel_PDF, size_t(env->pdf_width) * env->pdf_height * sizeof(float), st);
+        r |= c->environment_samples.upload(env->samples, size_t(env->sample_count) * sizeof(HiprLightSample), st);
+    }
     if (r) return r < 0 ? r : HIPR_ERROR_HIP;
     HIP_TRY(hipStreamSynchronize(st));
     DeviceScene& d = c->scene;
@@ -472,6 +483,10 @@ int hipr_upload_scene(HiprContext* c, const HiprSceneDesc* s) {
     d.lights = c->lights.as<HiprLight>();
     d.textures = c->textures.as<HiprTexture>();
     d.texels = c->texels.as<uint8_t>();
+    d.env_map_ID = env ? env->environment_map_ID : 0;
+    d.env_per_pixel_PDF = env ? c->environment_PDF.as<float>() : nullptr;
+    d.env_samples = env ? c->environment_samples.as<float4>() : nullptr;
+    d.env_pdf_width = env ? env->pdf_width : 0u; d.env_pdf_height = env ? env->pdf_height : 0u; d.env_sample_count = env ? env->sample_count : 0u;
     d.node_count = s->node_count;
     d.triangle_count = s->triangle_count;
     d.light_count = s->light_count;

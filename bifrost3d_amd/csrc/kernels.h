@@ -45,6 +45,11 @@ struct DeviceScene {
     const HiprTexture* textures;
     const uint8_t* texels;
     const float4* sample_offsets;
+    // presampled environment light (HiprEnvironment); env_map_ID == 0: the environment is the constant tint
+    const float* env_per_pixel_PDF;
+    const float4* env_samples;       // 2 float4 per HiprLightSample: radiance + PDF, direction + distance
+    int env_map_ID;
+    uint32_t env_pdf_width, env_pdf_height, env_sample_count;
     const uint32_t* sobol_tables;   // SOBOL_TABLE_WORDS words, see sobol4ui_tables
     DeviceTables tables;
     uint32_t node_count, wide_node_count, triangle_count, light_count;
@@ -350,6 +355,30 @@ HD float material_coverage(const DeviceScene& sc, const HiprMaterial& m, f2 uv) 
     if (m.coverage_texture_ID) tex = sample_texture(sc, m.coverage_texture_ID, uv).x;
     if (m.flags & HIPR_MATERIAL_CUTOUT) return tex < m.coverage ? 0.0f : 1.0f;
     return m.coverage * tex;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Presampled environment light (ORS/LightSources/PresampledEnvironmentLightImpl.h:18-41, OR/Utils.h:288-292)
+// ---------------------------------------------------------------------------------------------
+HD f2 direction_to_latlong_texcoord(f3 direction) {
+    const float u = (atan2f(direction.z, direction.x) + HIPR_PI) * 0.5f / HIPR_PI;
+    const float v = (asinf(direction.y) + HIPR_PI * 0.5f) / HIPR_PI;
+    return {u, v};
+}
+// Solid angle PDF of sampling `direction` from the environment: nearest, clamped lookup of the per-texel PDF over sin(theta).
+HD float environment_pdf(const DeviceScene& sc, f3 direction) {
+    const f2 uv = direction_to_latlong_texcoord(direction);
+    const float sin_theta = sqrtf(1.0f - direction.y * direction.y);
+    const int w = int(sc.env_pdf_width), h = int(sc.env_pdf_height);
+    int x = int(floorf(uv.x * w)), y = int(floorf(uv.y * h));
+    x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
+    y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
+    const float pdf = sc.env_per_pixel_PDF[x + y * w] / sin_theta;
+    return sin_theta == 0.0f ? -0.0f : pdf;   // PDF::delta_dirac(0) at the poles
+}
+HD f3 environment_evaluate(const DeviceScene& sc, f3 direction) {
+    const f4 texel = sample_texture(sc, sc.env_map_ID, direction_to_latlong_texcoord(direction));
+    return mk3(sc.env_tint[0], sc.env_tint[1], sc.env_tint[2]) * mk3(texel.x, texel.y, texel.z);
 }
 
 HD f2 triangle_texcoord(const DeviceScene& sc, const HiprInstance& inst, uint32_t prim, float u, float v) {

@@ -54,7 +54,13 @@ HD void shade_path(const DeviceScene& sc, const HiprCameraState& cam, int entry,
             if (entry == HIPR_ENTRY_DEPTH) out.add_radiance = mk3(length(ro - 1e30f * rd));
             return;
         }
-        out.add_radiance = throughput * mk3(sc.env_tint[0], sc.env_tint[1], sc.env_tint[2]);
+        // miss program (SimpleRGPs.cu:349-362): the tint, or the environment map weighted against the BSDF sample that got here
+        f3 environment = mk3(sc.env_tint[0], sc.env_tint[1], sc.env_tint[2]);
+        if (sc.env_map_ID) {
+            environment = environment_evaluate(sc, rd);
+            if (pdf_valid_not_delta(bsdf_pdf)) environment *= balance_heuristic(pdf_value(bsdf_pdf), pdf_value(environment_pdf(sc, rd)));
+        }
+        out.add_radiance = throughput * environment;
         return;
     }
     if (id & HIPR_HIT_LIGHT) {
@@ -203,7 +209,14 @@ HD void shade_path(const DeviceScene& sc, const HiprCameraState& cam, int entry,
             const int light_count = int(sc.light_count);
             int li = int(r.z * light_count);
             li = li > light_count - 1 ? light_count - 1 : li;
-            LightSample c = light_sample_radiance(sc.lights[li], position, mk2(r.x, r.y));
+            LightSample c;
+            if ((sc.lights[li].flags & HIPR_LIGHT_TYPE_MASK) == HIPR_LIGHT_PRESAMPLED_ENVIRONMENT) {   // table lookup, PresampledEnvironmentLightImpl.h:22-27
+                int index = int(r.x * float(sc.env_sample_count));
+                index = index > int(sc.env_sample_count) - 1 ? int(sc.env_sample_count) - 1 : index;
+                const float4 a = sc.env_samples[2 * index], b = sc.env_samples[2 * index + 1];
+                c = {mk3(a.x, a.y, a.z) * mk3(sc.env_tint[0], sc.env_tint[1], sc.env_tint[2]), a.w, mk3(b.x, b.y, b.z), b.w};
+            } else
+                c = light_sample_radiance(sc.lights[li], position, mk2(r.x, r.y));
             c.radiance *= float(light_count);
             c.radiance *= fabsf(dot(tbn.n, c.dir)) / pdf_value(c.pdf);
             Response f = shading_evaluate_with_PDF<MODELS>(shading, wo, to_local(tbn, c.dir));

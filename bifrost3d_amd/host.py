@@ -35,6 +35,7 @@ def load_host_library() -> C.CDLL:
     lib.hiprh_bvh_wide_node_count.argtypes = [vp]; lib.hiprh_bvh_wide_node_count.restype = C.c_uint
     lib.hiprh_bvh_wide_stack_entries.argtypes = [vp]; lib.hiprh_bvh_wide_stack_entries.restype = C.c_uint
     lib.hiprh_bvh_wide_nodes.argtypes = [vp]; lib.hiprh_bvh_wide_nodes.restype = C.POINTER(capi.HiprWideNode)
+    lib.hiprh_pmjbn_samples.argtypes = [C.POINTER(C.c_float), C.c_uint, C.c_uint]
     lib.hiprh_bvh_destroy.argtypes = [vp]
     lib.hiprh_encode_octahedral.argtypes = [C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_short)]
     _lib = lib
@@ -44,9 +45,9 @@ def load_host_library() -> C.CDLL:
 class Scene:
     """A flattened scene owned by the C++ host library (what handle_updates() would hand to hipr_upload_scene)."""
 
-    def __init__(self, name: str, diffuse_only: bool = False, param0: int = 0, param1: int = 0):
+    def __init__(self, name: str, diffuse_only: bool = False, param0: int = 0, param1: int = 0, environment: bool = False):
         self.lib = load_host_library()
-        self.handle = self.lib.hiprh_scene_create(name.encode(), 1 if diffuse_only else 0, param0, param1)
+        self.handle = self.lib.hiprh_scene_create(name.encode(), (1 if diffuse_only else 0) | (2 if environment else 0), param0, param1)
         if not self.handle:
             raise capi.HiprError(f"unknown scene '{name}'")
         self.name = name

@@ -488,11 +488,15 @@ public:
     static Core::Bitmask<Change> get_changes(SceneRootID id) { return m().get_changes(id); }
     static RGB get_environment_tint(SceneRootID id) { return m()[id].tint; }
     static void set_environment_tint(SceneRootID id, RGB tint) { m()[id].tint = tint; m().flag(id, Change::EnvironmentTint); }
+    // A latitude-longitude texture lighting the scene; the renderer importance samples it (BF/Scene/SceneRoot.h).
+    static Assets::TextureID get_environment_map(SceneRootID id) { return m()[id].environment_map; }
+    static void set_environment_map(SceneRootID id, Assets::TextureID map) { m()[id].environment_map = map; m().flag(id, Change::EnvironmentMap); }
+    static Core::Iterable<SceneRootID> get_iterable() { return m().get_iterable(); }
     static SceneNodeID get_root_node(SceneRootID id) { return m()[id].root; }
     static void reset_change_notifications() { m().reset_change_notifications(); }
     static void deallocate() { m().clear(); }
 private:
-    struct Record { std::string name; RGB tint = RGB(0.0f); SceneNodeID root; };
+    struct Record { std::string name; RGB tint = RGB(0.0f); SceneNodeID root; Assets::TextureID environment_map; };
     static Core::Manager<SceneRootID, Record, Change>& m() { static Core::Manager<SceneRootID, Record, Change> s; return s; }
 };
 
@@ -504,6 +508,8 @@ public:
     SceneNode get_root_node() const { return SceneRoots::get_root_node(m_ID); }
     RGB get_environment_tint() const { return SceneRoots::get_environment_tint(m_ID); }
     void set_environment_tint(RGB t) { SceneRoots::set_environment_tint(m_ID, t); }
+    Assets::TextureID get_environment_map() const { return SceneRoots::get_environment_map(m_ID); }
+    void set_environment_map(Assets::TextureID map) { SceneRoots::set_environment_map(m_ID, map); }
     Core::Bitmask<SceneRoots::Change> get_changes() const { return SceneRoots::get_changes(m_ID); }
 private:
     SceneRootID m_ID;

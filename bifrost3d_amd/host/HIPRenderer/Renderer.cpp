@@ -11,6 +11,7 @@
 // edits, and the rebuild is off the render path.
 #include "Renderer.h"
 
+#include "PresampledEnvironment.h"
 #include "../SceneBuilder.h"
 #include "../../../include/hiprenderer_c.h"
 
@@ -150,6 +151,20 @@ void flatten_bifrost_scene(SceneBuilder& sb) {
         case LightSources::Type::Directional: sb.add_light(SceneBuilder::directional_light(t.rotation.forward(), power)); break;
         }
     }
+    // Environment map of the scene (OR/Renderer.cpp:1136-1160): only four channel images, importance sampled through presampled lights.
+    for (SceneRootID scene_ID : SceneRoots::get_iterable()) {
+        const TextureID environment_map = SceneRoots::get_environment_map(scene_ID);
+        if (environment_map == TextureID::invalid_UID()) continue;
+        const ImageID image = Textures::get_image_ID(environment_map);
+        if (channel_count(Images::get_pixel_format(image)) != 4) {
+            printf("HIPRenderer only supports environments with 4 channels. '%s' has %u.\n", Images::get_name(image).c_str(), unsigned(channel_count(Images::get_pixel_format(image))));
+            continue;
+        }
+        const InfiniteAreaLight light(environment_map);
+        PresampledEnvironment presampled = presample_environment(light);
+        sb.set_environment(environment_map.get_index(), presampled.pdf_width, presampled.pdf_height, std::move(presampled.per_pixel_PDF), std::move(presampled.samples));
+        break;   // one scene root is rendered
+    }
     sb.finalize();
 }
 
@@ -280,6 +295,10 @@ struct Renderer::Implementation {
                 scene_state.environment_tint[0] = scene_state.environment_tint[1] = scene_state.environment_tint[2] = 0.0f;
                 should_reset_accumulations = true;
                 continue;
+            }
+            if (changes.any_set(SceneRoots::Change::EnvironmentMap, SceneRoots::Change::Created) && SceneRoots::get_environment_map(scene_ID) != TextureID::invalid_UID()) {
+                scene_dirty = true;
+                should_reset_accumulations = true;
             }
             if (changes.any_set(SceneRoots::Change::EnvironmentTint, SceneRoots::Change::Created)) {
                 RGB tint = SceneRoots::get_environment_tint(scene_ID);

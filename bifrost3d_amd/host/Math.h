@@ -20,6 +20,10 @@ struct Vector2i { int x, y; Vector2i() = default; constexpr Vector2i(int x, int 
 struct Vector2s { short x, y; };
 struct Vector3ui { unsigned int x, y, z; };
 
+const float nearly_one = 0xffffff / float(1 << 24);   // Constants.h:19
+
+struct RGBA { float r, g, b, a; };
+
 struct Vector3f {
     float x, y, z;
     Vector3f() = default;
@@ -45,6 +49,18 @@ inline Vector3f cross(Vector3f a, Vector3f b) { return {a.y * b.z - a.z * b.y, a
 inline float magnitude_squared(Vector3f v) { return dot(v, v); }
 inline float magnitude(Vector3f v) { return std::sqrt(dot(v, v)); }
 inline Vector3f normalize(Vector3f v) { float m = magnitude(v); return v / m; }
+
+// Latitude-longitude environment map parameterisation (BF/Math/Utils.h:90-101).
+inline Vector2f direction_to_latlong_texcoord(Vector3f direction) {
+    const float u = (std::atan2(direction.z, direction.x) + PI<float>()) * 0.5f / PI<float>();
+    const float v = (std::asin(direction.y) + PI<float>() * 0.5f) / PI<float>();
+    return {u, v};
+}
+inline Vector3f latlong_texcoord_to_direction(Vector2f uv) {
+    const float phi = uv.x * 2.0f * PI<float>(), theta = uv.y * PI<float>();
+    const float sin_theta = std::sin(theta);
+    return -Vector3f(sin_theta * std::cos(phi), std::cos(theta), sin_theta * std::sin(phi));
+}
 
 struct RGB {
     float r, g, b;

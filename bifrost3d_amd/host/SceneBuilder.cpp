@@ -132,6 +132,18 @@ uint32_t SceneBuilder::add_model(uint32_t mesh, uint32_t material, const Transfo
 
 void SceneBuilder::add_light(const HiprLight& light) { m_lights.push_back(light); }
 
+void SceneBuilder::set_environment(uint32_t texture_index, uint32_t pdf_width, uint32_t pdf_height, std::vector<float> per_pixel_PDF, std::vector<HiprLightSample> samples) {
+    m_environment_PDF = std::move(per_pixel_PDF);
+    m_environment_samples = std::move(samples);
+    m_environment = {int32_t(texture_index), pdf_width, pdf_height, nullptr, nullptr, uint32_t(m_environment_samples.size())};
+    m_has_environment = true;
+    if (m_environment_samples.size() > 1) {   // next_event_estimation_possible (PresampledEnvironmentMap.h:64)
+        HiprLight light = {};
+        light.flags = HIPR_LIGHT_PRESAMPLED_ENVIRONMENT;
+        m_lights.push_back(light);
+    }
+}
+
 void SceneBuilder::force_shading_model(uint16_t shading_model) {
     for (size_t i = 1; i < m_materials.size(); ++i) m_materials[i].shading_model = shading_model;
 }
@@ -188,6 +200,9 @@ void SceneBuilder::finalize(uint32_t bvh_max_depth) {
     d.bvh_max_depth = m_bvh.max_depth;
     d.wide_nodes = m_bvh.wide_nodes.data(); d.wide_node_count = uint32_t(m_bvh.wide_nodes.size());
     d.wide_stack_entries = m_bvh.wide_stack_entries;
+    m_environment.per_pixel_PDF = m_environment_PDF.data();
+    m_environment.samples = m_environment_samples.data();
+    d.environment = m_has_environment ? &m_environment : nullptr;
 }
 
 HiprCameraState make_camera_state(const CameraDescription& camera, float aspect_ratio, uint32_t accumulations, float path_regularization_PDF_scale) {

@@ -51,6 +51,9 @@ public:
     // model_index: the MeshModel UID index used for InstanceID; 0 = next sequential index. Returns the index used.
     uint32_t add_model(uint32_t mesh, uint32_t material, const Transform& transform, uint32_t model_index = 0);
     void add_light(const HiprLight& light);
+    // The lat-long image is texture `texture_index` (add_texture); PDF texels and samples as PresampledEnvironment.h builds them. With two or
+    // more samples the environment also joins the light list for next event estimation (OptiXRenderer/Renderer.cpp:1160-1196).
+    void set_environment(uint32_t texture_index, uint32_t pdf_width, uint32_t pdf_height, std::vector<float> per_pixel_PDF, std::vector<HiprLightSample> samples);
 
     static HiprLight sphere_light(Vector3f position, RGB power, float radius);
     static HiprLight spot_light(Vector3f position, Vector3f direction, RGB power, float radius, float cos_angle);
@@ -88,6 +91,10 @@ private:
     std::vector<uint32_t> m_instance_mesh;
     std::vector<HiprTriangle> m_triangles;
     BvhBuildResult m_bvh;
+    std::vector<float> m_environment_PDF;
+    std::vector<HiprLightSample> m_environment_samples;
+    HiprEnvironment m_environment = {};
+    bool m_has_environment = false;
     HiprSceneDesc m_desc = {};
     HiprSceneState m_state = {};
     AABB m_bounds = AABB::invalid();

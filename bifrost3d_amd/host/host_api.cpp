@@ -7,11 +7,46 @@
 #include <cstring>
 #include <string>
 
+#include "HIPRenderer/PresampledEnvironment.h"
+#include "RNG.h"
+
+#include <cmath>
+
 using namespace HIPRenderer;
+
+// A small procedural sky for tests and benchmarks: horizon-to-zenith gradient, dark ground, one bright sun disc. 64 x 32 RGBA float.
+static void add_procedural_environment(SceneBuilder& sb) {
+    using namespace Bifrost;
+    const unsigned width = 64, height = 32;
+    std::vector<float> pixels(size_t(width) * height * 4);
+    const Math::Vector3f sun = Math::normalize(Math::Vector3f(0.4f, 0.7f, -0.3f));
+    for (unsigned y = 0; y < height; ++y)
+        for (unsigned x = 0; x < width; ++x) {
+            const Math::Vector3f direction = Math::latlong_texcoord_to_direction({(x + 0.5f) / width, (y + 0.5f) / height});
+            const float up = direction.y;
+            float r = up > 0 ? 0.35f + 0.25f * (1 - up) : 0.08f, g = up > 0 ? 0.55f + 0.2f * (1 - up) : 0.07f, b = up > 0 ? 0.9f : 0.06f;
+            const float alignment = Math::dot(direction, sun);
+            if (alignment > 0.97f) { const float s = (alignment - 0.97f) / 0.03f; r += 60.0f * s; g += 55.0f * s; b += 45.0f * s; }
+            float* p = pixels.data() + 4 * (x + size_t(y) * width);
+            p[0] = r; p[1] = g; p[2] = b; p[3] = 1.0f;
+        }
+    const Assets::ImageID image = Assets::Images::create2D("procedural sky", Assets::PixelFormat::RGBA_Float, false, width, height, pixels.data(), pixels.size() * 4);
+    const Assets::TextureID texture = Assets::Textures::create2D(image, Assets::MagnificationFilter::Linear, Assets::MinificationFilter::Linear, Assets::WrapMode::Repeat,
+                                                                 Assets::WrapMode::Clamp);
+    const Assets::InfiniteAreaLight light(texture);
+    PresampledEnvironment presampled = presample_environment(light, 1024);
+    ImageData data;
+    data.width = width; data.height = height; data.format = HIPR_TEXEL_RGBA32F; data.is_sRGB = false;
+    data.pixels.assign(reinterpret_cast<const uint8_t*>(pixels.data()), reinterpret_cast<const uint8_t*>(pixels.data()) + pixels.size() * 4);
+    const uint32_t texture_index = sb.add_texture(data, true, false, true, true);
+    sb.set_environment(texture_index, presampled.pdf_width, presampled.pdf_height, std::move(presampled.per_pixel_PDF), std::move(presampled.samples));
+    Assets::Textures::destroy(texture);
+    Assets::Images::destroy(image);
+}
 
 extern "C" {
 
-// name: "cornell" | "atrium" | "quad" | "empty_ortho". variant bit 0: force every material to the Diffuse
+// name: "cornell" | "atrium" | "quad" | "empty_ortho". variant bit 1: light the scene with a procedural environment map. variant bit 0: force every material to the Diffuse
 // shading model (BASELINE.json config 2). param0/param1: atrium target triangles + seed, ortho width + height.
 void* hiprh_scene_create(const char* name, unsigned variant, unsigned param0, unsigned param1) {
     if (!name) return nullptr;
@@ -23,6 +58,7 @@ void* hiprh_scene_create(const char* name, unsigned variant, unsigned param0, un
     else if (n == "empty_ortho") Scenes::create_empty_ortho_scene(*sb, param0, param1, RGB(0.1f, 0.5f, 2.0f));
     else { delete sb; return nullptr; }
     if (variant & 1u) sb->force_shading_model(HIPR_SHADING_DIFFUSE);
+    if (variant & 2u) add_procedural_environment(*sb);
     sb->finalize();
     return sb;
 }
@@ -62,6 +98,10 @@ const unsigned* hiprh_bvh_order(void* h) { return static_cast<BvhHandle*>(h)->re
 unsigned hiprh_bvh_wide_node_count(void* h) { return unsigned(static_cast<BvhHandle*>(h)->result.wide_nodes.size()); }
 unsigned hiprh_bvh_wide_stack_entries(void* h) { return static_cast<BvhHandle*>(h)->result.wide_stack_entries; }
 const HiprWideNode* hiprh_bvh_wide_nodes(void* h) { return static_cast<BvhHandle*>(h)->result.wide_nodes.data(); }
+// The host's progressive multi-jittered blue-noise points (host/RNG.cpp), for the cross-check against the oracle's generator.
+void hiprh_pmjbn_samples(float* out_xy, unsigned count, unsigned candidates) {
+    Bifrost::Math::RNG::fill_progressive_multijittered_bluenoise_samples(reinterpret_cast<Bifrost::Math::Vector2f*>(out_xy), reinterpret_cast<Bifrost::Math::Vector2f*>(out_xy) + count, candidates);
+}
 void hiprh_bvh_destroy(void* h) { delete static_cast<BvhHandle*>(h); }
 
 void hiprh_encode_octahedral(const float* normals_n3, int n, short* out_n2) {

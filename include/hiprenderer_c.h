@@ -160,6 +160,28 @@ typedef struct HiprTexture {
 
 enum { HIPR_TEXEL_R8 = 1, HIPR_TEXEL_RGBA8 = 4, HIPR_TEXEL_R32F = 17, HIPR_TEXEL_RGBA32F = 20 };
 
+/* OR/Types.h:265-272 LightSample: what sampling a light returns. The environment light is PRE-sampled on the host. */
+typedef struct HiprLightSample {
+    float radiance[3];
+    float PDF;
+    float direction_to_light[3];
+    float distance;
+} HiprLightSample;
+
+/* Importance sampled latitude-longitude environment map (PresampledEnvironmentLight, OR/Types.h:270-277, built by
+ * OR/PresampledEnvironmentMap.cpp:19-101): the image is HiprSceneDesc::textures[environment_map_ID] (RGBA8 or RGBA32F);
+ * `per_pixel_PDF` is the solid angle PDF of every PDF texel without its 1 / sin(theta) factor (nearest lookup, clamp);
+ * `samples` are sample_count (a power of two >= 2) light samples drawn on the host from progressive multi-jittered points.
+ * The environment takes part in next event estimation through a light of type HIPR_LIGHT_PRESAMPLED_ENVIRONMENT in `lights`
+ * (the host appends it, OR/Renderer.cpp:1160-1196); its radiance is scaled by HiprSceneState::environment_tint. */
+typedef struct HiprEnvironment {
+    int32_t environment_map_ID;
+    uint32_t pdf_width, pdf_height;
+    const float* per_pixel_PDF;
+    const HiprLightSample* samples;
+    uint32_t sample_count;
+} HiprEnvironment;
+
 /* The flat scene the host produces in handle_updates() (OR/Renderer.cpp:578-1205). */
 typedef struct HiprSceneDesc {
     const HiprBvhNode* nodes;            uint32_t node_count;
@@ -177,6 +199,7 @@ typedef struct HiprSceneDesc {
     uint32_t bvh_max_depth;              /* deepest leaf, root = 1; selects the LDS stack size */
     const HiprWideNode* wide_nodes;      uint32_t wide_node_count;  /* the same tree collapsed to 4-wide nodes; may be NULL / 0 */
     uint32_t wide_stack_entries;         /* most entries a traversal of wide_nodes can have on its stack */
+    const HiprEnvironment* environment;  /* NULL: the environment is the constant HiprSceneState::environment_tint */
 } HiprSceneDesc;
 
 /* OR/Types.h:507-523 SceneStateGPU, without OptiX buffer ids. */

@@ -503,12 +503,52 @@ struct Payload {
     float4 sample4f(uint32_t d) const { return rng::sample4f(accumulation, pixel_hash, 8u * bounces + d); }
 };
 
+// ---------------------------------------------------------------------------------------------
+// Presampled environment light (ORS/LightSources/PresampledEnvironmentLightImpl.h:18-41, OR/Utils.h:288-292). The samples and
+// the per-texel PDF image arrive in HiprSceneDesc::environment, built by the host as OR/PresampledEnvironmentMap.cpp:19-101 does.
+// ---------------------------------------------------------------------------------------------
+static inline float2 direction_to_latlong_texcoord(float3 direction) {
+    const float PI = 3.14159265358979323846f;
+    float u = (atan2f(direction.z, direction.x) + PI) * 0.5f / PI;
+    float v = (asinf(direction.y) + PI * 0.5f) / PI;
+    return {u, v};
+}
+
+static PDF environment_pdf(const HiprEnvironment& env, float3 direction) {
+    float2 uv = direction_to_latlong_texcoord(direction);
+    float sin_theta = sqrtf(1.0f - direction.y * direction.y);
+    int w = int(env.pdf_width), h = int(env.pdf_height);
+    int x = int(floorf(uv.x * w)), y = int(floorf(uv.y * h));   // nearest filtering, clamp to edge
+    x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
+    y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
+    float pdf = env.per_pixel_PDF[x + y * w] / sin_theta;
+    return sin_theta == 0.0f ? PDF::delta_dirac(0) : PDF(pdf);
+}
+
+static float3 environment_evaluate(const HiprSceneDesc& scene, const HiprSceneState& state, float3 direction) {
+    float4 texel = sample_texture(scene, scene.environment->environment_map_ID, direction_to_latlong_texcoord(direction));
+    return make_float3(state.environment_tint[0], state.environment_tint[1], state.environment_tint[2]) * make_float3(texel.x, texel.y, texel.z);
+}
+
+static LightSample environment_sample(const HiprEnvironment& env, const HiprSceneState& state, float random_x) {
+    int index = int(random_x * float(env.sample_count));
+    if (index > int(env.sample_count) - 1) index = int(env.sample_count) - 1;
+    const HiprLightSample& s = env.samples[index];
+    LightSample ls;
+    ls.radiance = make_float3(s.radiance[0], s.radiance[1], s.radiance[2]) * make_float3(state.environment_tint[0], state.environment_tint[1], state.environment_tint[2]);
+    ls.pdf = PDF(s.PDF);
+    ls.direction_to_light = {s.direction_to_light[0], s.direction_to_light[1], s.direction_to_light[2]};
+    ls.distance = s.distance;
+    return ls;
+}
+
 template <typename Model>
-static LightSample sample_single_light(const HiprSceneDesc& scene, const Model& material, float3 p, float3 wo, const TBN& tbn, float3 u) {
+static LightSample sample_single_light(const HiprSceneDesc& scene, const HiprSceneState& state, const Model& material, float3 p, float3 wo, const TBN& tbn, float3 u) {
     int light_count = int(scene.light_count);
     int li = int(u.z * light_count);
     if (li > light_count - 1) li = light_count - 1;
-    LightSample ls = Lights::sample_radiance(scene.lights[li], p, make_float2(u.x, u.y));
+    LightSample ls = (scene.lights[li].flags & HIPR_LIGHT_TYPE_MASK) == HIPR_LIGHT_PRESAMPLED_ENVIRONMENT ? environment_sample(*scene.environment, state, u.x)
+                                                                                                     : Lights::sample_radiance(scene.lights[li], p, make_float2(u.x, u.y));
     ls.radiance *= float(light_count);
     float N_dot_L = dot(tbn.normal, ls.direction_to_light);
     ls.radiance *= fabsf(N_dot_L) / ls.pdf.value();
@@ -531,7 +571,7 @@ static LightSample reestimated_light_samples(const HiprSceneDesc& scene, const H
     int n = state.next_event_sample_count;
     for (int s = 0; s < n; ++s) {
         float4 r = toroidal_shift(base, offsets[s]);
-        LightSample candidate = sample_single_light(scene, material, p, wo, tbn, make_float3(r.x, r.y, r.z));
+        LightSample candidate = sample_single_light(scene, state, material, p, wo, tbn, make_float3(r.x, r.y, r.z));
         float w_old = sum(kept.radiance), w_new = sum(candidate.radiance);
         float p_new = w_new / (w_old + w_new);
         if (r.w < p_new) {
@@ -660,8 +700,12 @@ float3 path_trace_pixel(const HiprSceneDesc& scene, const HiprSceneState& state,
         if (counters) counters->closest_rays++;
 
         if (hit.id == HIT_MISS) {
-            // miss program (SimpleRGPs.cu:349-362); environment maps are a later tier, tint only.
+            // miss program (SimpleRGPs.cu:349-362) + evaluate_intersection (LightImpl.h:86-97) for an environment map
             float3 env = {state.environment_tint[0], state.environment_tint[1], state.environment_tint[2]};
+            if (scene.environment && scene.environment->environment_map_ID) {
+                env = environment_evaluate(scene, state, ray.direction);
+                if (payload.bsdf_PDF.use_for_MIS()) env *= MIS_weight(payload.bsdf_PDF, environment_pdf(*scene.environment, ray.direction));
+            }
             payload.radiance += payload.throughput * env;
             payload.throughput = {0, 0, 0};
         } else if (hit.id & HIT_LIGHT_BIT) {

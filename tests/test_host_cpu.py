@@ -273,3 +273,42 @@ def test_oracle_wide_traversal_equals_bvh2_and_brute_force():
     sb, _ = o.trace_shadow(scene.desc, rays, use_bvh=0)
     sw, _ = o.trace_shadow(scene.desc, rays, use_bvh=2)
     assert np.array_equal(sb, sw)
+
+
+def test_host_blue_noise_points_equal_the_oracle_restatement():
+    """host/RNG.cpp and oracle/pmjbn.cpp restate the same generator (BF/Math/RNG.cpp:21-199) independently: identical point sets.
+    The environment light is presampled from these points (host/HIPRenderer/PresampledEnvironment.cpp)."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    from oracle_bindings import get_oracle
+    lib = load_host_library()
+    n = 4096
+    host = np.zeros((n, 2), np.float32)
+    lib.hiprh_pmjbn_samples(host.ctypes.data_as(C.POINTER(C.c_float)), n, 8)
+    assert np.array_equal(host, get_oracle(False).pmjbn(n, 8))
+    assert 0.0 <= host.min() and host.max() < 1.0
+
+
+def test_presampled_environment_scene_description():
+    """variant bit 1 of the host scenes: a procedural sky as HiprEnvironment (PDF image at the 128-row minimum height, 1024 samples,
+    an environment light appended to the light list) whose samples are unit directions with PDFs matching the PDF image."""
+    scene = Scene("cornell", environment=True)
+    d = scene.desc
+    env = d.environment.contents
+    assert d.light_count == 2 and d.lights[1].flags & 7 == 4   # HIPR_LIGHT_PRESAMPLED_ENVIRONMENT
+    assert (env.pdf_width, env.pdf_height, env.sample_count) == (64, 128, 1024)
+    assert d.textures[env.environment_map_ID].format == 20      # HIPR_TEXEL_RGBA32F
+    samples = np.ctypeslib.as_array(C.cast(env.samples, C.POINTER(C.c_float)), shape=(env.sample_count, 8))
+    pdf_image = np.ctypeslib.as_array(env.per_pixel_PDF, shape=(env.pdf_height, env.pdf_width))
+    direction = samples[:, 4:7]
+    assert np.allclose(np.linalg.norm(direction, axis=1), 1.0, atol=1e-5)
+    u = (np.arctan2(direction[:, 2], direction[:, 0]) + np.pi) * 0.5 / np.pi
+    v = (np.arcsin(np.clip(direction[:, 1], -1, 1)) + np.pi * 0.5) / np.pi
+    x = np.clip((u * env.pdf_width).astype(int), 0, env.pdf_width - 1)
+    y = np.clip((v * env.pdf_height).astype(int), 0, env.pdf_height - 1)
+    sin_theta = np.sqrt(1.0 - direction[:, 1] ** 2)
+    reconstructed = pdf_image[y, x] / sin_theta
+    interior = (np.abs(u * env.pdf_width - np.round(u * env.pdf_width)) > 1e-3) & (np.abs(v * env.pdf_height - np.round(v * env.pdf_height)) > 1e-3)
+    assert np.allclose(reconstructed[interior], samples[interior, 3], rtol=2e-3)
+    # the sun dominates the importance: most samples point into its few texels
+    sun = np.array([0.4, 0.7, -0.3]) / np.linalg.norm([0.4, 0.7, -0.3])
+    assert (direction @ sun > 0.95).mean() > 0.3

@@ -19,6 +19,9 @@ def run(flag):
 def test_host_side_renderer_cases():
     out = run("--cpu")
     assert "flattened_cornell_box_matches_the_scene_builder" in out and " 0 failed." in out
+    for name in ("distribution2D_non_constant_function", "infinite_area_light_consistent_PDF_and_evaluate", "infinite_area_light_diffuse_integrates_to_white",
+                 "infinite_area_light_PDF_resampling", "per_pixel_PDF_reconstructs_the_solid_angle_PDF"):
+        assert f"[       OK ] EnvironmentFixture.{name}" in out, out[-4000:]
     for name in ("obj_shapes_materials_and_nodes", "single_shape_is_its_own_root_and_missing_files_fail", "viewer_defaults_place_camera_light_and_clip_planes"):
         assert f"[       OK ] LoaderFixture.{name}" in out, out[-4000:]
 
@@ -30,3 +33,4 @@ def test_reference_renderer_cases_on_gpu():
                  "scene_changes_restart_accumulation", "render_target_pitch_is_respected", "cornell_box_through_the_renderer_matches_the_c_abi", "adaptor_presents_the_flipped_viewport"):
         assert f"[       OK ] RendererFixture.{name}" in out, out[-4000:]
     assert "[       OK ] LoaderFixture.loaded_obj_renders_through_the_renderer" in out, out[-4000:]
+    assert "[       OK ] EnvironmentFixture.renderer_shows_the_environment_map_behind_an_empty_scene" in out, out[-4000:]
