@@ -680,6 +680,12 @@ int hipr_render_pass(HiprContext* c, const HiprCameraState* camera, void* out_ha
                 fprintf(stderr, " %s %.1f us", c->timed[i].kernel == HIPR_KERNEL_SHADE ? "shade" : (c->timed[i].kernel == HIPR_KERNEL_TRACE_SHADOW ? "shadow" : "trace"), ms * 1e3f);
             }
             fprintf(stderr, " -> %u paths continue, %u shadow rays\n", w.host_counts[2 * parity], w.host_counts[2 * parity + 1]);
+            if (dc.node_iterations != p.node_iterations) {
+                const double ni = double(dc.node_iterations - p.node_iterations), ti = double(dc.triangle_iterations - p.triangle_iterations);
+                fprintf(stderr, "[hipr]     wave iterations: %.0f node (%.1f lanes working) + %.0f triangle (%.1f lanes working); %.1f lanes busy on average; %llu refills\n", ni,
+                        double(dc.node_lanes - p.node_lanes) / ni, ti, ti > 0 ? double(dc.triangle_lanes - p.triangle_lanes) / ti : 0.0,
+                        double(dc.busy_lanes - p.busy_lanes) / (ni + ti), dc.refills - p.refills);
+            }
             c->trace_log_previous = dc;
         }
         return HIPR_OK;

@@ -90,6 +90,8 @@ struct FrameInfo {
 
 struct DeviceCounters {
     unsigned long long shaded_hits, closest_nodes, closest_triangles, shadow_nodes, shadow_triangles;
+    // diagnostics of the persistent kernels (instrumented builds): wave iterations by kind and the lanes that did work in them
+    unsigned long long node_iterations, node_lanes, triangle_iterations, triangle_lanes, busy_lanes, refills;
 };
 
 // Blocks that share an XCD (blockIdx % 8) get a contiguous range of chunks so that spatially
@@ -592,6 +594,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(5))
     int cur = 0, sp = 0;
     uint32_t tri_cur = 0, tri_end = 0;
     uint32_t nodes = 0, tris = 0, shadow_nodes = 0, shadow_tris = 0;
+    uint32_t diag_node_iterations = 0, diag_node_lanes = 0, diag_triangle_iterations = 0, diag_triangle_lanes = 0, diag_busy_lanes = 0, diag_refills = 0;   // lane 0 only
 
     // Work item encoding: >= 0 inner node index, < 0 leaf ~((first << 3) | (count - 1)), TRACE_DONE = nothing left.
     constexpr int TRACE_DONE = 0x7FFFFFFF;
@@ -621,6 +624,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(5))
         }
         // ---- refill idle lanes from the wave's private range -------------------------------------------------------
         const unsigned long long idle = __ballot(!active);
+        if (INSTRUMENT && lane == 0 && idle && !exhausted) ++diag_refills;
         if (idle && !exhausted) {
             while (chunk_next >= chunk_end && !exhausted) {
                 const uint32_t shard_begin = uint32_t((unsigned long long)n * shard / TRACE_SHARDS);
@@ -697,6 +701,12 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(5))
             const unsigned long long tmask = __ballot(tri_mode), nmask = __ballot(node_mode);
             int next_item = TRACE_DONE;     // the item this lane continues with; selects only, no divergent state updates
             bool take_next = false, need_pop = false;
+            if (INSTRUMENT && lane == 0) {
+                const bool triangles = __popcll(tmask) > __popcll(nmask);
+                diag_triangle_iterations += triangles; diag_triangle_lanes += triangles ? __popcll(tmask) : 0;
+                diag_node_iterations += !triangles; diag_node_lanes += triangles ? 0 : __popcll(nmask);
+                diag_busy_lanes += __popcll(tmask | nmask);
+            }
             if (__popcll(tmask) > __popcll(nmask)) {
                 if (tri_mode) {
                     const uint32_t i = tri_cur;
@@ -793,6 +803,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(5))
     }
 
     if (INSTRUMENT) {
+        wave_add(&counters->node_iterations, diag_node_iterations); wave_add(&counters->node_lanes, diag_node_lanes);
+        wave_add(&counters->triangle_iterations, diag_triangle_iterations); wave_add(&counters->triangle_lanes, diag_triangle_lanes);
+        wave_add(&counters->busy_lanes, diag_busy_lanes); wave_add(&counters->refills, diag_refills);
         if (MODE != TRACE_SHADOW) { wave_add(&counters->closest_nodes, nodes); wave_add(&counters->closest_triangles, tris); }
         if (MODE != TRACE_CLOSEST) { wave_add(&counters->shadow_nodes, shadow_nodes); wave_add(&counters->shadow_triangles, shadow_tris); }
     }
