@@ -47,6 +47,8 @@ def parse_args():
     p.add_argument("--width", type=int, default=1920)
     p.add_argument("--height", type=int, default=1080)
     p.add_argument("--scene", default="cornell_diffuse", choices=["cornell_diffuse", "cornell", "atrium"])
+    p.add_argument("--scene-file", default=None, help="render a model file (.gltf / .glb / .obj, PNG textures) set up the way SimpleViewer sets up a scene from its command line; "
+                   "not the headline workload: the line's config.workload names the file")
     p.add_argument("--atrium-triangles", type=int, default=260000)
     p.add_argument("--bounces", type=int, default=4)
     p.add_argument("--spp-per-pass", type=int, default=8, help="accumulations traced together per step and GPU (HiprFrameDesc::samples_per_pass)")
@@ -63,6 +65,10 @@ def parse_args():
 
 def make_scene(args):
     from bifrost3d_amd.host import Scene
+    if args.scene_file:
+        scene = Scene("file:" + args.scene_file)
+        args.scene = "file:" + os.path.basename(args.scene_file)
+        return scene, f"{os.path.basename(args.scene_file)} ({scene.desc.triangle_count} triangles) with the SimpleViewer defaults (camera from the scene bounds, one directional light)"
     if args.scene == "cornell_diffuse":
         return Scene("cornell", diffuse_only=True), "SimpleViewer Cornell box (34 triangles, 1 sphere light), all materials Diffuse"
     if args.scene == "cornell":
@@ -320,7 +326,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_seconds)
-            if args.scene != "atrium" or args.atrium_triangles <= 300000:
+            if scene.desc.triangle_count <= 300000:
                 out["config"]["rmse_vs_oracle"] = rmse_against_oracle(ctx, scene, args)
         print(json.dumps(out))
         sys.stdout.flush()

@@ -21,6 +21,10 @@ def load_host_library() -> C.CDLL:
     vp = C.c_void_p
     lib.hiprh_scene_create.argtypes = [C.c_char_p, C.c_uint, C.c_uint, C.c_uint]
     lib.hiprh_scene_create.restype = vp
+    lib.hiprh_scene_load.argtypes = [C.c_char_p, C.c_uint]
+    lib.hiprh_scene_load.restype = vp
+    lib.hiprh_png_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_ubyte), C.c_size_t]
+    lib.hiprh_png_load.restype = C.c_size_t
     lib.hiprh_scene_destroy.argtypes = [vp]
     lib.hiprh_scene_desc.argtypes = [vp]
     lib.hiprh_scene_desc.restype = C.POINTER(capi.HiprSceneDesc)
@@ -42,14 +46,31 @@ def load_host_library() -> C.CDLL:
     return lib
 
 
+def load_png(path: str, flip: bool = False) -> np.ndarray:
+    """Decode a PNG with the host library's decoder into (height, width, channels) uint8; rows top-down unless `flip`."""
+    lib = load_host_library()
+    w, h, c = C.c_uint(), C.c_uint(), C.c_uint()
+    size = lib.hiprh_png_load(path.encode(), int(flip), C.byref(w), C.byref(h), C.byref(c), None, 0)
+    if size == 0:
+        raise capi.HiprError(f"could not decode '{path}'")
+    out = np.empty(size, dtype=np.uint8)
+    lib.hiprh_png_load(path.encode(), int(flip), None, None, None, out.ctypes.data_as(C.POINTER(C.c_ubyte)), size)
+    return out.reshape(h.value, w.value, c.value)
+
+
 class Scene:
     """A flattened scene owned by the C++ host library (what handle_updates() would hand to hipr_upload_scene)."""
 
     def __init__(self, name: str, diffuse_only: bool = False, param0: int = 0, param1: int = 0, environment: bool = False):
         self.lib = load_host_library()
-        self.handle = self.lib.hiprh_scene_create(name.encode(), (1 if diffuse_only else 0) | (2 if environment else 0), param0, param1)
-        if not self.handle:
-            raise capi.HiprError(f"unknown scene '{name}'")
+        if name.startswith("file:"):    # a model file set up the way SimpleViewer sets up its command-line scene
+            self.handle = self.lib.hiprh_scene_load(name[5:].encode(), 1 if diffuse_only else 0)
+            if not self.handle:
+                raise capi.HiprError(f"could not load '{name[5:]}'")
+        else:
+            self.handle = self.lib.hiprh_scene_create(name.encode(), (1 if diffuse_only else 0) | (2 if environment else 0), param0, param1)
+            if not self.handle:
+                raise capi.HiprError(f"unknown scene '{name}'")
         self.name = name
 
     def __del__(self):

@@ -2,12 +2,64 @@
 #include "Bifrost.h"
 #include "Scenes.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <limits>
 
 namespace Bifrost {
 
 namespace Assets {
+namespace MeshUtils {
+
+Mesh deep_clone(Mesh mesh) {
+    MeshFlags buffers = MeshFlag::Position;
+    if (mesh.get_normals()) buffers |= MeshFlag::Normal;
+    if (mesh.get_texcoords()) buffers |= MeshFlag::Texcoord;
+    if (mesh.get_tint_and_roughness()) buffers |= MeshFlag::TintAndRoughness;
+    if (mesh.get_emission()) buffers |= MeshFlag::Emissive;
+    const unsigned primitives = mesh.get_primitive_count(), vertices = mesh.get_vertex_count();
+    Mesh clone(mesh.get_name() + "_clone", primitives, vertices, buffers);
+    std::copy_n(mesh.get_primitives(), primitives, clone.get_primitives());
+    std::copy_n(mesh.get_positions(), vertices, clone.get_positions());
+    if (mesh.get_normals()) std::copy_n(mesh.get_normals(), vertices, clone.get_normals());
+    if (mesh.get_texcoords()) std::copy_n(mesh.get_texcoords(), vertices, clone.get_texcoords());
+    if (mesh.get_tint_and_roughness()) std::copy_n(mesh.get_tint_and_roughness(), vertices, clone.get_tint_and_roughness());
+    if (mesh.get_emission()) std::copy_n(mesh.get_emission(), vertices, clone.get_emission());
+    clone.set_bounds(mesh.get_bounds());
+    return clone;
+}
+
+void transform_mesh(Mesh mesh, Matrix3x4f affine) {
+    const float (&a)[3][4] = affine.m;
+    AABB bounds = {Vector3f(std::numeric_limits<float>::infinity()), Vector3f(-std::numeric_limits<float>::infinity())};
+    Vector3f* positions = mesh.get_positions();
+    for (unsigned v = 0; v < mesh.get_vertex_count(); ++v) {
+        const Vector3f p = positions[v];
+        positions[v] = Vector3f(a[0][0] * p.x + a[0][1] * p.y + a[0][2] * p.z + a[0][3],
+                                a[1][0] * p.x + a[1][1] * p.y + a[1][2] * p.z + a[1][3],
+                                a[2][0] * p.x + a[2][1] * p.y + a[2][2] * p.z + a[2][3]);
+        bounds.grow_to_contain(positions[v]);
+    }
+    mesh.set_bounds(bounds);
+
+    if (Vector3f* normals = mesh.get_normals()) {
+        // transpose(invert(L)) is the cofactor matrix over the determinant.
+        const float c[3][3] = {{a[1][1] * a[2][2] - a[1][2] * a[2][1], a[1][2] * a[2][0] - a[1][0] * a[2][2], a[1][0] * a[2][1] - a[1][1] * a[2][0]},
+                               {a[0][2] * a[2][1] - a[0][1] * a[2][2], a[0][0] * a[2][2] - a[0][2] * a[2][0], a[0][1] * a[2][0] - a[0][0] * a[2][1]},
+                               {a[0][1] * a[1][2] - a[0][2] * a[1][1], a[0][2] * a[1][0] - a[0][0] * a[1][2], a[0][0] * a[1][1] - a[0][1] * a[1][0]}};
+        const float inv_det = 1.0f / (a[0][0] * c[0][0] + a[0][1] * c[0][1] + a[0][2] * c[0][2]);
+        for (unsigned v = 0; v < mesh.get_vertex_count(); ++v) {
+            const Vector3f n = normals[v];
+            normals[v] = normalize(Vector3f((c[0][0] * n.x + c[0][1] * n.y + c[0][2] * n.z) * inv_det,
+                                            (c[1][0] * n.x + c[1][1] * n.y + c[1][2] * n.z) * inv_det,
+                                            (c[2][0] * n.x + c[2][1] * n.y + c[2][2] * n.z) * inv_det));
+        }
+    }
+}
+
+} // namespace MeshUtils
+
 namespace MeshCreation {
 
 static Mesh from_data(const std::string& name, const HIPRenderer::MeshData& d, MeshFlags buffers, AABB bounds) {

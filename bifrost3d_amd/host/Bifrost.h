@@ -173,6 +173,7 @@ public:
     static const void* get_pixels(ImageID id) { return m()[id].pixels.data(); }
     static void* get_mutable_pixels(ImageID id) { m().flag(id, Change::PixelsUpdated); return m()[id].pixels.data(); }
     static bool has(ImageID id) { return m().has(id); }
+    static Core::Iterable<ImageID> get_iterable() { return m().get_iterable(); }
     static unsigned get_pixel_count(ImageID id) { return m()[id].width * m()[id].height; }
     static const std::string& get_name(ImageID id) { return m()[id].name; }
     static void reset_change_notifications() { m().reset_change_notifications(); }
@@ -297,6 +298,7 @@ public:
     Material(MaterialID id = MaterialID::invalid_UID()) : m_ID(id) {}
     Material(const std::string& name, const Materials::Data& data) : m_ID(Materials::create(name, data)) {}
     static Material invalid() { return Material(); }
+    bool exists() const { return m_ID != MaterialID::invalid_UID(); }
     const std::string& get_name() const { return Materials::get_name(m_ID); }
     static Material create_dielectric(const std::string& name, RGB tint, float roughness, float specularity = 0.04f) { return Materials::create(name, Materials::Data::create_dielectric(tint, roughness, specularity)); }
     static Material create_metal(const std::string& name, RGB tint, float roughness) { return Materials::create(name, Materials::Data::create_metal(tint, roughness)); }
@@ -364,6 +366,8 @@ public:
     static Core::Iterable<MeshID> get_changed_meshes() { return m().get_changed(); }
     static Core::Bitmask<Change> get_changes(MeshID id) { return m().get_changes(id); }
     static const std::string& get_name(MeshID id) { return m()[id].name; }
+    static bool has(MeshID id) { return m().has(id); }
+    static Core::Iterable<MeshID> get_iterable() { return m().get_iterable(); }
     static unsigned get_primitive_count(MeshID id) { return (unsigned)m()[id].primitives.size(); }
     static unsigned get_vertex_count(MeshID id) { return (unsigned)m()[id].positions.size(); }
     static Vector3ui* get_primitives(MeshID id) { return m()[id].primitives.data(); }
@@ -405,6 +409,11 @@ public:
 private:
     MeshID m_ID;
 };
+
+namespace MeshUtils {
+Mesh deep_clone(Mesh mesh);                                     // BF/Assets/Mesh.cpp deep_clone: every buffer and the bounds copied
+void transform_mesh(Mesh mesh, Matrix3x4f affine_transform);    // BF/Assets/Mesh.cpp:211-238: positions, bounds, normals by the inverse transpose
+}
 
 namespace MeshCreation {
 Mesh plane(unsigned quads_per_edge, MeshFlags buffers = MeshFlag::AllBuffers);                              // BF/Assets/MeshCreation.cpp:30-75
@@ -479,7 +488,7 @@ public:
     enum class Change : unsigned char { None = 0, Created = 1, Destroyed = 2, EnvironmentTint = 4, EnvironmentMap = 8 };
     static SceneRootID create(const std::string& name, RGB environment_tint) {
         SceneRootID id = m().allocate();
-        m()[id] = {name, environment_tint, SceneNodes::create(name + " root")};
+        m()[id] = {name, environment_tint, SceneNodes::create(name + " root"), {}};
         m().flag(id, Change::Created);
         return id;
     }

@@ -131,6 +131,7 @@ struct Quaternionf {
 };
 inline Quaternionf conjugate(Quaternionf q) { return Quaternionf(-q.x, -q.y, -q.z, q.w); }
 inline Quaternionf inverse_unit(Quaternionf q) { return conjugate(q); }
+inline float magnitude(Quaternionf q) { return std::sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w); }
 inline Quaternionf normalize(Quaternionf q) {
     float m = std::sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
     return Quaternionf(q.x / m, q.y / m, q.z / m, q.w / m);
@@ -190,6 +191,31 @@ inline Matrix3x3f to_matrix3x3(Quaternionf q) {
              {2.0f * (x * y + w * z), 1.0f - 2.0f * (x * x + z * z), 2.0f * (z * y - w * x)},
              {2.0f * (x * z - w * y), 2.0f * (z * y + w * x), 1.0f - 2.0f * (x * x + y * y)}}};
 }
+// Conversions.h:36-70: rotation matrix to quaternion (x, y, z, w), branch on the trace and otherwise on the largest diagonal
+// element. Evaluated in T: the glTF loader decomposes its matrices in double and rounds after normalising.
+template <typename T>
+inline void to_quaternion(const T (&m)[3][3], T (&q)[4]) {
+    const T trace = m[0][0] + m[1][1] + m[2][2];
+    if (trace > T(0)) {
+        T s = std::sqrt(trace + T(1));
+        q[3] = s * T(0.5);
+        s = T(0.5) / s;
+        q[0] = (m[2][1] - m[1][2]) * s; q[1] = (m[0][2] - m[2][0]) * s; q[2] = (m[1][0] - m[0][1]) * s;
+        return;
+    }
+    const int next[3] = {1, 2, 0};
+    int i = 0;
+    if (m[1][1] > m[0][0]) i = 1;
+    if (m[2][2] > m[i][i]) i = 2;
+    const int j = next[i], k = next[j];
+    T s = std::sqrt((m[i][i] - (m[j][j] + m[k][k])) + T(1));
+    q[i] = s * T(0.5);
+    s = T(0.5) / s;
+    q[3] = (m[k][j] - m[j][k]) * s;
+    q[j] = (m[j][i] + m[i][j]) * s;
+    q[k] = (m[k][i] + m[i][k]) * s;
+}
+inline Quaternionf to_quaternion(const Matrix3x3f& m) { float q[4]; to_quaternion(m.m, q); return Quaternionf(q[0], q[1], q[2], q[3]); }
 inline Matrix3x4f to_matrix3x4(Transform t) {
     const Matrix3x3f r = to_matrix3x3(t.rotation);
     const float s = t.scale;

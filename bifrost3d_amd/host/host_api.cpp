@@ -8,7 +8,12 @@
 #include <string>
 
 #include "HIPRenderer/PresampledEnvironment.h"
+#include "HIPRenderer/Renderer.h"
+#include "ImageIO/PngImage.h"
+#include "ObjLoader/ObjLoader.h"
 #include "RNG.h"
+#include "SceneLoading.h"
+#include "glTFLoader/glTFLoader.h"
 
 #include <cmath>
 
@@ -61,6 +66,56 @@ void* hiprh_scene_create(const char* name, unsigned variant, unsigned param0, un
     if (variant & 2u) add_procedural_environment(*sb);
     sb->finalize();
     return sb;
+}
+
+// A model file (.obj, .gltf, .glb) set up the way SimpleViewer sets up a scene loaded from its command line
+// (apps/SimpleViewer/main.cpp:330-429): sky-blue environment tint, cut-out detection, camera placed from the scene bounds,
+// the default directional light when the file brings none. Textures: PNG only (ImageIO/PngImage.h). Null when the file
+// cannot be loaded. The Bifrost managers are scratch space here: whatever they held is dropped.
+void* hiprh_scene_load(const char* path, unsigned variant) {
+    using namespace Bifrost;
+    if (!path) return nullptr;
+    deallocate_all();
+    Scene::SceneRoot scene = Scene::SceneRoot("Model scene", RGB(0.68f, 0.92f, 1.0f));
+    Scene::SceneNode loaded = Scene::SceneNode::invalid();
+    if (ObjLoader::file_supported(path)) loaded = ObjLoader::load(path, PngImage::load);
+    else if (glTFLoader::file_supported(path)) loaded = glTFLoader::load(path);
+    if (loaded == Scene::SceneNode::invalid()) { deallocate_all(); return nullptr; }
+    loaded.set_parent(scene.get_root_node());
+    SceneLoading::detect_and_flag_cutout_materials();
+    const Scene::CameraID camera_ID = Scene::Cameras::create("Camera", scene.get_ID(), Math::Matrix4x4f::identity(), Math::Matrix4x4f::identity());
+    const SceneLoading::ViewerDefaults defaults = SceneLoading::apply_viewer_defaults(scene.get_root_node(), camera_ID, true);
+
+    if (variant & 1u)
+        for (Assets::MaterialID material_ID : Assets::Materials::get_iterable()) Assets::Material(material_ID).set_shading_model(Assets::ShadingModel::Diffuse);
+
+    SceneBuilder* sb = new SceneBuilder();
+    sb->set_environment_tint(Scene::SceneRoots::get_environment_tint(scene.get_ID()));
+    flatten_bifrost_scene(*sb);
+    sb->camera.transform = Scene::Cameras::get_transform(camera_ID);
+    sb->camera.near_plane = defaults.near_plane;
+    sb->camera.far_plane = defaults.far_plane;
+    deallocate_all();
+    return sb;
+}
+
+// Decodes a PNG file into 8 bit pixels (tests: cross-check of the decoder against an independent one). Returns the byte count
+// the image needs, 0 when the file cannot be decoded; copies the pixels when `capacity` is large enough. flip: bottom row first.
+size_t hiprh_png_load(const char* path, int flip, unsigned* width, unsigned* height, unsigned* channels, unsigned char* out, size_t capacity) {
+    using namespace Bifrost::Assets;
+    if (!path) return 0;
+    Image image = PngImage::load(path);
+    if (!image.exists()) return 0;
+    const unsigned w = image.get_width(), h = image.get_height(), c = unsigned(channel_count(image.get_pixel_format()));
+    const size_t bytes = size_t(w) * h * c;
+    if (width) *width = w;
+    if (height) *height = h;
+    if (channels) *channels = c;
+    if (out && capacity >= bytes)
+        for (unsigned y = 0; y < h; ++y)
+            std::memcpy(out + size_t(y) * w * c, image.get_pixels<unsigned char>() + size_t(flip ? y : h - 1 - y) * w * c, size_t(w) * c);
+    Images::destroy(image.get_ID());
+    return bytes;
 }
 
 void hiprh_scene_destroy(void* scene) { delete static_cast<SceneBuilder*>(scene); }

@@ -349,3 +349,23 @@ def test_environment_map_image_matches_oracle(ctx, oracle_q, scene_name):
     plain = Scene("cornell") if scene_name == "cornell" else Scene("atrium", param0=20000, param1=3)
     dark, _ = render_gpu(ctx, plain, w, h, 2, 4)
     assert abs(float(gpu[..., :3].mean()) - float(dark[..., :3].mean())) > 0.01
+
+
+@pytest.mark.parametrize("binary_container", [False, True])
+def test_loaded_gltf_image_matches_oracle(ctx, oracle_q, tmp_path, binary_container):
+    """file -> glTFLoader -> SimpleViewer defaults -> flattened scene -> the C-ABI: a glTF scene (instanced meshes under TRS and
+    matrix nodes, sheared copies, unindexed geometry) renders the same image on the device as in the oracle."""
+    pytest.importorskip("scipy")
+    from test_loaders_cpu import _write_synthetic_gltf
+    scene = Scene("file:" + _write_synthetic_gltf(str(tmp_path), binary_container))
+    assert scene.desc.triangle_count == 260 and scene.desc.light_count == 1
+    w, h, spp = 64, 36, 8
+    gpu, gc = render_gpu(ctx, scene, w, h, spp, 4)
+    cpu, cc, _ = oracle_q.render(scene.desc, scene.state, scene.camera(w, h, max_bounce_count=4), w, h, spp, use_bvh=ctx.oracle_search())
+    assert np.isfinite(gpu).all()
+    rel = np.abs(gpu[..., :3] - cpu[..., :3]) / (np.abs(cpu[..., :3]) + 1e-3)
+    assert (rel.max(axis=-1) <= 2e-3).mean() >= 0.95, float((rel.max(axis=-1) <= 2e-3).mean())
+    assert gc["closest_rays"] == cc["closest_rays"] or abs(gc["closest_rays"] - cc["closest_rays"]) <= 0.003 * cc["closest_rays"]
+    # the camera placed from the scene bounds (a scene size away from its centre) sees the model: part of the frame is not the sky-blue environment
+    sky = np.array([0.68, 0.92, 1.0])
+    assert (np.abs(gpu[..., :3] - sky).max(axis=-1) > 0.05).mean() > 0.01

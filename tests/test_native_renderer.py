@@ -24,6 +24,9 @@ def test_host_side_renderer_cases():
         assert f"[       OK ] EnvironmentFixture.{name}" in out, out[-4000:]
     for name in ("obj_shapes_materials_and_nodes", "single_shape_is_its_own_root_and_missing_files_fail", "viewer_defaults_place_camera_light_and_clip_planes"):
         assert f"[       OK ] LoaderFixture.{name}" in out, out[-4000:]
+    for name in ("json_reader", "png_round_trip", "triangle_is_mirrored_into_the_left_handed_frame", "hierarchy_transforms_and_residual_scaling",
+                 "materials_and_texture_channel_regrouping", "binary_container_and_vertex_colours", "malformed_files_create_nothing"):
+        assert f"[       OK ] glTFFixture.{name}" in out, out[-4000:]
 
 
 @pytest.mark.gpu
@@ -33,4 +36,5 @@ def test_reference_renderer_cases_on_gpu():
                  "scene_changes_restart_accumulation", "render_target_pitch_is_respected", "cornell_box_through_the_renderer_matches_the_c_abi", "adaptor_presents_the_flipped_viewport"):
         assert f"[       OK ] RendererFixture.{name}" in out, out[-4000:]
     assert "[       OK ] LoaderFixture.loaded_obj_renders_through_the_renderer" in out, out[-4000:]
+    assert "[       OK ] glTFFixture.loaded_gltf_renders_through_the_renderer" in out, out[-4000:]
     assert "[       OK ] EnvironmentFixture.renderer_shows_the_environment_map_behind_an_empty_scene" in out, out[-4000:]
