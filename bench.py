@@ -46,11 +46,11 @@ def parse_args():
     p.add_argument("--warmup", type=int, default=4)
     p.add_argument("--width", type=int, default=1920)
     p.add_argument("--height", type=int, default=1080)
-    p.add_argument("--scene", default="cornell_diffuse", choices=["cornell_diffuse", "cornell", "atrium"])
+    p.add_argument("--scene", default="cornell_diffuse", choices=["cornell_diffuse", "cornell", "atrium", "material", "material_coat"])
     p.add_argument("--scene-file", default=None, help="render a model file (.gltf / .glb / .obj, PNG textures) set up the way SimpleViewer sets up a scene from its command line; "
                    "not the headline workload: the line's config.workload names the file")
     p.add_argument("--atrium-triangles", type=int, default=260000)
-    p.add_argument("--bounces", type=int, default=4)
+    p.add_argument("--bounces", type=int, default=None, help="max_bounce_count; default 4, and 32 for the material scenes (the viewer's setting, apps/SimpleViewer/main.cpp:353)")
     p.add_argument("--spp-per-pass", type=int, default=8, help="accumulations traced together per step and GPU (HiprFrameDesc::samples_per_pass)")
     p.add_argument("--wavefronts", type=int, default=1, choices=[1, 2],
                    help="2: each pass runs as two half-frame wavefronts on two streams (one shades while the other traces); faster, but concurrent kernels "
@@ -65,6 +65,8 @@ def parse_args():
 
 def make_scene(args):
     from bifrost3d_amd.host import Scene
+    if args.bounces is None:
+        args.bounces = 32 if args.scene in ("material", "material_coat") and not args.scene_file else 4
     if args.scene_file:
         scene = Scene("file:" + args.scene_file)
         args.scene = "file:" + os.path.basename(args.scene_file)
@@ -73,6 +75,10 @@ def make_scene(args):
         return Scene("cornell", diffuse_only=True), "SimpleViewer Cornell box (34 triangles, 1 sphere light), all materials Diffuse"
     if args.scene == "cornell":
         return Scene("cornell"), "SimpleViewer Cornell box (34 triangles, 1 sphere light), reference materials"
+    if args.scene in ("material", "material_coat"):
+        return (Scene("material", coat=args.scene == "material_coat"),
+                "SimpleViewer material scene (BASELINE config 3): 7 shader balls (procedural stand-in for Shaderball.gltf, 179 k triangles) blending dielectric to gold"
+                + (", coat 1 / coat roughness 0.7" if args.scene == "material_coat" else "") + ", checkered textured floor, directional light, 32 bounces")
     return Scene("atrium", param0=args.atrium_triangles, param1=1), f"procedural atrium ({args.atrium_triangles} triangles target), DefaultShading"
 
 

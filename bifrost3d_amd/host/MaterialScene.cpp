@@ -1,0 +1,219 @@
+// MaterialScene.cpp -- see MaterialScene.h.
+#include "MaterialScene.h"
+
+#include "glTFLoader/glTFLoader.h"
+
+#include <cmath>
+#include <cstdio>
+#include <vector>
+
+using namespace Bifrost;
+using namespace Bifrost::Assets;
+using namespace Bifrost::Math;
+using namespace Bifrost::Scene;
+
+namespace ViewerScenes {
+
+namespace {
+
+const RGB gold_tint = RGB(1.000f, 0.766f, 0.336f);      // BF/Assets/Material.h:67
+
+inline float lerp(float a, float b, float t) { return a + (b - a) * t; }
+inline RGB lerp(RGB a, RGB b, float t) { return RGB(lerp(a.r, b.r, t), lerp(a.g, b.g, t), lerp(a.b, b.b, t)); }
+
+MeshModel attached_mesh_model(SceneNode node) {
+    for (MeshModelID model_ID : MeshModels::get_iterable())
+        if (MeshModels::get_scene_node_ID(model_ID) == node.get_ID()) return model_ID;
+    return MeshModel();
+}
+
+template <typename F>
+void apply_to_children_recursively(SceneNode node, F&& f) {
+    for (SceneNodeID child : node.get_children()) { f(SceneNode(child)); apply_to_children_recursively(SceneNode(child), f); }
+}
+
+void apply_delta_transform(SceneNode node, Transform delta) { node.set_global_transform(node.get_global_transform() * delta); }   // BF/Scene/SceneNode.cpp:227-234
+
+// Material.cpp:121-141: a new node per node of the hierarchy, sharing meshes and materials.
+SceneNode shallow_clone(SceneNode node) {
+    SceneNode cloned_node = SceneNode(node.get_name(), node.get_global_transform());
+    MeshModel mesh_model = attached_mesh_model(node);
+    if (mesh_model.get_ID() != MeshModelID::invalid_UID()) MeshModel(cloned_node, mesh_model.get_mesh(), mesh_model.get_material());
+    for (SceneNodeID child : node.get_children()) {
+        SceneNode cloned_child = shallow_clone(SceneNode(child));
+        cloned_child.set_parent(cloned_node);
+    }
+    return cloned_node;
+}
+
+void replace_material(Material material, SceneNode parent_node, const std::string& child_scene_node_name) {     // Utils.cpp:64-72
+    apply_to_children_recursively(parent_node, [&](SceneNode node) {
+        if (node.get_name() != child_scene_node_name) return;
+        MeshModel mesh_model = attached_mesh_model(node);
+        if (mesh_model.get_ID() != MeshModelID::invalid_UID()) MeshModels::set_material_ID(mesh_model.get_ID(), material.get_ID());
+    });
+}
+
+// BF/Assets/MeshCreation.cpp:328-392 revolved_sphere: a latitude-longitude sphere of radius 0.5, the pole rows collapsed to points
+// and their degenerate triangles left out.
+Mesh revolved_sphere(const std::string& name, unsigned longitude_quads, unsigned latitude_quads) {
+    const unsigned latitude_size = latitude_quads + 1, longitude_size = longitude_quads + 1;
+    const float radius = 0.5f;
+    MeshFlags buffers = MeshFlag::Position; buffers |= MeshFlag::Normal; buffers |= MeshFlag::Texcoord;
+    Mesh mesh = Mesh(name, (latitude_quads * longitude_quads - longitude_quads) * 2, latitude_size * longitude_size, buffers);
+    for (unsigned y = 0; y < latitude_size; ++y)
+        for (unsigned x = 0; x < longitude_size; ++x) {
+            const unsigned v = y * longitude_size + x;
+            const Vector2f tc = {float(x) * (1.0f / longitude_quads), float(y) * (1.0f / latitude_quads)};
+            const float theta = tc.y * PI<float>(), phi = tc.x * 2.0f * PI<float>(), sin_theta = std::sin(theta);
+            mesh.get_texcoords()[v] = tc;
+            mesh.get_positions()[v] = Vector3f(-sin_theta * std::sin(phi), std::cos(theta), sin_theta * std::cos(phi)) * radius;
+            mesh.get_normals()[v] = normalize(mesh.get_positions()[v]);
+        }
+    for (unsigned x = 0; x < longitude_size; ++x) {
+        mesh.get_positions()[x] = Vector3f(0, radius, 0);
+        mesh.get_positions()[(latitude_size - 1) * longitude_size + x] = Vector3f(0, -radius, 0);
+    }
+    Vector3ui* primitives = mesh.get_primitives();
+    for (unsigned y = 0; y < latitude_quads; ++y)
+        for (unsigned x = 0; x < longitude_quads; ++x) {
+            const unsigned base = x + y * longitude_size;
+            if (y != 0) *primitives++ = Vector3ui{base, base + 1, base + longitude_size};
+            if (y != latitude_quads - 1) *primitives++ = Vector3ui{base + 1, base + longitude_size + 1, base + longitude_size};
+        }
+    mesh.set_bounds(AABB{Vector3f(-radius), Vector3f(radius)});
+    return mesh;
+}
+
+SceneNode create_procedural_shader_ball(Material outer_material, Material inner_material) {
+    SceneNode ball_node = SceneNode("ShaderBall");
+    SceneNode outer_node = SceneNode("Node5");
+    MeshModel(outer_node, revolved_sphere("ShaderBallOuter", 96, 64), outer_material);
+    outer_node.set_parent(ball_node);
+
+    // The rubber part: a flattened sphere under the ball that reaches out beyond it as a base.
+    Mesh base = revolved_sphere("ShaderBallBase", 104, 66);
+    const Matrix3x4f squash = {{{0.9f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.16f, 0.0f, -0.42f}, {0.0f, 0.0f, 0.9f, 0.0f}}};
+    MeshUtils::transform_mesh(base, squash);
+    SceneNode inner_node = SceneNode("Node2");
+    MeshModel(inner_node, base, inner_material);
+    inner_node.set_parent(ball_node);
+    return ball_node;
+}
+
+} // namespace
+
+SceneNode create_checkered_floor(float floor_size, float checker_size) {
+    const unsigned size = 2;
+    unsigned char tint_roughness_pixels[size * size * 4];
+    for (unsigned y = 0; y < size; ++y)
+        for (unsigned x = 0; x < size; ++x) {
+            const bool is_black = (x & 1) != (y & 1);
+            unsigned char* pixel = tint_roughness_pixels + (x + y * size) * 4u;
+            pixel[0] = pixel[1] = pixel[2] = is_black ? 1 : 255;
+            pixel[3] = is_black ? 15 : 255;
+        }
+    Image tint_roughness_image = Image::create2D("Floor color", PixelFormat::RGBA32, true, size, size, tint_roughness_pixels);
+
+    Materials::Data material_data = Materials::Data::create_dielectric(RGB(1.0f), 0.4f, 0.04f);
+    material_data.tint_roughness_texture_ID = Textures::create2D(tint_roughness_image.get_ID(), MagnificationFilter::None, MinificationFilter::Trilinear);
+    material_data.flags = MaterialFlag::ThinWalled;
+    Material material = Material("Floor", material_data);
+
+    // Mesh scaled to the floor size, texture coordinates to match the checker size.
+    MeshFlags buffers = MeshFlag::Position; buffers |= MeshFlag::Texcoord;
+    Mesh plane_mesh = MeshCreation::plane(2, buffers);
+    for (unsigned v = 0; v < plane_mesh.get_vertex_count(); ++v) plane_mesh.get_positions()[v] = plane_mesh.get_positions()[v] * floor_size;
+    const float uv_scale = floor_size / (2 * checker_size);     // a texture is 2 x 2 checkers
+    for (unsigned v = 0; v < plane_mesh.get_vertex_count(); ++v) {
+        Vector2f& texcoord = plane_mesh.get_texcoords()[v];
+        texcoord = Vector2f{(texcoord.x - 0.5f) * uv_scale, (texcoord.y - 0.5f) * uv_scale};     // centred: texcoords stay precise near the middle of the floor
+    }
+    plane_mesh.compute_bounds();
+
+    SceneNode plane_node = SceneNode("Floor");
+    MeshModel(plane_node, plane_mesh, material);
+    return plane_node;
+}
+
+SceneNode load_shader_ball(const std::string& shader_ball_path, Material material) {
+    Material rubber_material = Material::create_dielectric("Rubber", RGB(0.05f), 1);    // the inside
+    if (shader_ball_path.empty()) return create_procedural_shader_ball(material, rubber_material);
+
+    printf("Mori knob curtesy of Yasutoshi Mori\n");
+    SceneNode shader_ball_node = glTFLoader::load(shader_ball_path);
+    if (shader_ball_node == SceneNode::invalid()) return shader_ball_node;
+
+    std::vector<MeshModel> discarded;
+    apply_to_children_recursively(shader_ball_node, [&](SceneNode node) {
+        MeshModel mesh_model = attached_mesh_model(node);
+        if (mesh_model.get_ID() == MeshModelID::invalid_UID()) return;
+        if (node.get_name() == "Node5") MeshModels::set_material_ID(mesh_model.get_ID(), material.get_ID());
+        else if (node.get_name() == "Node2") MeshModels::set_material_ID(mesh_model.get_ID(), rubber_material.get_ID());
+        else discarded.push_back(mesh_model);     // anything but the shader ball
+    });
+    for (MeshModel mesh_model : discarded) {
+        Meshes::destroy(mesh_model.get_mesh().get_ID());
+        Materials::destroy(mesh_model.get_material().get_ID());
+        MeshModels::destroy(mesh_model.get_ID());
+    }
+    return shader_ball_node;
+}
+
+void create_material_scene(CameraID camera_ID, SceneNode root_node, const std::string& shader_ball_path, bool coat) {
+    { // Camera.
+        Transform cam_transform = Cameras::get_transform(camera_ID);
+        cam_transform.translation = Vector3f(0, 5.5f, -18.5f);
+        cam_transform.look_at(Vector3f(0, 0.5f, 0.0f));
+        Cameras::set_transform(camera_ID, cam_transform);
+    }
+    { // A directional light.
+        Transform light_transform = Transform(Vector3f(20.0f, 20.0f, -20.0f));
+        light_transform.look_at(Vector3f::zero());
+        SceneNode light_node = SceneNode("light", light_transform);
+        light_node.set_parent(root_node);
+        LightSources::create_directional_light(light_node.get_ID(), RGB(3.0f, 2.9f, 2.5f));
+    }
+    { // Checkered floor.
+        SceneNode floor_node = create_checkered_floor(400, 1);
+        floor_node.set_global_transform(Transform(Vector3f(0, -1.0f, 0)));
+        floor_node.set_parent(root_node);
+    }
+
+    // The blended materials (Material.cpp:30-47).
+    const int material_count = 7;
+    Materials::Data material0_data = Materials::Data::create_dielectric(RGB(0.02f, 0.27f, 0.33f), 1.0f, 0.04f);
+    Materials::Data material1_data = Materials::Data::create_metal(gold_tint, 0.02f);
+    material1_data.specularity = material0_data.specularity;
+    Material materials[material_count];
+    for (int m = 0; m < material_count; ++m) {
+        const float lerp_t = m / (material_count - 1.0f);
+        Materials::Data material_data = {};
+        material_data.tint = lerp(material0_data.tint, material1_data.tint, lerp_t);
+        material_data.roughness = lerp(material0_data.roughness, material1_data.roughness, lerp_t);
+        material_data.specularity = lerp(material0_data.specularity, material1_data.specularity, lerp_t);
+        material_data.metallic = lerp(material0_data.metallic, material1_data.metallic, lerp_t);
+        material_data.coverage = lerp(material0_data.coverage, material1_data.coverage, lerp_t);
+        if (coat) { material_data.coat = 1.0f; material_data.coat_roughness = 0.7f; }
+        materials[m] = Material("Lerped material " + std::to_string(m), material_data);
+    }
+
+    { // The material models.
+        const float shader_ball_distance = 1.2f;
+        SceneNode shader_ball_node = load_shader_ball(shader_ball_path, materials[0]);
+        if (shader_ball_node == SceneNode::invalid()) return;
+        shader_ball_node.set_global_transform(Transform(Vector3f::zero(), Quaternionf::identity(), 2.0f));
+        const float shader_ball_pos_x = -shader_ball_distance * 0.5f * (material_count - 1);
+        apply_delta_transform(shader_ball_node, Transform(Vector3f(shader_ball_pos_x, 0, 0)));
+        shader_ball_node.set_parent(root_node);
+
+        for (int m = 1; m < material_count; ++m) {
+            SceneNode shader_ball_node_clone = shallow_clone(shader_ball_node);
+            apply_delta_transform(shader_ball_node_clone, Transform(Vector3f(m * shader_ball_distance, 0, 0)));
+            shader_ball_node_clone.set_parent(root_node);
+            replace_material(materials[m], shader_ball_node_clone, "Node5");     // the outer surface shows the tested material
+        }
+    }
+}
+
+} // namespace ViewerScenes

@@ -10,6 +10,7 @@
 #include "HIPRenderer/PresampledEnvironment.h"
 #include "HIPRenderer/Renderer.h"
 #include "ImageIO/PngImage.h"
+#include "MaterialScene.h"
 #include "ObjLoader/ObjLoader.h"
 #include "RNG.h"
 #include "SceneLoading.h"
@@ -53,8 +54,11 @@ extern "C" {
 
 // name: "cornell" | "atrium" | "quad" | "empty_ortho". variant bit 1: light the scene with a procedural environment map. variant bit 0: force every material to the Diffuse
 // shading model (BASELINE.json config 2). param0/param1: atrium target triangles + seed, ortho width + height.
+static void* create_material_scene(const std::string& shader_ball_path, unsigned variant);
+
 void* hiprh_scene_create(const char* name, unsigned variant, unsigned param0, unsigned param1) {
     if (!name) return nullptr;
+    if (!std::strncmp(name, "material", 8) && (name[8] == 0 || name[8] == ':')) return create_material_scene(name[8] ? name + 9 : "", variant);
     SceneBuilder* sb = new SceneBuilder();
     std::string n = name;
     if (n == "cornell") Scenes::create_cornell_box(*sb, param0 ? param0 : 1u);   // param0: quads per wall edge
@@ -65,6 +69,31 @@ void* hiprh_scene_create(const char* name, unsigned variant, unsigned param0, un
     if (variant & 1u) sb->force_shading_model(HIPR_SHADING_DIFFUSE);
     if (variant & 2u) add_procedural_environment(*sb);
     sb->finalize();
+    return sb;
+}
+
+// "material" | "material:<path to Shaderball.gltf>": SimpleViewer's material test scene (BASELINE.json config 3) built in the
+// Bifrost managers and flattened, with the viewer's clip planes and its 32 bounces (apps/SimpleViewer/main.cpp:353,428-429).
+// variant bit 0: all materials Diffuse; bit 2: the coated variant. The Bifrost managers are scratch space here.
+static void* create_material_scene(const std::string& shader_ball_path, unsigned variant) {
+    using namespace Bifrost;
+    deallocate_all();
+    Scene::SceneRoot scene = Scene::SceneRoot("Model scene", RGB(0.68f, 0.92f, 1.0f));
+    const Scene::CameraID camera_ID = Scene::Cameras::create("Camera", scene.get_ID(), Math::Matrix4x4f::identity(), Math::Matrix4x4f::identity());
+    ViewerScenes::create_material_scene(camera_ID, scene.get_root_node(), shader_ball_path, (variant & 4u) != 0);
+    if (Assets::MeshModels::get_iterable().size() < 2) { deallocate_all(); return nullptr; }     // the shader ball did not load
+    const SceneLoading::ViewerDefaults defaults = SceneLoading::apply_viewer_defaults(scene.get_root_node(), camera_ID, false);
+    if (variant & 1u)
+        for (Assets::MaterialID material_ID : Assets::Materials::get_iterable()) Assets::Material(material_ID).set_shading_model(Assets::ShadingModel::Diffuse);
+
+    SceneBuilder* sb = new SceneBuilder();
+    sb->set_environment_tint(Scene::SceneRoots::get_environment_tint(scene.get_ID()));
+    flatten_bifrost_scene(*sb);
+    sb->camera.transform = Scene::Cameras::get_transform(camera_ID);
+    sb->camera.near_plane = defaults.near_plane;
+    sb->camera.far_plane = defaults.far_plane;
+    sb->camera.max_bounce_count = 32;
+    deallocate_all();
     return sb;
 }
 

@@ -369,3 +369,24 @@ def test_loaded_gltf_image_matches_oracle(ctx, oracle_q, tmp_path, binary_contai
     # the camera placed from the scene bounds (a scene size away from its centre) sees the model: part of the frame is not the sky-blue environment
     sky = np.array([0.68, 0.92, 1.0])
     assert (np.abs(gpu[..., :3] - sky).max(axis=-1) > 0.05).mean() > 0.01
+
+
+@pytest.mark.parametrize("coat", [False, True])
+def test_material_scene_image_matches_oracle(ctx, oracle_q, coat):
+    """BASELINE config 3: the viewer's material scene (seven shader balls from rough dielectric to polished gold, optionally
+    coated, on the checkered floor whose texture carries roughness in alpha, repeat wrapping, nearest magnification), 179 k
+    triangles through the wide-BVH kernels, 32 bounces."""
+    scene = Scene("material", coat=coat)
+    assert scene.camera(64, 36).max_bounce_count == 32
+    w, h, spp = 96, 54, 4
+    gpu, gc = render_gpu(ctx, scene, w, h, spp, 32)
+    assert ctx.trace_variant() == capi.TRACE_WIDE_PERSISTENT
+    cpu, cc, _ = oracle_q.render(scene.desc, scene.state, scene.camera(w, h, max_bounce_count=32), w, h, spp, use_bvh=ctx.oracle_search())
+    assert np.isfinite(gpu).all()
+    rel = np.abs(gpu[..., :3] - cpu[..., :3]) / (np.abs(cpu[..., :3]) + 1e-3)
+    assert (rel.max(axis=-1) <= 2e-3).mean() >= 0.95, float((rel.max(axis=-1) <= 2e-3).mean())
+    for key in ("closest_rays", "shadow_rays"):
+        assert abs(gc[key] - cc[key]) <= 0.003 * cc[key], (key, gc[key], cc[key])
+    # the floor's checker is there: neighbouring texels of very different brightness below the horizon
+    lower = gpu[: h // 3, :, :3].mean(axis=-1)
+    assert lower.max() > 4 * lower.min()

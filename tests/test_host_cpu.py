@@ -312,3 +312,39 @@ def test_presampled_environment_scene_description():
     # the sun dominates the importance: most samples point into its few texels
     sun = np.array([0.4, 0.7, -0.3]) / np.linalg.norm([0.4, 0.7, -0.3])
     assert (direction @ sun > 0.95).mean() > 0.3
+
+
+def test_material_scene_description():
+    """BASELINE config 3, apps/SimpleViewer/Scenes/Material.cpp:143-188: seven shader balls (two models each) and the floor,
+    blended materials from a rough teal dielectric to polished gold, the floor's checker texture with roughness in alpha."""
+    from bifrost3d_amd.host import Scene
+    scene = Scene("material")
+    d = scene.desc
+    assert d.instance_count == 15 and d.light_count == 1
+    assert d.triangle_count == 7 * (12096 + 13520) + 8
+    assert d.texture_count == 2                      # slot 0 is the invalid texture
+    cam = scene.camera(64, 36)
+    assert cam.max_bounce_count == 32
+    assert tuple(round(v, 2) for v in scene.state.environment_tint) == (0.68, 0.92, 1.0)
+    unorm16 = lambda bits: bits / 65535.0      # coat and coat roughness travel as unorm16 (OR/Types.h Material)
+    materials = [d.materials[i] for i in range(d.material_count)]
+    named = {i: m for i, m in enumerate(materials)}
+    outer = sorted({d.instances[i].material_index for i in range(d.instance_count)})
+    blended = [named[i] for i in outer if named[i].metallic > 0 or abs(named[i].tint[0] - 0.02) < 1e-6]
+    assert len(blended) == 7
+    blended.sort(key=lambda m: m.metallic)
+    for k, m in enumerate(blended):
+        t = k / 6.0
+        assert abs(m.metallic - t) < 1e-6 and abs(m.roughness - (1.0 + (0.02 - 1.0) * t)) < 1e-6
+        assert abs(m.tint[0] - (0.02 + (1.0 - 0.02) * t)) < 1e-6 and abs(m.specularity - 0.04) < 1e-7
+        assert unorm16(m.coat) == 0.0
+    floor = [named[i] for i in outer if named[i].tint_roughness_texture_ID != 0]
+    assert len(floor) == 1 and abs(floor[0].roughness - 0.4) < 1e-7 and floor[0].flags & 1      # thin walled
+    coated_scene = Scene("material", coat=True)     # keep the owner of the description alive
+    coated = coated_scene.desc
+    assert sum(1 for i in range(coated.material_count) if unorm16(coated.materials[i].coat) == 1.0 and abs(unorm16(coated.materials[i].coat_roughness) - 0.7) < 1e-3) == 7
+    # the balls stand 2.4 apart on the floor at y = -1
+    tris = scene.triangles()[:, :9].copy().view(np.float32).reshape(-1, 3, 3)
+    assert abs(tris[..., 1].min() + 1.0) < 1e-5
+    inside = np.abs(tris[..., 0]).max(axis=1) < 50.0          # everything but the floor
+    assert abs(tris[inside][..., 0].min() + 8.2) < 0.15 and abs(tris[inside][..., 0].max() - 8.2) < 0.15
