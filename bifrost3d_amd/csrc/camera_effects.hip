@@ -3,8 +3,8 @@
 // (extensions/DX11Renderer/DX11Renderer/CameraEffects.{h,cpp} and Shaders/CameraEffects/*.hlsl), whose stages and arithmetic
 // each kernel cites. All of it is HBM-bound image work: one pass over the 8 B/pixel frame per stage.
 //
-//   k_exposure_histogram        64-bin log-luminance histogram: LDS histograms replicated 16 x per wave, one global atomic per bin and block
-//   k_exposure_from_histogram   one wave: prefix sum, percentile clamp, weighted luminance, eye adaptation
+//   k_exposure_histogram        64-bin log-luminance histogram: LDS histograms replicated 16 x per wave, one histogram per block to global memory
+//   k_exposure_from_histogram   one wave: sums the blocks' histograms, prefix sum, percentile clamp, weighted luminance, eye adaptation
 //   k_log_luminance_partials / k_log_average_finish   two-level sum of log2 luminance -> log average or key-value exposure
 //   k_exposure_from_bias        fixed exposure with eye adaptation
 //   k_bloom_horizontal / k_bloom_vertical   separable Gaussian through bilinearly placed taps, half4 intermediates
@@ -65,8 +65,9 @@ struct ExposureConstants {
 // ---- exposure histogram (ReduceExposureHistogram.hlsl:27-70) ---------------------------------------------------------------------
 // Blocks stride over the viewport's pixels in row-major order (coalesced 8 B loads). Each wave owns 16 copies of the 64 bins in
 // LDS, lane l counts into copy l % 16: a flat region of the image, where all 64 lanes hit one bin, costs 4 serialised LDS
-// atomics instead of 64.
-__global__ __launch_bounds__(REDUCE_BLOCK) void k_exposure_histogram(DeviceFrame frame, float min_log_luminance, float max_log_luminance, uint32_t* __restrict__ histogram) {
+// atomics instead of 64. Every block writes its own 64 bins; whoever consumes the histogram adds the blocks up (a few hundred
+// coalesced loads), which costs less than tens of thousands of global atomics meeting in 64 addresses, and needs no clearing.
+__global__ __launch_bounds__(REDUCE_BLOCK) void k_exposure_histogram(DeviceFrame frame, float min_log_luminance, float max_log_luminance, uint32_t* __restrict__ block_histograms) {
     __shared__ uint32_t s_bins[(REDUCE_BLOCK / 64) * HISTOGRAM_REPLICAS * BINS];
     for (uint32_t i = threadIdx.x; i < (REDUCE_BLOCK / 64) * HISTOGRAM_REPLICAS * BINS; i += REDUCE_BLOCK) s_bins[i] = 0u;
     __syncthreads();
@@ -86,17 +87,44 @@ __global__ __launch_bounds__(REDUCE_BLOCK) void k_exposure_histogram(DeviceFrame
     if (threadIdx.x < BINS) {
         uint32_t total = 0;
         for (int copy = 0; copy < (REDUCE_BLOCK / 64) * HISTOGRAM_REPLICAS; ++copy) total += s_bins[copy * BINS + threadIdx.x];
-        if (total) atomicAdd(&histogram[threadIdx.x], total);
+        block_histograms[blockIdx.x * BINS + threadIdx.x] = total;
     }
 }
 
+// Adds up the blocks' histograms with all 16 waves of a 1024-thread block (wave w takes blocks w, w + 16, ...): a single wave
+// walking hundreds of rows one load after the other would take longer than the histogram pass itself. Result in s_total[0..63].
+constexpr int SUM_BLOCK = 1024;
+__device__ __forceinline__ void sum_block_histograms(const uint32_t* __restrict__ block_histograms, uint32_t block_count, uint32_t* s_partial, uint32_t* s_total) {
+    const uint32_t wave = threadIdx.x / 64, bin = threadIdx.x % 64;
+    uint32_t total = 0;
+#pragma unroll 4
+    for (uint32_t b = wave; b < block_count; b += SUM_BLOCK / 64) total += block_histograms[b * BINS + bin];
+    s_partial[wave * BINS + bin] = total;
+    __syncthreads();
+    if (threadIdx.x < BINS) {
+        uint32_t sum = 0;
+        for (int w = 0; w < SUM_BLOCK / 64; ++w) sum += s_partial[w * BINS + threadIdx.x];
+        s_total[threadIdx.x] = sum;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(SUM_BLOCK) void k_sum_histograms(const uint32_t* __restrict__ block_histograms, uint32_t block_count, uint32_t* __restrict__ histogram) {
+    __shared__ uint32_t s_partial[(SUM_BLOCK / 64) * BINS], s_total[BINS];
+    sum_block_histograms(block_histograms, block_count, s_partial, s_total);
+    if (threadIdx.x < BINS) histogram[threadIdx.x] = s_total[threadIdx.x];
+}
+
 // ---- exposure from the histogram (ReduceExposureHistogram.hlsl:82-154): one wave, lane = bin ----------------------------------------
-__global__ __launch_bounds__(64) void k_exposure_from_histogram(const uint32_t* __restrict__ histogram, ExposureConstants c, float* __restrict__ linear_exposure) {
-    __shared__ float s_prefix[BINS + 1];
+__global__ __launch_bounds__(SUM_BLOCK) void k_exposure_from_histogram(const uint32_t* __restrict__ block_histograms, uint32_t block_count, ExposureConstants c, float* __restrict__ linear_exposure) {
+    __shared__ uint32_t s_partial[(SUM_BLOCK / 64) * BINS], s_total[BINS];
+    sum_block_histograms(block_histograms, block_count, s_partial, s_total);
+    if (threadIdx.x >= BINS) return;        // the rest is one wave's work, lane = bin
     const int bin = threadIdx.x;
+    const uint32_t bin_total = s_total[bin];
 
     // Exclusive prefix sum of the bin counts. The values are whole numbers below 2^24, so any summation order is exact in f32.
-    const float count = float(histogram[bin]);
+    const float count = float(bin_total);
     float inclusive = count;
     for (int offset = 1; offset < BINS; offset <<= 1) {
         const float below = __shfl_up(inclusive, offset);
@@ -106,11 +134,9 @@ __global__ __launch_bounds__(64) void k_exposure_from_histogram(const uint32_t* 
     const float max_pixel_count = total * c.max_percentage;
     const float min_pixel_count = total * c.min_percentage;
     // Clamp the prefix sum to the percentile window: counts above the upper bound and below the lower bound drop out.
-    s_prefix[bin] = fmaxf(0.0f, fminf(inclusive - count, max_pixel_count) - min_pixel_count);
-    if (bin == BINS - 1) s_prefix[BINS] = max_pixel_count - min_pixel_count;
-    __syncthreads();
-
-    const float bin_count = s_prefix[bin + 1] - s_prefix[bin];
+    const float clamped = fmaxf(0.0f, fminf(inclusive - count, max_pixel_count) - min_pixel_count);
+    const float next_clamped = __shfl_down(clamped, 1);
+    const float bin_count = (bin == BINS - 1 ? max_pixel_count - min_pixel_count : next_clamped) - clamped;
     const float normalized_index = (bin + 0.5f) / BINS;
     const float bin_log_luminance = c.min_log_luminance + normalized_index * (c.max_log_luminance - c.min_log_luminance);
     float weighted = exp2f(bin_log_luminance) * bin_count;
@@ -223,6 +249,7 @@ __global__ __launch_bounds__(256) void k_bloom_vertical(const uint2* __restrict_
 struct TonemapConstants {
     float bloom_threshold, vignette_strength, film_grain_strength, delta_time;
     float black_clip, toe, slope, shoulder, white_clip;
+    float toe_scale, shoulder_scale, toe_match, shoulder_match;     // the curve's frame-uniform parameters (Tonemapping.hlsl:79-94), evaluated once on the host
     float sRGB_to_AP1[9];     // XYZ_to_AP1 * D65_to_D60 * sRGB_to_XYZ, multiplied on the host in f32 like the shader compiler's constant folding
 };
 
@@ -235,18 +262,7 @@ __device__ float3_ unreal4(float3_ color, const TonemapConstants& c) {     // To
     const float pre_luminance = working.x * 0.2722287168f + working.y * 0.6740817658f + working.z * 0.0536895174f;
     working = lerp3({pre_luminance, pre_luminance, pre_luminance}, working, 0.96f);
 
-    const float toe_scale = 1.0f + c.black_clip - c.toe;
-    const float shoulder_scale = 1.0f + c.white_clip - c.shoulder;
-    const float in_match = 0.18f, out_match = 0.18f;
-    float toe_match;
-    if (c.toe > 0.8f)
-        toe_match = (1.0f - c.toe - out_match) / c.slope + log10f(in_match);
-    else {
-        const float bt = (out_match + c.black_clip) / toe_scale - 1.0f;
-        toe_match = log10f(in_match) - 0.5f * logf((1.0f + bt) / (1.0f - bt)) * (toe_scale / c.slope);
-    }
-    const float straight_match = (1.0f - c.toe) / c.slope - toe_match;
-    const float shoulder_match = c.shoulder / c.slope - straight_match;
+    const float toe_scale = c.toe_scale, shoulder_scale = c.shoulder_scale, toe_match = c.toe_match, shoulder_match = c.shoulder_match;
 
     float tone[3];
     const float channels[3] = {working.x, working.y, working.z};
@@ -359,6 +375,8 @@ struct HiprCameraEffects {
     std::string last_error;
 
     uint32_t* histogram = nullptr;          // 64 bins
+    uint32_t* block_histograms = nullptr;   // MAX_PARTIALS x 64 bins, one row per block of the histogram kernel
+    unsigned histogram_blocks = 0;
     float* linear_exposure = nullptr;       // carried from frame to frame
     float* partials = nullptr;              // MAX_PARTIALS
     float* scratch_scalar = nullptr;
@@ -406,7 +424,7 @@ ExposureConstants exposure_constants(const HiprCameraEffectsSettings& s, float d
 unsigned reduce_blocks(const HiprCameraEffects* fx, const HiprFrameView& frame) {
     const uint64_t pixels = uint64_t(frame.viewport.width) * uint64_t(frame.viewport.height);
     const uint64_t wanted = (pixels + REDUCE_BLOCK * 4 - 1) / (REDUCE_BLOCK * 4);       // at least four pixels per thread before another block pays for itself
-    return unsigned(std::min<uint64_t>(std::max<uint64_t>(wanted, 1), std::min<uint64_t>(MAX_PARTIALS, fx->compute_units * 4ull)));
+    return unsigned(std::min<uint64_t>(std::max<uint64_t>(wanted, 1), std::min<uint64_t>(MAX_PARTIALS, fx->compute_units * 2ull)));
 }
 
 struct StageTimer {
@@ -424,8 +442,8 @@ struct StageTimer {
 };
 
 int enqueue_histogram(HiprCameraEffects* fx, const HiprCameraEffectsSettings& s, const HiprFrameView& frame) {
-    FX_HIP(hipMemsetAsync(fx->histogram, 0, BINS * sizeof(uint32_t), fx->stream));
-    hipLaunchKernelGGL(k_exposure_histogram, dim3(reduce_blocks(fx, frame)), dim3(REDUCE_BLOCK), 0, fx->stream, device_frame(frame), s.min_log_luminance, s.max_log_luminance, fx->histogram);
+    fx->histogram_blocks = reduce_blocks(fx, frame);
+    hipLaunchKernelGGL(k_exposure_histogram, dim3(fx->histogram_blocks), dim3(REDUCE_BLOCK), 0, fx->stream, device_frame(frame), s.min_log_luminance, s.max_log_luminance, fx->block_histograms);
     FX_HIP(hipGetLastError());
     return HIPR_OK;
 }
@@ -533,7 +551,7 @@ int hipr_camera_effects_create(int device_index, HiprCameraEffects** out) {
     if (hipGetDeviceProperties(&properties, device_index) == hipSuccess && properties.multiProcessorCount > 0) fx->compute_units = unsigned(properties.multiProcessorCount);
     if (hipStreamCreateWithFlags(&fx->stream, hipStreamNonBlocking) != hipSuccess) return cleanup(HIPR_ERROR_HIP);
     if (hipMalloc(&fx->histogram, BINS * sizeof(uint32_t)) != hipSuccess || hipMalloc(&fx->linear_exposure, sizeof(float)) != hipSuccess ||
-        hipMalloc(&fx->partials, MAX_PARTIALS * sizeof(float)) != hipSuccess || hipMalloc(&fx->scratch_scalar, sizeof(float)) != hipSuccess)
+        hipMalloc(&fx->partials, MAX_PARTIALS * sizeof(float)) != hipSuccess || hipMalloc(&fx->block_histograms, MAX_PARTIALS * BINS * sizeof(uint32_t)) != hipSuccess || hipMalloc(&fx->scratch_scalar, sizeof(float)) != hipSuccess)
         return cleanup(HIPR_ERROR_OUT_OF_MEMORY);
     if (hipMemset(fx->linear_exposure, 0, sizeof(float)) != hipSuccess) return cleanup(HIPR_ERROR_HIP);
     if (hipEventCreate(&fx->event_begin) != hipSuccess || hipEventCreate(&fx->event_end) != hipSuccess) return cleanup(HIPR_ERROR_HIP);
@@ -545,7 +563,7 @@ void hipr_camera_effects_destroy(HiprCameraEffects* fx) {
     if (!fx) return;
     (void)hipSetDevice(fx->device);
     if (fx->stream) (void)hipStreamSynchronize(fx->stream);
-    for (void* p : {(void*)fx->histogram, (void*)fx->linear_exposure, (void*)fx->partials, (void*)fx->scratch_scalar, (void*)fx->taps, (void*)fx->ping, (void*)fx->pong})
+    for (void* p : {(void*)fx->histogram, (void*)fx->block_histograms, (void*)fx->linear_exposure, (void*)fx->partials, (void*)fx->scratch_scalar, (void*)fx->taps, (void*)fx->ping, (void*)fx->pong})
         if (p) (void)hipFree(p);
     if (fx->event_begin) (void)hipEventDestroy(fx->event_begin);
     if (fx->event_end) (void)hipEventDestroy(fx->event_end);
@@ -589,6 +607,8 @@ int hipr_camera_effects_reduce_histogram(HiprCameraEffects* fx, const HiprCamera
     FX_HIP(hipSetDevice(fx->device));
     const int status = enqueue_histogram(fx, *settings, *frame);
     if (status != HIPR_OK) return status;
+    hipLaunchKernelGGL(k_sum_histograms, dim3(1), dim3(SUM_BLOCK), 0, fx->stream, fx->block_histograms, fx->histogram_blocks, fx->histogram);
+    FX_HIP(hipGetLastError());
     FX_HIP(hipMemcpyAsync(out_histogram_host, fx->histogram, BINS * sizeof(uint32_t), hipMemcpyDeviceToHost, fx->stream));
     FX_HIP(hipStreamSynchronize(fx->stream));
     return HIPR_OK;
@@ -599,7 +619,7 @@ int hipr_camera_effects_exposure_from_histogram(HiprCameraEffects* fx, const Hip
     FX_HIP(hipSetDevice(fx->device));
     FX_HIP(hipMemcpyAsync(fx->histogram, histogram_host, BINS * sizeof(uint32_t), hipMemcpyHostToDevice, fx->stream));
     FX_HIP(hipMemcpyAsync(fx->scratch_scalar, io_linear_exposure_host, sizeof(float), hipMemcpyHostToDevice, fx->stream));
-    hipLaunchKernelGGL(k_exposure_from_histogram, dim3(1), dim3(BINS), 0, fx->stream, fx->histogram, exposure_constants(*settings, delta_time), fx->scratch_scalar);
+    hipLaunchKernelGGL(k_exposure_from_histogram, dim3(1), dim3(SUM_BLOCK), 0, fx->stream, fx->histogram, 1u, exposure_constants(*settings, delta_time), fx->scratch_scalar);
     FX_HIP(hipGetLastError());
     FX_HIP(hipMemcpyAsync(io_linear_exposure_host, fx->scratch_scalar, sizeof(float), hipMemcpyDeviceToHost, fx->stream));
     FX_HIP(hipStreamSynchronize(fx->stream));
@@ -652,7 +672,7 @@ int hipr_camera_effects_process(HiprCameraEffects* fx, const HiprCameraEffectsSe
         if (s.exposure_mode == HIPR_EXPOSURE_HISTOGRAM) {
             const int status = enqueue_histogram(fx, s, *frame);
             if (status != HIPR_OK) return status;
-            hipLaunchKernelGGL(k_exposure_from_histogram, dim3(1), dim3(BINS), 0, fx->stream, fx->histogram, exposure, fx->linear_exposure);
+            hipLaunchKernelGGL(k_exposure_from_histogram, dim3(1), dim3(SUM_BLOCK), 0, fx->stream, fx->block_histograms, fx->histogram_blocks, exposure, fx->linear_exposure);
         } else if (s.exposure_mode == HIPR_EXPOSURE_LOG_AVERAGE) {
             const int status = enqueue_log_average(fx, *frame, 1, exposure, fx->linear_exposure);
             if (status != HIPR_OK) return status;
@@ -673,6 +693,19 @@ int hipr_camera_effects_process(HiprCameraEffects* fx, const HiprCameraEffectsSe
     constants.bloom_threshold = s.bloom_threshold; constants.vignette_strength = s.vignette; constants.film_grain_strength = s.film_grain; constants.delta_time = delta_time;
     constants.black_clip = s.tonemapping_black_clip; constants.toe = s.tonemapping_toe; constants.slope = s.tonemapping_slope; constants.shoulder = s.tonemapping_shoulder;
     constants.white_clip = s.tonemapping_white_clip;
+    {   // Tonemapping.hlsl:79-94
+        constants.toe_scale = 1.0f + constants.black_clip - constants.toe;
+        constants.shoulder_scale = 1.0f + constants.white_clip - constants.shoulder;
+        const float in_match = 0.18f, out_match = 0.18f;
+        if (constants.toe > 0.8f)
+            constants.toe_match = (1.0f - constants.toe - out_match) / constants.slope + std::log10(in_match);
+        else {
+            const float bt = (out_match + constants.black_clip) / constants.toe_scale - 1.0f;
+            constants.toe_match = std::log10(in_match) - 0.5f * std::log((1.0f + bt) / (1.0f - bt)) * (constants.toe_scale / constants.slope);
+        }
+        const float straight_match = (1.0f - constants.toe) / constants.slope - constants.toe_match;
+        constants.shoulder_match = constants.shoulder / constants.slope - straight_match;
+    }
     {
         const float D65_to_D60[9] = {1.01303f, 0.00610531f, -0.014971f, 0.00769823f, 0.998165f, -0.00503203f, -0.00284131f, 0.00468516f, 0.924507f};
         const float sRGB_to_XYZ[9] = {0.4124564f, 0.3575761f, 0.1804375f, 0.2126729f, 0.7151522f, 0.0721750f, 0.0193339f, 0.1191920f, 0.9503041f};

@@ -12,6 +12,7 @@
 // no image IO, single scene root semantics as used by the renderer.
 #pragma once
 
+#include "CameraEffects.h"
 #include "Math.h"
 
 #include <algorithm>
@@ -540,6 +541,7 @@ public:
         CameraID id = m().allocate();
         Record& r = m()[id];
         r.name = name; r.scene = scene; r.projection = projection; r.inverse_projection = inverse_projection; r.transform = Transform::identity();
+        r.effects_settings = Math::CameraEffects::Settings::preset();     // Camera.cpp:157
         m().flag(id, Change::Created);
         return id;
     }
@@ -557,10 +559,24 @@ public:
     static Matrix4x4f get_inverse_projection_matrix(CameraID id) { return m()[id].inverse_projection; }
     static void set_projection_matrices(CameraID id, Matrix4x4f p, Matrix4x4f ip) { m()[id].projection = p; m()[id].inverse_projection = ip; }
     static Matrix4x4f get_inverse_view_projection_matrix(CameraID id) { return to_matrix4x4(m()[id].transform) * m()[id].inverse_projection; }   // Camera.h:112-114
+    // The part of the window the camera renders to, normalised (Camera.h:116-124); the whole window by default.
+    static void set_viewport(CameraID id, float x, float y, float width, float height) { Record& r = m()[id]; r.viewport[0] = x; r.viewport[1] = y; r.viewport[2] = width; r.viewport[3] = height; }
+    static void get_window_viewport(CameraID id, Vector2i window_size, int& x, int& y, int& width, int& height) {
+        const Record& r = m()[id];
+        x = int(r.viewport[0] * window_size.x); y = int(r.viewport[1] * window_size.y); width = int(r.viewport[2] * window_size.x); height = int(r.viewport[3] * window_size.y);
+    }
+    static Math::CameraEffects::Settings get_effects_settings(CameraID id) { return m()[id].effects_settings; }                 // Camera.h:126-127
+    static void set_effects_settings(CameraID id, Math::CameraEffects::Settings settings) { m()[id].effects_settings = settings; }
+    static Core::Iterable<CameraID> get_iterable() { return m().get_iterable(); }
     static void reset_change_notifications() { m().reset_change_notifications(); }
     static void deallocate() { m().clear(); }
 private:
-    struct Record { std::string name; SceneRootID scene; Core::RendererID renderer; Transform transform = Transform::identity(); Matrix4x4f projection = Matrix4x4f::identity(), inverse_projection = Matrix4x4f::identity(); };
+    struct Record {
+        std::string name; SceneRootID scene; Core::RendererID renderer; Transform transform = Transform::identity();
+        Matrix4x4f projection = Matrix4x4f::identity(), inverse_projection = Matrix4x4f::identity();
+        float viewport[4] = {0.0f, 0.0f, 1.0f, 1.0f};
+        Math::CameraEffects::Settings effects_settings = Math::CameraEffects::Settings::preset();
+    };
     static Core::Manager<CameraID, Record, Change>& m() { static Core::Manager<CameraID, Record, Change> s; return s; }
 };
 

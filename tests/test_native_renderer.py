@@ -27,6 +27,7 @@ def test_host_side_renderer_cases():
     for name in ("json_reader", "png_round_trip", "triangle_is_mirrored_into_the_left_handed_frame", "hierarchy_transforms_and_residual_scaling",
                  "materials_and_texture_channel_regrouping", "binary_container_and_vertex_colours", "malformed_files_create_nothing"):
         assert f"[       OK ] glTFFixture.{name}" in out, out[-4000:]
+    assert "[       OK ] CompositorFixture.cameras_carry_the_effects_preset" in out, out[-4000:]
 
 
 @pytest.mark.gpu
@@ -37,4 +38,5 @@ def test_reference_renderer_cases_on_gpu():
         assert f"[       OK ] RendererFixture.{name}" in out, out[-4000:]
     assert "[       OK ] LoaderFixture.loaded_obj_renders_through_the_renderer" in out, out[-4000:]
     assert "[       OK ] glTFFixture.loaded_gltf_renders_through_the_renderer" in out, out[-4000:]
+    assert "[       OK ] CompositorFixture.composites_two_cameras_into_their_viewports" in out, out[-4000:]
     assert "[       OK ] EnvironmentFixture.renderer_shows_the_environment_map_behind_an_empty_scene" in out, out[-4000:]
