@@ -107,7 +107,7 @@ struct HiprContext {
     int wavefront_count = 1;                // set by hipr_set_frame: small frames run as one wavefront
 
     // scene
-    DeviceBuffer shade_triangles, wide_nodes, environment_PDF, environment_samples;
+    DeviceBuffer shade_triangles, trace_triangles, wide_nodes, environment_PDF, environment_samples;
     DeviceBuffer nodes, triangles, instances, indices, geometry, texcoords, tints, emissions, materials, lights, textures, texels;
     DeviceBuffer ggx_rho, dielectric_rho, alpha, sample_offsets, sobol_tables;
     DeviceScene scene = {};
@@ -380,7 +380,7 @@ int hipr_destroy(HiprContext* c) {
     if (!c) return HIPR_OK;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    DeviceBuffer* all[] = {&c->shade_triangles, &c->wide_nodes, &c->environment_PDF, &c->environment_samples, &c->nodes, &c->triangles, &c->instances, &c->indices, &c->geometry, &c->texcoords, &c->tints, &c->emissions, &c->materials,
+    DeviceBuffer* all[] = {&c->shade_triangles, &c->trace_triangles, &c->wide_nodes, &c->environment_PDF, &c->environment_samples, &c->nodes, &c->triangles, &c->instances, &c->indices, &c->geometry, &c->texcoords, &c->tints, &c->emissions, &c->materials,
                            &c->lights, &c->textures, &c->texels, &c->ggx_rho, &c->dielectric_rho, &c->alpha, &c->sample_offsets, &c->sobol_tables, &c->radiance,
                            &c->accumulation, &c->scratch_accumulation, &c->counters, &c->work_counters, &c->debug_a, &c->debug_b, &c->debug_c};
     for (DeviceBuffer* b : all) b->release();
@@ -494,6 +494,9 @@ int hipr_upload_scene(HiprContext* c, const HiprSceneDesc* s) {
         if (c->shade_triangles.resize(size_t(s->triangle_count) * SHADE_TRIANGLE_QUADS * sizeof(float4))) return HIPR_ERROR_OUT_OF_MEMORY;
         d.shade_triangles = c->shade_triangles.as<float4>();
         hipLaunchKernelGGL(k_build_shade_triangles, dim3((s->triangle_count + 255) / 256), dim3(256), 0, st, d, c->shade_triangles.as<float4>());
+        if (c->trace_triangles.resize(size_t(s->triangle_count) * 3 * sizeof(float4))) return HIPR_ERROR_OUT_OF_MEMORY;
+        d.trace_triangles = c->trace_triangles.as<float4>();
+        hipLaunchKernelGGL(k_build_trace_triangles, dim3((s->triangle_count + 255) / 256), dim3(256), 0, st, d.triangles, s->triangle_count, c->trace_triangles.as<float4>());
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(st));
     }

@@ -34,6 +34,7 @@ struct DeviceScene {
     const uint4* wide_nodes;         // HiprWideNode, 4 x uint4 each: what the persistent kernels traverse
     const float4* triangles;
     const float4* shade_triangles;   // SHADE_TRIANGLE_QUADS float4 per triangle, built on upload (k_build_shade_triangles)
+    const float4* trace_triangles;   // 3 float4 per triangle: v0, e1 = v1 - v0, e2 = v2 - v0, then instance / primitive / flags as in `triangles` (k_build_trace_triangles)
     const HiprInstance* instances;
     const uint32_t* indices;
     const float4* geometry;
@@ -171,34 +172,30 @@ HD bool slab(f3 inv, f3 ood, float lox, float hix, float loy, float hiy, float l
     return tnear <= tfar;
 }
 
-HD bool intersect_triangle(f3 v0, f3 v1, f3 v2, f3 o, f3 d, float& t, float& u, float& v) {
-    f3 e1 = v1 - v0, e2 = v2 - v0;
-    f3 p = cross_fma(d, e2);
-    float det = dot_fma(e1, p);
-    if (!(det != 0.0f)) return false;
-    float inv = 1.0f / det;
-    f3 tv = o - v0;
-    u = dot_fma(tv, p) * inv;
-    if (!(u >= 0.0f && u <= 1.0f)) return false;
-    f3 q = cross_fma(tv, e1);
-    v = dot_fma(d, q) * inv;
-    if (!(v >= 0.0f && u + v <= 1.0f)) return false;
-    t = dot_fma(e2, q) * inv;
-    return true;
-}
-
-// The same arithmetic without early outs (every lane of a wave runs the whole test anyway): identical t, u, v and verdict.
-HD bool intersect_triangle_full(f3 v0, f3 v1, f3 v2, f3 o, f3 d, float& t, float& u, float& v) {
-    const f3 e1 = v1 - v0, e2 = v2 - v0;
+// Ray / triangle test (DESIGN.md "Triangle test"): Moeller-Trumbore on v0 and the two edges e1 = v1 - v0, e2 = v2 - v0, which
+// the upload computes once per triangle (k_build_trace_triangles). The inside decision is taken on the UNNORMALISED barycentrics
+// un = tv . (d x e2), vn = d . (tv x e1) against the determinant, with its sign folded in by flipping sign bits:
+//     inside  <=>  det != 0  and  un * s >= 0  and  vn * s >= 0  and  un * s + vn * s <= |det|          (s = sign of det)
+// so the division 1 / det and the three products that yield t, u, v are only evaluated for rays inside a triangle -- in a wave
+// of coherent rays that is a small minority of the tests (triangle_hit_values). The oracle takes the same decision on the
+// same values (oracle/integrator.cpp intersect_triangle), which keeps hits and counters bit-identical.
+struct TriangleTest { float det, un, vn; f3 q; };
+HD bool triangle_inside(f3 v0, f3 e1, f3 e2, f3 o, f3 d, TriangleTest& r) {
     const f3 p = cross_fma(d, e2);
-    const float det = dot_fma(e1, p);
-    const float inv = 1.0f / det;
+    r.det = dot_fma(e1, p);
     const f3 tv = o - v0;
-    u = dot_fma(tv, p) * inv;
-    const f3 q = cross_fma(tv, e1);
-    v = dot_fma(d, q) * inv;
-    t = dot_fma(e2, q) * inv;
-    return (det != 0.0f) & (u >= 0.0f) & (u <= 1.0f) & (v >= 0.0f) & (u + v <= 1.0f);
+    r.un = dot_fma(tv, p);
+    r.q = cross_fma(tv, e1);
+    r.vn = dot_fma(d, r.q);
+    const uint32_t sign = __float_as_uint(r.det) & 0x80000000u;
+    const float us = __uint_as_float(__float_as_uint(r.un) ^ sign), vs = __uint_as_float(__float_as_uint(r.vn) ^ sign);
+    return (r.det != 0.0f) & (us >= 0.0f) & (vs >= 0.0f) & (us + vs <= fabsf(r.det));
+}
+HD void triangle_hit_values(const TriangleTest& r, f3 e2, float& t, float& u, float& v) {
+    const float inv = 1.0f / r.det;
+    u = r.un * inv;
+    v = r.vn * inv;
+    t = dot_fma(e2, r.q) * inv;
 }
 
 // `stack` points at this lane's column of the LDS stack; entry k is stack[k * STRIDE].
@@ -260,11 +257,13 @@ HD float4 closest_hit(const DeviceScene& sc, f3 o, f3 d, float tmin, uint32_t sk
         uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
         for (uint32_t i = first; i < first + count; ++i) {
             ++tris;
-            const float4* tp = sc.triangles + 3 * size_t(i);
+            const float4* tp = sc.trace_triangles + 3 * size_t(i);
             float4 a = tp[0], b = tp[1], c = tp[2];
             if (i == skip) continue;
+            TriangleTest test;
+            if (!triangle_inside(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), o, d, test)) continue;
             float t, u, v;
-            if (!intersect_triangle(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), o, d, t, u, v)) continue;
+            triangle_hit_values(test, mk3(b.z, b.w, c.x), t, u, v);
             if (!(t > tmin)) continue;
             if (t < best_t || (t == best_t && i < best_id)) { best_t = t; best_u = u; best_v = v; best_id = i; }
         }
@@ -410,10 +409,12 @@ HD f3 shadow_transmittance(const DeviceScene& sc, f3 o, f3 d, float tmin, float 
         uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
         for (uint32_t i = first; i < first + count; ++i) {
             ++tris;
-            const float4* tp = sc.triangles + 3 * size_t(i);
+            const float4* tp = sc.trace_triangles + 3 * size_t(i);
             float4 a = tp[0], b = tp[1], c = tp[2];
+            TriangleTest test;
+            if (!triangle_inside(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), o, d, test)) continue;
             float t, u, v;
-            if (!intersect_triangle(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), o, d, t, u, v)) continue;
+            triangle_hit_values(test, mk3(b.z, b.w, c.x), t, u, v);
             if (!(t > tmin && t < tmax)) continue;
             float coverage = 1.0f;
             if (!(__float_as_uint(c.w) & HIPR_TRIANGLE_OPAQUE)) {
@@ -476,12 +477,15 @@ __global__ __launch_bounds__(256) void k_trace_closest_small(DeviceScene sc, Pat
         const uint32_t skip = meta.y;
         float best_t = __builtin_inff(), best_u = 0.0f, best_v = 0.0f;
         uint32_t best_id = HIPR_HIT_MISS;
-        const ConstantFloat4Pointer triangles = as_constant(sc.triangles);
+        const ConstantFloat4Pointer triangles = as_constant(sc.trace_triangles);
         for (uint32_t t = 0; t < sc.triangle_count; ++t) {   // uniform: scalar loads of the triangle
             const ScalarFloat4 a = triangles[3 * t], b = triangles[3 * t + 1], c = triangles[3 * t + 2];
+            TriangleTest test;
+            const bool inside = triangle_inside(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), o, d, test) & (t != skip);
+            if (!__any(inside)) continue;       // wave-uniform: most triangles are missed by every ray of the wave
             float tt, u, v;
-            const bool hit = intersect_triangle_full(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), o, d, tt, u, v);
-            const bool closer = hit & (t != skip) & (tt > tmin) & ((tt < best_t) | ((tt == best_t) & (t < best_id)));
+            triangle_hit_values(test, mk3(b.z, b.w, c.x), tt, u, v);
+            const bool closer = inside & (tt > tmin) & ((tt < best_t) | ((tt == best_t) & (t < best_id)));
             best_t = closer ? tt : best_t; best_u = closer ? u : best_u; best_v = closer ? v : best_v; best_id = closer ? t : best_id;
         }
         if (INSTRUMENT) tris += sc.triangle_count;
@@ -510,14 +514,17 @@ __global__ __launch_bounds__(256) void k_trace_shadow_small(DeviceScene sc, Shad
         const float tmax = ro.w;
         f3 rad = mk3(rr.x, rr.y, rr.z);
         bool blocked = false;
-        const ConstantFloat4Pointer triangles = as_constant(sc.triangles);
+        const ConstantFloat4Pointer triangles = as_constant(sc.trace_triangles);
         for (uint32_t t = 0; t < sc.triangle_count; ++t) {
             if (!__any(!blocked)) break;
             const ScalarFloat4 a = triangles[3 * t], b = triangles[3 * t + 1], c = triangles[3 * t + 2];
             if (INSTRUMENT) tris += blocked ? 0u : 1u;
+            TriangleTest test;
+            const bool inside = triangle_inside(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), o, d, test) & !blocked;
+            if (!__any(inside)) continue;
             float tt, u, v;
-            const bool hit = intersect_triangle_full(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), o, d, tt, u, v);
-            if (!blocked && hit && tt > 0.0f && tt < tmax) {
+            triangle_hit_values(test, mk3(b.z, b.w, c.x), tt, u, v);
+            if (inside && tt > 0.0f && tt < tmax) {
                 float coverage = 1.0f;
                 if (!(__float_as_uint(c.w) & HIPR_TRIANGLE_OPAQUE)) {
                     const HiprInstance& inst = sc.instances[__float_as_uint(c.y)];
@@ -712,10 +719,12 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(5))
                     const uint32_t i = tri_cur;
                     tri_cur = i + 1u;
                     if (INSTRUMENT) { tris += is_shadow ? 0u : 1u; shadow_tris += is_shadow ? 1u : 0u; }
-                    const float4* tp = sc.triangles + 3 * size_t(i);
+                    const float4* tp = sc.trace_triangles + 3 * size_t(i);
                     const float4 a = tp[0], b = tp[1], c = tp[2];
-                    float t, u, v;
-                    const bool hit = intersect_triangle_full(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), o, d, t, u, v);
+                    TriangleTest test;
+                    const bool hit = triangle_inside(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), o, d, test);
+                    float t = 0.0f, u = 0.0f, v = 0.0f;
+                    if (__any(hit)) triangle_hit_values(test, mk3(b.z, b.w, c.x), t, u, v);     // the lanes in this branch agree to skip the division
                     need_pop = tri_cur == tri_end;
                     if constexpr (MODE != TRACE_CLOSEST) {
                         if (is_shadow && hit && t > tmin && t < tmax) {
@@ -821,6 +830,18 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(5))
 //   quad 3   : uv0.xy, uv1.xy       quad 4: uv2.xy, bits(tint0), bits(tint1)       quad 5: bits(tint2), 0, 0, 0
 // Per-vertex emission (rare) still goes through the instance.
 // ---------------------------------------------------------------------------------------------
+// What the trace kernels read per triangle: the vertex and the two edges the test works on (the edges rounded once, here, as
+// the oracle rounds them), ids and flags where the uploaded triangle has them.
+__global__ __launch_bounds__(256) void k_build_trace_triangles(const float4* __restrict__ triangles, uint32_t triangle_count, float4* __restrict__ out) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= triangle_count) return;
+    const float4 a = triangles[3 * size_t(t)], b = triangles[3 * size_t(t) + 1], c = triangles[3 * size_t(t) + 2];
+    const f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(a.w, b.x, b.y) - v0, e2 = mk3(b.z, b.w, c.x) - v0;
+    out[3 * size_t(t)] = make_float4(v0.x, v0.y, v0.z, e1.x);
+    out[3 * size_t(t) + 1] = make_float4(e1.y, e1.z, e2.x, e2.y);
+    out[3 * size_t(t) + 2] = make_float4(e2.z, c.y, c.z, c.w);
+}
+
 __global__ __launch_bounds__(256) void k_build_shade_triangles(DeviceScene sc, float4* out) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= sc.triangle_count) return;

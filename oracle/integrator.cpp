@@ -46,23 +46,24 @@ static inline float3 cross_fma(float3 a, float3 b) {
     return {fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x))};
 }
 
+// Moeller-Trumbore on v0, e1 = v1 - v0, e2 = v2 - v0 with the inside decision on the unnormalised barycentrics (the sign of the
+// determinant folded in by flipping sign bits) and the division only for rays inside: kernels.h triangle_inside / triangle_hit_values.
 bool intersect_triangle(const HiprTriangle& tri, float3 o, float3 d, float& t, float& u, float& v) {
     float3 v0 = {tri.v0[0], tri.v0[1], tri.v0[2]};
     float3 e1 = make_float3(tri.v1[0], tri.v1[1], tri.v1[2]) - v0;
     float3 e2 = make_float3(tri.v2[0], tri.v2[1], tri.v2[2]) - v0;
     float3 p = cross_fma(d, e2);
     float det = dot_fma(e1, p);
-    if (!(det != 0.0f))
+    float3 tv = o - v0;
+    float un = dot_fma(tv, p);
+    float3 q = cross_fma(tv, e1);
+    float vn = dot_fma(d, q);
+    float us = std::signbit(det) ? -un : un, vs = std::signbit(det) ? -vn : vn;
+    if (!((det != 0.0f) && (us >= 0.0f) && (vs >= 0.0f) && (us + vs <= std::fabs(det))))
         return false;
     float inv = 1.0f / det;
-    float3 tv = o - v0;
-    u = dot_fma(tv, p) * inv;
-    if (!(u >= 0.0f && u <= 1.0f))
-        return false;
-    float3 q = cross_fma(tv, e1);
-    v = dot_fma(d, q) * inv;
-    if (!(v >= 0.0f && u + v <= 1.0f))
-        return false;
+    u = un * inv;
+    v = vn * inv;
     t = dot_fma(e2, q) * inv;
     return true;
 }
