@@ -4,19 +4,20 @@
   python bench.py --gpus N --steps K --warmup W
 (for N > 1 the driver launches it under torch.distributed.run, one rank per GPU over RCCL).
 
-A "step" is one pass of the hot path over one batch of synthetic input: 8 accumulations (samples per pixel) of the
-1920x1080 frame traced together = 16 588 800 camera paths followed to completion (<= 5 surface interactions, next event
+A "step" is one pass of the hot path over one batch of synthetic input: 32 accumulations (samples per pixel) of the
+1920x1080 frame traced together = 66 355 200 camera paths followed to completion (<= 5 surface interactions, next event
 estimation with 3 RIS candidates, shadow rays), folded one by one into the f64 running mean and written as half4. The
 reference traces one accumulation per launch; batching is a property of the wavefront design (HiprFrameDesc::samples_per_pass):
-the image is bit-identical for any batch size (tests), while the per-bounce launches get 8x the rays and their long-ray tails
-and launch gaps amortise (measured, DESIGN.md: 1 -> 8 samples per pass is +27 % on the Cornell box and +66 % on the atrium;
-`--spp-per-pass 1` reproduces the one-accumulation-per-pass numbers).
+the image is bit-identical for any batch size (tests), while the per-bounce launches get 32x the rays and their long-ray tails
+and launch gaps amortise (measured, DESIGN.md: 1 -> 8 samples per pass is +27 % on the Cornell box and +66 % on the atrium,
+8 -> 32 another +3 % / +11 %; the queues of 32 take 13.6 GB of the 288 GB; `--spp-per-pass 1` reproduces the
+one-accumulation-per-pass numbers).
 Workload (BASELINE.json configs[1]): SimpleViewer Cornell box, every material forced to the Diffuse shading
 model, max_bounce_count 4 (34 triangles: traced by the exhaustive-search kernels; `--scene atrium` is the 251 k-triangle
 Sponza-class stand-in, traced by the fused persistent kernel over the compressed wide BVH). Inputs (scene, BVH, tables) are
 resident in HBM before the timed region; the output
 frame stays in HBM. N > 1: tiles of 8x8 pixels are dealt round-robin to the ranks and a step traces N
-x 8 accumulations of the frame, so every GPU keeps the same 16 588 800 paths per step as N grows ("weak" scaling;
+x 32 accumulations of the frame, so every GPU keeps the same 66 355 200 paths per step as N grows ("weak" scaling;
 no data-path collective). The timed region ends with the RCCL gather of the half4 tiles to rank 0 plus the
 scatter kernel that assembles the frame.
 
@@ -42,7 +43,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICR
 def parse_args():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=32)
+    p.add_argument("--steps", type=int, default=16)
     p.add_argument("--warmup", type=int, default=4)
     p.add_argument("--width", type=int, default=1920)
     p.add_argument("--height", type=int, default=1080)
@@ -51,7 +52,7 @@ def parse_args():
                    "not the headline workload: the line's config.workload names the file")
     p.add_argument("--atrium-triangles", type=int, default=260000)
     p.add_argument("--bounces", type=int, default=None, help="max_bounce_count; default 4, and 32 for the material scenes (the viewer's setting, apps/SimpleViewer/main.cpp:353)")
-    p.add_argument("--spp-per-pass", type=int, default=8, help="accumulations traced together per step and GPU (HiprFrameDesc::samples_per_pass)")
+    p.add_argument("--spp-per-pass", type=int, default=32, help="accumulations traced together per step and GPU (HiprFrameDesc::samples_per_pass)")
     p.add_argument("--wavefronts", type=int, default=1, choices=[1, 2],
                    help="2: each pass runs as two half-frame wavefronts on two streams (one shades while the other traces); faster, but concurrent kernels "
                         "inflate the per-kernel timers the roofline is computed from, so the default stays 1")
