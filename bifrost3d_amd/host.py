@@ -61,14 +61,14 @@ def load_png(path: str, flip: bool = False) -> np.ndarray:
 class Scene:
     """A flattened scene owned by the C++ host library (what handle_updates() would hand to hipr_upload_scene)."""
 
-    def __init__(self, name: str, diffuse_only: bool = False, param0: int = 0, param1: int = 0, environment: bool = False, coat: bool = False):
+    def __init__(self, name: str, diffuse_only: bool = False, param0: int = 0, param1: int = 0, environment: bool = False, coat: bool = False, spot: bool = False):
         self.lib = load_host_library()
         if name.startswith("file:"):    # a model file set up the way SimpleViewer sets up its command-line scene
             self.handle = self.lib.hiprh_scene_load(name[5:].encode(), 1 if diffuse_only else 0)
             if not self.handle:
                 raise capi.HiprError(f"could not load '{name[5:]}'")
         else:
-            self.handle = self.lib.hiprh_scene_create(name.encode(), (1 if diffuse_only else 0) | (2 if environment else 0) | (4 if coat else 0), param0, param1)
+            self.handle = self.lib.hiprh_scene_create(name.encode(), (1 if diffuse_only else 0) | (2 if environment else 0) | (4 if coat else 0) | (8 if spot else 0), param0, param1)
             if not self.handle:
                 raise capi.HiprError(f"unknown scene '{name}'")
         self.name = name

@@ -216,4 +216,93 @@ void create_material_scene(CameraID camera_ID, SceneNode root_node, const std::s
     }
 }
 
+void create_glass_scene(CameraID camera_ID, SceneNode root_node, const std::string& shader_ball_path, const std::string& diamond_path) {
+    auto dielectric_specularity = [](float ior_o, float ior_i) { const float r = (ior_o - ior_i) / (ior_o + ior_i); return r * r; };     // BF/Math/Utils.h:202-204
+    const float glass_specularity = dielectric_specularity(1.0f, 1.52f), diamond_specularity = dielectric_specularity(1.0f, 2.42f);   // BF/Assets/Material.h:45-58
+
+    { // Camera.
+        Transform cam_transform = Cameras::get_transform(camera_ID);
+        cam_transform.translation = Vector3f(0, 3.0f, -10.0f);
+        cam_transform.look_at(Vector3f(0, 1.0f, 0.0f));
+        Cameras::set_transform(camera_ID, cam_transform);
+    }
+    { // A directional light.
+        Transform light_transform = Transform(Vector3f(20.0f, 20.0f, -20.0f));
+        light_transform.look_at(Vector3f::zero());
+        SceneNode light_node = SceneNode("Directional light", light_transform);
+        light_node.set_parent(root_node);
+        LightSources::create_directional_light(light_node.get_ID(), RGB(3.0f, 2.9f, 2.5f));
+    }
+    { // A sphere light.
+        SceneNode sphere_light_node = SceneNode("Sphere light", Transform(Vector3f(1, 5, 2)));
+        LightSources::create_sphere_light(sphere_light_node.get_ID(), RGB(800.0f, 600.0f, 600.0f), 1.0f);
+        sphere_light_node.set_parent(root_node);
+    }
+    { // Floor.
+        SceneNode floor_node = create_checkered_floor(400, 1);
+        floor_node.set_global_transform(Transform(Vector3f(0, -1.0f, 0)));
+        floor_node.set_parent(root_node);
+    }
+    { // Glass shader ball.
+        Material glass_material = Materials::create("Glass shader ball", Materials::Data::create_transmissive(RGB(0.95f), 0.25f, glass_specularity));
+        SceneNode shader_ball_node = load_shader_ball(shader_ball_path, glass_material);
+        if (shader_ball_node != SceneNode::invalid()) {
+            shader_ball_node.set_global_transform(Transform(Vector3f(0, -0.25f, 0), Quaternionf::from_angle_axis(0.1f * PI<float>(), Vector3f::up()), 1.5f));
+            shader_ball_node.set_parent(root_node);
+        }
+    }
+    { // Magnifying glass: the lens and a handle.
+        Material lens_material = Materials::create("Magnifying glass", Materials::Data::create_transmissive(RGB(0.975f), 0.0f, glass_specularity));
+        Mesh lens_mesh = revolved_sphere("Lens", 64, 32);
+        for (unsigned v = 0; v < lens_mesh.get_vertex_count(); ++v) {
+            lens_mesh.get_positions()[v].z *= 0.1f;
+            Vector3f& normal = lens_mesh.get_normals()[v];
+            normal = normalize(Vector3f(normal.x * 0.1f, normal.y * 0.1f, normal.z));
+        }
+        lens_mesh.compute_bounds();
+        SceneNode lens_node = SceneNode("Glass", Transform(Vector3f(3, 0.1f, 0)));
+        MeshModel(lens_node, lens_mesh, lens_material);
+        lens_node.set_parent(root_node);
+
+        Material frame_material = Material::create_metal("Magnifying glass frame", gold_tint, 0.5f);
+        MeshFlags buffers = MeshFlag::Position; buffers |= MeshFlag::Normal;
+        Mesh handle_mesh = MeshCreation::box(1, Vector3f(0.08f, 0.6f, 0.08f), buffers);
+        SceneNode handle_node = SceneNode("Magnifying glass handle", Transform(Vector3f(3, 0.1f - 0.8f, 0)));
+        MeshModel(handle_node, handle_mesh, frame_material);
+        handle_node.set_parent(root_node);
+    }
+    { // Diamond.
+        Material diamond_material = Materials::create("Diamond", Materials::Data::create_transmissive(RGB(0.94f), 0.0f, diamond_specularity));
+        if (!diamond_path.empty()) {
+            SceneNode diamond_node = glTFLoader::load(diamond_path);
+            if (diamond_node != SceneNode::invalid()) {
+                diamond_node.set_global_transform(Transform(Vector3f(-3, 0, 0), Quaternionf::from_angle_axis(-0.5f * PI<float>(), Vector3f::right())));
+                diamond_node.set_parent(root_node);
+                if (diamond_node.get_name() == "pCone1_DiamondOutside_0") {     // a single-node file is its own root
+                    MeshModel model = attached_mesh_model(diamond_node);
+                    if (model.get_ID() != MeshModelID::invalid_UID()) MeshModels::set_material_ID(model.get_ID(), diamond_material.get_ID());
+                }
+                replace_material(diamond_material, diamond_node, "pCone1_DiamondOutside_0");
+            }
+        } else {
+            // A brilliant's silhouette from a coarse revolved sphere: flat table, wide girdle, pointed pavilion; flat facets (no vertex normals).
+            Mesh sphere = revolved_sphere("Diamond", 8, 4);
+            MeshFlags buffers = MeshFlag::Position;
+            Mesh gem = Mesh("Diamond", sphere.get_primitive_count(), sphere.get_vertex_count(), buffers);
+            for (unsigned t = 0; t < sphere.get_primitive_count(); ++t) gem.get_primitives()[t] = sphere.get_primitives()[t];
+            for (unsigned v = 0; v < sphere.get_vertex_count(); ++v) {
+                Vector3f p = sphere.get_positions()[v] * 2.0f;        // unit radius
+                if (p.y > 0.0f) p.y *= 0.35f;                          // crown: low and wide
+                p.y = p.y > 0.3f ? 0.3f : p.y;                         // table
+                gem.get_positions()[v] = Vector3f(p.x * 0.8f, p.y * 0.9f, p.z * 0.8f);
+            }
+            gem.compute_bounds();
+            Meshes::destroy(sphere.get_ID());
+            SceneNode diamond_node = SceneNode("pCone1_DiamondOutside_0", Transform(Vector3f(-3, -0.1f, 0)));
+            MeshModel(diamond_node, gem, diamond_material);
+            diamond_node.set_parent(root_node);
+        }
+    }
+}
+
 } // namespace ViewerScenes

@@ -25,4 +25,12 @@ Bifrost::Scene::SceneNode load_shader_ball(const std::string& shader_ball_path, 
 // coated variant of the reference's shading tests (ShadingModelTestUtils.h:39-44).
 void create_material_scene(Bifrost::Scene::CameraID camera_ID, Bifrost::Scene::SceneNode root_node, const std::string& shader_ball_path, bool coat);
 
+// The transmissive part of the viewer's glass scene (apps/SimpleViewer/Scenes/Glass.cpp:27-140): camera at (0, 3, -10) looking at
+// (0, 1, 0), the directional light and the large sphere light, the checkered floor, a frosted glass shader ball (roughness 0.25),
+// the magnifying glass (a smooth glass lens: a revolved sphere flattened to a tenth, with its gold handle as a stretched box)
+// and a diamond. `diamond_path` empty: a faceted stand-in (an 8 x 2 revolved sphere pulled into a brilliant's proportions) with
+// the diamond's specularity takes the place of Resources/Diamond.glb; otherwise the asset is loaded and its outer surface
+// re-materialed as Glass.cpp:116-125 does. The pool of water of the original is left out.
+void create_glass_scene(Bifrost::Scene::CameraID camera_ID, Bifrost::Scene::SceneNode root_node, const std::string& shader_ball_path, const std::string& diamond_path);
+
 } // namespace ViewerScenes

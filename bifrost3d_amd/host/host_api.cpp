@@ -55,10 +55,12 @@ extern "C" {
 // name: "cornell" | "atrium" | "quad" | "empty_ortho". variant bit 1: light the scene with a procedural environment map. variant bit 0: force every material to the Diffuse
 // shading model (BASELINE.json config 2). param0/param1: atrium target triangles + seed, ortho width + height.
 static void* create_material_scene(const std::string& shader_ball_path, unsigned variant);
+static void* create_glass_scene(const std::string& resource_directory, unsigned variant);
 
 void* hiprh_scene_create(const char* name, unsigned variant, unsigned param0, unsigned param1) {
     if (!name) return nullptr;
     if (!std::strncmp(name, "material", 8) && (name[8] == 0 || name[8] == ':')) return create_material_scene(name[8] ? name + 9 : "", variant);
+    if (!std::strncmp(name, "glass", 5) && (name[5] == 0 || name[5] == ':')) return create_glass_scene(name[5] ? name + 6 : "", variant);
     SceneBuilder* sb = new SceneBuilder();
     std::string n = name;
     if (n == "cornell") Scenes::create_cornell_box(*sb, param0 ? param0 : 1u);   // param0: quads per wall edge
@@ -68,6 +70,8 @@ void* hiprh_scene_create(const char* name, unsigned variant, unsigned param0, un
     else { delete sb; return nullptr; }
     if (variant & 1u) sb->force_shading_model(HIPR_SHADING_DIFFUSE);
     if (variant & 2u) add_procedural_environment(*sb);
+    if (variant & 8u)   // a spot light as well (tests): a disc of radius 0.04 below the ceiling, a 35 degree cone aimed at the short box
+        sb->add_light(SceneBuilder::spot_light(Vector3f(0.2f, 0.42f, -0.1f), Bifrost::Math::normalize(Vector3f(-0.35f, -1.0f, 0.15f)), RGB(1.5f, 1.2f, 0.9f), 0.04f, std::cos(35.0f * 3.14159265f / 180.0f)));
     sb->finalize();
     return sb;
 }
@@ -82,6 +86,31 @@ static void* create_material_scene(const std::string& shader_ball_path, unsigned
     const Scene::CameraID camera_ID = Scene::Cameras::create("Camera", scene.get_ID(), Math::Matrix4x4f::identity(), Math::Matrix4x4f::identity());
     ViewerScenes::create_material_scene(camera_ID, scene.get_root_node(), shader_ball_path, (variant & 4u) != 0);
     if (Assets::MeshModels::get_iterable().size() < 2) { deallocate_all(); return nullptr; }     // the shader ball did not load
+    const SceneLoading::ViewerDefaults defaults = SceneLoading::apply_viewer_defaults(scene.get_root_node(), camera_ID, false);
+    if (variant & 1u)
+        for (Assets::MaterialID material_ID : Assets::Materials::get_iterable()) Assets::Material(material_ID).set_shading_model(Assets::ShadingModel::Diffuse);
+
+    SceneBuilder* sb = new SceneBuilder();
+    sb->set_environment_tint(Scene::SceneRoots::get_environment_tint(scene.get_ID()));
+    flatten_bifrost_scene(*sb);
+    sb->camera.transform = Scene::Cameras::get_transform(camera_ID);
+    sb->camera.near_plane = defaults.near_plane;
+    sb->camera.far_plane = defaults.far_plane;
+    sb->camera.max_bounce_count = 32;
+    deallocate_all();
+    return sb;
+}
+
+// "glass" | "glass:<directory with Shaderball.gltf and Diamond.glb>": the transmissive part of the viewer's glass scene
+// (apps/SimpleViewer/Scenes/Glass.cpp), flattened like the material scene; procedural stand-ins without the directory.
+static void* create_glass_scene(const std::string& resource_directory, unsigned variant) {
+    using namespace Bifrost;
+    deallocate_all();
+    Scene::SceneRoot scene = Scene::SceneRoot("Model scene", RGB(0.68f, 0.92f, 1.0f));
+    const Scene::CameraID camera_ID = Scene::Cameras::create("Camera", scene.get_ID(), Math::Matrix4x4f::identity(), Math::Matrix4x4f::identity());
+    const std::string shader_ball = resource_directory.empty() ? "" : resource_directory + "/Shaderball.gltf", diamond = resource_directory.empty() ? "" : resource_directory + "/Diamond.glb";
+    ViewerScenes::create_glass_scene(camera_ID, scene.get_root_node(), shader_ball, diamond);
+    if (Assets::MeshModels::get_iterable().size() < 5) { deallocate_all(); return nullptr; }     // floor, ball (2), lens, handle, diamond
     const SceneLoading::ViewerDefaults defaults = SceneLoading::apply_viewer_defaults(scene.get_root_node(), camera_ID, false);
     if (variant & 1u)
         for (Assets::MaterialID material_ID : Assets::Materials::get_iterable()) Assets::Material(material_ID).set_shading_model(Assets::ShadingModel::Diffuse);

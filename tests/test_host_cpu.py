@@ -348,3 +348,20 @@ def test_material_scene_description():
     assert abs(tris[..., 1].min() + 1.0) < 1e-5
     inside = np.abs(tris[..., 0]).max(axis=1) < 50.0          # everything but the floor
     assert abs(tris[inside][..., 0].min() + 8.2) < 0.15 and abs(tris[inside][..., 0].max() - 8.2) < 0.15
+
+
+def test_glass_scene_and_spot_variant_descriptions():
+    """The transmissive part of apps/SimpleViewer/Scenes/Glass.cpp and the Cornell box with an extra spot light."""
+    from bifrost3d_amd.host import Scene
+    glass = Scene("glass")
+    d = glass.desc
+    assert d.instance_count == 6 and d.light_count == 2          # floor, ball outside + inside, lens, handle, diamond; directional + sphere light
+    assert glass.camera(64, 36).max_bounce_count == 32
+    models = [d.materials[d.instances[i].material_index] for i in range(d.instance_count)]
+    transmissive = [m for m in models if m.shading_model == capi.SHADING_TRANSMISSIVE]
+    assert len(transmissive) == 3
+    specularities = sorted(round(m.specularity, 4) for m in transmissive)
+    assert specularities == [round(((1 - 1.52) / (1 + 1.52)) ** 2, 4)] * 2 + [round(((1 - 2.42) / (1 + 2.42)) ** 2, 4)]      # glass, glass, diamond
+    assert sorted(round(m.roughness, 2) for m in transmissive) == [0.0, 0.0, 0.25]
+    spot = Scene("cornell", spot=True)
+    assert spot.desc.light_count == 2 and Scene("cornell").desc.light_count == 1
