@@ -425,3 +425,34 @@ def test_spot_light_image_matches_oracle(ctx, oracle_q):
         assert abs(gc[key] - cc[key]) <= 0.003 * cc[key], (key, gc[key], cc[key])
     dark, _ = render_gpu(ctx, plain, w, h, spp, 4)
     assert float(gpu[..., :3].mean()) > 1.03 * float(dark[..., :3].mean())      # the spot adds light (half the frame is sky)
+
+
+@pytest.mark.parametrize("scene_name", ["cornell", "atrium_full"])
+def test_full_size_properties(ctx, scene_name):
+    """BASELINE.json's sizes (1920x1080; the 251 k-triangle atrium of configs[3]) through size-independent properties, where the
+    oracle would take minutes: the frame is finite, every camera path is traced, a frame split over two tile phases (what two
+    GPUs would render) assembles bit for bit into the single-GPU frame, batching four accumulations is bit-identical to four
+    passes, and the running mean converges (4 and 8 accumulations agree within Monte Carlo noise)."""
+    scene = Scene("cornell") if scene_name == "cornell" else Scene("atrium", param0=260000, param1=1)
+    w, h = 1920, 1080
+    full, counters = render_gpu(ctx, scene, w, h, 4, 4, samples_per_pass=4)
+    assert np.isfinite(full).all() and counters["camera_rays"] == 4 * w * h
+    assert counters["closest_rays"] >= counters["camera_rays"] and counters["shadow_rays"] > 0
+
+    one_by_one, _ = render_gpu(ctx, scene, w, h, 4, 4, samples_per_pass=1)
+    assert np.array_equal(one_by_one, full)
+
+    tiles_x, tiles_y = (w + 7) // 8, (h + 7) // 8
+    assembled = np.zeros_like(full)
+    for phase in range(2):
+        part, _ = render_gpu(ctx, scene, w, h, 4, 4, samples_per_pass=4, tile_phase=phase, tile_stride=2)
+        k = np.arange(part.shape[0])
+        tile = (k // 64) * 2 + phase
+        x, y = (tile % tiles_x) * 8 + (k % 64) % 8, (tile // tiles_x) * 8 + (k % 64) // 8
+        valid = (x < w) & (y < h) & (tile < tiles_x * tiles_y)
+        assembled[y[valid], x[valid]] = part[valid]
+    assert np.array_equal(assembled, full)
+
+    eight, _ = render_gpu(ctx, scene, w, h, 8, 4, samples_per_pass=4)      # twice the accumulations: the same image within Monte Carlo noise
+    assert abs(float(full[..., :3].mean()) - float(eight[..., :3].mean())) < 0.01 * float(full[..., :3].mean())
+    assert rmse(full, eight) < 0.75 * rmse(full, np.zeros_like(full))
