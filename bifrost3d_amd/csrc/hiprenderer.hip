@@ -941,6 +941,21 @@ int hipr_debug_shading(HiprContext* c, int shading_model, const float* params10,
     return HIPR_OK;
 }
 
+int hipr_debug_light(HiprContext* c, const HiprLight* light, const float* position3, const float* in_n3, uint32_t n, int mode, float* out_n8) {
+    if (int s = check_context(c)) return s;
+    if (!light || !position3 || !in_n3 || !out_n8 || mode < 0 || mode > 1) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_debug_light: bad argument");
+    if (mode == 1 && (light->flags & HIPR_LIGHT_TYPE_MASK) != HIPR_LIGHT_SPOT) return fail(HIPR_ERROR_UNSUPPORTED, "hipr_debug_light: evaluate / pdf by direction is exposed for spot lights only");
+    if (n == 0) return HIPR_OK;
+    DeviceBuffer bp, bi, bo;
+    if (bp.upload(position3, 3 * 4, c->stream) | bi.upload(in_n3, size_t(n) * 12, c->stream) | bo.resize(size_t(n) * 32)) return HIPR_ERROR_OUT_OF_MEMORY;
+    hipr::launch_debug_light(c->stream, *light, bp.as<float>(), bi.as<float>(), int(n), mode, bo.as<float>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out_n8, bo.ptr, size_t(n) * 32, hipMemcpyDeviceToHost));
+    bp.release(); bi.release(); bo.release();
+    return HIPR_OK;
+}
+
 int hipr_debug_sobol(HiprContext* c, const uint32_t* triples, uint32_t n, uint32_t* out_uint4) {
     if (int s = check_context(c)) return s;
     if (!triples || !out_uint4) return fail(HIPR_ERROR_INVALID_ARGUMENT, "null argument");

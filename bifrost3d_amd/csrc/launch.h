@@ -24,6 +24,7 @@ struct ShadeLaunch {
 void launch_shade(int shading_models, const ShadeLaunch& args);
 
 // All pointers are device pointers; see k_debug_shading (shade.hip).
+void launch_debug_light(hipStream_t stream, const HiprLight& light, const float* position3, const float* in_n3, int n, int mode, float* out_n8);
 void launch_debug_shading(hipStream_t stream, const DeviceTables& tables, int model, const float* params10, const float* wo_n3, const float* in_n3, int n, int mode,
                           float* out_n7);
 

@@ -55,6 +55,26 @@ __global__ void k_debug_shading(DeviceTables tables, int model, const float* par
     }
 }
 
+// The light sources as the shade kernel evaluates them. mode 0: sample_radiance(light, position, u = in.xy) -> radiance[3], PDF,
+// direction_to_light[3], distance. mode 1 (spot lights): evaluate(light, position, direction = in) -> radiance[3], pdf(...), 0, 0, 0, 0.
+__global__ void k_debug_light(HiprLight light, const float* position3, const float* in_n3, int n, int mode, float* out_n8) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const f3 position = {position3[0], position3[1], position3[2]}, in = {in_n3[3 * i], in_n3[3 * i + 1], in_n3[3 * i + 2]};
+    float* o = out_n8 + 8 * i;
+    if (mode == 0) {
+        const LightSample s = light_sample_radiance(light, position, mk2(in.x, in.y));
+        o[0] = s.radiance.x; o[1] = s.radiance.y; o[2] = s.radiance.z; o[3] = s.pdf; o[4] = s.dir.x; o[5] = s.dir.y; o[6] = s.dir.z; o[7] = s.distance;
+    } else {
+        const f3 radiance = spot_evaluate(light, position, in);
+        o[0] = radiance.x; o[1] = radiance.y; o[2] = radiance.z; o[3] = spot_pdf(light, position, in); o[4] = o[5] = o[6] = o[7] = 0.0f;
+    }
+}
+
+void launch_debug_light(hipStream_t stream, const HiprLight& light, const float* position3, const float* in_n3, int n, int mode, float* out_n8) {
+    hipLaunchKernelGGL(k_debug_light, dim3((n + 63) / 64), dim3(64), 0, stream, light, position3, in_n3, n, mode, out_n8);
+}
+
 void launch_debug_shading(hipStream_t stream, const DeviceTables& tables, int model, const float* params, const float* wo_n3, const float* in_n3, int n, int mode,
                           float* out_n7) {
     hipLaunchKernelGGL(k_debug_shading, dim3((n + 63) / 64), dim3(64), 0, stream, tables, model, params, wo_n3, in_n3, n, mode, out_n7);

@@ -134,6 +134,20 @@ class Context:
                                                 int(mode), out.ctypes.data_as(fp)), "hipr_debug_shading")
         return out
 
+    def debug_light(self, light: capi.HiprLight, position, inputs, mode=0):
+        """mode 0: sample_radiance(light, position, u = inputs[:, :2]) -> (n, 8) radiance, PDF, direction, distance;
+        mode 1 (spot lights): evaluate and pdf for the directions in `inputs` -> (n, 8) radiance, pdf, 0, 0, 0, 0."""
+        inputs = np.ascontiguousarray(inputs, np.float32)
+        if inputs.ndim == 2 and inputs.shape[1] == 2:
+            inputs = np.concatenate([inputs, np.zeros((len(inputs), 1), np.float32)], axis=1)
+        inputs = np.ascontiguousarray(inputs.reshape(-1, 3))
+        position = np.ascontiguousarray(position, np.float32)
+        out = np.zeros((len(inputs), 8), np.float32)
+        fp = C.POINTER(C.c_float)
+        self._check(self.lib.hipr_debug_light(self.handle, C.byref(light), position.ctypes.data_as(fp), inputs.ctypes.data_as(fp), len(inputs), int(mode), out.ctypes.data_as(fp)),
+                    "hipr_debug_light")
+        return out
+
     def debug_sobol(self, triples):
         triples = np.ascontiguousarray(triples, np.uint32).reshape(-1, 3)
         out = np.zeros((len(triples), 4), np.uint32)

@@ -370,6 +370,11 @@ int hipr_debug_generate(HiprContext* context, const HiprCameraState* camera, uin
  * direction[3]; mode 1: evaluate_with_PDF(wo, wi = in) -> out7 = f[3], pdf, 0, 0, 0. Host pointers. */
 int hipr_debug_shading(HiprContext* context, int shading_model, const float* params10, const float* wo_n3, const float* in_n3, uint32_t n, int mode,
                        float* out_n7);
+/* The light sources as the shade kernel evaluates them, for the reference's light tests (ORT/LightSources/SphereLightTest.h,
+ * SpotLightTest.h). mode 0: LightSources::sample_radiance(light, position, u = in.xy) -> out8 = radiance[3], PDF,
+ * direction_to_light[3], distance. mode 1 (spot lights only): out8 = evaluate(light, position, direction = in)[3],
+ * pdf(light, position, direction), 0, 0, 0, 0. Host pointers; position3 is shared by the n inputs. */
+int hipr_debug_light(HiprContext* context, const HiprLight* light, const float* position3, const float* in_n3, uint32_t n, int mode, float* out_n8);
 int hipr_debug_sobol(HiprContext* context, const uint32_t* accumulation_pixelhash_dimension, uint32_t n, uint32_t* out_uint4);
 /* K2: closest hit for n rays. rays: float4 origin_tmin + float4 direction_tmax per ray; skip: global triangle index
  * to ignore per ray (0xFFFFFFFF = none). out_hits: float4 {t, u, v, bits(tri_or_light)} per ray. */

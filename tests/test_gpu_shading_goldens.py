@@ -100,3 +100,51 @@ def test_device_shading_models_follow_the_oracle(ctx, oracle, goldens, model, or
         assert finite.mean() > 0.5
         err = np.abs(gpu[finite, 0:4] - cpu[finite, 0:4]) / (np.abs(cpu[finite, 0:4]) + 1e-2)
         assert (err.max(axis=1) <= 2e-3).mean() >= 0.99, (name, float(np.quantile(err.max(axis=1), 0.99)))
+
+
+# ---- G8: the reference's light tests replayed on the device (ORT/LightSources/SphereLightTest.h, SpotLightTest.h) ---------------
+
+def test_G8_lights_on_device(ctx, oracle):
+    import math
+    from test_oracle_lights import cosine_sample, pdf_is_valid, samples02, sphere_light, spot_light
+    u1024, u16 = samples02(oracle, 1024), samples02(oracle, 16)
+
+    # SphereLight.power_preservation_when_radius_changes
+    normal = np.array([0.0, 1.0, 0.0])
+    for radius, tolerance in {0.0: 1e-4, 1.0: 0.0001, 2.0: 0.001, 5.0: 0.001, 9.0: 0.004}.items():
+        s = ctx.debug_light(sphere_light((0.0, 10.0, 0.0), radius, 10.0), np.zeros(3), u1024)
+        luminances = s[:, 0].astype(np.float64) * (s[:, 4:7].astype(np.float64) @ normal) / np.abs(s[:, 3].astype(np.float64))
+        assert abs(math.fsum(luminances) / 1024 * (4.0 * math.pi * 100.0) - 10.0) < tolerance, radius
+
+    # device == oracle on the samples themselves (the shade TU's approximate divide / sqrt / sincos: 1e-5 relative)
+    rng = np.random.default_rng(3)
+    for light in (sphere_light((0.3, 2.0, -0.4), 0.5, 7.0), sphere_light((0.0, 1.0, 0.0), 0.0, 3.0), spot_light((0.1, 3.0, 0.2), (0.0, -1.0, 0.0), 0.7, 5.0, 0.6),
+                  spot_light((0.0, 2.0, 0.0), (0.6, -0.8, 0.0), 0.0, 5.0, 0.8)):
+        position = rng.uniform(-1.0, 1.0, 3).astype(np.float32)
+        gpu, cpu = ctx.debug_light(light, position, u1024[:256]), oracle.light_sample(light, position, u1024[:256])
+        assert np.allclose(gpu, cpu, rtol=2e-5, atol=2e-6)
+
+    # SpotLight.consistent_PDF_and_radiance
+    light_position, light_direction = np.array([0.0, 10.0, 0.0]), np.array([0.0, -1.0, 0.0])
+    for p in range(16):
+        position = (light_position + 2.0 * light_direction + 2.0 * cosine_sample(u16[p])).astype(np.float32)
+        for radius in (1.0, 4.0, 13.0):
+            for cos_angle in (0.1, 0.5, 0.9):
+                light = spot_light(light_position, light_direction, radius, 10.0, cos_angle)
+                sampled = ctx.debug_light(light, position, u16)
+                evaluated = ctx.debug_light(light, position, sampled[:, 4:7], mode=1)
+                for s, e in zip(sampled, evaluated):
+                    if pdf_is_valid(float(s[3])) or pdf_is_valid(float(e[3])):
+                        assert float(e[3]) == pytest.approx(float(s[3]), rel=1e-4)
+                    if s[0] > 0.0:
+                        assert float(e[0]) == pytest.approx(float(s[0]), abs=1e-4)
+
+    # SpotLight.pdf_rejects_rays_that_miss
+    hit = np.array([1.0, 10.0, 0.0]) / math.sqrt(101.0)
+    miss = np.array([3.0, 10.0, 0.0]) / math.sqrt(109.0)
+    towards = ctx.debug_light(spot_light((0.0, 10.0, 0.0), (0.0, -1.0, 0.0), 2.0, 10.0, 0.5), np.zeros(3), np.stack([hit, miss]), mode=1)
+    assert pdf_is_valid(float(towards[0, 3])) and not pdf_is_valid(float(towards[1, 3]))
+    away = ctx.debug_light(spot_light((0.0, 10.0, 0.0), (0.0, 1.0, 0.0), 2.0, 10.0, 0.5), np.zeros(3), np.stack([hit, miss]), mode=1)
+    assert not pdf_is_valid(float(away[0, 3])) and not pdf_is_valid(float(away[1, 3]))
+    with pytest.raises(capi.HiprError):
+        ctx.debug_light(sphere_light((0, 1, 0), 1.0, 1.0), np.zeros(3), np.stack([hit]), mode=1)
