@@ -437,3 +437,26 @@ def test_scrambled_sobol_is_stratified(oracle):
         assert len(set((s[:, dim] >> 24).tolist())) == n
     assert np.array_equal(s, oracle.sobol4ui(t))
     assert not np.array_equal(s, oracle.sobol4ui(np.array([[i, 12346, 7] for i in range(n)], np.uint32)))
+
+
+def test_G4_table_sizes_and_PDF_encoding(oracle):
+    """ShadingModelUtils.{GGX_rho,dielectric_GGX_rho,GGX_minimum_roughness}_texture_size and ..._PDF_encoding_consistent
+    (ORT/ShadingModels/UtilsTest.h:23-66): the table data and the code that indexes them agree on the sizes, and the
+    minimum-roughness lookup encodes the PDF the way the table was fitted (Assets/Shading/EstimateGGXBoundedVNDFAlpha.cpp:88-100)."""
+    from bifrost3d_amd import capi
+    base, full, light, dense, alpha = capi.load_tables()
+    assert base.size == 32 * 32 and full.size == 32 * 32                       # GGX_angle_sample_count x GGX_roughness_sample_count
+    assert light.size == 16 * 16 * 16 * 2 and dense.size == 16 * 16 * 16 * 2      # dielectric angle x roughness x ior, (total, reflected)
+    assert alpha.size == 32 * 32                                                # max_PDF_sample_count x wo_dot_normal_sample_count
+    table = alpha.reshape(32, 32)       # rows: cos theta, columns: encoded PDF
+
+    def bilinear(u, v):                 # BF/Math/ImageSampling.h:18-61, clamped texel-centre-free lookup over [0, 1]
+        x, y = min(max(u, 0.0), 1.0) * 31, min(max(v, 0.0), 1.0) * 31
+        x0, y0 = min(int(x), 30), min(int(y), 30)
+        fx, fy = x - x0, y - y0
+        return ((table[y0, x0] * (1 - fx) + table[y0, x0 + 1] * fx) * (1 - fy) + (table[y0 + 1, x0] * (1 - fx) + table[y0 + 1, x0 + 1] * fx) * fy)
+
+    for pdf in (0.1, 1.0, 10.0, 1000.0, 100000.0):
+        encoded = (pdf / (1.0 + pdf) - 0.13) / 0.87
+        for cos_theta in (0.1, 0.5, 0.9):
+            assert oracle.lib.oracle_estimate_alpha(cos_theta, pdf) == pytest.approx(float(bilinear(encoded, cos_theta)), rel=1e-4, abs=1e-6)
