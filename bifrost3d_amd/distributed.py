@@ -64,8 +64,8 @@ def gather_to_root(local, world: int, rank: int):
     if world == 1:
         return local.unsqueeze(0)
     if rank == 0:
-        parts = [torch.empty_like(local) for _ in range(world)]
-        dist.gather(local, gather_list=parts, dst=0)
-        return torch.stack(parts)
+        gathered = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+        dist.gather(local, gather_list=list(gathered.unbind(0)), dst=0)      # the ranks' tiles land in place: no stacking copy afterwards
+        return gathered
     dist.gather(local, gather_list=None, dst=0)
     return None
