@@ -7,7 +7,8 @@
 //   k_exposure_from_histogram   one wave: sums the blocks' histograms, prefix sum, percentile clamp, weighted luminance, eye adaptation
 //   k_log_luminance_partials / k_log_average_finish   two-level sum of log2 luminance -> log average or key-value exposure
 //   k_exposure_from_bias        fixed exposure with eye adaptation
-//   k_bloom_horizontal / k_bloom_vertical   separable Gaussian through bilinearly placed taps, half4 intermediates
+//   k_bloom_horizontal / k_bloom_vertical (+ _tiled)   separable Gaussian through bilinearly placed taps, half4 intermediates; the tiled
+//                               forms stage a block's texel neighbourhood in LDS
 //   k_tonemap<MODE>             exposure * (clamped pixel + bloom), vignette, operator, film grain -> RGBA16F / RGBA32F / RGBA8 sRGB
 #include "../../include/hipr_camera_effects_c.h"
 
@@ -17,6 +18,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -245,6 +247,78 @@ __global__ __launch_bounds__(256) void k_bloom_vertical(const uint2* __restrict_
     out[uint32_t(x) + size_t(y) * uint32_t(width)] = pack_rgba(sum.x, sum.y, sum.z, 1.0f);
 }
 
+// The same two passes with the texels a block needs staged in LDS first. A tap reads two neighbouring texels on either side of
+// the pixel, so a pixel touches the 4 * sample_count texels around it: from global memory that is 108 loads per pixel and pass
+// at 1080p (support 54), all L1 / L2 hits but each an instruction; staged, a block of 256 pixels loads every texel of its
+// neighbourhood once (2.7 x / 4.4 x its own pixels) and the taps read LDS. Same operations in the same order: bit-identical output.
+// reach = 2 * sample_count texels on either side of a pixel (the outermost tap's far neighbour).
+__global__ __launch_bounds__(256) void k_bloom_horizontal_tiled(DeviceFrame frame, const __half2* __restrict__ taps, int sample_count, float threshold, uint2* __restrict__ out) {
+    extern __shared__ uint2 s_texels[];      // [4 rows][64 + 2 * reach]
+    const int reach = 2 * sample_count, tile_width = 64 + 2 * reach;
+    const int tile_x = blockIdx.x * 64 + frame.x - reach, tile_y = blockIdx.y * 4 + frame.y;      // frame coordinates of the tile's first staged texel
+    const int max_x = int(frame.pitch) - 1, max_y = int(frame.rows) - 1;
+    for (int i = threadIdx.x; i < 4 * tile_width; i += 256) {
+        const int r = i / tile_width, c = i - r * tile_width;
+        const int px = min(max(tile_x + c, 0), max_x), py = min(max(tile_y + r, 0), max_y);
+        s_texels[i] = frame.pixels[uint32_t(px) + size_t(py) * frame.pitch];
+    }
+    __syncthreads();
+
+    const int lane_x = threadIdx.x & 63, r = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + lane_x, y = blockIdx.y * 4 + r;
+    if (x >= frame.width || y >= frame.height) return;
+    const uint2* row = s_texels + r * tile_width;
+    const float centre = float(x + frame.x);
+    float3_ sum = {0.0f, 0.0f, 0.0f};
+    for (int s = 0; s < sample_count; ++s) {
+        const float offset = __low2float(taps[s]), weight = __high2float(taps[s]);
+        const float lower_position = centre - offset, upper_position = centre + offset;
+        const float lower_floor = floorf(lower_position), upper_floor = floorf(upper_position);
+        const int lower_index = int(lower_floor) - tile_x, upper_index = int(upper_floor) - tile_x;
+        const float3_ lower = lerp3(unpack_rgb(row[lower_index]), unpack_rgb(row[lower_index + 1]), lower_position - lower_floor);
+        const float3_ upper = lerp3(unpack_rgb(row[upper_index]), unpack_rgb(row[upper_index + 1]), upper_position - upper_floor);
+        sum.x += (fmaxf(lower.x - threshold, 0.0f) + fmaxf(upper.x - threshold, 0.0f)) * weight;
+        sum.y += (fmaxf(lower.y - threshold, 0.0f) + fmaxf(upper.y - threshold, 0.0f)) * weight;
+        sum.z += (fmaxf(lower.z - threshold, 0.0f) + fmaxf(upper.z - threshold, 0.0f)) * weight;
+    }
+    out[uint32_t(x) + size_t(y) * uint32_t(frame.width)] = pack_rgba(sum.x, sum.y, sum.z, 1.0f);
+}
+
+// Tiles of 32 columns x 32 rows: lane % 32 is the column (consecutive 8 B LDS words, coalesced stores), thread / 32 one of eight
+// groups of four rows.
+__global__ __launch_bounds__(256) void k_bloom_vertical_tiled(const uint2* __restrict__ in, int width, int height, const __half2* __restrict__ taps, int sample_count, uint2* __restrict__ out) {
+    extern __shared__ uint2 s_texels[];      // [32 + 2 * reach rows][32 columns]
+    const int reach = 2 * sample_count, tile_rows = 32 + 2 * reach;
+    const int tile_x = blockIdx.x * 32, tile_y = blockIdx.y * 32 - reach;
+    for (int i = threadIdx.x; i < tile_rows * 32; i += 256) {
+        const int r = i >> 5, c = i & 31;
+        const int px = min(tile_x + c, width - 1), py = min(max(tile_y + r, 0), height - 1);
+        s_texels[i] = in[uint32_t(px) + size_t(py) * uint32_t(width)];
+    }
+    __syncthreads();
+
+    const int column = threadIdx.x & 31, x = tile_x + column;
+    if (x >= width) return;
+    for (int k = 0; k < 4; ++k) {
+        const int y = blockIdx.y * 32 + (threadIdx.x >> 5) * 4 + k;
+        if (y >= height) return;
+        const float centre = float(y);
+        float3_ sum = {0.0f, 0.0f, 0.0f};
+        for (int s = 0; s < sample_count; ++s) {
+            const float offset = __low2float(taps[s]), weight = __high2float(taps[s]);
+            const float upper_position = centre + offset, lower_position = centre - offset;
+            const float upper_floor = floorf(upper_position), lower_floor = floorf(lower_position);
+            const int upper_index = (int(upper_floor) - tile_y) * 32 + column, lower_index = (int(lower_floor) - tile_y) * 32 + column;
+            const float3_ upper = lerp3(unpack_rgb(s_texels[upper_index]), unpack_rgb(s_texels[upper_index + 32]), upper_position - upper_floor);
+            const float3_ lower = lerp3(unpack_rgb(s_texels[lower_index]), unpack_rgb(s_texels[lower_index + 32]), lower_position - lower_floor);
+            sum.x += (upper.x + lower.x) * weight;
+            sum.y += (upper.y + lower.y) * weight;
+            sum.z += (upper.z + lower.z) * weight;
+        }
+        out[uint32_t(x) + size_t(y) * uint32_t(width)] = pack_rgba(sum.x, sum.y, sum.z, 1.0f);
+    }
+}
+
 // ---- tonemapping (Tonemapping.hlsl:38-227) -----------------------------------------------------------------------------------------
 struct TonemapConstants {
     float bloom_threshold, vignette_strength, film_grain_strength, delta_time;
@@ -388,6 +462,7 @@ struct HiprCameraEffects {
     uint2* ping = nullptr; uint2* pong = nullptr;   // viewport-sized half4 intermediates, grow only (CameraEffects.cpp:78-98)
     size_t intermediate_pixels = 0;
 
+    bool direct_bloom = false;              // HIPR_BLOOM_DIRECT=1: the kernels without LDS staging (comparison runs)
     bool instrument = false;
     hipEvent_t event_begin = nullptr, event_end = nullptr;
     HiprCameraEffectsTimes times = {};
@@ -517,13 +592,19 @@ int enqueue_bloom(HiprCameraEffects* fx, float threshold, int support, const Hip
     if (status != HIPR_OK) return status;
     const dim3 grid((frame.viewport.width + 63) / 64, (frame.viewport.height + 3) / 4), block(256);
     const int sample_count = support / 2;
+    // LDS the tiled kernels stage (their 64 KB default limit decides; wider filters fall back to the direct kernels)
+    const size_t horizontal_lds = size_t(4) * (64 + 4 * sample_count) * sizeof(uint2), vertical_lds = size_t(32 + 4 * sample_count) * 32 * sizeof(uint2);
+    const bool tiled = sample_count > 0 && !fx->direct_bloom && horizontal_lds <= 64 * 1024 && vertical_lds <= 64 * 1024;
     {
         StageTimer timer(fx, &fx->times.bloom_horizontal_ms, &fx->times.bloom_horizontal_launches);
-        hipLaunchKernelGGL(k_bloom_horizontal, grid, block, 0, fx->stream, device_frame(frame), fx->taps, sample_count, threshold, fx->pong);
+        if (tiled) hipLaunchKernelGGL(k_bloom_horizontal_tiled, grid, block, horizontal_lds, fx->stream, device_frame(frame), fx->taps, sample_count, threshold, fx->pong);
+        else hipLaunchKernelGGL(k_bloom_horizontal, grid, block, 0, fx->stream, device_frame(frame), fx->taps, sample_count, threshold, fx->pong);
     }
     {
         StageTimer timer(fx, &fx->times.bloom_vertical_ms, &fx->times.bloom_vertical_launches);
-        hipLaunchKernelGGL(k_bloom_vertical, grid, block, 0, fx->stream, fx->pong, frame.viewport.width, frame.viewport.height, fx->taps, sample_count, out ? out : fx->ping);
+        const dim3 tile_grid((frame.viewport.width + 31) / 32, (frame.viewport.height + 31) / 32);
+        if (tiled) hipLaunchKernelGGL(k_bloom_vertical_tiled, tile_grid, block, vertical_lds, fx->stream, fx->pong, frame.viewport.width, frame.viewport.height, fx->taps, sample_count, out ? out : fx->ping);
+        else hipLaunchKernelGGL(k_bloom_vertical, grid, block, 0, fx->stream, fx->pong, frame.viewport.width, frame.viewport.height, fx->taps, sample_count, out ? out : fx->ping);
     }
     FX_HIP(hipGetLastError());
     return HIPR_OK;
@@ -550,6 +631,7 @@ int hipr_camera_effects_create(int device_index, HiprCameraEffects** out) {
     hipDeviceProp_t properties;
     if (hipGetDeviceProperties(&properties, device_index) == hipSuccess && properties.multiProcessorCount > 0) fx->compute_units = unsigned(properties.multiProcessorCount);
     if (hipStreamCreateWithFlags(&fx->stream, hipStreamNonBlocking) != hipSuccess) return cleanup(HIPR_ERROR_HIP);
+    if (const char* direct = getenv("HIPR_BLOOM_DIRECT")) fx->direct_bloom = atoi(direct) != 0;
     if (hipMalloc(&fx->histogram, BINS * sizeof(uint32_t)) != hipSuccess || hipMalloc(&fx->linear_exposure, sizeof(float)) != hipSuccess ||
         hipMalloc(&fx->partials, MAX_PARTIALS * sizeof(float)) != hipSuccess || hipMalloc(&fx->block_histograms, MAX_PARTIALS * BINS * sizeof(uint32_t)) != hipSuccess || hipMalloc(&fx->scratch_scalar, sizeof(float)) != hipSuccess)
         return cleanup(HIPR_ERROR_OUT_OF_MEMORY);

@@ -260,3 +260,18 @@ def test_errors_are_reported(fx):
         fx.process(s, 1 / 60.0, frame)
     with pytest.raises(capi.HiprError):
         fx.bloom(1.0, -3, frame)
+
+
+def test_tiled_bloom_is_bit_identical_to_the_direct_kernels(fx, monkeypatch):
+    """The LDS-staged bloom passes do the direct kernels' operations in the same order: identical halfs, for viewports, odd sizes
+    and filters from 2 to 108 pixels of support."""
+    monkeypatch.setenv("HIPR_BLOOM_DIRECT", "1")
+    direct = camera_effects.CameraEffects(0)
+    monkeypatch.delenv("HIPR_BLOOM_DIRECT")
+    try:
+        pixels = random_frame(211, 333, 21, stops=3.0)
+        frame, direct_frame = fx.upload(pixels), direct.upload(pixels)
+        for support, viewport in ((2, None), (11, None), (54, None), (108, None), (54, (7, 5, 301, 190)), (9, (300, 200, 33, 11))):
+            assert np.array_equal(fx.bloom(1.0, support, frame, viewport).view(np.uint16), direct.bloom(1.0, support, direct_frame, viewport).view(np.uint16)), (support, viewport)
+    finally:
+        direct.close()
