@@ -388,6 +388,13 @@ def test_G7_specularity_constants(oracle, goldens):
         expected = lib.oracle_dielectric_specularity(1.5, base_ior)
         actual = lib.oracle_adjust_dielectric_specularity(1.5, lib.oracle_dielectric_specularity(1.0, base_ior))
         assert abs(expected - actual) <= 1e-7
+    coat = [1.5, 1.5, 1.5]           # Specularity.scaling_conductor_specularity_under_coat, MiscTest.h:233-250
+    for base_ior in (c["gold_ior"], c["titanium_ior"]):
+        for extinction in (c["gold_extinction"], c["titanium_extinction"]):
+            expected = oracle.vec3_call("oracle_conductor_specularity", coat, base_ior, extinction)
+            through_air = oracle.vec3_call("oracle_conductor_specularity", one, base_ior, extinction)
+            actual = oracle.vec3_call("oracle_adjust_conductor_specularity", coat, list(map(float, through_air)), extinction)
+            np.testing.assert_allclose(actual, expected, atol=0.02)
 
 
 def test_G7_fix_backfacing_shading_normal(oracle):
