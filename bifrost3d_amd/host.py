@@ -25,6 +25,7 @@ def load_host_library() -> C.CDLL:
     lib.hiprh_scene_load.restype = vp
     lib.hiprh_png_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_ubyte), C.c_size_t]
     lib.hiprh_png_load.restype = C.c_size_t
+    lib.hiprh_make_camera.argtypes = [C.POINTER(C.c_float), C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.POINTER(capi.HiprCameraState)]
     lib.hiprh_scene_destroy.argtypes = [vp]
     lib.hiprh_scene_desc.argtypes = [vp]
     lib.hiprh_scene_desc.restype = C.POINTER(capi.HiprSceneDesc)
@@ -56,6 +57,18 @@ def load_png(path: str, flip: bool = False) -> np.ndarray:
     out = np.empty(size, dtype=np.uint8)
     lib.hiprh_png_load(path.encode(), int(flip), None, None, None, out.ctypes.data_as(C.POINTER(C.c_ubyte)), size)
     return out.reshape(h.value, w.value, c.value)
+
+
+def make_camera(width: int, height: int, position=(0.0, 0.0, 0.0), rotation=(0.0, 0.0, 0.0, 1.0), field_of_view=np.pi / 4, near=0.1, far=100.0, orthographic=None,
+                accumulations: int = 0, max_bounce_count: int = 4) -> capi.HiprCameraState:
+    """Camera state for a free camera: perspective (field of view, near, far) or orthographic=(width, height, depth)."""
+    lib = load_host_library()
+    ortho = orthographic if orthographic is not None else (1.0, 1.0, 1000.0)
+    params = np.array(list(position) + list(rotation) + [field_of_view, near, far, 1.0 if orthographic is not None else 0.0] + list(ortho), np.float32)
+    cam = capi.HiprCameraState()
+    if lib.hiprh_make_camera(params.ctypes.data_as(C.POINTER(C.c_float)), width, height, accumulations, max_bounce_count, C.byref(cam)) != 0:
+        raise capi.HiprError("hiprh_make_camera failed")
+    return cam
 
 
 class Scene:

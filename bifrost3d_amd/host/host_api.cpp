@@ -196,6 +196,19 @@ int hiprh_scene_camera(void* scene, unsigned width, unsigned height, unsigned ac
     return 0;
 }
 
+// A camera state for a caller's camera (tests of the camera-ray stage against the reference's ground-truth rays, BifrostTests/Scene/
+// CameraTest.h). params14: position[3], rotation quaternion x y z w, field of view, near, far, orthographic flag, ortho width, height, depth.
+int hiprh_make_camera(const float* params14, unsigned width, unsigned height, unsigned accumulations, unsigned max_bounce_count, HiprCameraState* out) {
+    if (!params14 || !out || !width || !height) return -1;
+    CameraDescription cam;
+    cam.transform = Transform(Vector3f(params14[0], params14[1], params14[2]), Bifrost::Math::Quaternionf(params14[3], params14[4], params14[5], params14[6]), 1.0f);
+    cam.field_of_view = params14[7]; cam.near_plane = params14[8]; cam.far_plane = params14[9];
+    cam.orthographic = params14[10] != 0.0f; cam.ortho_width = params14[11]; cam.ortho_height = params14[12]; cam.ortho_depth = params14[13];
+    cam.max_bounce_count = max_bounce_count;
+    *out = make_camera_state(cam, float(width) / float(height), accumulations, 0.5f);
+    return 0;
+}
+
 // Stand-alone BVH build over caller triangles (tests): returns a handle owning nodes + order.
 struct BvhHandle { BvhBuildResult result; };
 void* hiprh_bvh_build(const HiprTriangle* triangles, unsigned count, unsigned max_depth) {

@@ -456,3 +456,19 @@ def test_full_size_properties(ctx, scene_name):
     eight, _ = render_gpu(ctx, scene, w, h, 8, 4, samples_per_pass=4)      # twice the accumulations: the same image within Monte Carlo noise
     assert abs(float(full[..., :3].mean()) - float(eight[..., :3].mean())) < 0.01 * float(full[..., :3].mean())
     assert rmse(full, eight) < 0.75 * rmse(full, np.zeros_like(full))
+
+
+def test_camera_rays_match_the_reference_ground_truth(ctx, cornell):
+    """K1 against the 'Unity QED' rays of the reference's camera tests (BifrostTests/Scene/CameraTest.h:305-383) and its
+    orthographic expectations (:78-111), for translated and rotated cameras."""
+    from test_host_cpu import check_camera_rays_against_the_reference
+    ctx.upload_scene(cornell)
+
+    def generate(cam, w, h, pixels):
+        ctx.set_frame(w, h)
+        o, d, px = ctx.debug_generate(cam, 0)
+        index = {int(p): i for i, p in enumerate(px)}
+        rows = [index[int(x) | (int(y) << 16)] for x, y in pixels]
+        return o[rows], d[rows]
+
+    check_camera_rays_against_the_reference(generate)

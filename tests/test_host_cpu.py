@@ -365,3 +365,58 @@ def test_glass_scene_and_spot_variant_descriptions():
     assert sorted(round(m.roughness, 2) for m in transmissive) == [0.0, 0.0, 0.25]
     spot = Scene("cornell", spot=True)
     assert spot.desc.light_count == 2 and Scene("cornell").desc.light_count == 1
+
+
+# ---- the camera-ray stage against the reference's ground-truth rays (BifrostTests/Scene/CameraTest.h:62-111, 305-383) -------------
+
+def unity_camera_cases():
+    """(position, rotation quaternion, expected direction and origin of the ray through viewport corner (0, 0), expected centre
+    direction). The corner rays are the reference test's 'Unity QED' rays for a pi/4, 8:6 perspective camera with the near plane
+    at 1: rays start on the near plane."""
+    import math
+    axis = np.array([1.0, 2.0, 3.0]) / math.sqrt(14.0)
+    half = math.radians(30.0) / 2
+    q = tuple(axis * math.sin(half)) + (math.cos(half),)
+
+    def rotate(v):
+        x, y, z, w = q
+        u, v = np.array([x, y, z]), np.asarray(v, np.float64)
+        return v + 2.0 * np.cross(u, np.cross(u, v) + w * v)
+
+    forward = np.array([0.0, 0.0, 1.0])
+    rotated_origin = np.array([-0.02948, -0.68276, 1.00477])
+    return [((0, 0, 0), (0, 0, 0, 1), (-0.45450, -0.34087, 0.82294), (-0.55228, -0.41421, 1.00000), forward),
+            ((100, 10, -30), (0, 0, 0, 1), (-0.45450, -0.34087, 0.82294), (99.44772, 9.58579, -29.00000), forward),
+            ((0, 0, 0), q, (-0.02426, -0.56188, 0.82687), rotated_origin, rotate(forward)),
+            ((100, 10, -30), q, (-0.02426, -0.56188, 0.82687), rotated_origin + np.array([100.0, 10.0, -30.0]), rotate(forward))]
+
+
+def check_camera_rays_against_the_reference(generate):
+    """`generate(camera, width, height, pixels) -> origins, directions` of the stage under test (oracle or device)."""
+    import math
+    from bifrost3d_amd.host import make_camera
+    width, height = 800, 600       # 8:6 like the reference's camera; a pixel is 0.06 degrees wide, the test allows 0.5
+    limit = math.cos(math.radians(0.5))
+    pixels = np.array([[0, 0], [width // 2, height // 2]], np.uint32)
+    for position, rotation, corner, corner_origin, centre in unity_camera_cases():
+        cam = make_camera(width, height, position, rotation, math.pi / 4, 1.0, 1000.0)
+        origins, directions = generate(cam, width, height, pixels)
+        assert float(directions[0, :3] @ np.asarray(corner)) > limit, (position, rotation, directions[0])
+        assert float(directions[1, :3] @ centre) > limit
+        assert np.allclose(np.linalg.norm(directions[:, :3], axis=1), 1.0, atol=1e-6)
+        assert np.allclose(origins[0, :3], np.asarray(corner_origin), atol=2e-3), (origins[0], corner_origin)      # on the near plane, within a pixel (1.4e-3) of the corner
+    # Orthographic, width 8, height 4, depth 16 (CameraTest.h:78-111): the rays start at (-4 .. 4, -2 .. 2, 0) as the camera test
+    # expects. Their directions follow the renderer's ray generation, not CameraUtils: fill_ray_info (ORS/SimpleRGPs.cu:44-56)
+    # normalises inverse_projection * (x, y, 1, 1) without the perspective divide, i.e. (x * 4, y * 2, 16) -- the rays of an
+    # orthographic camera fan out slightly in the reference's path tracer, and so they do here.
+    cam = make_camera(800, 400, orthographic=(8.0, 4.0, 16.0))
+    pixels = np.array([[0, 0], [799, 399]], np.uint32)
+    origins, directions = generate(cam, 800, 400, pixels)
+    assert np.allclose(origins[0, :3], [-4.0, -2.0, 0.0], atol=0.011) and np.allclose(origins[1, :3], [4.0, 2.0, 0.0], atol=0.011)      # within a pixel of the corners
+    for k, (x, y) in enumerate(((0.5 / 800, 0.5 / 400), (799.5 / 800, 399.5 / 400))):
+        expected = np.array([(2 * x - 1) * 4.0, (2 * y - 1) * 2.0, 16.0])
+        assert np.allclose(directions[k, :3], expected / np.linalg.norm(expected), atol=1e-6)
+
+
+def test_oracle_camera_rays_match_the_reference_ground_truth(oracle):
+    check_camera_rays_against_the_reference(lambda cam, w, h, pixels: oracle.generate_rays(cam, w, h, 0, pixels))
