@@ -28,6 +28,9 @@ def test_host_side_renderer_cases():
                  "materials_and_texture_channel_regrouping", "binary_container_and_vertex_colours", "malformed_files_create_nothing"):
         assert f"[       OK ] glTFFixture.{name}" in out, out[-4000:]
     assert "[       OK ] CompositorFixture.cameras_carry_the_effects_preset" in out, out[-4000:]
+    for name in ("transform_applies_translation_rotation_and_scale", "transform_matrix_representation", "quaternion_axis_helpers_and_matrix_representation", "quaternion_look_in",
+                 "octahedral_normal_encode_decode", "blue_noise_points_fill_exactly_the_requested_range"):
+        assert f"[       OK ] MathFixture.{name}" in out, out[-4000:]
 
 
 @pytest.mark.gpu
