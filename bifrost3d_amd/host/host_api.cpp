@@ -238,4 +238,34 @@ void hiprh_encode_octahedral(const float* normals_n3, int n, short* out_n2) {
     }
 }
 
+// The host's environment light over an RGBA float latitude-longitude image: samples (radiance[3], PDF, direction[3], distance)
+// for n random pairs, PDF(direction) of those directions, the PDF image's size and, capacity allowing, the per pixel PDF.
+// Same argument list as oracle/ref/reference_api.cpp's ref_infinite_area_light, which runs the reference's own class.
+int hiprh_infinite_area_light(int width, int height, const float* rgba, const float* u_n2, int n, float* out_samples_n8, float* out_pdf_n, int* out_pdf_size2,
+                              float* out_per_pixel_PDF, int per_pixel_capacity) {
+    using namespace Bifrost;
+    const Assets::ImageID image = Assets::Images::create2D("environment", Assets::PixelFormat::RGBA_Float, false, unsigned(width), unsigned(height), rgba, size_t(width) * height * 16);
+    const Assets::TextureID texture = Assets::Textures::create2D(image, Assets::MagnificationFilter::Linear, Assets::MinificationFilter::Linear, Assets::WrapMode::Repeat,
+                                                                 Assets::WrapMode::Clamp);
+    int status = 0;
+    {
+        const Assets::InfiniteAreaLight light(texture);
+        for (int i = 0; i < n; ++i) {
+            const Assets::LightSample s = light.sample({u_n2[2 * i], u_n2[2 * i + 1]});
+            float* o = out_samples_n8 + 8 * i;
+            o[0] = s.radiance.r; o[1] = s.radiance.g; o[2] = s.radiance.b; o[3] = s.PDF;
+            o[4] = s.direction_to_light.x; o[5] = s.direction_to_light.y; o[6] = s.direction_to_light.z; o[7] = s.distance;
+            out_pdf_n[i] = light.PDF(s.direction_to_light);
+        }
+        out_pdf_size2[0] = int(light.get_PDF_width()); out_pdf_size2[1] = int(light.get_PDF_height());
+        if (out_per_pixel_PDF && per_pixel_capacity >= out_pdf_size2[0] * out_pdf_size2[1])
+            Assets::InfiniteAreaLightUtils::reconstruct_solid_angle_PDF_sans_sin_theta(light, out_per_pixel_PDF);
+        else if (out_per_pixel_PDF)
+            status = 1;
+    }
+    Assets::Textures::destroy(texture);
+    Assets::Images::destroy(image);
+    return status;
+}
+
 } // extern "C"
