@@ -257,6 +257,44 @@ def test_G5_metallic_interpolation(oracle, goldens):
                 assert np.all(np.abs(lerp - rho(metallic)) <= tol)
 
 
+def test_G5_coat_interpolation(oracle, goldens):
+    """DefaultShadingModel.coat_interpolation (DefaultShadingTest.h:326-408): a partial coat is the interpolation of the uncoated and
+    the fully coated material once all three are brought to the same effective roughness (a rough coat roughens the base; the
+    partially coated material's input roughness is found by the reference's bisection). rho within 1 %, specularity bounded."""
+    plastic = goldens["materials"]["plastic"]
+
+    def model(roughness, coat, coat_roughness, cos_theta):
+        m = dict(plastic, roughness=roughness, coat=coat, coat_roughness=coat_roughness)
+        return oracle.default_shading_info(shading_params(m), cos_theta)
+
+    def with_target_roughness(coat, coat_roughness, cos_theta, target):
+        roughness, adjustment = 0.5, 0.25                      # in f64 like the reference; the material takes the f32 value
+        previous = np.float32(roughness)
+        while True:
+            info = model(float(np.float32(roughness)), coat, coat_roughness, cos_theta)
+            if abs(float(info["roughness"]) - target) < 1e-8:
+                return info
+            roughness += -adjustment if info["roughness"] > target else adjustment
+            if np.float32(roughness) == previous:
+                return info
+            previous = np.float32(roughness)
+            adjustment *= 0.5
+
+    for coat_roughness in (0.0, 0.5, 1.0):
+        for cos_theta in (0.2, 0.4, 0.6, 0.8, 1.0):
+            coated = model(plastic["roughness"], 1.0, coat_roughness, cos_theta)
+            if coat_roughness > 0.0:
+                assert np.float32(plastic["roughness"]) < coated["roughness"]
+            plain = model(float(coated["roughness"]), 0.0, coat_roughness, cos_theta)
+            assert abs(float(plain["roughness"]) - float(coated["roughness"])) <= 4 * np.spacing(coated["roughness"])      # EXPECT_FLOAT_EQ: 4 ULP
+            for coat in (0.25, 0.5, 0.75):
+                partial = with_target_roughness(coat, coat_roughness, cos_theta, float(coated["roughness"]))
+                assert abs(float(partial["roughness"]) - float(coated["roughness"])) <= 1e-6
+                assert coated["specularity"][0] <= partial["specularity"][0] <= plain["specularity"][0]
+                expected = plain["rho"] + np.float32(coat) * (coated["rho"] - plain["rho"])
+                assert np.all(np.abs(expected - partial["rho"]) <= 0.01 * np.abs(expected)), (coat_roughness, cos_theta, coat, expected, partial["rho"])
+
+
 def test_G5_default_shading_consistency(oracle, goldens):
     """ShadingModelTestUtils::consistency_test (ShadingModelTestUtils.h:51-66): sample == evaluate_with_PDF within 2e-5."""
     wo = normalize([1, 1, 1])
