@@ -268,4 +268,18 @@ int hiprh_infinite_area_light(int width, int height, const float* rgba, const fl
     return status;
 }
 
+// The host's software texture lookup (Assets::sample2D); same argument list as oracle/ref/reference_api.cpp's ref_sample2D.
+void hiprh_sample2D(int format, int is_sRGB, int width, int height, const void* pixels, int byte_count, int magnification, int minification, int wrap_U, int wrap_V,
+                    const float* uv_n2, int n, float* out_n4) {
+    using namespace Bifrost::Assets;
+    const ImageID image = Images::create2D("texture", PixelFormat(format), is_sRGB != 0, unsigned(width), unsigned(height), pixels, size_t(byte_count));
+    const TextureID texture = Textures::create2D(image, MagnificationFilter(magnification), MinificationFilter(minification), WrapMode(wrap_U), WrapMode(wrap_V));
+    for (int i = 0; i < n; ++i) {
+        const Bifrost::Math::RGBA c = sample2D(texture, {uv_n2[2 * i], uv_n2[2 * i + 1]});
+        out_n4[4 * i] = c.r; out_n4[4 * i + 1] = c.g; out_n4[4 * i + 2] = c.b; out_n4[4 * i + 3] = c.a;
+    }
+    Textures::destroy(texture);
+    Images::destroy(image);
+}
+
 } // extern "C"

@@ -197,6 +197,13 @@ float oracle_adjust_dielectric_specularity(float exterior_ior, float spec) { ret
 void oracle_adjust_conductor_specularity(const float* exterior_ior, const float* spec, const float* ext, float* out3) {
     put3(out3, adjust_conductor_specularity_to_exterior_medium(f3(exterior_ior), f3(spec), f3(ext)));
 }
+// PDF wrapper semantics (OR/Types.h:155-204). kind: 0 PDF(value), 1 PDF::delta_dirac(value), 2 PDF::invalid(). out4 = value(), is_valid, use_for_MIS, is_delta_dirac.
+void oracle_pdf_semantics(int kind, float value, int disable_MIS, float* out4) {
+    PDF pdf = kind == 0 ? PDF(value) : kind == 1 ? PDF::delta_dirac(value) : PDF::invalid();
+    if (disable_MIS) pdf.disable_MIS();
+    out4[0] = pdf.value(); out4[1] = pdf.is_valid(); out4[2] = pdf.use_for_MIS(); out4[3] = pdf.is_delta_dirac();
+}
+int oracle_ggx_effectively_smooth_roughness(float roughness) { return GGX::effectively_smooth(GGX::alpha_from_roughness(roughness)); }
 float oracle_balance_heuristic(float a, float b) { return balance_heuristic(a, b); }
 float oracle_power_heuristic(float a, float b) { return power_heuristic(a, b); }
 float oracle_E_FON(float cos_theta, float roughness, int exact) { return exact ? OrenNayar::E_FON_exact(cos_theta, roughness) : OrenNayar::E_FON_approx(cos_theta, roughness); }

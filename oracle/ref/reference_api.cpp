@@ -138,6 +138,22 @@ void ref_rays_from_viewport_points(const float* position3, const float* rotation
     SceneRoots::destroy(scene.get_ID());
 }
 
+// ---- Assets/Texture.cpp sample2D over Images::get_pixel (Image.cpp) --------------------------------------------------------------------
+// format / filters / wrap modes by enum value (the host mirror keeps the reference's); out_n4 = linear RGBA per texcoord.
+void ref_sample2D(int format, int is_sRGB, int width, int height, const void* pixels, int byte_count, int magnification, int minification, int wrap_U, int wrap_V,
+                  const float* uv_n2, int n, float* out_n4) {
+    allocate_managers();
+    Image image = Image::create2D("texture", PixelFormat(format), is_sRGB != 0, Vector2ui(width, height));
+    std::memcpy(image.get_pixels(), pixels, size_t(byte_count));
+    Texture texture = Texture::create2D(image, MagnificationFilter(magnification), MinificationFilter(minification), WrapMode(wrap_U), WrapMode(wrap_V));
+    for (int i = 0; i < n; ++i) {
+        const RGBA c = sample2D(texture, Vector2f(uv_n2[2 * i], uv_n2[2 * i + 1]));
+        out_n4[4 * i] = c.r; out_n4[4 * i + 1] = c.g; out_n4[4 * i + 2] = c.b; out_n4[4 * i + 3] = c.a;
+    }
+    Textures::destroy(texture.get_ID());
+    Images::destroy(image.get_ID());
+}
+
 // ---- Assets/InfiniteAreaLight.cpp over Image / Texture / Distribution2D -------------------------------------------------------------
 // An RGBA float latitude-longitude image -> samples (radiance[3], PDF, direction[3], distance) for n random pairs, PDF(direction) of
 // those sample directions, the PDF image's size and (when capacity allows) the per pixel solid angle PDF sans sin(theta).

@@ -43,6 +43,7 @@ def lib():
         _lib.ref_jenkins_hash.argtypes = [C.c_uint32]; _lib.ref_jenkins_hash.restype = C.c_uint32
         _lib.ref_sample02.argtypes = [C.c_uint32, _fp]
         _lib.ref_power_heuristic.argtypes = [f, f]; _lib.ref_power_heuristic.restype = f
+        _lib.ref_sample2D.argtypes = [i, i, i, i, C.c_void_p, i, i, i, i, i, _fp, i, _fp]
         _lib.ref_infinite_area_light.argtypes = [i, i, _fp, _fp, i, _fp, _fp, C.POINTER(i), _fp, i]
     return _lib
 
@@ -98,6 +99,15 @@ def rays(position, rotation, near, far, fov, aspect, viewport_points: np.ndarray
     points = np.ascontiguousarray(viewport_points, np.float32)
     out = np.empty((len(points), 6), np.float32)
     lib().ref_rays_from_viewport_points(fptr(position), fptr(rotation), near, far, fov, aspect, fptr(points), len(points), fptr(out))
+    return out
+
+
+def sample2D(fn, pixel_format: int, is_sRGB: bool, pixels: np.ndarray, magnification: int, minification: int, wrap_U: int, wrap_V: int, uv: np.ndarray) -> np.ndarray:
+    """fn: ref_sample2D or the host library's hiprh_sample2D. pixels: [height, width(, channels)] u8 or f32."""
+    pixels, uv = np.ascontiguousarray(pixels), np.ascontiguousarray(uv, np.float32)
+    out = np.empty((len(uv), 4), np.float32)
+    fn(pixel_format, int(is_sRGB), pixels.shape[1], pixels.shape[0], pixels.ctypes.data_as(C.c_void_p), pixels.nbytes, magnification, minification, wrap_U, wrap_V, fptr(uv),
+       len(uv), fptr(out))
     return out
 
 

@@ -398,6 +398,28 @@ def test_G6_thin_sheet_rmse(oracle, goldens):
 # ------------------------------------------------------------------------------------------------
 # G7: MIS / PDF semantics, specularity constants, normals
 # ------------------------------------------------------------------------------------------------
+def test_G7_PDF_wrapper_semantics(oracle):
+    """MonteCarlo.PDF (MiscTest.h:81-139): plain, too small, delta-dirac and invalid PDFs, before and after disable_MIS; and
+    GGX.zero_roughness_converted_to_effectively_smooth_alpha (GGXTest.h:449-453)."""
+    import ctypes as C
+    oracle.lib.oracle_pdf_semantics.argtypes = [C.c_int, C.c_float, C.c_int, C.POINTER(C.c_float)]
+
+    def state(kind, value=0.0, disable=False):
+        out = np.zeros(4, np.float32)
+        oracle.lib.oracle_pdf_semantics(kind, value, int(disable), out.ctypes.data_as(C.POINTER(C.c_float)))
+        return float(out[0]), bool(out[1]), bool(out[2]), bool(out[3])          # value, is_valid, use_for_MIS, is_delta_dirac
+
+    assert state(0, 0.5) == (0.5, True, True, False)
+    assert state(0, 0.5, disable=True) == (0.5, True, False, True)
+    tiny = float(np.float32(1e-6) * np.float32(0.5))                             # MIN_VALID_PDF * 0.5
+    assert state(0, tiny) == (tiny, False, False, False)
+    assert state(0, tiny, disable=True) == (tiny, False, False, True)
+    assert state(1, 1.0)[1:] == (True, False, True) and state(1, 1.0, disable=True)[1:] == (True, False, True)
+    assert state(2)[1:] == (False, False, True) and state(2, disable=True)[1:] == (False, False, True)
+    assert oracle.lib.oracle_ggx_effectively_smooth_roughness(C.c_float(0.0)) == 1
+    assert oracle.lib.oracle_ggx_effectively_smooth_roughness(C.c_float(0.1)) == 0
+
+
 def test_G7_balance_heuristic(oracle):
     b, p = oracle.lib.oracle_balance_heuristic, oracle.lib.oracle_power_heuristic
     assert b(1.0, 1.0) == pytest.approx(0.5)

@@ -177,6 +177,33 @@ def test_octahedral_normals_match_the_reference(oracle):
     assert np.allclose(decoded, ref.octahedral_decode(theirs), atol=1e-6)
 
 
+# ---- software textures -------------------------------------------------------------------------------------------------------------------
+
+PIXEL_FORMATS = {"Alpha8": (1, np.uint8, 1), "Intensity8": (2, np.uint8, 1), "RGB24": (3, np.uint8, 3), "RGBA32": (4, np.uint8, 4), "Intensity_Float": (5, np.float32, 1),
+                 "RGB_Float": (6, np.float32, 3), "RGBA_Float": (7, np.float32, 4)}
+
+
+@pytest.mark.parametrize("name", list(PIXEL_FORMATS))
+def test_host_texture_lookup_matches_the_reference(name):
+    """Assets::sample2D over Images::get_pixel (Texture.cpp:114-176, Image.cpp:221-286) against the host's, for every pixel format,
+    sRGB decoding of the 8-bit colour formats, nearest / bilinear filtering and clamp / repeat wrapping, texcoords beyond [0, 1]."""
+    from bifrost3d_amd.host import load_host_library
+    host = load_host_library()
+    host.hiprh_sample2D.argtypes = ref.lib().ref_sample2D.argtypes
+    value, dtype, channels = PIXEL_FORMATS[name]
+    rng = np.random.default_rng(value)
+    width, height = 7, 5
+    shape = (height, width) if channels == 1 else (height, width, channels)
+    pixels = rng.integers(0, 256, shape).astype(np.uint8) if dtype == np.uint8 else (rng.random(shape) * 4).astype(np.float32)
+    uv = np.vstack([rng.uniform(-1.5, 2.5, (300, 2)), [[0, 0], [1, 1], [0.5, 0.5], [1.0, 0.0], [0.999999, 0.999999]], (np.mgrid[0:7, 0:5].reshape(2, -1).T + 0.5) / [7, 5]])
+    for is_sRGB in ([False, True] if name in ("RGB24", "RGBA32") else [False]):
+        for magnification, minification in ((0, 0), (1, 1)):
+            for wrap_U, wrap_V in ((0, 0), (1, 1), (1, 0)):
+                theirs = ref.sample2D(ref.lib().ref_sample2D, value, is_sRGB, pixels, magnification, minification, wrap_U, wrap_V, uv)
+                ours = ref.sample2D(host.hiprh_sample2D, value, is_sRGB, pixels, magnification, minification, wrap_U, wrap_V, uv)
+                assert np.allclose(ours, theirs, rtol=1e-6, atol=1e-6), (name, is_sRGB, magnification, wrap_U, wrap_V, float(np.abs(ours - theirs).max()))
+
+
 # ---- environment light ------------------------------------------------------------------------------------------------------------------
 
 def sky(width, height, seed):
