@@ -64,6 +64,21 @@ def test_alpha_estimation_matches_the_reference_function(oracle):
         assert oracle.lib.oracle_estimate_alpha(float(cos_theta), float(pdf)) == lib.ref_estimate_alpha(float(cos_theta), float(pdf)), (cos_theta, pdf)
 
 
+def test_PDF_encoding_and_sRGB_transfer_match_the_reference():
+    """encode_PDF as the alpha table was fitted with (EstimateGGXBoundedVNDFAlpha.cpp:88-100; the oracle and the kernels index the
+    table with the same expression) and Color.h's sRGB transfer functions, which the RGBA8_SRGB camera-effects target and the
+    8-bit sRGB texel decode follow."""
+    lib = ref.lib()
+    for pdf in np.exp(np.random.default_rng(6).uniform(-6, 14, 200)).astype(np.float32):
+        expected = (pdf / (np.float32(1.0) + pdf) - np.float32(0.13)) / np.float32(0.87)
+        assert math.isclose(lib.ref_encode_PDF(float(pdf)), float(expected), rel_tol=1e-6, abs_tol=1e-7)
+    for v in np.linspace(0.0, 1.0, 257):
+        linear = v / 12.92 if v < 0.04045 else ((v + 0.055) / 1.055) ** 2.4
+        assert math.isclose(lib.ref_sRGB_to_linear(float(v)), linear, rel_tol=2e-6, abs_tol=1e-7)
+        encoded = v * 12.92 if v < 0.0031308 else 1.055 * v ** (1 / 2.4) - 0.055
+        assert math.isclose(lib.ref_linear_to_sRGB(float(v)), encoded, rel_tol=2e-6, abs_tol=2e-7)
+
+
 # ---- random numbers ------------------------------------------------------------------------------------------------------------------
 
 def test_rng_header_functions_match_the_reference(oracle):
