@@ -53,13 +53,16 @@ def parse_args():
     p.add_argument("--atrium-triangles", type=int, default=260000)
     p.add_argument("--bounces", type=int, default=None, help="max_bounce_count; default 4, and 32 for the material scenes (the viewer's setting, apps/SimpleViewer/main.cpp:353)")
     p.add_argument("--spp-per-pass", type=int, default=32, help="accumulations traced together per step and GPU (HiprFrameDesc::samples_per_pass)")
-    p.add_argument("--wavefronts", type=int, default=1, choices=[1, 2],
-                   help="2: each pass runs as two half-frame wavefronts on two streams (one shades while the other traces); faster, but concurrent kernels "
-                        "inflate the per-kernel timers the roofline is computed from, so the default stays 1")
+    p.add_argument("--wavefronts", type=int, default=2, choices=[1, 2],
+                   help="2 (default): each pass runs as two half-frame wavefronts on two streams, one shades while the other traces (bit-identical image, "
+                        "+24 %% Cornell / +6 %% atrium); the per-kernel durations the roofline uses are then those of co-running kernels, and the line also "
+                        "carries roofline.alone, the dominant kernel measured with one wavefront after the timed region. 1: one wavefront throughout")
     p.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                    help="gloo + --share-device runs the N > 1 code path with every rank on GPU 0 (a functional test of the tiling / gather / scatter logic on a 1-GPU box; the gather then goes through host memory)")
     p.add_argument("--share-device", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-alone-region", action="store_true", help="skip the one-wavefront region after the timed region (roofline.alone); the profiling runs use it so that "
+                                                                  "every dispatch of a kernel in the profile belongs to the same launch shape")
     p.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     return p.parse_args()
 
@@ -83,7 +86,7 @@ def make_scene(args):
     return Scene("atrium", param0=args.atrium_triangles, param1=1), f"procedural atrium ({args.atrium_triangles} triangles target), DefaultShading"
 
 
-def load_measured_traffic(args):
+def load_measured_traffic(args, wavefronts=None):
     """HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in
     separate runs of this same command; bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024, the gfx950 correction of
     MI355X_MICROARCH.md "HBM"). Only used when the recorded command matches this run's workload; otherwise traffic is null."""
@@ -97,6 +100,7 @@ def load_measured_traffic(args):
     key = f"{args.scene}:{args.width}x{args.height}:spp{args.spp_per_pass}:bounces{args.bounces}"
     if args.scene == "atrium":
         key += f":tris{args.atrium_triangles}"
+    key += f":wf{wavefronts or args.wavefronts}"      # launches of a half-frame wavefront move half the bytes
     entry = table.get(key, {})
     return {k: v["traffic_bytes_per_launch"] for k, v in entry.get("kernels", {}).items()}
 
@@ -269,38 +273,64 @@ def main():
         #                  + 48 B per shadow ray queued + 32 B radiance read-modify-write per queued ray
         #   trace_shadow   48 B record + 32 B radiance rmw per shadow ray, + 64 B per node + 48 B per triangle
         #   accumulate     16 B radiance per sample + 64 B f64 accumulation rmw + 8 B half4 per owned pixel
-        n_closest, n_shadow, n_camera, n_hits = (counters[k] for k in ("closest_rays", "shadow_rays", "camera_rays", "shaded_hits"))
         from bifrost3d_amd import capi
-        # exhaustive-search kernels (<= 64 triangles): the triangle array is read once per 64-ray wave through the scalar cache
-        tri_share = 1.0 / 64.0 if ctx.trace_variant() == capi.TRACE_EXHAUSTIVE else 1.0
-        kernel_bytes = {
-            "generate": 80.0 * n_camera,
-            "trace_closest": n_closest * (48 + 16 + 64 * nodes_per_ray + 48 * tris_per_ray * tri_share),
-            "shade": 80.0 * n_closest + 352.0 * n_hits + 64.0 * max(0, n_closest - n_camera) + 48.0 * n_shadow + 32.0 * n_closest,
-            "trace_shadow": n_shadow * (48 + 32 + 64 * shadow_nodes_per_ray + 48 * shadow_tris_per_ray * tri_share),
-            "accumulate": 16.0 * n_camera + (64.0 + 8.0) * n_camera / max(1, S),
-        }
         small = ctx.trace_variant() == capi.TRACE_EXHAUSTIVE
-        kernel_names = {"generate": "k_generate", "trace_closest": "k_trace_closest_small" if small else "k_trace_closest", "shade": "k_shade",
-                        "trace_shadow": "k_trace_shadow_small" if small else "k_trace_shadow",
-                        "accumulate": "k_accumulate", "trace": "k_trace_persistent<TRACE_FUSED> (closest-hit rays of bounce k + shadow rays of bounce k-1)"}
-        kernel_times = dict(times)
-        if ctx.trace_is_fused():   # one launch serves both ray kinds: bytes and time of the two are reported together
-            kernel_bytes["trace"] = kernel_bytes.pop("trace_closest") + kernel_bytes.pop("trace_shadow")
-            a, b = kernel_times.pop("trace_closest"), kernel_times.pop("trace_shadow")
-            kernel_times["trace"] = {"ms": a["ms"] + b["ms"], "launches": a["launches"] + b["launches"]}
+        fused = ctx.trace_is_fused()
         measured_traffic = load_measured_traffic(args)
-        rooflines = {}
-        for name, nbytes in kernel_bytes.items():
-            t = kernel_times.get(name)
-            if not t or t["ms"] <= 0 or t["launches"] == 0:
-                continue
-            gbs = nbytes / (t["ms"] * 1e-3) / 1e9
-            rooflines[name] = {"bound": "hbm", "kernel": kernel_names[name], "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                               "traffic": measured_traffic.get(name), "avg_launch_ms": t["ms"] / t["launches"], "launches": t["launches"],
-                               "algorithmic_bytes_per_launch": nbytes / t["launches"], "total_ms": t["ms"]}
+
+        def rooflines_of(counters, times):
+            n_closest, n_shadow, n_camera, n_hits = (counters[k] for k in ("closest_rays", "shadow_rays", "camera_rays", "shaded_hits"))
+            # exhaustive-search kernels (<= 64 triangles): the triangle array is read once per 64-ray wave through the scalar cache
+            tri_share = 1.0 / 64.0 if small else 1.0
+            kernel_bytes = {
+                "generate": 80.0 * n_camera,
+                "trace_closest": n_closest * (48 + 16 + 64 * nodes_per_ray + 48 * tris_per_ray * tri_share),
+                "shade": 80.0 * n_closest + 352.0 * n_hits + 64.0 * max(0, n_closest - n_camera) + 48.0 * n_shadow + 32.0 * n_closest,
+                "trace_shadow": n_shadow * (48 + 32 + 64 * shadow_nodes_per_ray + 48 * shadow_tris_per_ray * tri_share),
+                "accumulate": 16.0 * n_camera + (64.0 + 8.0) * n_camera / max(1, S),
+            }
+            kernel_names = {"generate": "k_generate", "trace_closest": "k_trace_closest_small" if small else "k_trace_closest", "shade": "k_shade",
+                            "trace_shadow": "k_trace_shadow_small" if small else "k_trace_shadow",
+                            "accumulate": "k_accumulate", "trace": "k_trace_persistent<TRACE_FUSED> (closest-hit rays of bounce k + shadow rays of bounce k-1)"}
+            kernel_times = dict(times)
+            if fused:   # one launch serves both ray kinds: bytes and time of the two are reported together
+                kernel_bytes["trace"] = kernel_bytes.pop("trace_closest") + kernel_bytes.pop("trace_shadow")
+                a, b = kernel_times.pop("trace_closest"), kernel_times.pop("trace_shadow")
+                kernel_times["trace"] = {"ms": a["ms"] + b["ms"], "launches": a["launches"] + b["launches"]}
+            rooflines = {}
+            for name, nbytes in kernel_bytes.items():
+                t = kernel_times.get(name)
+                if not t or t["ms"] <= 0 or t["launches"] == 0:
+                    continue
+                gbs = nbytes / (t["ms"] * 1e-3) / 1e9
+                rooflines[name] = {"bound": "hbm", "kernel": kernel_names[name], "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                   "traffic": measured_traffic.get(name), "avg_launch_ms": t["ms"] / t["launches"], "launches": t["launches"],
+                                   "algorithmic_bytes_per_launch": nbytes / t["launches"], "total_ms": t["ms"]}
+            return rooflines, kernel_times
+
+        rooflines, kernel_times = rooflines_of(counters, times)
         dominant = max(rooflines, key=lambda n: rooflines[n]["total_ms"])
         roofline = dict(rooflines[dominant])
+        if args.wavefronts > 1 and not args.no_alone_region:
+            # With two wavefronts a kernel shares the machine with the other wavefront's (that is the point: one shades while the other
+            # traces), so the durations above -- and `achieved` with them -- are those of co-running kernels. The same kernel alone on
+            # the machine: a short extra region with one wavefront, after and outside the timed region.
+            ctx.set_wavefront_count(1)
+            ctx.set_frame(W, H, tile_phase=rank, tile_stride=world, samples_per_pass=S)
+            run_pass(0)
+            ctx.synchronize()
+            ctx.reset_counters()
+            ctx.reset_timers()
+            for k in range(4):
+                run_pass((k + 1) * S)
+            ctx.synchronize()
+            alone, _ = rooflines_of(ctx.counters(), ctx.kernel_times())
+            if dominant in alone:
+                roofline["alone"] = {k: alone[dominant][k] for k in ("achieved", "frac", "avg_launch_ms", "launches", "algorithmic_bytes_per_launch")}
+                roofline["alone"]["traffic"] = load_measured_traffic(args, 1).get(dominant)
+                roofline["alone"]["note"] = "the same kernel with one wavefront (nothing co-running), 4 steps after the timed region"
+        if args.wavefronts > 1:
+            roofline["co_running"] = "two half-frame wavefronts on two streams: this kernel's launches overlap the other wavefront's kernels"
         roofline.update({"nodes_per_ray": nodes_per_ray, "triangles_per_ray": tris_per_ray, "shadow_nodes_per_ray": shadow_nodes_per_ray,
                          "shadow_triangles_per_ray": shadow_tris_per_ray, "selection": "kernel with the largest total time in the timed region"})
         out = {

@@ -103,7 +103,7 @@ struct HiprContext {
     hipStream_t own_stream = nullptr, stream = nullptr, copy_stream = nullptr;
     hipEvent_t pass_start = nullptr;
     Wavefront wavefronts[MAX_WAVEFRONTS];
-    int wavefront_limit = 1;                // hipr_set_wavefront_count / HIPR_WAVEFRONTS: 2 overlaps one half-frame's shading with the other's tracing
+    int wavefront_limit = 2;                // hipr_set_wavefront_count / HIPR_WAVEFRONTS: 2 overlaps one half-frame's shading with the other's tracing (never slower, measured)
     int wavefront_count = 1;                // set by hipr_set_frame: small frames run as one wavefront
 
     // scene
