@@ -53,7 +53,7 @@ def parse_args():
     p.add_argument("--atrium-triangles", type=int, default=260000)
     p.add_argument("--bounces", type=int, default=None, help="max_bounce_count; default 4, and 32 for the material scenes (the viewer's setting, apps/SimpleViewer/main.cpp:353)")
     p.add_argument("--spp-per-pass", type=int, default=32, help="accumulations traced together per step and GPU (HiprFrameDesc::samples_per_pass)")
-    p.add_argument("--wavefronts", type=int, default=2, choices=[1, 2],
+    p.add_argument("--wavefronts", type=int, default=2, choices=[1, 2, 3, 4],
                    help="2 (default): each pass runs as two half-frame wavefronts on two streams, one shades while the other traces (bit-identical image, "
                         "+24 %% Cornell / +6 %% atrium); the per-kernel durations the roofline uses are then those of co-running kernels, and the line also "
                         "carries roofline.alone, the dominant kernel measured with one wavefront after the timed region. 1: one wavefront throughout")

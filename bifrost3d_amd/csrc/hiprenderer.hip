@@ -93,7 +93,7 @@ struct Wavefront {
         *this = Wavefront();
     }
 };
-constexpr int MAX_WAVEFRONTS = 2;
+constexpr int MAX_WAVEFRONTS = 4;
 constexpr int COUNT_PAIR_STRIDE = 16;   // uint32 words between the two queue-size pairs of a wavefront (one 64 B line each)
 
 } // namespace
@@ -190,7 +190,7 @@ uint32_t grid_for(uint32_t items, uint32_t block, uint32_t max_blocks) {
     return (blocks + 7u) & ~7u;   // multiple of 8: xcd_chunk() needs every XCD to own the same number of chunks
 }
 
-constexpr uint32_t WORK_SETS = 64;                                        // launches served before the ring is re-zeroed
+constexpr uint32_t WORK_SETS = 256;                                       // launches served before the ring is re-zeroed
 constexpr uint32_t WORK_SET_WORDS = TRACE_SHARDS * TRACE_SHARD_STRIDE;   // one claim counter per shard, 64 B apart
 constexpr uint32_t WORK_COUNTERS = WORK_SETS * WORK_SET_WORDS;
 
@@ -538,14 +538,20 @@ int hipr_set_frame(HiprContext* c, const HiprFrameDesc* f) {
     c->n_slots = uint32_t(slots);
     int r = 0;
     // Split the slots over the wavefronts on a tile (= wave) boundary; small frames stay one wavefront.
-    c->wavefront_count = (c->wavefront_limit > 1 && slots >= 2u * 65536u) ? 2 : 1;
-    const uint64_t first_share = c->wavefront_count == 1 ? slots : ((slots / 2 + 63) / 64) * 64;
+    c->wavefront_count = int(std::max<uint64_t>(1, std::min<uint64_t>(uint64_t(c->wavefront_limit), slots / 65536u)));
+    const uint64_t share = ((slots + c->wavefront_count - 1) / c->wavefront_count + 63) / 64 * 64;
     for (int g = 0; g < MAX_WAVEFRONTS; ++g) {
         Wavefront& w = c->wavefronts[g];
-        w.first_slot = g == 0 ? 0u : uint32_t(first_share);
-        w.n_slots = g >= c->wavefront_count ? 0u : uint32_t(g == 0 ? first_share : slots - first_share);
+        const uint64_t first = std::min<uint64_t>(slots, share * g);
+        w.first_slot = uint32_t(first);
+        w.n_slots = g >= c->wavefront_count ? 0u : uint32_t(std::min<uint64_t>(share, slots - first));
         const size_t bytes = size_t(std::max(w.n_slots, 64u)) * 16;
-        if (g >= c->wavefront_count) continue;
+        if (g >= c->wavefront_count) {   // queues of wavefronts this frame does not use go back to the allocator
+            for (auto& buffers : w.path) for (DeviceBuffer& b : buffers) b.release();
+            w.hits.release();
+            for (DeviceBuffer& b : w.shadow) b.release();
+            continue;
+        }
         for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) r |= w.path[i][j].resize(bytes);
         r |= w.hits.resize(bytes);
         for (int j = 0; j < 3; ++j) r |= w.shadow[j].resize(bytes);
@@ -695,8 +701,8 @@ int hipr_render_pass(HiprContext* c, const HiprCameraState* camera, void* out_ha
     };
 
     // Start every wavefront: camera rays + bounce 0.
-    uint32_t alive[MAX_WAVEFRONTS] = {0, 0}, bounce[MAX_WAVEFRONTS] = {0, 0};
-    bool running[MAX_WAVEFRONTS] = {false, false};
+    uint32_t alive[MAX_WAVEFRONTS] = {}, bounce[MAX_WAVEFRONTS] = {};
+    bool running[MAX_WAVEFRONTS] = {};
     for (int g = 0; g < c->wavefront_count; ++g) {
         Wavefront& w = c->wavefronts[g];
         if (g > 0) HIP_TRY(hipStreamWaitEvent(w.stream, c->pass_start, 0));

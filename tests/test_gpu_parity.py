@@ -301,21 +301,23 @@ def test_tint_quad_G10(ctx):
 
 
 @pytest.mark.parametrize("scene_name", ["cornell", "atrium"])
-def test_two_wavefronts_are_bit_identical(ctx, cornell, atrium, scene_name):
-    """hipr_set_wavefront_count(2) splits a pass into two half-frame wavefronts on two streams (one shades while the other
-    traces). Every path still owns its radiance slot and sees the same kernel order, so the accumulation must not change."""
+def test_wavefront_count_does_not_change_the_image(ctx, cornell, atrium, scene_name):
+    """hipr_set_wavefront_count(n) splits a pass into n shares of the path slots on n streams (one shades while another traces;
+    the default is 2). Every path still owns its radiance slot and sees the same kernel order, so the accumulation must not change."""
     scene = cornell if scene_name == "cornell" else atrium
-    w, h, spp = 512, 300, 2          # 153 600 pixels: above the 131 072-slot threshold below which a frame stays one wavefront
-    one, c1 = render_gpu(ctx, scene, w, h, spp, 4)
-    ctx.set_wavefront_count(2)
+    w, h, spp = 640, 416, 2          # 266 240 pixels: enough for four wavefronts (one per 65 536 path slots at most)
+    images, counters = {}, {}
     try:
-        two, c2 = render_gpu(ctx, scene, w, h, spp, 4)
+        for count in (1, 2, 3, 4):
+            ctx.set_wavefront_count(count)
+            images[count], counters[count] = render_gpu(ctx, scene, w, h, spp, 4)
     finally:
-        ctx.set_wavefront_count(1)
+        ctx.set_wavefront_count(2)
         ctx.set_frame(w, h)
-    assert np.array_equal(one, two)
-    for key in ("camera_rays", "closest_rays", "shadow_rays"):
-        assert c1[key] == c2[key], key
+    for count in (2, 3, 4):
+        assert np.array_equal(images[1], images[count]), count
+        for key in ("camera_rays", "closest_rays", "shadow_rays"):
+            assert counters[1][key] == counters[count][key], (count, key)
 
 
 def test_tessellated_cornell_renders_the_same_image(ctx, oracle_q, cornell_tessellated):
