@@ -133,6 +133,7 @@ struct HiprContext {
     int active_trace_variant() const { return use_persistent() ? HIPR_TRACE_WIDE_PERSISTENT : (use_exhaustive() ? HIPR_TRACE_EXHAUSTIVE : HIPR_TRACE_BVH2); }
     int cu_count = 256;
     int blocks_per_cu_override = 0;     // HIPR_BLOCKS_PER_CU
+    int shade_blocks_per_cu = 2;        // persistent shade blocks per CU (HIPR_SHADE_BLOCKS_PER_CU)
     int refill_below = 40;              // persistent kernels refill a wave once fewer lanes than this are busy (HIPR_REFILL_BELOW)
     int persistent_blocks_per_cu[3][3] = {{0, 0, 0}, {0, 0, 0}};   // [shadow][stack bucket]
 
@@ -276,7 +277,7 @@ void launch_trace_fused(HiprContext* c, const Wavefront& w, const PathState& in,
 
 void launch_shade(HiprContext* c, const Wavefront& w, const HiprCameraState& camera, int cur, uint32_t alive, const uint32_t* in_count, uint32_t* out_counts) {
     // persistent blocks: two per CU stay resident (2 waves per SIMD), each walks the queue with a grid stride
-    ShadeLaunch a = {grid_for(alive, SHADE_BLOCK, uint32_t(c->cu_count) * 2u), w.stream, c->scene, camera, c->entry, w.path_state(cur), w.hits.as<float4>(), w.path_state(1 - cur),
+    ShadeLaunch a = {grid_for(alive, SHADE_BLOCK, uint32_t(c->cu_count) * uint32_t(c->shade_blocks_per_cu)), w.stream, c->scene, camera, c->entry, w.path_state(cur), w.hits.as<float4>(), w.path_state(1 - cur),
                      w.shadow_queue(), c->radiance.as<float4>(), in_count, reinterpret_cast<unsigned long long*>(out_counts), c->counters.as<DeviceCounters>()};
     hipr::launch_shade(c->shading_models, a);
 }
@@ -347,6 +348,7 @@ int hipr_create(int device_id, HiprContext** out_context) {
     if (hipGetDeviceProperties(&props, device_id) == hipSuccess && props.multiProcessorCount > 0) c->cu_count = props.multiProcessorCount;
     if (const char* v = getenv("HIPR_TRACE_VARIANT")) c->trace_variant = atoi(v);
     if (const char* v = getenv("HIPR_REFILL_BELOW")) c->refill_below = atoi(v);
+    if (const char* v = getenv("HIPR_SHADE_BLOCKS_PER_CU")) c->shade_blocks_per_cu = std::max(1, atoi(v));
     if (const char* v = getenv("HIPR_BLOCKS_PER_CU")) c->blocks_per_cu_override = atoi(v);
     if (const char* v = getenv("HIPR_WAVEFRONTS")) c->wavefront_limit = std::max(1, std::min(MAX_WAVEFRONTS, atoi(v)));
     if (const char* v = getenv("HIPR_TRACE_LOG")) c->trace_log = atoi(v) != 0;
