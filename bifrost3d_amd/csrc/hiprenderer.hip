@@ -107,7 +107,7 @@ struct HiprContext {
     int wavefront_count = 1;                // set by hipr_set_frame: small frames run as one wavefront
 
     // scene
-    DeviceBuffer shade_triangles, trace_triangles, wide_nodes, environment_PDF, environment_samples;
+    DeviceBuffer shade_triangles, trace_triangles, trace_items, wide_nodes, environment_PDF, environment_samples;
     DeviceBuffer nodes, triangles, instances, indices, geometry, texcoords, tints, emissions, materials, lights, textures, texels;
     DeviceBuffer ggx_rho, dielectric_rho, alpha, sample_offsets, sobol_tables;
     DeviceScene scene = {};
@@ -189,6 +189,48 @@ uint32_t grid_for(uint32_t items, uint32_t block, uint32_t max_blocks) {
     uint32_t blocks = (items + block - 1) / block;
     blocks = std::max(1u, std::min(blocks, max_blocks));
     return (blocks + 7u) & ~7u;   // multiple of 8: xcd_chunk() needs every XCD to own the same number of chunks
+}
+
+// Items of the exhaustive search (kernels.h "Exhaustive-search items"): every triangle in order, except that a triangle (a, b, c)
+// and a LATER one of the same instance and flags that is (a, c, d) in some rotation, with bit-identical shared corners and
+// d = a + (c - b) within 1e-5 of the longest edge component, are merged into the parallelogram item (a, b - a, d - a) at the first
+// one's place. Only scenes of at most SMALL_SCENE_TRIANGLES triangles -- the ones searched exhaustively by default -- are paired: above
+// that an exhaustive search (HIPR_TRACE_VARIANT) stays per triangle and bit-identical to the BVH searches.
+constexpr uint32_t PAIRING_LIMIT = SMALL_SCENE_TRIANGLES;
+void build_trace_items(const HiprTriangle* triangles, uint32_t count, std::vector<float>& items) {
+    auto corner = [&](uint32_t t, int k) -> const float* { const HiprTriangle& tri = triangles[t]; return k % 3 == 0 ? tri.v0 : (k % 3 == 1 ? tri.v1 : tri.v2); };
+    auto same = [](const float* p, const float* q) { return std::memcmp(p, q, 12) == 0; };
+    auto bits = [](uint32_t v) { float f; std::memcpy(&f, &v, 4); return f; };
+    std::vector<bool> merged(count, false);
+    items.clear();
+    for (uint32_t i = 0; i < count; ++i) {
+        if (merged[i]) continue;
+        int ra = 0, rb = 0;
+        uint32_t partner = UINT32_MAX;
+        for (uint32_t j = i + 1; count <= PAIRING_LIMIT && j < count && partner == UINT32_MAX; ++j) {
+            if (merged[j] || triangles[j].instance_index != triangles[i].instance_index || triangles[j].flags != triangles[i].flags) continue;
+            for (int x = 0; x < 3 && partner == UINT32_MAX; ++x)
+                for (int y = 0; y < 3 && partner == UINT32_MAX; ++y) {
+                    const float *a = corner(i, x), *b = corner(i, x + 1), *c = corner(i, x + 2), *a2 = corner(j, y), *c2 = corner(j, y + 1), *d = corner(j, y + 2);
+                    if (!same(a, a2) || !same(c, c2)) continue;
+                    float longest = 0.0f, off = 0.0f;
+                    for (int k = 0; k < 3; ++k) {
+                        longest = std::fmax(longest, std::fmax(std::fabs(b[k] - a[k]), std::fabs(d[k] - a[k])));
+                        off = std::fmax(off, std::fabs(d[k] - (a[k] + (c[k] - b[k]))));
+                    }
+                    if (off <= 1e-5f * longest) { partner = j; ra = x; rb = y; }
+                }
+        }
+        const float *a = corner(i, ra), *b = corner(i, ra + 1), *d = partner == UINT32_MAX ? corner(i, ra + 2) : corner(partner, rb + 2);
+        // stored vertex k of a triangle is corner (k - rotation) mod 3 of its half: u = weight of vertex 1, v = weight of vertex 2
+        const uint32_t selectors = partner == UINT32_MAX ? 0u : uint32_t((4 - ra) % 3) | uint32_t((5 - ra) % 3) << 2 | uint32_t((4 - rb) % 3) << 4 | uint32_t((5 - rb) % 3) << 6;
+        const float item[16] = {a[0], a[1], a[2], b[0] - a[0], b[1] - a[1], b[2] - a[2], d[0] - a[0], d[1] - a[1], d[2] - a[2],
+                                bits(triangles[i].instance_index), bits(triangles[i].primitive_index), bits(triangles[i].flags | (partner == UINT32_MAX ? 0u : HIPR_ITEM_QUAD)),
+                                bits(i), bits(partner == UINT32_MAX ? i : partner), bits(partner == UINT32_MAX ? triangles[i].primitive_index : triangles[partner].primitive_index),
+                                bits(selectors)};
+        items.insert(items.end(), item, item + 16);
+        if (partner != UINT32_MAX) merged[partner] = true;
+    }
 }
 
 constexpr uint32_t WORK_SETS = 256;                                       // launches served before the ring is re-zeroed
@@ -382,7 +424,7 @@ int hipr_destroy(HiprContext* c) {
     if (!c) return HIPR_OK;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    DeviceBuffer* all[] = {&c->shade_triangles, &c->trace_triangles, &c->wide_nodes, &c->environment_PDF, &c->environment_samples, &c->nodes, &c->triangles, &c->instances, &c->indices, &c->geometry, &c->texcoords, &c->tints, &c->emissions, &c->materials,
+    DeviceBuffer* all[] = {&c->shade_triangles, &c->trace_triangles, &c->trace_items, &c->wide_nodes, &c->environment_PDF, &c->environment_samples, &c->nodes, &c->triangles, &c->instances, &c->indices, &c->geometry, &c->texcoords, &c->tints, &c->emissions, &c->materials,
                            &c->lights, &c->textures, &c->texels, &c->ggx_rho, &c->dielectric_rho, &c->alpha, &c->sample_offsets, &c->sobol_tables, &c->radiance,
                            &c->accumulation, &c->scratch_accumulation, &c->counters, &c->work_counters, &c->debug_a, &c->debug_b, &c->debug_c};
     for (DeviceBuffer* b : all) b->release();
@@ -501,6 +543,16 @@ int hipr_upload_scene(HiprContext* c, const HiprSceneDesc* s) {
         hipLaunchKernelGGL(k_build_trace_triangles, dim3((s->triangle_count + 255) / 256), dim3(256), 0, st, d.triangles, s->triangle_count, c->trace_triangles.as<float4>());
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(st));
+    }
+    d.trace_items = nullptr;
+    d.trace_item_count = 0;
+    if (s->triangle_count && (s->triangle_count <= SMALL_SCENE_TRIANGLES || c->trace_variant == HIPR_TRACE_EXHAUSTIVE)) {
+        std::vector<float> items;
+        build_trace_items(s->triangles, s->triangle_count, items);
+        if (c->trace_items.upload(items.data(), items.size() * sizeof(float), st)) return HIPR_ERROR_OUT_OF_MEMORY;
+        HIP_TRY(hipStreamSynchronize(st));
+        d.trace_items = c->trace_items.as<float4>();
+        d.trace_item_count = uint32_t(items.size() / 16);
     }
     c->stack_size = s->bvh_max_depth <= 16 ? 16 : (s->bvh_max_depth <= 32 ? 32 : 64);
     int models = 0;

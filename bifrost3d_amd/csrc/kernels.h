@@ -35,6 +35,7 @@ struct DeviceScene {
     const float4* triangles;
     const float4* shade_triangles;   // SHADE_TRIANGLE_QUADS float4 per triangle, built on upload (k_build_shade_triangles)
     const float4* trace_triangles;   // 3 float4 per triangle: v0, e1 = v1 - v0, e2 = v2 - v0, then instance / primitive / flags as in `triangles` (k_build_trace_triangles)
+    const float4* trace_items;       // exhaustive search only: 4 float4 per item, a triangle or two triangles merged into a parallelogram (build_trace_items)
     const HiprInstance* instances;
     const uint32_t* indices;
     const float4* geometry;
@@ -53,7 +54,7 @@ struct DeviceScene {
     uint32_t env_pdf_width, env_pdf_height, env_sample_count;
     const uint32_t* sobol_tables;   // SOBOL_TABLE_WORDS words, see sobol4ui_tables
     DeviceTables tables;
-    uint32_t node_count, wide_node_count, triangle_count, light_count;
+    uint32_t node_count, wide_node_count, triangle_count, light_count, trace_item_count;
     float env_tint[3];
     int next_event_sample_count;
 };
@@ -196,6 +197,39 @@ HD void triangle_hit_values(const TriangleTest& r, f3 e2, float& t, float& u, fl
     u = r.un * inv;
     v = r.vn * inv;
     t = dot_fma(e2, r.q) * inv;
+}
+
+
+// Exhaustive-search items (scenes of at most SMALL_SCENE_TRIANGLES triangles): a triangle, or TWO triangles that form a
+// parallelogram (a, b, c) + (a, c, d) with d = a + (c - b), tested as one: the same Moeller-Trumbore solve against e1 = b - a and
+// e2 = d - a yields (s, r) with the parallelogram being 0 <= s, r <= 1; s >= r is the half of (a, b, c), whose corner weights are
+// (1 - s, s - r, r); the other half is (a, c, d) with (1 - r, s, r - s). A box side or a wall costs one test instead of two.
+// Item layout (4 float4): {v0, e1.x} {e1.yz, e2.xy} {e2.z, instance, primitive A, flags} {triangle A, triangle B, primitive B, selectors};
+// selectors: 2 bits each, which corner weight of the half is the triangle's u (weight of its vertex 1) and v (vertex 2): u of A,
+// v of A, u of B, v of B. The host builds the items at upload (hiprenderer.hip build_trace_items); the oracle restates the pairing.
+constexpr uint32_t HIPR_ITEM_QUAD = 2u;   // next to HIPR_TRIANGLE_OPAQUE in the item's flags
+struct ItemTest { float det, un, vn, us, vs; f3 q; };
+HD bool item_inside(f3 v0, f3 e1, f3 e2, bool quad, f3 o, f3 d, ItemTest& r) {
+    const f3 p = cross_fma(d, e2);
+    r.det = dot_fma(e1, p);
+    const f3 tv = o - v0;
+    r.un = dot_fma(tv, p);
+    r.q = cross_fma(tv, e1);
+    r.vn = dot_fma(d, r.q);
+    const uint32_t sign = __float_as_uint(r.det) & 0x80000000u;
+    r.us = __uint_as_float(__float_as_uint(r.un) ^ sign);
+    r.vs = __uint_as_float(__float_as_uint(r.vn) ^ sign);
+    const float limit = fabsf(r.det);
+    const bool upper = quad ? ((r.us <= limit) & (r.vs <= limit)) : (r.us + r.vs <= limit);   // `quad` is wave uniform
+    return (r.det != 0.0f) & (r.us >= 0.0f) & (r.vs >= 0.0f) & upper;
+}
+// Barycentrics of the hit triangle from the solve's (s, r): `second_half` = the hit is in (a, c, d); `selectors` as in the item.
+HD void item_barycentrics(bool quad, bool second_half, uint32_t selectors, float s, float r, float& u, float& v) {
+    if (!quad) { u = s; v = r; return; }
+    const float w0 = second_half ? 1.0f - r : 1.0f - s, w1 = second_half ? s : s - r, w2 = second_half ? r - s : r;
+    const uint32_t cu = (selectors >> (second_half ? 4 : 0)) & 3u, cv = (selectors >> (second_half ? 6 : 2)) & 3u;
+    u = cu == 0 ? w0 : (cu == 1 ? w1 : w2);
+    v = cv == 0 ? w0 : (cv == 1 ? w1 : w2);
 }
 
 // `stack` points at this lane's column of the LDS stack; entry k is stack[k * STRIDE].
@@ -475,20 +509,27 @@ __global__ __launch_bounds__(256) void k_trace_closest_small(DeviceScene sc, Pat
         const f3 o = mk3(ro.x, ro.y, ro.z), d = mk3(rd.x, rd.y, rd.z);
         const float tmin = ro.w;
         const uint32_t skip = meta.y;
-        float best_t = __builtin_inff(), best_u = 0.0f, best_v = 0.0f;
-        uint32_t best_id = HIPR_HIT_MISS;
-        const ConstantFloat4Pointer triangles = as_constant(sc.trace_triangles);
-        for (uint32_t t = 0; t < sc.triangle_count; ++t) {   // uniform: scalar loads of the triangle
-            const ScalarFloat4 a = triangles[3 * t], b = triangles[3 * t + 1], c = triangles[3 * t + 2];
-            TriangleTest test;
-            const bool inside = triangle_inside(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), o, d, test) & (t != skip);
-            if (!__any(inside)) continue;       // wave-uniform: most triangles are missed by every ray of the wave
-            float tt, u, v;
-            triangle_hit_values(test, mk3(b.z, b.w, c.x), tt, u, v);
-            const bool closer = inside & (tt > tmin) & ((tt < best_t) | ((tt == best_t) & (t < best_id)));
-            best_t = closer ? tt : best_t; best_u = closer ? u : best_u; best_v = closer ? v : best_v; best_id = closer ? t : best_id;
+        float best_t = __builtin_inff(), best_s = 0.0f, best_r = 0.0f;
+        uint32_t best_id = HIPR_HIT_MISS, best_code = 0;   // code: selectors | quad << 8 | second half << 9
+        const ConstantFloat4Pointer items = as_constant(sc.trace_items);
+        for (uint32_t t = 0; t < sc.trace_item_count; ++t) {   // uniform: scalar loads of the item
+            const ScalarFloat4 a = items[4 * t], b = items[4 * t + 1], c = items[4 * t + 2], m = items[4 * t + 3];
+            const bool quad = (__float_as_uint(c.w) & HIPR_ITEM_QUAD) != 0;
+            ItemTest test;
+            bool inside = item_inside(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), quad, o, d, test);
+            const bool second_half = quad & (test.us < test.vs);
+            const uint32_t id = second_half ? __float_as_uint(m.y) : __float_as_uint(m.x);
+            inside &= id != skip;
+            if (!__any(inside)) continue;       // wave-uniform: most items are missed by every ray of the wave
+            const float inv = 1.0f / test.det;
+            const float tt = dot_fma(mk3(b.z, b.w, c.x), test.q) * inv;
+            const bool closer = inside & (tt > tmin) & ((tt < best_t) | ((tt == best_t) & (id < best_id)));
+            best_t = closer ? tt : best_t; best_s = closer ? test.un * inv : best_s; best_r = closer ? test.vn * inv : best_r; best_id = closer ? id : best_id;
+            best_code = closer ? ((__float_as_uint(m.w) & 0xFFu) | (quad ? 256u : 0u) | (second_half ? 512u : 0u)) : best_code;
         }
-        if (INSTRUMENT) tris += sc.triangle_count;
+        float best_u, best_v;
+        item_barycentrics((best_code & 256u) != 0, (best_code & 512u) != 0, best_code & 0xFFu, best_s, best_r, best_u, best_v);
+        if (INSTRUMENT) tris += sc.trace_item_count;
         for (uint32_t li = 0; li < sc.light_count; ++li) {   // analytic area lights, LightSources.cu:31-70
             const HiprLight l = load_light_uniform(sc.lights, li);
             const uint32_t type = l.flags & HIPR_LIGHT_TYPE_MASK;
@@ -514,21 +555,25 @@ __global__ __launch_bounds__(256) void k_trace_shadow_small(DeviceScene sc, Shad
         const float tmax = ro.w;
         f3 rad = mk3(rr.x, rr.y, rr.z);
         bool blocked = false;
-        const ConstantFloat4Pointer triangles = as_constant(sc.trace_triangles);
-        for (uint32_t t = 0; t < sc.triangle_count; ++t) {
+        const ConstantFloat4Pointer items = as_constant(sc.trace_items);
+        for (uint32_t t = 0; t < sc.trace_item_count; ++t) {
             if (!__any(!blocked)) break;
-            const ScalarFloat4 a = triangles[3 * t], b = triangles[3 * t + 1], c = triangles[3 * t + 2];
+            const ScalarFloat4 a = items[4 * t], b = items[4 * t + 1], c = items[4 * t + 2], m = items[4 * t + 3];
             if (INSTRUMENT) tris += blocked ? 0u : 1u;
-            TriangleTest test;
-            const bool inside = triangle_inside(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), o, d, test) & !blocked;
+            const bool quad = (__float_as_uint(c.w) & HIPR_ITEM_QUAD) != 0;
+            ItemTest test;
+            const bool inside = item_inside(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), quad, o, d, test) & !blocked;
             if (!__any(inside)) continue;
-            float tt, u, v;
-            triangle_hit_values(test, mk3(b.z, b.w, c.x), tt, u, v);
+            const float inv = 1.0f / test.det;
+            const float tt = dot_fma(mk3(b.z, b.w, c.x), test.q) * inv;
             if (inside && tt > 0.0f && tt < tmax) {
                 float coverage = 1.0f;
                 if (!(__float_as_uint(c.w) & HIPR_TRIANGLE_OPAQUE)) {
+                    const bool second_half = quad & (test.us < test.vs);
+                    float u, v;
+                    item_barycentrics(quad, second_half, __float_as_uint(m.w) & 0xFFu, test.un * inv, test.vn * inv, u, v);
                     const HiprInstance& inst = sc.instances[__float_as_uint(c.y)];
-                    coverage = material_coverage(sc, sc.materials[inst.material_index], triangle_texcoord(sc, inst, __float_as_uint(c.z), u, v));
+                    coverage = material_coverage(sc, sc.materials[inst.material_index], triangle_texcoord(sc, inst, second_half ? __float_as_uint(m.z) : __float_as_uint(c.z), u, v));
                 }
                 rad *= 1.0f - coverage;
                 if (rad.x < 0.0000001f && rad.y < 0.0000001f && rad.z < 0.0000001f) { rad = mk3(0.0f); blocked = true; }

@@ -2,6 +2,11 @@
 #include "integrator.h"
 
 #include <cmath>
+#include <cstring>
+#include <atomic>
+#include <map>
+#include <mutex>
+#include <vector>
 
 namespace oracle {
 
@@ -80,11 +85,120 @@ static inline void consider_triangle(const HiprSceneDesc& scene, uint32_t i, con
         best = {t, u, v, i};
 }
 
+// ---------------------------------------------------------------------------------------------
+// Exhaustive search over ITEMS (kernels.h "Exhaustive-search items"): a triangle, or two triangles of one instance that form a
+// parallelogram (a, b, c) + (a, c, d), tested with one solve against b - a and d - a. Restated here from the specification, not
+// shared with the product: the pairing rule (first later triangle that fits, bit-identical shared corners, d = a + (c - b) within
+// 1e-5 of the longest edge component, only in scenes of at most 64 triangles), the half decision on the unnormalised values and the corner
+// weights (1 - s, s - r, r) / (1 - r, s, r - s) must all agree for hits to be bit-identical.
+// ---------------------------------------------------------------------------------------------
+struct SearchItem {
+    float3 origin, edge1, edge2;
+    bool parallelogram;
+    uint32_t triangle[2];   // scene triangle of the half s >= r and of the half s < r
+    int rotation[2];        // which stored vertex of each triangle is the shared corner a
+};
+
+static inline float3 vertex_of(const HiprTriangle& tri, int k) {
+    const float* p = k % 3 == 0 ? tri.v0 : (k % 3 == 1 ? tri.v1 : tri.v2);
+    return {p[0], p[1], p[2]};
+}
+static inline bool identical(float3 p, float3 q) { return std::memcmp(&p, &q, sizeof(float3)) == 0; }
+
+static std::vector<SearchItem> make_search_items(const HiprSceneDesc& scene) {
+    const uint32_t n = scene.triangle_count;
+    std::vector<SearchItem> items;
+    std::vector<char> taken(n, 0);
+    for (uint32_t first = 0; first < n; ++first) {
+        if (taken[first]) continue;
+        const HiprTriangle& ta = scene.triangles[first];
+        SearchItem item = {vertex_of(ta, 0), vertex_of(ta, 1) - vertex_of(ta, 0), vertex_of(ta, 2) - vertex_of(ta, 0), false, {first, first}, {0, 0}};
+        for (uint32_t second = first + 1; n <= 64 && second < n && !item.parallelogram; ++second) {
+            const HiprTriangle& tb = scene.triangles[second];
+            if (taken[second] || tb.instance_index != ta.instance_index || tb.flags != ta.flags) continue;
+            for (int turn_a = 0; turn_a < 3 && !item.parallelogram; ++turn_a)
+                for (int turn_b = 0; turn_b < 3 && !item.parallelogram; ++turn_b) {
+                    float3 a = vertex_of(ta, turn_a), b = vertex_of(ta, turn_a + 1), c = vertex_of(ta, turn_a + 2), d = vertex_of(tb, turn_b + 2);
+                    if (!identical(a, vertex_of(tb, turn_b)) || !identical(c, vertex_of(tb, turn_b + 1))) continue;
+                    float3 e1 = b - a, e2 = d - a, fourth = a + (c - b);
+                    float longest = std::fmax(std::fmax(std::fmax(std::fabs(e1.x), std::fabs(e2.x)), std::fmax(std::fabs(e1.y), std::fabs(e2.y))), std::fmax(std::fabs(e1.z), std::fabs(e2.z)));
+                    float off = std::fmax(std::fmax(std::fabs(d.x - fourth.x), std::fabs(d.y - fourth.y)), std::fabs(d.z - fourth.z));
+                    if (off <= 1e-5f * longest) {
+                        item = {a, e1, e2, true, {first, second}, {turn_a, turn_b}};
+                        taken[second] = 1;
+                    }
+                }
+        }
+        items.push_back(item);
+    }
+    return items;
+}
+
+// The items of a scene are a function of its triangles. They are built once per API call: every extern "C" entry that searches
+// exhaustively starts with reset_search_items() (scene memory is reused between calls, a pointer is no identity across them), and
+// within a call each thread remembers the list it looked up last.
+static std::mutex items_guard;
+static std::map<std::pair<const HiprTriangle*, uint32_t>, std::vector<SearchItem>> items_cache;
+static std::atomic<uint64_t> items_generation{1};
+void reset_search_items() {
+    std::lock_guard<std::mutex> lock(items_guard);
+    items_cache.clear();
+    ++items_generation;
+}
+static const std::vector<SearchItem>& search_items(const HiprSceneDesc& scene) {
+    thread_local const HiprTriangle* last_triangles = nullptr;
+    thread_local uint32_t last_count = 0;
+    thread_local uint64_t last_generation = 0;
+    thread_local const std::vector<SearchItem>* last_items = nullptr;
+    if (last_items && last_triangles == scene.triangles && last_count == scene.triangle_count && last_generation == items_generation.load())
+        return *last_items;
+    std::lock_guard<std::mutex> lock(items_guard);
+    auto key = std::make_pair(scene.triangles, scene.triangle_count);
+    auto found = items_cache.find(key);
+    if (found == items_cache.end()) found = items_cache.emplace(key, make_search_items(scene)).first;
+    last_triangles = scene.triangles; last_count = scene.triangle_count; last_generation = items_generation.load(); last_items = &found->second;
+    return *last_items;
+}
+
+uint32_t search_item_count(const HiprSceneDesc& scene) { return uint32_t(search_items(scene).size()); }
+
+struct ItemHit { bool inside; int half; float t, u, v; };
+static inline ItemHit intersect_item(const SearchItem& item, float3 o, float3 d) {
+    float3 p = cross_fma(d, item.edge2);
+    float det = dot_fma(item.edge1, p);
+    float3 tv = o - item.origin;
+    float un = dot_fma(tv, p);
+    float3 q = cross_fma(tv, item.edge1);
+    float vn = dot_fma(d, q);
+    float us = std::signbit(det) ? -un : un, vs = std::signbit(det) ? -vn : vn, limit = std::fabs(det);
+    bool upper = item.parallelogram ? (us <= limit && vs <= limit) : (us + vs <= limit);
+    if (!((det != 0.0f) && (us >= 0.0f) && (vs >= 0.0f) && upper))
+        return {false, 0, 0, 0, 0};
+    int half = item.parallelogram && us < vs ? 1 : 0;
+    float inv = 1.0f / det, s = un * inv, r = vn * inv;
+    ItemHit hit = {true, half, dot_fma(item.edge2, q) * inv, s, r};
+    if (item.parallelogram) {
+        // corner weights of the half in the order (a, b, c) or (a, c, d); the triangle's stored vertex k is corner (k - rotation) mod 3
+        float weights[3] = {half ? 1.0f - r : 1.0f - s, half ? s : s - r, half ? r - s : r};
+        int rotation = item.rotation[half];
+        hit.u = weights[(1 - rotation + 3) % 3];
+        hit.v = weights[(2 - rotation + 3) % 3];
+    }
+    return hit;
+}
+
 Hit closest_hit_bruteforce(const HiprSceneDesc& scene, const Ray& ray, uint32_t skip, TraversalCounters* counters) {
     Hit best = {ray.tmax, 0, 0, HIT_MISS};
-    for (uint32_t i = 0; i < scene.triangle_count; ++i)
-        consider_triangle(scene, i, ray, skip, best);
-    if (counters) counters->triangles += scene.triangle_count;   // the exhaustive kernels count every triangle of every ray
+    const std::vector<SearchItem>& items = search_items(scene);
+    for (const SearchItem& item : items) {
+        ItemHit hit = intersect_item(item, ray.origin, ray.direction);
+        uint32_t id = item.triangle[hit.half];
+        if (!hit.inside || id == skip || !(hit.t > ray.tmin))
+            continue;
+        if (hit.t < best.t || (hit.t == best.t && id < best.id))
+            best = {hit.t, hit.u, hit.v, id};
+    }
+    if (counters) counters->triangles += items.size();   // the exhaustive kernels count every item of every ray
     return best;
 }
 
@@ -418,10 +532,20 @@ static inline bool shadow_triangle(const HiprSceneDesc& scene, uint32_t i, const
 }
 
 float3 shadow_bruteforce(const HiprSceneDesc& scene, const Ray& ray, float3 radiance, TraversalCounters* counters) {
-    for (uint32_t i = 0; i < scene.triangle_count; ++i) {
+    for (const SearchItem& item : search_items(scene)) {
         if (counters) counters->triangles++;
-        if (shadow_triangle(scene, i, ray, radiance))
-            break;
+        ItemHit hit = intersect_item(item, ray.origin, ray.direction);
+        if (!hit.inside || !(hit.t > ray.tmin && hit.t < ray.tmax))
+            continue;
+        const HiprTriangle& tri = scene.triangles[item.triangle[hit.half]];
+        float coverage = 1.0f;
+        if (!(tri.flags & HIPR_TRIANGLE_OPAQUE)) {
+            const HiprInstance& inst = scene.instances[tri.instance_index];
+            coverage = material_coverage(scene, scene.materials[inst.material_index], triangle_texcoord(scene, tri, hit.u, hit.v));
+        }
+        radiance *= 1.0f - coverage;
+        if (radiance.x < 0.0000001f && radiance.y < 0.0000001f && radiance.z < 0.0000001f)
+            return {0, 0, 0};   // rtTerminateRay
     }
     return radiance;
 }

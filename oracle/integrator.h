@@ -38,6 +38,8 @@ void generate_camera_ray(const HiprCameraState& cam, int x, int y, int width, in
 
 // --- intersection -----------------------------------------------------------------------------
 bool intersect_triangle(const HiprTriangle& tri, float3 o, float3 d, float& t, float& u, float& v);
+uint32_t search_item_count(const HiprSceneDesc& scene);
+void reset_search_items();   // call at the start of every API entry that may search exhaustively (integrator.cpp search_items)
 Hit closest_hit_bruteforce(const HiprSceneDesc& scene, const Ray& ray, uint32_t skip_triangle, TraversalCounters* counters = nullptr);
 Hit closest_hit_bvh(const HiprSceneDesc& scene, const Ray& ray, uint32_t skip_triangle, TraversalCounters* counters);
 Hit closest_hit_wide(const HiprSceneDesc& scene, const Ray& ray, uint32_t skip_triangle, TraversalCounters* counters);   // compressed 4-wide BVH

@@ -277,6 +277,7 @@ static inline Ray ray_of(const float* r8) { return {f3(r8), r8[3], f3(r8 + 4), r
 // rays: float4 origin+tmin, float4 direction+tmax. out_hits: float4 {t, u, v, bits(id)}. counters2: nodes, triangles (may be NULL).
 void oracle_trace_closest(const HiprSceneDesc* scene, const float* rays, const uint32_t* skip, uint32_t n, int use_bvh, int with_lights,
                           float* out_hits, uint64_t* counters2) {
+    reset_search_items();
     TraversalCounters total;
 #pragma omp parallel
     {
@@ -296,7 +297,10 @@ void oracle_trace_closest(const HiprSceneDesc* scene, const float* rays, const u
 }
 
 // Shadow rays with unit radiance: one transmittance float per ray.
+uint32_t oracle_search_item_count(const HiprSceneDesc* scene) { reset_search_items(); return search_item_count(*scene); }
+
 void oracle_trace_shadow(const HiprSceneDesc* scene, const float* rays, uint32_t n, int use_bvh, float* out_transmittance, uint64_t* counters2) {
+    reset_search_items();
     TraversalCounters total;
 #pragma omp parallel
     {
@@ -319,6 +323,7 @@ void oracle_trace_shadow(const HiprSceneDesc* scene, const float* rays, uint32_t
 // counters9 follows HiprCounters (iterations unused). Returns elapsed seconds.
 double oracle_render_entry(const HiprSceneDesc* scene, const HiprSceneState* state, const HiprCameraState* cam, int width, int height,
                            uint32_t accumulation_count, int use_bvh, int entry, double* accum_rgba, uint64_t* counters9) {
+    reset_search_items();
     std::vector<float4> offsets(256);
     for (int i = 0; i < 256; ++i) offsets[i] = rng::sample_offset(i);
     RenderSettings settings;

@@ -149,6 +149,44 @@ def test_bvh_traversal_equals_exhaustive_search(oracle):
     assert np.array_equal(a, b)
 
 
+def test_exhaustive_search_items_pair_the_cornell_box_into_parallelograms(oracle):
+    """The exhaustive search tests two triangles that form a parallelogram as ONE item (kernels.h "Exhaustive-search items"; restated
+    in oracle/integrator.cpp). The Cornell box is 5 walls + 2 boxes = 17 parallelograms; the hits must be the hits of the
+    per-triangle search (BVH2 path): same triangle, same distance and barycentrics up to the rounding of the different solve."""
+    import ctypes as C
+    from bifrost3d_amd import capi
+    oracle.lib.oracle_search_item_count.argtypes = [C.POINTER(capi.HiprSceneDesc)]
+    oracle.lib.oracle_search_item_count.restype = C.c_uint32
+    for name, triangles, items in (("cornell", 34, 17), ("quad", 2, 1)):
+        scene = Scene(name)
+        assert scene.desc.triangle_count == triangles
+        assert oracle.lib.oracle_search_item_count(C.byref(scene.desc)) == items
+    scene = Scene("cornell")
+    rng = np.random.default_rng(8)
+    n = 20000
+    rays = np.zeros((n, 8), np.float32)
+    rays[:, 0:3] = rng.uniform(-0.45, 0.45, (n, 3))
+    d = rng.normal(size=(n, 3))
+    rays[:, 4:7] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    rays[:, 7] = np.inf
+    per_triangle, _ = oracle.trace_closest(scene.desc, rays, use_bvh=1, with_lights=False)
+    per_item, (_, tested) = oracle.trace_closest(scene.desc, rays, use_bvh=0, with_lights=False)
+    assert tested == 17 * n
+    same = per_triangle[:, 3].view(np.uint32) == per_item[:, 3].view(np.uint32)
+    # The boxes stand ON the floor: their bottom faces and the floor tie in distance, and the two solves round differently.
+    tie = np.abs(per_triangle[:, 0] - per_item[:, 0]) <= 1e-6
+    assert (same | tie).all() and same.mean() >= 0.995
+    hit = same & (per_triangle[:, 3].view(np.uint32) != 0xFFFFFFFF)
+    assert hit.mean() > 0.8                                                       # the box is open towards the camera
+    assert np.allclose(per_item[hit, 0], per_triangle[hit, 0], rtol=2e-5, atol=1e-6)
+    assert np.allclose(per_item[hit, 1:3], per_triangle[hit, 1:3], atol=3e-5)
+    assert len(np.unique(per_item[hit, 3].view(np.uint32))) >= 30                 # both halves of the parallelograms are reported
+    rays[:, 7] = rng.uniform(0.05, 1.5, n)
+    a, _ = oracle.trace_shadow(scene.desc, rays, use_bvh=1)
+    b, _ = oracle.trace_shadow(scene.desc, rays, use_bvh=0)
+    assert (np.asarray(a).reshape(n, -1) != np.asarray(b).reshape(n, -1)).any(axis=1).mean() <= 1e-3
+
+
 def test_octahedral_encode_precise_roundtrip(oracle):
     """OctahedralNormal.equality_with_bifrost_implementation, ORT/MiscTest.h:32-52: host encoder + device decoder."""
     lib = load_host_library()
