@@ -193,7 +193,7 @@ uint32_t grid_for(uint32_t items, uint32_t block, uint32_t max_blocks) {
 
 // Items of the exhaustive search (kernels.h "Exhaustive-search items"): every triangle in order, except that a triangle (a, b, c)
 // and a LATER one of the same instance and flags that is (a, c, d) in some rotation, with bit-identical shared corners and
-// d = a + (c - b) within 1e-5 of the longest edge component, are merged into the parallelogram item (a, b - a, d - a) at the first
+// d = a + (c - b) within 1e-6 of the longest edge component, are merged into the parallelogram item (a, b - a, d - a) at the first
 // one's place. Only scenes of at most SMALL_SCENE_TRIANGLES triangles -- the ones searched exhaustively by default -- are paired: above
 // that an exhaustive search (HIPR_TRACE_VARIANT) stays per triangle and bit-identical to the BVH searches.
 constexpr uint32_t PAIRING_LIMIT = SMALL_SCENE_TRIANGLES;
@@ -218,7 +218,7 @@ void build_trace_items(const HiprTriangle* triangles, uint32_t count, std::vecto
                         longest = std::fmax(longest, std::fmax(std::fabs(b[k] - a[k]), std::fabs(d[k] - a[k])));
                         off = std::fmax(off, std::fabs(d[k] - (a[k] + (c[k] - b[k]))));
                     }
-                    if (off <= 1e-5f * longest) { partner = j; ra = x; rb = y; }
+                    if (off <= 1e-6f * longest) { partner = j; ra = x; rb = y; }
                 }
         }
         const float *a = corner(i, ra), *b = corner(i, ra + 1), *d = partner == UINT32_MAX ? corner(i, ra + 2) : corner(partner, rb + 2);

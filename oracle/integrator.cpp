@@ -89,7 +89,7 @@ static inline void consider_triangle(const HiprSceneDesc& scene, uint32_t i, con
 // Exhaustive search over ITEMS (kernels.h "Exhaustive-search items"): a triangle, or two triangles of one instance that form a
 // parallelogram (a, b, c) + (a, c, d), tested with one solve against b - a and d - a. Restated here from the specification, not
 // shared with the product: the pairing rule (first later triangle that fits, bit-identical shared corners, d = a + (c - b) within
-// 1e-5 of the longest edge component, only in scenes of at most 64 triangles), the half decision on the unnormalised values and the corner
+// 1e-6 of the longest edge component, only in scenes of at most 64 triangles), the half decision on the unnormalised values and the corner
 // weights (1 - s, s - r, r) / (1 - r, s, r - s) must all agree for hits to be bit-identical.
 // ---------------------------------------------------------------------------------------------
 struct SearchItem {
@@ -123,7 +123,7 @@ static std::vector<SearchItem> make_search_items(const HiprSceneDesc& scene) {
                     float3 e1 = b - a, e2 = d - a, fourth = a + (c - b);
                     float longest = std::fmax(std::fmax(std::fmax(std::fabs(e1.x), std::fabs(e2.x)), std::fmax(std::fabs(e1.y), std::fabs(e2.y))), std::fmax(std::fabs(e1.z), std::fabs(e2.z)));
                     float off = std::fmax(std::fmax(std::fabs(d.x - fourth.x), std::fabs(d.y - fourth.y)), std::fabs(d.z - fourth.z));
-                    if (off <= 1e-5f * longest) {
+                    if (off <= 1e-6f * longest) {
                         item = {a, e1, e2, true, {first, second}, {turn_a, turn_b}};
                         taken[second] = 1;
                     }
