@@ -474,3 +474,28 @@ def test_camera_rays_match_the_reference_ground_truth(ctx, cornell):
         return o[rows], d[rows]
 
     check_camera_rays_against_the_reference(generate)
+
+
+@pytest.mark.gpu
+def test_parallelogram_items_of_any_vertex_order_bit_exact(ctx, oracle_q, tmp_path):
+    """Nine parallelograms whose two triangles are stored in every combination of vertex rotations (all selector values of the
+    exhaustive-search items): t, barycentrics, triangle id and counters of k_trace_closest_small equal the oracle's bit for bit,
+    and so does the shadow kernel's transmittance."""
+    from test_host_cpu import parallelogram_rays, write_parallelogram_rotations_obj
+    scene = Scene("file:" + write_parallelogram_rotations_obj(tmp_path / "rotations.obj"))
+    ctx.upload_scene(scene)
+    assert ctx.trace_variant() == capi.TRACE_EXHAUSTIVE
+    rays = parallelogram_rays(40000, 9)
+    skip = np.full(len(rays), 0xFFFFFFFF, np.uint32)
+    skip[::5] = np.random.default_rng(1).integers(0, 18, len(skip[::5]))
+    ctx.set_instrumentation(True)
+    ctx.reset_counters()
+    gpu = ctx.debug_trace_closest(rays, skip)
+    counters = ctx.counters()
+    ctx.set_instrumentation(False)
+    cpu, (_, tested) = oracle_q.trace_closest(scene.desc, rays, skip, use_bvh=0, with_lights=True)
+    assert np.array_equal(gpu.view(np.uint32), cpu.view(np.uint32))
+    assert counters["closest_triangles"] == tested == 9 * len(rays)
+    assert set(gpu[:, 3].view(np.uint32).tolist()) >= set(range(18))
+    rays[:, 7] = np.random.default_rng(2).uniform(0.5, 6.0, len(rays))
+    assert np.array_equal(ctx.debug_trace_shadow(rays), oracle_q.trace_shadow(scene.desc, rays, use_bvh=0)[0])

@@ -458,3 +458,51 @@ def check_camera_rays_against_the_reference(generate):
 
 def test_oracle_camera_rays_match_the_reference_ground_truth(oracle):
     check_camera_rays_against_the_reference(lambda cam, w, h, pixels: oracle.generate_rays(cam, w, h, 0, pixels))
+
+
+def write_parallelogram_rotations_obj(path):
+    """Nine parallelograms, each split into (a, b, c) + (a, c, d) with a different rotation of the two faces' vertex orders: every
+    selector combination of the exhaustive-search items."""
+    lines, v = [], 0
+    for turn_a in range(3):
+        for turn_b in range(3):
+            x, z = 1.5 * turn_a, 1.5 * turn_b
+            corners = [(x, 0.1 * turn_b, z), (x + 1.0, 0.0, z + 0.2), (x + 1.3, 0.4, z + 1.1), (x + 0.3, 0.4 + 0.1 * turn_b, z + 0.9)]   # d = a + (c - b)
+            lines += ["v %.9g %.9g %.9g" % c for c in corners]
+            first, second = [v + 1, v + 2, v + 3], [v + 1, v + 3, v + 4]
+            first, second = first[-turn_a:] + first[:-turn_a] if turn_a else first, second[-turn_b:] + second[:-turn_b] if turn_b else second
+            lines += ["f %d %d %d" % tuple(first), "f %d %d %d" % tuple(second)]
+            v += 4
+    path.write_text("\n".join(lines) + "\n")
+    return str(path)
+
+
+def parallelogram_rays(n, seed):
+    rng = np.random.default_rng(seed)
+    rays = np.zeros((n, 8), np.float32)
+    rays[:, 0:3] = rng.uniform([-0.5, 1.0, -0.5], [5.0, 3.0, 5.0], (n, 3))
+    target = rng.uniform([-0.2, 0.0, -0.2], [4.6, 0.5, 4.3], (n, 3))
+    d = target - rays[:, 0:3]
+    rays[:, 4:7] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    rays[:, 7] = np.inf
+    return rays
+
+
+def test_parallelogram_items_report_the_barycentrics_of_any_vertex_order(oracle, tmp_path):
+    import ctypes as C
+    scene = Scene("file:" + write_parallelogram_rotations_obj(tmp_path / "rotations.obj"))
+    assert scene.desc.triangle_count == 18
+    oracle.lib.oracle_search_item_count.argtypes = [C.POINTER(capi.HiprSceneDesc)]
+    oracle.lib.oracle_search_item_count.restype = C.c_uint32
+    assert oracle.lib.oracle_search_item_count(C.byref(scene.desc)) == 9
+    rays = parallelogram_rays(30000, 4)
+    per_triangle, _ = oracle.trace_closest(scene.desc, rays, use_bvh=1, with_lights=False)
+    per_item, _ = oracle.trace_closest(scene.desc, rays, use_bvh=0, with_lights=False)
+    ids = per_item[:, 3].view(np.uint32)
+    hit = ids != 0xFFFFFFFF
+    assert set(ids[hit].tolist()) == set(range(18))                       # both halves of all nine
+    same = per_triangle[:, 3].view(np.uint32) == ids
+    assert same.mean() >= 0.998                                            # rays through a diagonal may land on either half
+    both = same & hit
+    assert np.allclose(per_item[both, 0], per_triangle[both, 0], rtol=2e-5, atol=1e-6)
+    assert np.allclose(per_item[both, 1:3], per_triangle[both, 1:3], atol=3e-5)
