@@ -55,7 +55,7 @@ class HiprBvhNode(C.Structure):
 
 
 class HiprTexture(C.Structure):
-    _fields_ = [("width", c_u32), ("height", c_u32), ("texel_offset", c_u32), ("format", c_u8),
+    _fields_ = [("width", c_u32), ("height", c_u32), ("texel_offset", c_u64), ("format", c_u8),
                 ("wrap_u", c_u8), ("wrap_v", c_u8), ("filter", c_u8), ("is_sRGB", c_u8), ("_pad", c_u8 * 3)]
 
 
@@ -82,7 +82,7 @@ class HiprSceneDesc(C.Structure):
                 ("materials", C.POINTER(HiprMaterial)), ("material_count", c_u32),
                 ("lights", C.POINTER(HiprLight)), ("light_count", c_u32),
                 ("textures", C.POINTER(HiprTexture)), ("texture_count", c_u32),
-                ("texels", C.POINTER(c_u8)), ("texel_bytes", c_u32),
+                ("texels", C.POINTER(c_u8)), ("texel_bytes", c_u64),
                 ("bvh_max_depth", c_u32),
                 ("wide_nodes", C.POINTER(HiprWideNode)), ("wide_node_count", c_u32), ("wide_stack_entries", c_u32),
                 ("environment", C.POINTER(HiprEnvironment))]
@@ -95,7 +95,7 @@ class HiprSceneState(C.Structure):
 class HiprCameraState(C.Structure):
     _fields_ = [("view_to_world_rotation", c_f * 9), ("inverse_projection_matrix", c_f * 16),
                 ("inverse_view_projection_matrix", c_f * 16), ("accumulations", c_u32),
-                ("max_bounce_count", c_u32), ("path_regularization_PDF_scale", c_f)]
+                ("max_bounce_count", c_u32), ("path_regularization_PDF_scale", c_f), ("path_regularization_scale_decay", c_f)]
 
 
 class HiprTables(C.Structure):
@@ -125,17 +125,17 @@ class HiprKernelTimes(C.Structure):
 
 
 assert C.sizeof(HiprMaterial) == 64 and C.sizeof(HiprLight) == 48 and C.sizeof(HiprVertexGeometry) == 16
-assert C.sizeof(HiprTriangle) == 48 and C.sizeof(HiprBvhNode) == 64 and C.sizeof(HiprInstance) == 80
+assert C.sizeof(HiprTexture) == 24 and C.sizeof(HiprCameraState) == 180 and C.sizeof(HiprTriangle) == 48 and C.sizeof(HiprBvhNode) == 64 and C.sizeof(HiprInstance) == 80
 
 # Every symbol include/hiprenderer_c.h declares; tests check the library exports all of them.
 C_ABI_SYMBOLS = (
     "hipr_create", "hipr_destroy", "hipr_last_error", "hipr_device_count", "hipr_set_stream",
-    "hipr_upload_tables", "hipr_upload_scene", "hipr_set_scene_state", "hipr_set_entry_point", "hipr_use_scratch_accumulation",
+    "hipr_upload_tables", "hipr_upload_scene", "hipr_validate_scene", "hipr_set_scene_state", "hipr_set_entry_point", "hipr_use_scratch_accumulation",
     "hipr_set_frame", "hipr_owned_pixel_count",
     "hipr_render_pass", "hipr_read_accumulation", "hipr_scatter_tiles", "hipr_synchronize", "hipr_get_counters",
     "hipr_device_malloc", "hipr_device_free", "hipr_copy_to_host", "hipr_present_flipped",
     "hipr_reset_counters", "hipr_set_wavefront_count", "hipr_get_trace_variant", "hipr_set_instrumentation", "hipr_reset_timers", "hipr_get_kernel_times",
-    "hipr_debug_shading", "hipr_debug_light", "hipr_debug_generate", "hipr_debug_sobol", "hipr_debug_trace_closest", "hipr_debug_trace_shadow",
+    "hipr_debug_shading", "hipr_debug_light", "hipr_debug_generate", "hipr_debug_sobol", "hipr_debug_sample_offsets", "hipr_debug_trace_closest", "hipr_debug_trace_shadow",
 )
 
 
@@ -169,6 +169,7 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.hipr_set_stream.argtypes = [vp, vp]
     lib.hipr_upload_tables.argtypes = [vp, C.POINTER(HiprTables)]
     lib.hipr_upload_scene.argtypes = [vp, C.POINTER(HiprSceneDesc)]
+    lib.hipr_validate_scene.argtypes = [C.POINTER(HiprSceneDesc)]
     lib.hipr_set_scene_state.argtypes = [vp, C.POINTER(HiprSceneState)]
     lib.hipr_set_entry_point.argtypes = [vp, C.c_int]
     lib.hipr_use_scratch_accumulation.argtypes = [vp, C.c_int]
@@ -185,6 +186,7 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.hipr_get_kernel_times.argtypes = [vp, C.POINTER(HiprKernelTimes)]
     lib.hipr_debug_generate.argtypes = [vp, C.POINTER(HiprCameraState), c_u32, C.POINTER(c_f), C.POINTER(c_f), C.POINTER(c_u32)]
     lib.hipr_debug_sobol.argtypes = [vp, C.POINTER(c_u32), c_u32, C.POINTER(c_u32)]
+    lib.hipr_debug_sample_offsets.argtypes = [vp, C.POINTER(c_f)]
     lib.hipr_debug_trace_closest.argtypes = [vp, C.POINTER(c_f), C.POINTER(c_u32), c_u32, C.POINTER(c_f)]
     lib.hipr_debug_trace_shadow.argtypes = [vp, C.POINTER(c_f), c_u32, C.POINTER(c_f)]
     if path is None:

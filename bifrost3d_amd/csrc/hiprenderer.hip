@@ -270,7 +270,7 @@ template <int MODE, bool INSTRUMENT>
 void launch_persistent_for_stack(HiprContext* c, const Wavefront& w, const PathState& in, const uint32_t* closest_count, const uint32_t* shadow_count, uint32_t upper_bound) {
     // LDS stack entries by the worst case of the wide tree; beyond 32 the LDS stack is backed by a scratch array
     if (c->wide_stack_entries <= 16) launch_persistent<16, MODE, INSTRUMENT, false>(c, w, in, closest_count, shadow_count, upper_bound, 0);
-    else if (c->wide_stack_entries <= 32 || getenv("HIPR_EXPERIMENT_NO_STACK_OVERFLOW")) launch_persistent<32, MODE, INSTRUMENT, false>(c, w, in, closest_count, shadow_count, upper_bound, 1);
+    else if (c->wide_stack_entries <= 32) launch_persistent<32, MODE, INSTRUMENT, false>(c, w, in, closest_count, shadow_count, upper_bound, 1);
     else launch_persistent<32, MODE, INSTRUMENT, true>(c, w, in, closest_count, shadow_count, upper_bound, 2);
 }
 
@@ -328,6 +328,92 @@ int check_context(HiprContext* c) {
     if (!c) return fail(HIPR_ERROR_INVALID_ARGUMENT, "null context");
     HIP_TRY(hipSetDevice(c->device));
     return HIPR_OK;
+}
+
+// O(n) check of everything the kernels dereference through an index of the description (the header is public: a bad ID must be an
+// error code, not an out-of-bounds read on the GPU). Also derives the worst-case stack need of the wide tree instead of trusting
+// the caller's figure. Returns nullptr when the scene is sound, a message otherwise.
+const char* validate_scene(const HiprSceneDesc* s, uint32_t& wide_stack_need, char* message, size_t message_size) {
+#define INVALID(...) do { snprintf(message, message_size, __VA_ARGS__); return message; } while (0)
+    wide_stack_need = 0;
+    auto texel_size = [](uint8_t format) -> uint64_t {
+        return format == HIPR_TEXEL_R8 ? 1u : (format == HIPR_TEXEL_RGBA8 ? 4u : (format == HIPR_TEXEL_R32F ? 4u : (format == HIPR_TEXEL_RGBA32F ? 16u : 0u)));
+    };
+    if (s->texture_count && !s->textures) INVALID("texture_count is %u but textures is null", s->texture_count);
+    if (s->light_count && !s->lights) INVALID("light_count is %u but lights is null", s->light_count);
+    if (s->texel_bytes && !s->texels) INVALID("texel_bytes is %llu but texels is null", (unsigned long long)s->texel_bytes);
+    for (uint32_t i = 1; i < s->texture_count; ++i) {   // slot 0 = none
+        const HiprTexture& t = s->textures[i];
+        const uint64_t size = texel_size(t.format);
+        if (size == 0) INVALID("texture %u has the unknown texel format %u", i, unsigned(t.format));
+        if (t.width == 0 || t.height == 0) INVALID("texture %u is %u x %u", i, t.width, t.height);
+        const uint64_t bytes = uint64_t(t.width) * t.height * size;
+        if (t.texel_offset > s->texel_bytes || bytes > s->texel_bytes - t.texel_offset || t.texel_offset % (size == 16 ? 16 : 4) != 0)
+            INVALID("texture %u (%u x %u, offset %llu) does not fit the %llu byte texel pool", i, t.width, t.height, (unsigned long long)t.texel_offset, (unsigned long long)s->texel_bytes);
+    }
+    for (uint32_t i = 0; i < s->material_count; ++i) {
+        const HiprMaterial& m = s->materials[i];
+        const int32_t ids[4] = {m.tint_roughness_texture_ID, m.roughness_texture_ID, m.metallic_texture_ID, m.coverage_texture_ID};
+        for (int32_t id : ids)
+            if (id < 0 || (id > 0 && uint32_t(id) >= s->texture_count)) INVALID("material %u references texture %d of %u", i, id, s->texture_count);
+        if (m.shading_model > HIPR_SHADING_TRANSMISSIVE) INVALID("material %u has the unknown shading model %u", i, unsigned(m.shading_model));
+    }
+    const uint32_t primitive_total = s->index_count / 3;
+    for (uint32_t i = 0; i < s->instance_count; ++i) {
+        const HiprInstance& inst = s->instances[i];
+        if (inst.material_index < 0 || uint32_t(inst.material_index) >= s->material_count) INVALID("instance %u references material %d of %u", i, inst.material_index, s->material_count);
+        if (inst.index_offset > primitive_total || inst.vertex_offset > s->vertex_count) INVALID("instance %u starts outside the index / vertex pools", i);
+    }
+    for (uint32_t t = 0; t < s->triangle_count; ++t) {
+        const HiprTriangle& tri = s->triangles[t];
+        if (tri.instance_index >= s->instance_count) INVALID("triangle %u references instance %u of %u", t, tri.instance_index, s->instance_count);
+        const HiprInstance& inst = s->instances[tri.instance_index];
+        if (tri.primitive_index >= primitive_total - inst.index_offset) INVALID("triangle %u references primitive %u beyond the index pool", t, tri.primitive_index);
+        const uint32_t* idx = s->indices + 3 * size_t(inst.index_offset + tri.primitive_index);
+        for (int k = 0; k < 3; ++k)
+            if (idx[k] >= s->vertex_count - inst.vertex_offset) INVALID("triangle %u: vertex index %u is beyond the vertex pool", t, idx[k]);
+    }
+    auto leaf_ok = [&](int32_t ref) { const uint32_t code = uint32_t(~ref); return uint64_t(code >> 3) + (code & 7u) + 1u <= s->triangle_count; };
+    if (s->triangle_count && s->node_count == 0) INVALID("a scene with triangles needs a BVH");
+    for (uint32_t n = 0; n < s->node_count; ++n)
+        for (int k = 0; k < 2; ++k) {
+            const int32_t ref = s->nodes[n].child[k];
+            if (ref >= 0 ? uint32_t(ref) >= s->node_count : !leaf_ok(ref)) INVALID("BVH node %u: child %d is out of range", n, ref);
+        }
+    if (s->wide_nodes && s->wide_node_count) {
+        // need(node) = (children - 1) + max need(child): iterative post-order; a node reached twice or a cycle is an error
+        std::vector<uint32_t> need(s->wide_node_count, 0u);
+        std::vector<uint8_t> state(s->wide_node_count, 0);   // 0 unseen, 1 open, 2 done
+        std::vector<uint32_t> stack = {0u};
+        while (!stack.empty()) {
+            const uint32_t n = stack.back();
+            const HiprWideNode& w = s->wide_nodes[n];
+            if (state[n] == 0) {
+                state[n] = 1;
+                for (int k = 0; k < 4; ++k) {
+                    const int32_t ref = w.child[k];
+                    if (ref == HIPR_WIDE_EMPTY) continue;
+                    if (ref < 0) { if (!leaf_ok(ref)) INVALID("wide BVH node %u: leaf %d is out of range", n, ref); continue; }
+                    if (uint32_t(ref) >= s->wide_node_count || state[ref] != 0) INVALID("wide BVH node %u: child %d is out of range or shared", n, ref);
+                    stack.push_back(uint32_t(ref));
+                }
+            } else {
+                uint32_t children = 0, below = 0;
+                for (int k = 0; k < 4; ++k) {
+                    const int32_t ref = w.child[k];
+                    if (ref == HIPR_WIDE_EMPTY) continue;
+                    ++children;
+                    if (ref >= 0) below = std::max(below, need[ref]);
+                }
+                need[n] = (children ? children - 1u : 0u) + below;
+                state[n] = 2;
+                stack.pop_back();
+            }
+        }
+        wide_stack_need = need[0];
+    }
+    return nullptr;
+#undef INVALID
 }
 
 unsigned short to_unorm16(float v) { return (unsigned short)(v * 65535 + 0.5f); }
@@ -470,14 +556,27 @@ int hipr_upload_tables(HiprContext* c, const HiprTables* t) {
     return HIPR_OK;
 }
 
+int hipr_validate_scene(const HiprSceneDesc* s) {
+    if (!s) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_validate_scene: null scene");
+    if (s->triangle_count && (!s->nodes || !s->triangles || !s->instances || !s->indices || !s->geometry || !s->materials))
+        return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_validate_scene: missing geometry arrays");
+    uint32_t wide_stack_need = 0;
+    char invalid[256];
+    if (validate_scene(s, wide_stack_need, invalid, sizeof(invalid))) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_validate_scene: %s", invalid);
+    return HIPR_OK;
+}
+
 int hipr_upload_scene(HiprContext* c, const HiprSceneDesc* s) {
     if (int st = check_context(c)) return st;
     if (!s) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_upload_scene: null scene");
     if (s->triangle_count && (!s->nodes || !s->triangles || !s->instances || !s->indices || !s->geometry || !s->materials))
         return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_upload_scene: missing geometry arrays");
     if (s->bvh_max_depth > 64) return fail(HIPR_ERROR_UNSUPPORTED, "BVH depth %u exceeds the 64 entry LDS stack", s->bvh_max_depth);
-    if (s->wide_nodes && s->wide_stack_entries > 32u + uint32_t(TRACE_SPILL_ENTRIES))
-        return fail(HIPR_ERROR_UNSUPPORTED, "the wide BVH needs %u stack entries, more than the %u the traversal kernels provide", s->wide_stack_entries, 32u + uint32_t(TRACE_SPILL_ENTRIES));
+    uint32_t wide_stack_need = 0;
+    char invalid[256];
+    if (validate_scene(s, wide_stack_need, invalid, sizeof(invalid))) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_upload_scene: %s", invalid);
+    if (wide_stack_need > 32u + uint32_t(TRACE_SPILL_ENTRIES))
+        return fail(HIPR_ERROR_UNSUPPORTED, "the wide BVH needs %u stack entries, more than the %u the traversal kernels provide", wide_stack_need, 32u + uint32_t(TRACE_SPILL_ENTRIES));
     for (uint32_t i = 0; i < s->instance_count; ++i)
         if ((s->instances[i].mesh_flags & HIPR_MESH_TEXCOORDS && !s->texcoords) || (s->instances[i].mesh_flags & HIPR_MESH_TINTS && !s->tints) ||
             (s->instances[i].mesh_flags & HIPR_MESH_EMISSIVE && !s->emissions))
@@ -515,7 +614,7 @@ int hipr_upload_scene(HiprContext* c, const HiprSceneDesc* s) {
     d.nodes = c->nodes.as<float4>();
     d.wide_nodes = s->wide_nodes && s->wide_node_count ? c->wide_nodes.as<uint4>() : nullptr;
     d.wide_node_count = s->wide_nodes ? s->wide_node_count : 0u;
-    c->wide_stack_entries = s->wide_stack_entries;
+    c->wide_stack_entries = wide_stack_need;   // derived from the tree (validate_scene), not taken from the caller
     d.triangles = c->triangles.as<float4>();
     d.instances = c->instances.as<HiprInstance>();
     d.indices = c->indices.as<uint32_t>();
@@ -1025,6 +1124,14 @@ int hipr_debug_sobol(HiprContext* c, const uint32_t* triples, uint32_t n, uint32
     hipLaunchKernelGGL(k_debug_sobol, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->debug_a.as<uint32_t>(), n, c->debug_b.as<uint32_t>(), c->sobol_tables.as<uint32_t>());
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(out_uint4, c->debug_b.ptr, size_t(n) * 16, hipMemcpyDeviceToHost));
+    return HIPR_OK;
+}
+
+int hipr_debug_sample_offsets(HiprContext* c, float* out_256x4) {
+    if (int s = check_context(c)) return s;
+    if (!out_256x4) return fail(HIPR_ERROR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out_256x4, c->sample_offsets.ptr, 256 * 4 * sizeof(float), hipMemcpyDeviceToHost));
     return HIPR_OK;
 }
 

@@ -141,7 +141,8 @@ HD void shade_path(const DeviceScene& sc, const HiprCameraState& cam, int entry,
     in.metallic = mp.metallic_texture_ID ? mp.metallic * sample_texture(sc, mp.metallic_texture_ID, texcoord).x : mp.metallic;
     in.coat = mp.coat / 65535.0f;
     in.coat_roughness = mp.coat_roughness / 65535.0f;
-    const float max_PDF_hint = bsdf_pdf * cam.path_regularization_PDF_scale;
+    // PathRegularizationSettings::PDF_scale_at_accumulation (OR/PublicTypes.h:44), per path: a pass may carry several accumulations
+    const float max_PDF_hint = bsdf_pdf * (cam.path_regularization_PDF_scale * (1.0f + cam.path_regularization_scale_decay * float(int(accumulation))));
     Shading shading;
     if (HIPR_HAS_DIFFUSE(MODELS) && (MODELS == 2 || mp.shading_model == HIPR_SHADING_DIFFUSE)) shading = make_diffuse(in.tint, in.roughness);
     else if (HIPR_HAS_TRANSMISSIVE(MODELS) && (MODELS == 4 || transmissive)) shading = make_transmissive(sc.tables, in, cos_theta, max_PDF_hint);

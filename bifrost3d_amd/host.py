@@ -101,10 +101,11 @@ class Scene:
         self.lib.hiprh_scene_state(self.handle, C.byref(s))
         return s
 
-    def camera(self, width: int, height: int, accumulations: int = 0, max_bounce_count: int = -1, pdf_scale: float = 0.5) -> capi.HiprCameraState:
+    def camera(self, width: int, height: int, accumulations: int = 0, max_bounce_count: int = -1, pdf_scale: float = 0.5, scale_decay: float = 0.0) -> capi.HiprCameraState:
         cam = capi.HiprCameraState()
         if self.lib.hiprh_scene_camera(self.handle, width, height, accumulations, max_bounce_count, pdf_scale, C.byref(cam)) != 0:
             raise capi.HiprError("hiprh_scene_camera failed")
+        cam.path_regularization_scale_decay = scale_decay
         return cam
 
     def triangles(self) -> np.ndarray:

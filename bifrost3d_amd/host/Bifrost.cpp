@@ -83,7 +83,7 @@ Mesh plane(unsigned quads_per_edge, MeshFlags buffers) {
 
 Mesh box(unsigned quads_per_edge, Vector3f size, MeshFlags buffers) {
     if (quads_per_edge == 0) return Mesh();
-    auto data = HIPRenderer::Scenes::box(quads_per_edge, size, false);
+    auto data = HIPRenderer::Scenes::box(quads_per_edge, size, false, buffers.is_set(MeshFlag::Texcoord));
     return from_data("Box", data, buffers, AABB{size * -0.5f, size * 0.5f});
 }
 

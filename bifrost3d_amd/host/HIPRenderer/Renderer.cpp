@@ -340,7 +340,8 @@ struct Renderer::Implementation {
         std::memcpy(out.view_to_world_rotation, rotation.begin(), sizeof(out.view_to_world_rotation));
         out.accumulations = state.accumulations;
         out.max_bounce_count = state.max_bounce_count;
-        out.path_regularization_PDF_scale = path_regularization.PDF_scale_at_accumulation(int(state.accumulations));
+        out.path_regularization_PDF_scale = path_regularization.PDF_scale;       // PDF_scale_at_accumulation (OR/Renderer.cpp:1244) is evaluated per path on the device
+        out.path_regularization_scale_decay = path_regularization.scale_decay;
         return true;
     }
 

@@ -305,4 +305,60 @@ void create_glass_scene(CameraID camera_ID, SceneNode root_node, const std::stri
     }
 }
 
+// apps/SimpleViewer/Scenes/Opacity.h:27-104. `quads_per_edge` tessellates the box and the two planes (same surfaces and texture
+// coordinates, more triangles) so that the scene can be served by each of the three searches.
+void create_opacity_scene(CameraID camera_ID, SceneNode root_node, unsigned quads_per_edge) {
+    if (quads_per_edge == 0) quads_per_edge = 1;
+    { // Camera.
+        Transform cam_transform = Cameras::get_transform(camera_ID);
+        cam_transform.translation = Vector3f(0, 1, -6);
+        Cameras::set_transform(camera_ID, cam_transform);
+    }
+    { // Floor.
+        SceneNode floor_node = create_checkered_floor(400, 1);
+        floor_node.set_global_transform(Transform(Vector3f(0, -0.0005f, 0)));
+        floor_node.set_parent(root_node);
+        Material floor_material = attached_mesh_model(floor_node).get_material();
+        floor_material.set_tint(RGB(0.02f, 0.27f, 0.33f));
+        floor_material.set_roughness(0.3f);
+    }
+    { // Sphere light.
+        SceneNode light_node = SceneNode("Light", Transform(Vector3f(0.0f, 0.5f, 0.0f)));
+        light_node.set_parent(root_node);
+        LightSources::create_sphere_light(light_node.get_ID(), RGB(50.0f), 0.1f);
+    }
+    { // Cut-out box around the light: a 17 x 17 grid texture, every odd texel in both directions is a hole.
+        const unsigned width = 17, height = 17;
+        unsigned char pixels[width * height];
+        for (unsigned y = 0; y < height; ++y)
+            for (unsigned x = 0; x < width; ++x) pixels[x + y * width] = ((x & 1) == 0 || (y & 1) == 0) ? 255 : 0;
+        Image image = Image::create2D("Grid", PixelFormat::Alpha8, false, width, height, pixels);
+
+        Materials::Data material_data = Materials::Data::create_dielectric(RGB(0.005f, 0.01f, 0.25f), 0.05f, 0.04f);
+        material_data.coverage_texture_ID = Textures::create2D(image.get_ID(), MagnificationFilter::None, MinificationFilter::None);
+        material_data.flags = MaterialFlag::Cutout;
+        Material material = Materials::create("Plastic", material_data);
+
+        SceneNode box_node = SceneNode("Swizz box", Transform(Vector3f(0.0f, 0.5f, 0.0f)));
+        MeshFlags buffers = MeshFlag::Position; buffers |= MeshFlag::Texcoord;
+        Mesh box_mesh = MeshCreation::box(quads_per_edge, Vector3f::one(), buffers);
+        MeshModel(box_node, box_mesh, material);
+        box_node.set_parent(root_node);
+    }
+    { // Two partially covering, thin-walled planes in front of the box.
+        Materials::Data transparent_material_data = Materials::Data::create_dielectric(RGB(0.25f), 0.95f, 0.04f);
+        transparent_material_data.coverage = 0.75f;
+        transparent_material_data.flags = MaterialFlag::ThinWalled;
+        Material transparent_material = Materials::create("Transparent", transparent_material_data);
+        Mesh plane_mesh = MeshCreation::plane(quads_per_edge, MeshFlag::Position);
+        const Quaternionf rotation = Quaternionf::from_angle_axis(PI<float>() * 0.5f, Vector3f::right());
+        const Transform transforms[2] = {Transform(Vector3f(1.0f, 1.0f, -2.0f), rotation, 2.0f), Transform(Vector3f(0.0f, 0.25f, -3.0f), rotation, 1.0f)};
+        for (const Transform& transform : transforms) {
+            SceneNode plane_node = SceneNode("Plane", transform);
+            MeshModel(plane_node, plane_mesh, transparent_material);
+            plane_node.set_parent(root_node);
+        }
+    }
+}
+
 } // namespace ViewerScenes

@@ -33,4 +33,10 @@ void create_material_scene(Bifrost::Scene::CameraID camera_ID, Bifrost::Scene::S
 // re-materialed as Glass.cpp:116-125 does. The pool of water of the original is left out.
 void create_glass_scene(Bifrost::Scene::CameraID camera_ID, Bifrost::Scene::SceneNode root_node, const std::string& shader_ball_path, const std::string& diamond_path);
 
+// The viewer's opacity scene (apps/SimpleViewer/Scenes/Opacity.h:27-104): camera at (0, 1, -6), the checkered floor (teal, roughness 0.3),
+// a sphere light of power 50 inside a unit box whose material is a CUT-OUT driven by a 17 x 17 Alpha8 grid texture (nearest lookup),
+// and two thin-walled planes of coverage 0.75 in front of it. The scene that exercises stochastic coverage rejection
+// (ORS/MonteCarlo.cu:152-164) and the shadow any-hit transmittance product (:278-285).
+void create_opacity_scene(Bifrost::Scene::CameraID camera_ID, Bifrost::Scene::SceneNode root_node, unsigned quads_per_edge = 1);
+
 } // namespace ViewerScenes

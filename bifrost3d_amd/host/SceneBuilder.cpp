@@ -103,7 +103,7 @@ uint32_t SceneBuilder::add_texture(const ImageData& image, bool repeat_u, bool r
     HiprTexture t = {};
     t.width = image.width; t.height = image.height;
     while (m_texels.size() % 16) m_texels.push_back(0);
-    t.texel_offset = uint32_t(m_texels.size());
+    t.texel_offset = uint64_t(m_texels.size());
     t.format = image.format;
     t.wrap_u = repeat_u; t.wrap_v = repeat_v;
     t.filter = uint8_t((linear_mag ? 1 : 0) | (linear_min ? 2 : 0));
@@ -196,7 +196,7 @@ void SceneBuilder::finalize(uint32_t bvh_max_depth) {
     d.materials = m_materials.data(); d.material_count = uint32_t(m_materials.size());
     d.lights = m_lights.data(); d.light_count = uint32_t(m_lights.size());
     d.textures = m_textures.data(); d.texture_count = uint32_t(m_textures.size());
-    d.texels = m_texels.data(); d.texel_bytes = uint32_t(m_texels.size());
+    d.texels = m_texels.data(); d.texel_bytes = uint64_t(m_texels.size());
     d.bvh_max_depth = m_bvh.max_depth;
     d.wide_nodes = m_bvh.wide_nodes.data(); d.wide_node_count = uint32_t(m_bvh.wide_nodes.size());
     d.wide_stack_entries = m_bvh.wide_stack_entries;

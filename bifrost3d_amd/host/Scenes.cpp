@@ -38,7 +38,7 @@ MeshData plane(unsigned quads_per_edge, bool normals, bool texcoords) {
     return m;
 }
 
-MeshData box(unsigned quads_per_edge, Vector3f size, bool tints) {
+MeshData box(unsigned quads_per_edge, Vector3f size, bool tints, bool texcoords) {
     MeshData m;
     m.name = "Box";
     const unsigned verts_per_edge = quads_per_edge + 1;
@@ -59,6 +59,10 @@ MeshData box(unsigned quads_per_edge, Vector3f size, bool tints) {
     for (int s = 0; s < 6; ++s)
         for (unsigned v = 0; v < verts_per_side; ++v) m.normals.push_back(side_normals[s]);
     if (tints) m.tints.assign(m.positions.size(), 0xFFFFFFFFu);   // default_initialize_shading: UNorm8::one()
+    if (texcoords)   // every side carries the same (i, j) / quads_per_edge grid (MeshCreation.cpp:126-137)
+        for (int s = 0; s < 6; ++s)
+            for (unsigned i = 0; i < verts_per_edge; ++i)
+                for (unsigned j = 0; j < verts_per_edge; ++j) m.texcoords.push_back(Vector2f{float(i) * (1.0f / quads_per_edge), float(j) * (1.0f / quads_per_edge)});
     for (unsigned side_offset = 0; side_offset < 6 * verts_per_side; side_offset += verts_per_side)
         for (unsigned i = 0; i < quads_per_edge; ++i)
             for (unsigned j = 0; j < quads_per_edge; ++j) {

@@ -7,7 +7,7 @@ namespace HIPRenderer {
 namespace Scenes {
 
 MeshData plane(unsigned quads_per_edge, bool normals, bool texcoords);
-MeshData box(unsigned quads_per_edge, Vector3f size, bool tints);
+MeshData box(unsigned quads_per_edge, Vector3f size, bool tints, bool texcoords = false);
 
 // `wall_quads_per_edge` > 1 tessellates the five walls (same surfaces, more triangles): exercises the BVH2 kernels, which serve
 // scenes between the exhaustive-search and the wide-BVH size ranges.

@@ -56,11 +56,13 @@ extern "C" {
 // shading model (BASELINE.json config 2). param0/param1: atrium target triangles + seed, ortho width + height.
 static void* create_material_scene(const std::string& shader_ball_path, unsigned variant);
 static void* create_glass_scene(const std::string& resource_directory, unsigned variant);
+static void* create_opacity_scene(unsigned quads_per_edge, unsigned variant);
 
 void* hiprh_scene_create(const char* name, unsigned variant, unsigned param0, unsigned param1) {
     if (!name) return nullptr;
     if (!std::strncmp(name, "material", 8) && (name[8] == 0 || name[8] == ':')) return create_material_scene(name[8] ? name + 9 : "", variant);
     if (!std::strncmp(name, "glass", 5) && (name[5] == 0 || name[5] == ':')) return create_glass_scene(name[5] ? name + 6 : "", variant);
+    if (!std::strcmp(name, "opacity")) return create_opacity_scene(param0, variant);
     SceneBuilder* sb = new SceneBuilder();
     std::string n = name;
     if (n == "cornell") Scenes::create_cornell_box(*sb, param0 ? param0 : 1u);   // param0: quads per wall edge
@@ -111,6 +113,29 @@ static void* create_glass_scene(const std::string& resource_directory, unsigned 
     const std::string shader_ball = resource_directory.empty() ? "" : resource_directory + "/Shaderball.gltf", diamond = resource_directory.empty() ? "" : resource_directory + "/Diamond.glb";
     ViewerScenes::create_glass_scene(camera_ID, scene.get_root_node(), shader_ball, diamond);
     if (Assets::MeshModels::get_iterable().size() < 5) { deallocate_all(); return nullptr; }     // floor, ball (2), lens, handle, diamond
+    const SceneLoading::ViewerDefaults defaults = SceneLoading::apply_viewer_defaults(scene.get_root_node(), camera_ID, false);
+    if (variant & 1u)
+        for (Assets::MaterialID material_ID : Assets::Materials::get_iterable()) Assets::Material(material_ID).set_shading_model(Assets::ShadingModel::Diffuse);
+
+    SceneBuilder* sb = new SceneBuilder();
+    sb->set_environment_tint(Scene::SceneRoots::get_environment_tint(scene.get_ID()));
+    flatten_bifrost_scene(*sb);
+    sb->camera.transform = Scene::Cameras::get_transform(camera_ID);
+    sb->camera.near_plane = defaults.near_plane;
+    sb->camera.far_plane = defaults.far_plane;
+    sb->camera.max_bounce_count = 32;
+    deallocate_all();
+    return sb;
+}
+
+// "opacity": the viewer's opacity scene (apps/SimpleViewer/Scenes/Opacity.h), the reference's test bed for cut-outs and partial
+// coverage. param0 = quads per edge of the box and the planes (1 = as the viewer builds it: 24 triangles).
+static void* create_opacity_scene(unsigned quads_per_edge, unsigned variant) {
+    using namespace Bifrost;
+    deallocate_all();
+    Scene::SceneRoot scene = Scene::SceneRoot("Model scene", RGB(0.68f, 0.92f, 1.0f));
+    const Scene::CameraID camera_ID = Scene::Cameras::create("Camera", scene.get_ID(), Math::Matrix4x4f::identity(), Math::Matrix4x4f::identity());
+    ViewerScenes::create_opacity_scene(camera_ID, scene.get_root_node(), quads_per_edge);
     const SceneLoading::ViewerDefaults defaults = SceneLoading::apply_viewer_defaults(scene.get_root_node(), camera_ID, false);
     if (variant & 1u)
         for (Assets::MaterialID material_ID : Assets::Materials::get_iterable()) Assets::Material(material_ID).set_shading_model(Assets::ShadingModel::Diffuse);

@@ -155,6 +155,11 @@ class Context:
         self._check(self.lib.hipr_debug_sobol(self.handle, triples.ctypes.data_as(up), len(triples), out.ctypes.data_as(up)), "hipr_debug_sobol")
         return out
 
+    def debug_sample_offsets(self):
+        out = np.zeros((256, 4), np.float32)
+        self._check(self.lib.hipr_debug_sample_offsets(self.handle, out.ctypes.data_as(C.POINTER(C.c_float))), "hipr_debug_sample_offsets")
+        return out
+
     def debug_trace_closest(self, rays, skip=None):
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
         hits = np.zeros((len(rays), 4), np.float32)

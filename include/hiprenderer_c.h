@@ -150,7 +150,7 @@ typedef struct HiprWideNode {
  * Texels live in HiprSceneDesc::texels at `texel_offset` (bytes). */
 typedef struct HiprTexture {
     uint32_t width, height;
-    uint32_t texel_offset;
+    uint64_t texel_offset; /* 64 bit: a Sponza-class set of 4K maps exceeds 4 GiB once expanded to RGBA */
     uint8_t format;        /* HIPR_TEXEL_* */
     uint8_t wrap_u, wrap_v;/* 0 clamp, 1 repeat (BF/Assets/Texture.h:21-35) */
     uint8_t filter;        /* bit0: linear magnification, bit1: linear minification */
@@ -195,7 +195,7 @@ typedef struct HiprSceneDesc {
     const HiprMaterial* materials;       uint32_t material_count;   /* slot 0 = invalid material */
     const HiprLight* lights;             uint32_t light_count;
     const HiprTexture* textures;         uint32_t texture_count;    /* slot 0 = none */
-    const uint8_t* texels;               uint32_t texel_bytes;
+    const uint8_t* texels;               uint64_t texel_bytes;
     uint32_t bvh_max_depth;              /* deepest leaf, root = 1; selects the LDS stack size */
     const HiprWideNode* wide_nodes;      uint32_t wide_node_count;  /* the same tree collapsed to 4-wide nodes; may be NULL / 0 */
     uint32_t wide_stack_entries;         /* most entries a traversal of wide_nodes can have on its stack */
@@ -215,7 +215,11 @@ typedef struct HiprCameraState {
     float inverse_view_projection_matrix[16];
     uint32_t accumulations;
     uint32_t max_bounce_count;
+    /* PathRegularizationSettings (OR/PublicTypes.h:38-45). The scale applied to the paths of accumulation a is
+     * PDF_scale * (1.0f + scale_decay * float(a)), PublicTypes.h:44 PDF_scale_at_accumulation: the reference evaluates it on the
+     * host once per launch (OR/Renderer.cpp:1244); a pass here may carry several accumulations, so the kernel evaluates it per path. */
     float path_regularization_PDF_scale;
+    float path_regularization_scale_decay;
 } HiprCameraState;
 
 /* Precomputed tables uploaded at init (OR/Renderer.cpp:380-467). Float inputs are quantised to
@@ -278,6 +282,11 @@ int hipr_set_stream(HiprContext* context, void* hip_stream);
 /* ------------------------------------------------------------------------------------------- */
 int hipr_upload_tables(HiprContext* context, const HiprTables* tables);
 int hipr_upload_scene(HiprContext* context, const HiprSceneDesc* scene);
+/* The host-side checks hipr_upload_scene runs before anything reaches the device, on their own (no context, no GPU): every index
+ * the kernels follow -- material texture IDs, instance material / pool offsets, triangle instance / primitive / vertex indices,
+ * texture extents inside the texel pool, BVH2 and wide BVH child and leaf ranges -- must be in range; HIPR_ERROR_INVALID_ARGUMENT
+ * and a message in hipr_last_error() otherwise. (OptiX validates its node graph in rtContextValidate; this is the counterpart.) */
+int hipr_validate_scene(const HiprSceneDesc* scene);
 int hipr_set_scene_state(HiprContext* context, const HiprSceneState* state);
 
 /* Entry points, numbered like OR/Types.h:33-44. set_backend() of the host renderer maps Backend values onto them
@@ -377,6 +386,9 @@ int hipr_debug_shading(HiprContext* context, int shading_model, const float* par
  * pdf(light, position, direction), 0, 0, 0, 0. Host pointers; position3 is shared by the n inputs. */
 int hipr_debug_light(HiprContext* context, const HiprLight* light, const float* position3, const float* in_n3, uint32_t n, int mode, float* out_n8);
 int hipr_debug_sobol(HiprContext* context, const uint32_t* accumulation_pixelhash_dimension, uint32_t n, uint32_t* out_uint4);
+/* The 256 float4 reverse-Halton offsets the next event estimation candidates are drawn with, read back from the device
+ * (g_random_sample_offsets, OR/Renderer.cpp:323-336). out_256x4: host pointer to 1024 floats. */
+int hipr_debug_sample_offsets(HiprContext* context, float* out_256x4);
 /* K2: closest hit for n rays. rays: float4 origin_tmin + float4 direction_tmax per ray; skip: global triangle index
  * to ignore per ray (0xFFFFFFFF = none). out_hits: float4 {t, u, v, bits(tri_or_light)} per ray. */
 int hipr_debug_trace_closest(HiprContext* context, const float* rays, const uint32_t* skip, uint32_t n, float* out_hits);

@@ -267,6 +267,11 @@ static inline void traverse(const HiprSceneDesc& scene, const Ray& ray, float& t
 //   * the hit children are visited in ascending order of key = (bits(tnear) & 0x7FFFFFFC) | slot (distinct keys: a total
 //     order); the first becomes the current item, the others go on the stack, farthest first;
 //   * a leaf is an item like a node: its triangles are tested in storage order when it is taken.
+// Most entries any traverse_wide call has had on its stack since the last reset: lets a test prove that its rays drive the
+// traversal past the 32 entries the device keeps in LDS (the scratch-backed OVERFLOW kernels).
+static std::atomic<int> g_wide_stack_high_water{0};
+int wide_stack_high_water(bool reset) { const int v = g_wide_stack_high_water.load(); if (reset) g_wide_stack_high_water.store(0); return v; }
+
 template <typename LeafFn>
 static inline void traverse_wide(const HiprSceneDesc& scene, const Ray& ray, float& tmax, TraversalCounters* counters, LeafFn&& leaf) {
     if (scene.wide_node_count == 0)
@@ -309,6 +314,7 @@ static inline void traverse_wide(const HiprSceneDesc& scene, const Ray& ray, flo
             int hits = 0;
             while (hits < 4 && key[hits] != 0xFFFFFFFFu) ++hits;
             for (int k = hits - 1; k >= 1; --k) stack[sp++] = child[k];
+            if (sp > g_wide_stack_high_water.load(std::memory_order_relaxed)) g_wide_stack_high_water.store(sp, std::memory_order_relaxed);   // diagnostic, racy max is fine
             if (hits > 0) { item = child[0]; descended = true; }
         }
         if (!descended) {
@@ -792,7 +798,8 @@ static bool closest_hit_program(const HiprSceneDesc& scene, const HiprSceneState
     in.coat = unorm16(mp.coat);
     in.coat_roughness = unorm16(mp.coat_roughness);
     float3 bsdf_u = {bsdf_coverage_u.x, bsdf_coverage_u.y, bsdf_coverage_u.z};
-    PDF max_PDF_hint = payload.bsdf_PDF * cam.path_regularization_PDF_scale;
+    // OR/PublicTypes.h:44 PDF_scale_at_accumulation, evaluated for the accumulation of this path
+    PDF max_PDF_hint = payload.bsdf_PDF * (cam.path_regularization_PDF_scale * (1.0f + cam.path_regularization_scale_decay * float(int(payload.accumulation))));
 
     if (mp.shading_model == HIPR_SHADING_DIFFUSE) {
         DiffuseShading m = {in.tint, in.roughness};

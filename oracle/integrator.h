@@ -51,6 +51,7 @@ float3 shadow_wide(const HiprSceneDesc& scene, const Ray& ray, float3 radiance, 
 
 // --- textures / materials ---------------------------------------------------------------------
 float4 sample_texture(const HiprSceneDesc& scene, int texture_ID, float2 uv);
+int wide_stack_high_water(bool reset);   // diagnostic: deepest traverse_wide stack since the last reset
 float material_coverage(const HiprSceneDesc& scene, const HiprMaterial& m, float2 uv);
 
 // --- integrator -------------------------------------------------------------------------------

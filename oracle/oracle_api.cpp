@@ -28,6 +28,9 @@ static MaterialInputs inputs_of(const float* p) { return {{p[0], p[1], p[2]}, p[
 
 extern "C" {
 
+int oracle_wide_stack_high_water(int reset) { return oracle::wide_stack_high_water(reset != 0); }
+
+
 void oracle_set_tables(const float* base, const float* full, const float* light, const float* dense, const float* alphas, int quantize_unorm16) {
     tables().set(base, full, light, dense, alphas, quantize_unorm16 != 0);
 }

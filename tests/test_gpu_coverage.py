@@ -1,0 +1,253 @@
+"""GPU parity tests added in round 2 (through the C-ABI, against the pinned CPU oracle):
+
+  * partial coverage / cut-outs: shadow any-hit transmittance bit-exact on all three searches with non-opaque triangles and a
+    coverage texture, closest hits bit-exact, and the image of the viewer's opacity scene (stochastic coverage rejection)
+    -- ORS/MonteCarlo.cu:152-164,278-285, OR/Types.h:405-414, apps/SimpleViewer/Scenes/Opacity.h:27-104;
+  * next_event_sample_count in {1, 8, 64, 256} (clamp to 256, OR/Renderer.cpp:1390) and the 256 sample offsets themselves (:323-336);
+  * path regularisation with scale_decay != 0 (OR/PublicTypes.h:38-45);
+  * a tree that needs more than the 32 entry LDS stack (the OVERFLOW kernels) and a 1 M-triangle scene (BASELINE config 5's shape).
+"""
+import numpy as np
+import pytest
+
+from bifrost3d_amd import capi
+from bifrost3d_amd.host import Scene
+from test_coverage_cpu import deep_chain_rays, opacity_rays, write_deep_chain_obj
+
+pytestmark = pytest.mark.gpu
+
+OPACITY_VARIANT = {1: capi.TRACE_EXHAUSTIVE, 2: capi.TRACE_BVH2, 8: capi.TRACE_WIDE_PERSISTENT}
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from bifrost3d_amd.renderer import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def oracle_q():
+    from oracle_bindings import get_oracle
+    return get_oracle(True)
+
+
+def render_gpu(ctx, scene, w, h, spp, max_bounce, samples_per_pass=1, state=None, **camera_arguments):
+    ctx.upload_scene(scene)
+    if state is not None:
+        ctx.set_scene_state(state)
+    ctx.set_frame(w, h, 0, 1, samples_per_pass)
+    ctx.reset_counters()
+    for a in range(0, spp, samples_per_pass):
+        ctx.render_pass(scene.camera(w, h, accumulations=a, max_bounce_count=max_bounce, **camera_arguments), synchronize=True)
+    return ctx.read_accumulation(), ctx.counters()
+
+
+def image_metrics(gpu, cpu):
+    diff = gpu[..., :3] - cpu[..., :3]
+    rel = np.abs(diff) / (np.abs(cpu[..., :3]) + 1e-3)
+    return float((rel.max(axis=-1) <= 1e-3).mean()), float(np.sqrt(np.mean(diff ** 2)))
+
+
+@pytest.mark.parametrize("quads", [1, 2, 8])
+def test_shadow_rays_through_partial_coverage_bit_exact(ctx, oracle_q, quads):
+    """Non-opaque triangles on every search: the cut-out box (coverage texture, nearest lookup, threshold) and the coverage 0.75
+    planes. Transmittance = product of (1 - coverage) over ALL hits in (0, tmax), early out below 1e-7; counters equal."""
+    scene = Scene("opacity", param0=quads)
+    ctx.upload_scene(scene)
+    assert ctx.trace_variant() == OPACITY_VARIANT[quads]
+    ctx.set_instrumentation(True)
+    rays = opacity_rays(60000, 23 + quads, tmax=True)
+    gpu = ctx.debug_trace_shadow(rays)
+    counters = ctx.counters()
+    ctx.set_instrumentation(False)
+    cpu, (nodes, tris) = oracle_q.trace_shadow(scene.desc, rays, use_bvh=ctx.oracle_search())
+    assert np.array_equal(gpu, cpu)
+    assert counters["shadow_nodes"] == nodes and counters["shadow_triangles"] == tris
+    values = set(np.unique(gpu).tolist())
+    assert values <= {0.0, 0.0625, 0.25, 1.0} and values >= {0.0, 0.0625, 0.25, 1.0}, values
+
+
+@pytest.mark.parametrize("quads", [1, 2, 8])
+def test_closest_hits_in_the_opacity_scene_bit_exact(ctx, oracle_q, quads):
+    scene = Scene("opacity", param0=quads)
+    ctx.upload_scene(scene)
+    ctx.set_instrumentation(True)
+    rays = opacity_rays(40000, 5)
+    skip = np.full(len(rays), 0xFFFFFFFF, np.uint32)
+    gpu = ctx.debug_trace_closest(rays, skip)
+    counters = ctx.counters()
+    ctx.set_instrumentation(False)
+    cpu, (nodes, tris) = oracle_q.trace_closest(scene.desc, rays, skip, use_bvh=ctx.oracle_search(), with_lights=True)
+    assert np.array_equal(gpu.view(np.uint32), cpu.view(np.uint32))
+    assert counters["closest_nodes"] == nodes and counters["closest_triangles"] == tris
+
+
+@pytest.mark.parametrize("quads", [1, 2, 8])
+def test_opacity_scene_image_matches_oracle(ctx, oracle_q, quads):
+    """apps/SimpleViewer/Scenes/Opacity.h on the device: closest hits on the cut-out box and the 0.75 planes are rejected
+    stochastically against the BSDF sample's fourth dimension and retraced with tmin = nextafter(t) (MonteCarlo.cu:152-164);
+    shadow rays accumulate (1 - coverage). Closest-hit ray counts include the retraces and must agree with the oracle's."""
+    scene = Scene("opacity", param0=quads)
+    w, h, spp = 96, 54, 8
+    gpu, gc = render_gpu(ctx, scene, w, h, spp, 8)
+    cpu, cc, _ = oracle_q.render(scene.desc, scene.state, scene.camera(w, h, max_bounce_count=8), w, h, spp, use_bvh=ctx.oracle_search())
+    assert np.isfinite(gpu).all()
+    close, rmse = image_metrics(gpu, cpu)
+    print(f"opacity q={quads}: pixels within 1e-3: {close:.4f}, RMSE {rmse:.3e}, mean {float(cpu[..., :3].mean()):.3f}")
+    assert close >= 0.97, close
+    assert rmse <= 0.02 * float(cpu[..., :3].mean()), rmse
+    assert cc["closest_rays"] > cc["shaded_hits"] + 0.02 * cc["camera_rays"]          # rejected hits were retraced
+    for key in ("closest_rays", "shadow_rays", "shaded_hits"):
+        assert abs(gc[key] - cc[key]) <= 0.002 * cc[key], (key, gc[key], cc[key])
+
+
+def test_sample_offsets_on_the_device_bit_exact(ctx, oracle_q):
+    """The 256 reverse-Halton offsets as uploaded (hipr_create) against the oracle's restatement of OR/Renderer.cpp:323-336, bit for bit."""
+    assert np.array_equal(ctx.debug_sample_offsets().view(np.uint32), oracle_q.sample_offsets(256).view(np.uint32))
+
+
+@pytest.mark.parametrize("scene_name", ["cornell", "atrium"])
+@pytest.mark.parametrize("count", [1, 8, 64, 256, 1000])
+def test_next_event_sample_count(ctx, oracle_q, scene_name, count):
+    """RIS over `count` light candidates per hit, drawn with offsets 0 .. count - 1 (MonteCarlo.cu:91-123); 1000 is clamped to the
+    256 offsets that exist (OR/Renderer.cpp:1390-1392). The oracle takes the same count; image and ray counters agree."""
+    scene = Scene("cornell") if scene_name == "cornell" else Scene("atrium", param0=20000, param1=3)
+    state = scene.state
+    state.next_event_sample_count = count
+    w, h, spp = 48, 27, 4
+    gpu, gc = render_gpu(ctx, scene, w, h, spp, 4, state=state)
+    oracle_state = scene.state
+    oracle_state.next_event_sample_count = min(count, 256)
+    cpu, cc, _ = oracle_q.render(scene.desc, oracle_state, scene.camera(w, h, max_bounce_count=4), w, h, spp, use_bvh=ctx.oracle_search())
+    close, rmse = image_metrics(gpu, cpu)
+    print(f"{scene_name} NEE x{count}: pixels within 1e-3: {close:.4f}, RMSE {rmse:.3e}")
+    assert np.isfinite(gpu).all() and close >= 0.95, close
+    assert rmse <= 0.03 * max(1.0, float(cpu[..., :3].mean()))
+    for key in ("closest_rays", "shadow_rays"):
+        assert abs(gc[key] - cc[key]) <= 0.003 * cc[key], (key, gc[key], cc[key])
+    ctx.set_scene_state(scene.state)
+
+
+def test_more_candidates_change_the_estimate_not_its_mean(ctx):
+    """1 vs 64 candidates: different images (the estimator changed) of the same brightness (both unbiased up to the reference's clamps)."""
+    scene = Scene("cornell")
+    images = {}
+    for count in (1, 64):
+        state = scene.state
+        state.next_event_sample_count = count
+        images[count], _ = render_gpu(ctx, scene, 96, 54, 32, 4, samples_per_pass=8, state=state)
+    ctx.set_scene_state(scene.state)
+    assert not np.array_equal(images[1], images[64])
+    a, b = float(images[1][..., :3].mean()), float(images[64][..., :3].mean())
+    assert abs(a - b) < 0.03 * b, (a, b)
+
+
+@pytest.mark.parametrize("samples_per_pass", [1, 4])
+def test_path_regularization_scale_decay(ctx, oracle_q, samples_per_pass):
+    """PDF_scale_at_accumulation(a) = PDF_scale * (1 + scale_decay * a) per path (OR/PublicTypes.h:44): batched passes give the image of
+    one-by-one passes bit for bit, the image matches the oracle's, and it differs from the decay-free one."""
+    scene = Scene("cornell")
+    w, h, spp = 64, 36, 8
+    decayed, _ = render_gpu(ctx, scene, w, h, spp, 4, samples_per_pass=samples_per_pass, pdf_scale=0.25, scale_decay=0.75)
+    one_by_one, _ = render_gpu(ctx, scene, w, h, spp, 4, pdf_scale=0.25, scale_decay=0.75)
+    plain, _ = render_gpu(ctx, scene, w, h, spp, 4, pdf_scale=0.25)
+    assert np.array_equal(decayed, one_by_one)
+    assert not np.array_equal(decayed, plain)
+    cpu, _, _ = oracle_q.render(scene.desc, scene.state, scene.camera(w, h, max_bounce_count=4, pdf_scale=0.25, scale_decay=0.75), w, h, spp)
+    close, rmse = image_metrics(decayed, cpu)
+    assert close >= 0.97 and rmse <= 0.01, (close, rmse)
+
+
+def test_overflow_stack_kernels_bit_exact(ctx, oracle_q, tmp_path):
+    """A BVH whose worst-case traversal needs more than the 32 LDS stack entries: k_trace_persistent<32, *, *, true> keeps the
+    rest in a per-lane scratch array. Closest hits, shadow transmittance and counters equal the oracle's; the oracle's own stack
+    high-water mark proves these rays go past 32 entries."""
+    scene = Scene("file:" + write_deep_chain_obj(tmp_path / "chain.obj"))
+    assert scene.desc.wide_stack_entries > 32
+    ctx.upload_scene(scene)
+    assert ctx.trace_variant() == capi.TRACE_WIDE_PERSISTENT
+    ctx.set_instrumentation(True)
+    rays = deep_chain_rays(30000, 9)
+    skip = np.full(len(rays), 0xFFFFFFFF, np.uint32)
+    skip[::9] = np.random.default_rng(4).integers(0, 300, len(skip[::9]))
+    gpu = ctx.debug_trace_closest(rays, skip)
+    counters = ctx.counters()
+    oracle_q.lib.oracle_wide_stack_high_water(1)
+    cpu, (nodes, tris) = oracle_q.trace_closest(scene.desc, rays, skip, use_bvh=2, with_lights=True)
+    assert oracle_q.lib.oracle_wide_stack_high_water(1) > 40
+    assert np.array_equal(gpu.view(np.uint32), cpu.view(np.uint32))
+    assert counters["closest_nodes"] == nodes and counters["closest_triangles"] == tris
+    shadow_rays = deep_chain_rays(30000, 10, tmax=True)
+    gpu_s = ctx.debug_trace_shadow(shadow_rays)
+    counters = ctx.counters()
+    ctx.set_instrumentation(False)
+    cpu_s, (nodes, tris) = oracle_q.trace_shadow(scene.desc, shadow_rays, use_bvh=2)
+    assert np.array_equal(gpu_s, cpu_s)
+    assert counters["shadow_nodes"] == nodes and counters["shadow_triangles"] == tris
+    # and a full render through the fused launch (closest + shadow rays in one index space) of the same scene
+    w, h, spp = 48, 27, 4
+    image, gc = render_gpu(ctx, scene, w, h, spp, 4)
+    ref, cc, _ = oracle_q.render(scene.desc, scene.state, scene.camera(w, h, max_bounce_count=4), w, h, spp, use_bvh=2)
+    close, rmse = image_metrics(image, ref)
+    assert close >= 0.97 and rmse <= 0.01 * max(1.0, float(ref[..., :3].mean())), (close, rmse)
+    assert abs(gc["closest_rays"] - cc["closest_rays"]) <= 0.002 * cc["closest_rays"]
+
+
+def test_million_triangle_scene(ctx, oracle_q):
+    """BASELINE config 5's shape at test size: the 1 M-triangle atrium (seed 2), wide BVH of 250 k nodes. Stage parity bit-exact with
+    counters, a small image against the oracle, and at 3840 x 2160 the size-independent properties (finite, every camera path
+    traced, batching and two-phase tiling bit-identical)."""
+    scene = Scene("atrium", param0=1000000, param1=2)
+    assert scene.desc.triangle_count > 900000
+    ctx.upload_scene(scene)
+    assert ctx.trace_variant() == capi.TRACE_WIDE_PERSISTENT
+    rng = np.random.default_rng(21)
+    n = 40000
+    rays = np.zeros((n, 8), np.float32)
+    rays[:, 0:3] = rng.uniform(-14, 14, (n, 3))
+    rays[:, 1] = np.abs(rays[:, 1]) * 0.7
+    d = rng.normal(size=(n, 3))
+    rays[:, 4:7] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    rays[:, 7] = np.inf
+    skip = np.full(n, 0xFFFFFFFF, np.uint32)
+    ctx.set_instrumentation(True)
+    gpu = ctx.debug_trace_closest(rays, skip)
+    counters = ctx.counters()
+    cpu, (nodes, tris) = oracle_q.trace_closest(scene.desc, rays, skip, use_bvh=2, with_lights=True)
+    assert np.array_equal(gpu.view(np.uint32), cpu.view(np.uint32))
+    assert counters["closest_nodes"] == nodes and counters["closest_triangles"] == tris
+    rays[:, 7] = rng.uniform(0.05, 30.0, n)
+    gpu_s = ctx.debug_trace_shadow(rays)
+    counters = ctx.counters()
+    ctx.set_instrumentation(False)
+    cpu_s, (nodes, tris) = oracle_q.trace_shadow(scene.desc, rays, use_bvh=2)
+    assert np.array_equal(gpu_s, cpu_s) and counters["shadow_nodes"] == nodes and counters["shadow_triangles"] == tris
+
+    w, h, spp = 64, 36, 4
+    image, gc = render_gpu(ctx, scene, w, h, spp, 4)
+    ref, cc, _ = oracle_q.render(scene.desc, scene.state, scene.camera(w, h, max_bounce_count=4), w, h, spp, use_bvh=2)
+    close, rmse = image_metrics(image, ref)
+    print(f"1M atrium: pixels within 1e-3: {close:.4f}, RMSE {rmse:.3e}")
+    assert close >= 0.95 and np.isfinite(image).all()
+    for key in ("closest_rays", "shadow_rays"):
+        assert abs(gc[key] - cc[key]) <= 0.003 * cc[key], (key, gc[key], cc[key])
+
+    w, h = 3840, 2160
+    full, counters = render_gpu(ctx, scene, w, h, 2, 4, samples_per_pass=2)
+    assert np.isfinite(full).all() and counters["camera_rays"] == 2 * w * h and counters["shadow_rays"] > 0
+    one_by_one, _ = render_gpu(ctx, scene, w, h, 2, 4, samples_per_pass=1)
+    assert np.array_equal(one_by_one, full)
+    tiles_x, tiles_y = (w + 7) // 8, (h + 7) // 8
+    assembled = np.zeros_like(full)
+    for phase in range(2):
+        ctx.set_frame(w, h, phase, 2, 2)
+        ctx.render_pass(scene.camera(w, h, accumulations=0, max_bounce_count=4), synchronize=True)
+        part = ctx.read_accumulation()
+        k = np.arange(part.shape[0])
+        tile = (k // 64) * 2 + phase
+        x, y = (tile % tiles_x) * 8 + (k % 64) % 8, (tile // tiles_x) * 8 + (k % 64) // 8
+        valid = (x < w) & (y < h) & (tile < tiles_x * tiles_y)
+        assembled[y[valid], x[valid]] = part[valid]
+    assert np.array_equal(assembled, full)
