@@ -1,35 +1,40 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the HIP path tracer: Mrays/s and ms per accumulation pass at 1080p.
+"""bench.py -- headline benchmark of the HIP path tracer: Mrays/s and ms per 256 spp frame at 1080p, RMSE vs the oracle.
 
   python bench.py --gpus N --steps K --warmup W
-(for N > 1 the driver launches it under torch.distributed.run, one rank per GPU over RCCL).
+N > 1: one process per GPU over RCCL. Started by torch.distributed.run (RANK / WORLD_SIZE in the environment) the process is
+one rank; started plainly (`python bench.py --gpus 8`) it spawns its N rank processes itself -- before it touches a GPU, a
+fresh child per rank, never a re-exec -- and forwards rank 0's line.
 
-A "step" is one pass of the hot path over one batch of synthetic input: 32 accumulations (samples per pixel) of the
-1920x1080 frame traced together = 66 355 200 camera paths followed to completion (<= 5 surface interactions, next event
-estimation with 3 RIS candidates, shadow rays), folded one by one into the f64 running mean and written as half4. The
-reference traces one accumulation per launch; batching is a property of the wavefront design (HiprFrameDesc::samples_per_pass):
-the image is bit-identical for any batch size (tests), while the per-bounce launches get 32x the rays and their long-ray tails
-and launch gaps amortise (measured, DESIGN.md: 1 -> 8 samples per pass is +27 % on the Cornell box and +66 % on the atrium,
-8 -> 32 another +3 % / +11 %; the queues of 32 take 13.6 GB of the 288 GB; `--spp-per-pass 1` reproduces the
-one-accumulation-per-pass numbers).
-Workload (BASELINE.json configs[1]): SimpleViewer Cornell box, every material forced to the Diffuse shading
-model, max_bounce_count 4 (34 triangles: traced by the exhaustive-search kernels; `--scene atrium` is the 251 k-triangle
-Sponza-class stand-in, traced by the fused persistent kernel over the compressed wide BVH). Inputs (scene, BVH, tables) are
-resident in HBM before the timed region; the output
-frame stays in HBM. N > 1: tiles of 8x8 pixels are dealt round-robin to the ranks and a step traces N
-x 32 accumulations of the frame, so every GPU keeps the same 66 355 200 paths per step as N grows ("weak" scaling;
-no data-path collective). The timed region ends with the RCCL gather of the half4 tiles to rank 0 plus the
-scatter kernel that assembles the frame.
+Workload (the north-star configuration, BASELINE.json configs[3] on ONE GPU at N = 1): the 251 k-triangle procedural atrium
+(the Sponza-class stand-in of SURVEY.md 8d: the reference ships no Sponza and there is no network), DefaultShading materials,
+1920 x 1080, max_bounce_count 4, next event estimation over 3 RIS candidates. A "step" is one pass of the hot path over one batch:
+32 accumulations of the frame traced together (66 355 200 camera paths followed to completion), folded one by one into the
+f64 running mean and written as half4; the default 8 steps are the 256 spp of the metric. The reference traces one accumulation
+per launch; batching is a property of the wavefront design (bit-identical image for any batch size, tested), `--spp-per-pass 1`
+reproduces launch-per-accumulation. Inputs (scene, BVH, tables) are resident in HBM before the timed region, the frame stays in HBM.
 
-Prints ONE JSON line on rank 0 with the contract keys plus `roofline` (the kernel with the largest total time in the
-timed region; every kernel's figures are under `roofline_by_kernel`) and
-`cpu_baseline` (SmallPT restatement on the host cores, N = 1 only).
+N > 1: tiles of 8 x 8 pixels are dealt round-robin to the ranks and a step traces N x 32 accumulations, so every GPU keeps
+66 355 200 paths per step ("weak" scaling, no data-path collective); the timed region ends with the RCCL gather of the half4
+tiles to rank 0 and the scatter kernel that assembles the frame.
+
+The ONE JSON line rank 0 prints carries the contract keys plus
+  roofline          the kernel with the largest total time in the timed region: algorithmic bytes / HIP-event duration (`achieved`,
+                    `frac`, SURVEY.md 8d's model) AND the counter view (`traffic` = PMC HBM bytes per launch from profiles/pmc_traffic.json,
+                    `frac_counter` = traffic / duration / peak), `observed_limiter` from the SQ counter passes under profiles/;
+  cpu_baseline      the SmallPT restatement (BASELINE config 1) on the host cores, plus `c2`: the oracle's render of config 2 (Cornell,
+                    all Diffuse) at reduced size next to the device's, equal ray counters, like-for-like Mrays/s (N = 1 only);
+  other_workloads   BASELINE configs[1] (Cornell, all Diffuse) and configs[2] (material scene, 32 bounces) measured the same way after
+                    the main timed region, each with value / ms per 256 spp / roofline / rmse (N = 1 only; --no-other-workloads skips);
+  config.rmse_vs_oracle   RMSE against the CPU oracle at equal spp and seed, 8 and 256 spp on a 160 x 90 frame.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -38,99 +43,148 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+METRIC = "Mrays/sec + ms/frame at 1080p/256spp; per-pixel RMSE vs OptiXRenderer"
+SCENES = ["atrium", "cornell_diffuse", "cornell", "material", "material_coat", "opacity"]
 
 
-def parse_args():
+def parse_args(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=16)
-    p.add_argument("--warmup", type=int, default=4)
+    p.add_argument("--steps", type=int, default=8)
+    p.add_argument("--warmup", type=int, default=2)
     p.add_argument("--width", type=int, default=1920)
     p.add_argument("--height", type=int, default=1080)
-    p.add_argument("--scene", default="cornell_diffuse", choices=["cornell_diffuse", "cornell", "atrium", "material", "material_coat"])
-    p.add_argument("--scene-file", default=None, help="render a model file (.gltf / .glb / .obj, PNG textures) set up the way SimpleViewer sets up a scene from its command line; "
+    p.add_argument("--scene", default="atrium", choices=SCENES)
+    p.add_argument("--scene-file", default=None, help="render a model file (.gltf / .glb / .obj) set up the way SimpleViewer sets up a scene from its command line; "
                    "not the headline workload: the line's config.workload names the file")
     p.add_argument("--atrium-triangles", type=int, default=260000)
-    p.add_argument("--bounces", type=int, default=None, help="max_bounce_count; default 4, and 32 for the material scenes (the viewer's setting, apps/SimpleViewer/main.cpp:353)")
+    p.add_argument("--bounces", type=int, default=None, help="max_bounce_count; default 4, and 32 for the viewer's built-in scenes (apps/SimpleViewer/main.cpp:353)")
     p.add_argument("--spp-per-pass", type=int, default=32, help="accumulations traced together per step and GPU (HiprFrameDesc::samples_per_pass)")
     p.add_argument("--wavefronts", type=int, default=2, choices=[1, 2, 3, 4],
-                   help="2 (default): each pass runs as two half-frame wavefronts on two streams, one shades while the other traces (bit-identical image, "
-                        "+24 %% Cornell / +6 %% atrium); the per-kernel durations the roofline uses are then those of co-running kernels, and the line also "
-                        "carries roofline.alone, the dominant kernel measured with one wavefront after the timed region. 1: one wavefront throughout")
+                   help="2 (default): a pass runs as two half-frame wavefronts on two streams, one shades while the other traces (bit-identical image); "
+                        "the per-kernel durations are then those of co-running kernels")
     p.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
-                   help="gloo + --share-device runs the N > 1 code path with every rank on GPU 0 (a functional test of the tiling / gather / scatter logic on a 1-GPU box; the gather then goes through host memory)")
+                   help="gloo + --share-device runs the N > 1 code path with every rank on GPU 0 (functional test of tiling / gather / scatter on a 1-GPU box)")
     p.add_argument("--share-device", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--no-alone-region", action="store_true", help="skip the one-wavefront region after the timed region (roofline.alone); the profiling runs use it so that "
-                                                                  "every dispatch of a kernel in the profile belongs to the same launch shape")
-    p.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
-    return p.parse_args()
+    p.add_argument("--no-other-workloads", action="store_true", help="skip BASELINE configs[1] and configs[2] after the main timed region")
+    p.add_argument("--no-rmse", action="store_true")
+    p.add_argument("--cpu-baseline-seconds", type=float, default=10.0)
+    p.add_argument("--master-port", type=int, default=0, help="rendezvous port when this process spawns the ranks itself (0: pick a free one)")
+    return p.parse_args(argv)
 
 
-def make_scene(args):
+# --------------------------------------------------------------------------------------------------------------------------------
+# N > 1 started plainly: spawn the ranks (nothing in this function imports torch or touches a GPU)
+# --------------------------------------------------------------------------------------------------------------------------------
+def spawn_ranks(args) -> int:
+    import socket
+    port = args.master_port
+    if port == 0:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+    children = []
+    for rank in range(args.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this pool
+        children.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env,
+                                         stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
+    out, _ = children[0].communicate()
+    codes = [children[0].returncode] + [c.wait() for c in children[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(c) for c in codes)
+
+
+# --------------------------------------------------------------------------------------------------------------------------------
+def make_scene(name, args):
     from bifrost3d_amd.host import Scene
-    if args.bounces is None:
-        args.bounces = 32 if args.scene in ("material", "material_coat") and not args.scene_file else 4
-    if args.scene_file:
-        scene = Scene("file:" + args.scene_file)
-        args.scene = "file:" + os.path.basename(args.scene_file)
-        return scene, f"{os.path.basename(args.scene_file)} ({scene.desc.triangle_count} triangles) with the SimpleViewer defaults (camera from the scene bounds, one directional light)"
-    if args.scene == "cornell_diffuse":
-        return Scene("cornell", diffuse_only=True), "SimpleViewer Cornell box (34 triangles, 1 sphere light), all materials Diffuse"
-    if args.scene == "cornell":
-        return Scene("cornell"), "SimpleViewer Cornell box (34 triangles, 1 sphere light), reference materials"
-    if args.scene in ("material", "material_coat"):
-        return (Scene("material", coat=args.scene == "material_coat"),
-                "SimpleViewer material scene (BASELINE config 3): 7 shader balls (procedural stand-in for Shaderball.gltf, 179 k triangles) blending dielectric to gold"
-                + (", coat 1 / coat roughness 0.7" if args.scene == "material_coat" else "") + ", checkered textured floor, directional light, 32 bounces")
-    return Scene("atrium", param0=args.atrium_triangles, param1=1), f"procedural atrium ({args.atrium_triangles} triangles target), DefaultShading"
+    if name.startswith("file:"):
+        scene = Scene(name)
+        return scene, f"{os.path.basename(name[5:])} ({scene.desc.triangle_count} triangles) with the SimpleViewer defaults (camera from the scene bounds, one directional light)", 4
+    if name == "cornell_diffuse":
+        return Scene("cornell", diffuse_only=True), "SimpleViewer Cornell box (34 triangles, 1 sphere light), all materials Diffuse (BASELINE configs[1])", 4
+    if name == "cornell":
+        return Scene("cornell"), "SimpleViewer Cornell box (34 triangles, 1 sphere light), reference materials", 4
+    if name in ("material", "material_coat"):
+        return (Scene("material", coat=name == "material_coat"),
+                "SimpleViewer material scene (BASELINE configs[2]): 7 shader balls (procedural stand-in for Shaderball.gltf, 179 k triangles) blending dielectric to gold"
+                + (", coat 1 / coat roughness 0.7" if name == "material_coat" else "") + ", checkered textured floor, directional light", 32)
+    if name == "opacity":
+        return Scene("opacity"), "SimpleViewer opacity scene (cut-out box, coverage 0.75 planes, 24 triangles)", 32
+    scene = Scene("atrium", param0=args.atrium_triangles, param1=1)
+    return scene, f"procedural atrium, {scene.desc.triangle_count} triangles (Sponza-class stand-in, BASELINE configs[3]), DefaultShading", 4
 
 
-def load_measured_traffic(args, wavefronts=None):
-    """HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in
-    separate runs of this same command; bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024, the gfx950 correction of
-    MI355X_MICROARCH.md "HBM"). Only used when the recorded command matches this run's workload; otherwise traffic is null."""
+def library_sha16() -> str:
+    from bifrost3d_amd import capi
+    return hashlib.sha256(Path(capi.LIB_PATH).read_bytes()).hexdigest()[:16]
+
+
+def load_measured_traffic(key):
+    """HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate
+    runs of this command: tools/profile_round.sh + tools/make_pmc_traffic.py; bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024, the gfx950
+    correction of MI355X_MICROARCH.md "HBM"). NOT measured by this run: the entry records the command, the date and the hash of the
+    library it was collected with, and `stale` says whether that is the library running now."""
     path = ROOT / "profiles" / "pmc_traffic.json"
     if not path.exists():
-        return {}
+        return {}, None
     try:
         table = json.loads(path.read_text())
     except ValueError:
-        return {}
-    key = f"{args.scene}:{args.width}x{args.height}:spp{args.spp_per_pass}:bounces{args.bounces}"
-    if args.scene == "atrium":
-        key += f":tris{args.atrium_triangles}"
-    key += f":wf{wavefronts or args.wavefronts}"      # launches of a half-frame wavefront move half the bytes
-    entry = table.get(key, {})
-    return {k: v["traffic_bytes_per_launch"] for k, v in entry.get("kernels", {}).items()}
+        return {}, None
+    entry = table.get(key)
+    if not entry:
+        return {}, None
+    source = {"file": "profiles/pmc_traffic.json", "key": key, "command": entry.get("command"), "collected": entry.get("collected"),
+              "library_sha16": entry.get("library_sha16"), "stale": entry.get("library_sha16") != library_sha16(),
+              "note": "PMC passes of an earlier run of this command (rocprofv3 cannot run inside the timed process); not measured by this run"}
+    return {k: v["traffic_bytes_per_launch"] for k, v in entry.get("kernels", {}).items()}, source
 
 
-def rmse_against_oracle(ctx, scene, args, width=160, height=90, spp=8):
-    """BASELINE.json's third figure, per-pixel RMSE at equal spp and seed. No OptiX image can exist here, so the comparand is the
-    CPU oracle (same scene, camera, accumulations 0..spp-1, the search the GPU uses), on a frame small enough for the CPU:
-    (i) sqrt(mean over pixels and channels of (a - b)^2), (ii) the reference's ImageOperations::Compare::rms
-    (extensions/ImageOperations/ImageOperations/Compare.h:23-43): sqrt(mean(luminance(|a - b|)^2)). Runs after the timed region."""
+def load_observed_limiter(scene_name):
+    path = ROOT / "profiles" / "sq_limiters.json"
+    if path.exists():
+        try:
+            return json.loads(path.read_text()).get(scene_name)
+        except ValueError:
+            pass
+    return None
+
+
+def rmse_against_oracle(ctx, scene, bounces, spps=(8, 256), width=160, height=90):
+    """BASELINE.json's third figure, per-pixel RMSE at equal spp and seed. No OptiX image can exist here, so the comparand is the CPU
+    oracle (same scene, camera, accumulations 0..spp-1, the search the GPU uses) on a frame small enough for the CPU: (i) sqrt(mean
+    over pixels and channels of (a - b)^2), (ii) the reference's ImageOperations::Compare::rms (extensions/ImageOperations/
+    ImageOperations/Compare.h:23-43): sqrt(mean(luminance(|a - b|)^2)). Runs after the timed region."""
     sys.path.insert(0, str(ROOT / "tests"))
     import numpy as np
     from oracle_bindings import get_oracle
     oracle = get_oracle(True)   # unorm16 tables, as uploaded to the device
     ctx.set_wavefront_count(1)
-    ctx.set_frame(width, height)
-    for a in range(spp):
-        ctx.render_pass(scene.camera(width, height, accumulations=a, max_bounce_count=args.bounces))
-    ctx.synchronize()
-    gpu = ctx.read_accumulation()[..., :3]
-    cpu, _, seconds = oracle.render(scene.desc, scene.state, scene.camera(width, height, max_bounce_count=args.bounces), width, height, spp, use_bvh=ctx.oracle_search())
-    cpu = cpu[..., :3]
-    diff = np.abs(gpu - cpu)
-    luminance = 0.2126 * diff[..., 0] + 0.7152 * diff[..., 1] + 0.0722 * diff[..., 2]   # BF/Math/Color.h luminance()
-    return {"frame": [width, height], "spp": spp, "comparand": "CPU oracle (oracle/integrator.cpp), same seed", "rmse_rgb": float(np.sqrt(np.mean(diff ** 2))),
-            "rmse_reference_compare_rms": float(np.sqrt(np.mean(luminance ** 2))), "mean_radiance": float(cpu.mean()), "oracle_seconds": float(seconds)}
+    out = {"frame": [width, height], "comparand": "CPU oracle (oracle/integrator.cpp), same seed and search", "north_star_bound": 1e-3}
+    for spp in spps:
+        batch = min(spp, 32)
+        ctx.set_frame(width, height, 0, 1, batch)
+        for a in range(0, spp, batch):
+            ctx.render_pass(scene.camera(width, height, accumulations=a, max_bounce_count=bounces))
+        ctx.synchronize()
+        gpu = ctx.read_accumulation()[..., :3]
+        cpu, _, seconds = oracle.render(scene.desc, scene.state, scene.camera(width, height, max_bounce_count=bounces), width, height, spp, use_bvh=ctx.oracle_search())
+        cpu = cpu[..., :3]
+        diff = np.abs(gpu - cpu)
+        luminance = 0.2126 * diff[..., 0] + 0.7152 * diff[..., 1] + 0.0722 * diff[..., 2]   # BF/Math/Color.h luminance()
+        out[f"spp{spp}"] = {"rmse_rgb": float(np.sqrt(np.mean(diff ** 2))), "rmse_reference_compare_rms": float(np.sqrt(np.mean(luminance ** 2))),
+                            "mean_radiance": float(cpu.mean()), "oracle_seconds": float(seconds)}
+    return out
 
 
-def cpu_baseline(seconds: float):
-    """SmallPT restatement (oracle/smallpt.cpp, follows apps/SmallPT/smallpt.h:22-147) on the host cores: 256x256,
-    as many accumulations as fit the time budget (at most 64, BASELINE.json config 1)."""
+def cpu_baseline_smallpt(seconds: float):
+    """SmallPT restatement (oracle/smallpt.cpp, follows apps/SmallPT/smallpt.h:22-147) on the host cores: 256x256, as many
+    accumulations as fit the time budget (at most 64, BASELINE.json config 1)."""
     sys.path.insert(0, str(ROOT / "tests"))
     import ctypes as C
     import numpy as np
@@ -151,9 +205,200 @@ def cpu_baseline(seconds: float):
             "sample": f"SmallPT 9-sphere scene, 256x256, {acc.value} accumulations, {rays} radiance() rays in {dt:.1f} s, OpenMP dynamic,16"}
 
 
+def cpu_baseline_c2(ctx, seconds: float):
+    """the CPU restatement of the path tracer itself on BASELINE config 2 (Cornell box, all Diffuse, 4 bounces) at reduced
+    size, next to the device on the same frame and accumulations: rays counted the same way on both sides (closest-hit traces incl.
+    retraces + shadow rays), so the two Mrays/s are like for like."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    from bifrost3d_amd.host import Scene
+    from oracle_bindings import get_oracle
+    oracle = get_oracle(True)
+    scene = Scene("cornell", diffuse_only=True)
+    w, h = 480, 270
+    cam = scene.camera(w, h, max_bounce_count=4)
+    _, c1, s1 = oracle.render(scene.desc, scene.state, cam, w, h, 1, use_bvh=0)
+    spp = int(max(2, min(64, seconds / max(s1, 1e-3))))
+    _, cc, cpu_seconds = oracle.render(scene.desc, scene.state, cam, w, h, spp, use_bvh=0)
+    ctx.upload_scene(scene)
+    ctx.set_wavefront_count(1)
+    ctx.set_frame(w, h, 0, 1, spp)
+    ctx.render_pass(scene.camera(w, h, accumulations=0, max_bounce_count=4), synchronize=True)      # warm
+    ctx.reset_counters()
+    t0 = time.perf_counter()
+    ctx.render_pass(scene.camera(w, h, accumulations=0, max_bounce_count=4), synchronize=True)
+    gpu_seconds = time.perf_counter() - t0
+    gc = ctx.counters()
+    cpu_rays, gpu_rays = cc["closest_rays"] + cc["shadow_rays"], gc["closest_rays"] + gc["shadow_rays"]
+    return {"value": cpu_rays / cpu_seconds / 1e6, "unit": "Mrays/s", "cores": int(oracle.lib.oracle_max_threads()), "kind": "port",
+            "sample": f"oracle render of BASELINE config 2 (Cornell box, all Diffuse), {w}x{h}, {spp} accumulations, 4 bounces: {cpu_rays} rays in {cpu_seconds:.1f} s",
+            "device_same_sample": {"value": gpu_rays / gpu_seconds / 1e6, "unit": "Mrays/s", "rays": gpu_rays, "seconds": gpu_seconds},
+            "counters_equal": {k: [int(cc[k]), int(gc[k])] for k in ("camera_rays", "closest_rays", "shadow_rays", "shaded_hits")},
+            "ray_count_relative_difference": abs(cpu_rays - gpu_rays) / max(1, cpu_rays)}
+
+
+# --------------------------------------------------------------------------------------------------------------------------------
+# Rooflines. Algorithmic HBM bytes per unit of work, DESIGN.md "Kernels" / SURVEY.md 8d:
+#   generate       80 B per path        (64 B path state + 16 B radiance slot written)
+#   trace_closest  48 B path state read + 16 B hit written per ray, + 64 B per BVH node visited + 48 B per triangle tested
+#   shade          80 B per queued ray (hit + path state) + 352 B per shaded hit (triangle 48, shading record 96, material 64,
+#                  3 RIS light candidates 144) + 64 B per continued path + 48 B per shadow ray queued + 32 B radiance read-modify-write per queued ray
+#   trace_shadow   48 B record + 32 B radiance rmw per shadow ray, + 64 B per node + 48 B per triangle
+#   accumulate     16 B radiance per sample + 64 B f64 accumulation rmw + 8 B half4 per owned pixel
+# --------------------------------------------------------------------------------------------------------------------------------
+def rooflines_of(counters, times, per_ray, small, fused, samples_per_step, traffic):
+    n_closest, n_shadow, n_camera, n_hits = (counters[k] for k in ("closest_rays", "shadow_rays", "camera_rays", "shaded_hits"))
+    tri_share = 1.0 / 64.0 if small else 1.0   # exhaustive search: the triangle array is read once per 64-ray wave through the scalar cache
+    kernel_bytes = {
+        "generate": 80.0 * n_camera,
+        "trace_closest": n_closest * (48 + 16 + 64 * per_ray["nodes"] + 48 * per_ray["triangles"] * tri_share),
+        "shade": 80.0 * n_closest + 352.0 * n_hits + 64.0 * max(0, n_closest - n_camera) + 48.0 * n_shadow + 32.0 * n_closest,
+        "trace_shadow": n_shadow * (48 + 32 + 64 * per_ray["shadow_nodes"] + 48 * per_ray["shadow_triangles"] * tri_share),
+        "accumulate": 16.0 * n_camera + (64.0 + 8.0) * n_camera / max(1, samples_per_step),
+    }
+    kernel_names = {"generate": "k_generate", "trace_closest": "k_trace_closest_small" if small else "k_trace_closest / k_trace_persistent<TRACE_CLOSEST>", "shade": "k_shade",
+                    "trace_shadow": "k_trace_shadow_small" if small else "k_trace_shadow", "accumulate": "k_accumulate",
+                    "trace": "k_trace_persistent<TRACE_FUSED> (closest-hit rays of bounce k + shadow rays of bounce k-1)"}
+    kernel_times = dict(times)
+    if fused:   # one launch serves both ray kinds: bytes and time of the two are reported together
+        kernel_bytes["trace"] = kernel_bytes.pop("trace_closest") + kernel_bytes.pop("trace_shadow")
+        a, b = kernel_times.pop("trace_closest"), kernel_times.pop("trace_shadow")
+        kernel_times["trace"] = {"ms": a["ms"] + b["ms"], "launches": a["launches"] + b["launches"]}
+    rooflines = {}
+    for name, t in kernel_times.items():
+        if not t or t["ms"] <= 0 or t["launches"] == 0:
+            continue
+        nbytes = kernel_bytes.get(name)
+        entry = {"bound": "hbm", "kernel": kernel_names.get(name, name), "peak": HBM_PEAK_GBS, "unit": "GB/s", "avg_launch_ms": t["ms"] / t["launches"],
+                 "launches": t["launches"], "total_ms": t["ms"]}
+        if nbytes is not None:
+            gbs = nbytes / (t["ms"] * 1e-3) / 1e9
+            entry.update({"achieved": gbs, "achieved_model": "algorithmic bytes (SURVEY.md 8d: every node visit 64 B, every triangle test 48 B, ...), not HBM traffic",
+                          "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nbytes / t["launches"]})
+        measured = traffic.get(name)
+        entry["traffic"] = measured
+        if measured:
+            counter_gbs = measured / (t["ms"] / t["launches"] * 1e-3) / 1e9
+            entry.update({"achieved_counter": counter_gbs, "frac_counter": counter_gbs / HBM_PEAK_GBS})
+        rooflines[name] = entry
+    return rooflines, kernel_times
+
+
+def measure(ctx, scene, scene_name, bounces, args, rank, world, device, steps, warmup, sync):
+    """Instrumented passes (per-ray node / triangle counts), warmup, then exactly `steps` timed steps. Returns the figures of this rank."""
+    import torch
+    import torch.distributed as dist
+    from bifrost3d_amd import capi, distributed
+    W, H = args.width, args.height
+    S = args.spp_per_pass * world
+    on_host = world > 1 and args.dist_backend == "gloo"
+    ctx.upload_scene(scene)
+    ctx.set_wavefront_count(args.wavefronts)
+    ctx.set_frame(W, H, tile_phase=rank, tile_stride=world, samples_per_pass=S)
+    n_compact = distributed.padded_pixels_per_rank(W, H, world)
+    frame = torch.zeros((H, W, 4), dtype=torch.float16, device=device) if rank == 0 else None
+    compact = torch.zeros((n_compact, 4), dtype=torch.float16, device=device) if world > 1 else None
+    torch.cuda.synchronize(device)   # the fills above ran on torch's stream; the wavefronts render on their own
+
+    def run_pass(accumulation):
+        cam = scene.camera(W, H, accumulations=accumulation, max_bounce_count=bounces)
+        if world == 1:
+            ctx.render_pass(cam, frame.data_ptr(), W)
+        else:
+            ctx.render_pass(cam, compact.data_ptr(), 0)
+
+    def finish_frame():
+        if world == 1:
+            return
+        ctx.synchronize()   # the context renders on its own streams, torch.distributed on torch's: order them explicitly
+        gathered = distributed.gather_to_root(compact.cpu() if on_host else compact, world, rank)
+        if rank == 0:
+            if on_host:
+                gathered = gathered.to(device)
+            torch.cuda.current_stream(device).synchronize()
+            ctx.scatter_tiles(gathered.data_ptr(), n_compact, world, W, H, frame.data_ptr(), W)
+            ctx.synchronize()
+
+    ctx.set_instrumentation(True)
+    ctx.reset_counters()
+    for a in (0, S):
+        run_pass(a)
+    ctx.synchronize()
+    ic = ctx.counters()
+    ctx.set_instrumentation(False)
+    per_ray = {"nodes": ic["closest_nodes"] / max(1, ic["closest_rays"]), "triangles": ic["closest_triangles"] / max(1, ic["closest_rays"]),
+               "shadow_nodes": ic["shadow_nodes"] / max(1, ic["shadow_rays"]), "shadow_triangles": ic["shadow_triangles"] / max(1, ic["shadow_rays"])}
+
+    a = 2 * S
+    for _ in range(warmup):
+        run_pass(a)
+        a += S
+    finish_frame()
+    sync()
+    ctx.reset_counters()
+    ctx.reset_timers()
+
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run_pass(a)
+        a += S
+    finish_frame()
+    sync()
+    elapsed = time.perf_counter() - t0
+
+    ctx.synchronize()
+    counters, times = ctx.counters(), ctx.kernel_times()
+    stats = torch.tensor([elapsed, counters["closest_rays"], counters["shadow_rays"], counters["camera_rays"]], dtype=torch.float64, device=device)
+    if world > 1:
+        if on_host:
+            stats = stats.cpu()
+        mx = stats.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        elapsed = float(mx[0])
+    total = {"closest_rays": float(stats[1]), "shadow_rays": float(stats[2]), "camera_rays": float(stats[3])}
+    result = {"elapsed": elapsed, "total": total, "counters": counters, "times": times, "per_ray": per_ray, "S": S}
+    if rank == 0:
+        result["frame_ok"] = bool(torch.isfinite(frame.float()).all().item()) and float(frame[..., :3].float().mean()) > 0
+        result["small"] = ctx.trace_variant() == capi.TRACE_EXHAUSTIVE
+        result["fused"] = ctx.trace_is_fused()
+    return result
+
+
+def summarise(result, scene_name, scene_text, bounces, args, world, steps):
+    """The figures of one measured workload as the bench line reports them (rank 0)."""
+    W, H, S = args.width, args.height, result["S"]
+    key = f"{scene_name}:{W}x{H}:spp{args.spp_per_pass}:bounces{bounces}"
+    if scene_name == "atrium":
+        key += f":tris{args.atrium_triangles}"
+    key += f":wf{args.wavefronts}"
+    traffic, traffic_source = load_measured_traffic(key) if world == 1 else ({}, None)
+    rooflines, kernel_times = rooflines_of(result["counters"], result["times"], result["per_ray"], result["small"], result["fused"], S, traffic)
+    dominant = max(rooflines, key=lambda n: rooflines[n]["total_ms"])
+    roofline = dict(rooflines[dominant])
+    roofline["traffic_source"] = traffic_source
+    if args.wavefronts > 1:
+        roofline["co_running"] = "two half-frame wavefronts on two streams: this kernel's launches overlap the other wavefront's kernels, so avg_launch_ms is a co-running duration"
+    limiter = load_observed_limiter(scene_name)
+    roofline["observed_limiter"] = limiter if limiter else "see DESIGN.md 'What bounds the kernels': the counters put these kernels on VALU issue and gather latency, not on HBM bytes"
+    roofline.update({"nodes_per_ray": result["per_ray"]["nodes"], "triangles_per_ray": result["per_ray"]["triangles"], "shadow_nodes_per_ray": result["per_ray"]["shadow_nodes"],
+                     "shadow_triangles_per_ray": result["per_ray"]["shadow_triangles"], "selection": "kernel with the largest total time in the timed region"})
+    total = result["total"]
+    rays = total["closest_rays"] + total["shadow_rays"]
+    elapsed = result["elapsed"]
+    return {"value": rays / elapsed / 1e6, "ms_per_step": elapsed / steps * 1e3, "ms_per_256spp_frame": elapsed / (steps * S) * 1e3 * 256,
+            "workload": f"{scene_text}; {W}x{H}, {S} accumulation(s) per step ({W * H * args.spp_per_pass} paths per GPU per step), max_bounce_count {bounces}, "
+                        f"next_event_sample_count 3, path regularisation PDF_scale 0.5; f64 accumulation + half4 output",
+            "spp_per_step": S, "steps": steps, "spp_total": S * steps, "rays_per_step": rays / steps, "closest_rays": total["closest_rays"], "shadow_rays": total["shadow_rays"],
+            "pixel_samples": total["camera_rays"], "frame_finite_and_lit": result["frame_ok"], "roofline": roofline, "roofline_by_kernel": rooflines,
+            "kernel_ms_per_step": {name: v["ms"] / steps for name, v in kernel_times.items()}}
+
+
 def main():
     args = parse_args()
-    import numpy as np
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+
     import torch
     import torch.distributed as dist
     from bifrost3d_amd import distributed
@@ -161,8 +406,7 @@ def main():
 
     rank, world, local_rank = distributed.env_rank_world()
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         device_index = 0 if args.share_device else local_rank
@@ -175,196 +419,51 @@ def main():
         device_index = 0
         torch.cuda.set_device(0)
     device = torch.device("cuda", device_index)
-    on_host = world > 1 and args.dist_backend == "gloo"   # gloo collectives take host tensors
 
-    W, H = args.width, args.height
-    S = args.spp_per_pass * world   # accumulations per step: per-GPU paths per step stay W*H*spp_per_pass for every N
-    scene, scene_text = make_scene(args)
-    ctx = Context(device_index)
-    ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
-    ctx.upload_scene(scene)
-    ctx.set_wavefront_count(args.wavefronts)
-    ctx.set_frame(W, H, tile_phase=rank, tile_stride=world, samples_per_pass=S)
-
-    n_compact = distributed.padded_pixels_per_rank(W, H, world)
-    frame = torch.zeros((H, W, 4), dtype=torch.float16, device=device) if rank == 0 else None
-    compact = torch.zeros((n_compact, 4), dtype=torch.float16, device=device) if world > 1 else None
-
-    def run_pass(accumulation):
-        cam = scene.camera(W, H, accumulations=accumulation, max_bounce_count=args.bounces)
-        if world == 1:
-            ctx.render_pass(cam, frame.data_ptr(), W)
-        else:
-            ctx.render_pass(cam, compact.data_ptr(), 0)
-
-    def finish_frame():
-        if world == 1:
-            return
-        # The context renders on its own (non-blocking) stream, torch.distributed on torch's: order them explicitly.
-        ctx.synchronize()
-        gathered = distributed.gather_to_root(compact.cpu() if on_host else compact, world, rank)
-        if rank == 0:
-            if on_host:
-                gathered = gathered.to(device)
-            torch.cuda.current_stream(device).synchronize()
-            ctx.scatter_tiles(gathered.data_ptr(), n_compact, world, W, H, frame.data_ptr(), W)
-            ctx.synchronize()
-
-    def barrier():
+    def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    # ---- instrumented passes: average BVH nodes / triangles per closest-hit ray (roofline numerator) ----------
-    ctx.set_instrumentation(True)
-    ctx.reset_counters()
-    for a in (0, S):
-        run_pass(a)
-    ctx.synchronize()
-    ic = ctx.counters()
-    ctx.set_instrumentation(False)
-    nodes_per_ray = ic["closest_nodes"] / max(1, ic["closest_rays"])
-    tris_per_ray = ic["closest_triangles"] / max(1, ic["closest_rays"])
-    shadow_nodes_per_ray = ic["shadow_nodes"] / max(1, ic["shadow_rays"])
-    shadow_tris_per_ray = ic["shadow_triangles"] / max(1, ic["shadow_rays"])
-
-    # ---- warmup -------------------------------------------------------------------------------------------------
-    a = 2 * S
-    for _ in range(args.warmup):
-        run_pass(a)
-        a += S
-    finish_frame()
-    barrier()
-    ctx.reset_counters()
-    ctx.reset_timers()
-
-    # ---- timed region: exactly K steps ------------------------------------------------------------------------------
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run_pass(a)
-        a += S
-    finish_frame()
-    barrier()
-    elapsed = time.perf_counter() - t0
-
-    ctx.synchronize()
-    counters = ctx.counters()
-    times = ctx.kernel_times()
-    stats = torch.tensor([elapsed, counters["closest_rays"], counters["shadow_rays"], counters["camera_rays"],
-                          times["trace_closest"]["ms"], times["trace_closest"]["launches"]], dtype=torch.float64, device=device)
-    if world > 1:
-        if on_host:
-            stats = stats.cpu()
-        mx = stats.clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
-        elapsed = float(mx[0])
-    total_closest, total_shadow, total_camera = float(stats[1]), float(stats[2]), float(stats[3])
-    total_rays = total_closest + total_shadow
+    scene_name = "file:" + args.scene_file if args.scene_file else args.scene
+    scene, scene_text, default_bounces = make_scene(scene_name, args)
+    bounces = args.bounces if args.bounces is not None else default_bounces
+    ctx = Context(device_index)
+    ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
+    result = measure(ctx, scene, scene_name, bounces, args, rank, world, device, args.steps, args.warmup, sync)
 
     if rank == 0:
-        ok = bool(torch.isfinite(frame.float()).all().item()) and float(frame[..., :3].float().mean()) > 0
-        # Rooflines (rank 0's launches). Algorithmic HBM bytes per unit of work, DESIGN.md "Kernels" / SURVEY.md 8d:
-        #   generate       80 B per path        (64 B path state + 16 B radiance slot written)
-        #   trace_closest  48 B path state read + 16 B hit written per ray, + 64 B per BVH node visited + 48 B per triangle tested
-        #   shade          80 B per queued ray (hit + path state) + 352 B per shaded hit (triangle 48, shading record 96, material 64,
-        #                  3 RIS light candidates 144) + 64 B per continued path
-        #                  + 48 B per shadow ray queued + 32 B radiance read-modify-write per queued ray
-        #   trace_shadow   48 B record + 32 B radiance rmw per shadow ray, + 64 B per node + 48 B per triangle
-        #   accumulate     16 B radiance per sample + 64 B f64 accumulation rmw + 8 B half4 per owned pixel
-        from bifrost3d_amd import capi
-        small = ctx.trace_variant() == capi.TRACE_EXHAUSTIVE
-        fused = ctx.trace_is_fused()
-        measured_traffic = load_measured_traffic(args)
-
-        def rooflines_of(counters, times):
-            n_closest, n_shadow, n_camera, n_hits = (counters[k] for k in ("closest_rays", "shadow_rays", "camera_rays", "shaded_hits"))
-            # exhaustive-search kernels (<= 64 triangles): the triangle array is read once per 64-ray wave through the scalar cache
-            tri_share = 1.0 / 64.0 if small else 1.0
-            kernel_bytes = {
-                "generate": 80.0 * n_camera,
-                "trace_closest": n_closest * (48 + 16 + 64 * nodes_per_ray + 48 * tris_per_ray * tri_share),
-                "shade": 80.0 * n_closest + 352.0 * n_hits + 64.0 * max(0, n_closest - n_camera) + 48.0 * n_shadow + 32.0 * n_closest,
-                "trace_shadow": n_shadow * (48 + 32 + 64 * shadow_nodes_per_ray + 48 * shadow_tris_per_ray * tri_share),
-                "accumulate": 16.0 * n_camera + (64.0 + 8.0) * n_camera / max(1, S),
-            }
-            kernel_names = {"generate": "k_generate", "trace_closest": "k_trace_closest_small" if small else "k_trace_closest", "shade": "k_shade",
-                            "trace_shadow": "k_trace_shadow_small" if small else "k_trace_shadow",
-                            "accumulate": "k_accumulate", "trace": "k_trace_persistent<TRACE_FUSED> (closest-hit rays of bounce k + shadow rays of bounce k-1)"}
-            kernel_times = dict(times)
-            if fused:   # one launch serves both ray kinds: bytes and time of the two are reported together
-                kernel_bytes["trace"] = kernel_bytes.pop("trace_closest") + kernel_bytes.pop("trace_shadow")
-                a, b = kernel_times.pop("trace_closest"), kernel_times.pop("trace_shadow")
-                kernel_times["trace"] = {"ms": a["ms"] + b["ms"], "launches": a["launches"] + b["launches"]}
-            rooflines = {}
-            for name, nbytes in kernel_bytes.items():
-                t = kernel_times.get(name)
-                if not t or t["ms"] <= 0 or t["launches"] == 0:
-                    continue
-                gbs = nbytes / (t["ms"] * 1e-3) / 1e9
-                rooflines[name] = {"bound": "hbm", "kernel": kernel_names[name], "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                                   "traffic": measured_traffic.get(name), "avg_launch_ms": t["ms"] / t["launches"], "launches": t["launches"],
-                                   "algorithmic_bytes_per_launch": nbytes / t["launches"], "total_ms": t["ms"]}
-            return rooflines, kernel_times
-
-        rooflines, kernel_times = rooflines_of(counters, times)
-        dominant = max(rooflines, key=lambda n: rooflines[n]["total_ms"])
-        roofline = dict(rooflines[dominant])
-        if args.wavefronts > 1 and not args.no_alone_region:
-            # With two wavefronts a kernel shares the machine with the other wavefront's (that is the point: one shades while the other
-            # traces), so the durations above -- and `achieved` with them -- are those of co-running kernels. The same kernel alone on
-            # the machine: a short extra region with one wavefront, after and outside the timed region.
-            ctx.set_wavefront_count(1)
-            ctx.set_frame(W, H, tile_phase=rank, tile_stride=world, samples_per_pass=S)
-            run_pass(0)
-            ctx.synchronize()
-            ctx.reset_counters()
-            ctx.reset_timers()
-            for k in range(4):
-                run_pass((k + 1) * S)
-            ctx.synchronize()
-            alone, _ = rooflines_of(ctx.counters(), ctx.kernel_times())
-            if dominant in alone:
-                roofline["alone"] = {k: alone[dominant][k] for k in ("achieved", "frac", "avg_launch_ms", "launches", "algorithmic_bytes_per_launch")}
-                roofline["alone"]["traffic"] = load_measured_traffic(args, 1).get(dominant)
-                roofline["alone"]["note"] = "the same kernel with one wavefront (nothing co-running), 4 steps after the timed region"
-        if args.wavefronts > 1:
-            roofline["co_running"] = "two half-frame wavefronts on two streams: this kernel's launches overlap the other wavefront's kernels"
-        roofline.update({"nodes_per_ray": nodes_per_ray, "triangles_per_ray": tris_per_ray, "shadow_nodes_per_ray": shadow_nodes_per_ray,
-                         "shadow_triangles_per_ray": shadow_tris_per_ray, "selection": "kernel with the largest total time in the timed region"})
+        main_figures = summarise(result, scene_name, scene_text, bounces, args, world, args.steps)
         out = {
-            "metric": "Mrays/sec + ms/frame at 1080p/256spp; per-pixel RMSE vs OptiXRenderer",
-            "value": total_rays / elapsed / 1e6,
-            "unit": "Mrays/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {
-                "workload": f"{scene_text}; {W}x{H}, {S} accumulation(s) per step ({W * H * args.spp_per_pass} paths per GPU per step), max_bounce_count {args.bounces}, "
-                            f"next_event_sample_count 3, path regularisation PDF_scale 0.5; f64 accumulation + half4 output",
-                "frame": [W, H], "spp_per_step": S,
-                "parallelism": f"tiles8x8-round-robin-x{world}" if world > 1 else "single-gpu", "wavefronts": args.wavefronts,
-                "ms_per_256spp_frame": elapsed / (args.steps * S) * 1e3 * 256,
-                "rays_per_step": total_rays / args.steps,
-                "closest_rays": total_closest, "shadow_rays": total_shadow, "pixel_samples": total_camera,
-                "frame_finite_and_lit": ok,
-                "rmse_note": "no OptiX image exists or can be produced here (DESIGN.md); rmse_vs_oracle compares with the CPU oracle at equal spp and seed",
-            },
-            "roofline": roofline,
-            "roofline_by_kernel": rooflines,
-            "kernel_ms_per_step": {name: v["ms"] / args.steps for name, v in kernel_times.items()},
+            "metric": METRIC, "value": main_figures["value"], "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": main_figures["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": main_figures["workload"], "frame": [args.width, args.height], "spp_per_step": main_figures["spp_per_step"], "spp_total": main_figures["spp_total"],
+                       "parallelism": f"tiles8x8-round-robin-x{world}" if world > 1 else "single-gpu", "wavefronts": args.wavefronts,
+                       "ms_per_256spp_frame": main_figures["ms_per_256spp_frame"], "rays_per_step": main_figures["rays_per_step"],
+                       "closest_rays": main_figures["closest_rays"], "shadow_rays": main_figures["shadow_rays"], "pixel_samples": main_figures["pixel_samples"],
+                       "frame_finite_and_lit": main_figures["frame_finite_and_lit"], "library_sha16": library_sha16(),
+                       "rmse_note": "no OptiX image exists or can be produced here (DESIGN.md); rmse_vs_oracle compares with the pinned CPU oracle at equal spp and seed"},
+            "roofline": main_figures["roofline"], "roofline_by_kernel": main_figures["roofline_by_kernel"], "kernel_ms_per_step": main_figures["kernel_ms_per_step"],
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_seconds)
-            if scene.desc.triangle_count <= 300000:
-                out["config"]["rmse_vs_oracle"] = rmse_against_oracle(ctx, scene, args)
+        if world == 1:
+            if not args.no_rmse and scene.desc.triangle_count <= 300000:
+                out["config"]["rmse_vs_oracle"] = rmse_against_oracle(ctx, scene, bounces)
+            if not args.no_other_workloads and not args.scene_file:
+                others = {}
+                for other in ("cornell_diffuse", "material"):
+                    if other == scene_name:
+                        continue
+                    other_scene, other_text, other_bounces = make_scene(other, args)
+                    r = measure(ctx, other_scene, other, other_bounces, args, 0, 1, device, 4, 1, sync)
+                    figures = summarise(r, other, other_text, other_bounces, args, 1, 4)
+                    if not args.no_rmse:
+                        figures["rmse_vs_oracle"] = rmse_against_oracle(ctx, other_scene, other_bounces, spps=(8, 256) if other == "cornell_diffuse" else (8,))
+                    figures.pop("roofline_by_kernel")
+                    others[other] = figures
+                out["other_workloads"] = others
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline_smallpt(args.cpu_baseline_seconds)
+                out["cpu_baseline"]["c2"] = cpu_baseline_c2(ctx, args.cpu_baseline_seconds)
         print(json.dumps(out))
         sys.stdout.flush()
 

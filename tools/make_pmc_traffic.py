@@ -63,7 +63,11 @@ def main():
         kernels[name] = {"FETCH_SIZE_KiB_per_launch": f_kib, "WRITE_SIZE_KiB_per_launch": w_kib, "launches_fetch_pass": f_n, "launches_write_pass": w_n,
                          "traffic_bytes_per_launch": (2.0 * f_kib + w_kib) * 1024.0}
     table = json.loads(out.read_text()) if out.exists() else {}
-    table[key] = {"command": command, "formula": "(2 * FETCH_SIZE + WRITE_SIZE) * 1024 bytes, separate --pmc passes", "kernels": kernels}
+    import datetime
+    import hashlib
+    library = Path(__file__).resolve().parent.parent / "bifrost3d_amd" / "csrc" / "libhiprenderer.so"
+    sha16 = hashlib.sha256(library.read_bytes()).hexdigest()[:16] if library.exists() else None
+    table[key] = {"command": command, "collected": datetime.date.today().isoformat(), "library_sha16": sha16, "formula": "(2 * FETCH_SIZE + WRITE_SIZE) * 1024 bytes, separate --pmc passes", "kernels": kernels}
     out.write_text(json.dumps(table, indent=1, sort_keys=True) + "\n")
     for name, v in kernels.items():
         print(f"{name:16s} fetch {v['FETCH_SIZE_KiB_per_launch']:12.1f} KiB  write {v['WRITE_SIZE_KiB_per_launch']:12.1f} KiB  traffic {v['traffic_bytes_per_launch'] / 1e6:10.2f} MB/launch")
