@@ -132,7 +132,7 @@ C_ABI_SYMBOLS = (
     "hipr_create", "hipr_destroy", "hipr_last_error", "hipr_device_count", "hipr_set_stream",
     "hipr_upload_tables", "hipr_upload_scene", "hipr_validate_scene", "hipr_set_scene_state", "hipr_set_entry_point", "hipr_use_scratch_accumulation",
     "hipr_set_frame", "hipr_owned_pixel_count",
-    "hipr_render_pass", "hipr_read_accumulation", "hipr_scatter_tiles", "hipr_synchronize", "hipr_get_counters",
+    "hipr_render_pass", "hipr_set_samples_per_pass", "hipr_trace_pass", "hipr_accumulate_samples", "hipr_read_accumulation", "hipr_scatter_tiles", "hipr_synchronize", "hipr_get_counters",
     "hipr_device_malloc", "hipr_device_free", "hipr_copy_to_host", "hipr_present_flipped",
     "hipr_reset_counters", "hipr_set_wavefront_count", "hipr_get_trace_variant", "hipr_set_instrumentation", "hipr_reset_timers", "hipr_get_kernel_times",
     "hipr_debug_shading", "hipr_debug_light", "hipr_debug_generate", "hipr_debug_sobol", "hipr_debug_sample_offsets", "hipr_debug_trace_closest", "hipr_debug_trace_shadow",
@@ -176,6 +176,9 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.hipr_set_frame.argtypes = [vp, C.POINTER(HiprFrameDesc)]
     lib.hipr_owned_pixel_count.argtypes = [vp, C.POINTER(c_u32)]
     lib.hipr_render_pass.argtypes = [vp, C.POINTER(HiprCameraState), vp, c_u32, C.c_int]
+    lib.hipr_set_samples_per_pass.argtypes = [vp, c_u32]
+    lib.hipr_trace_pass.argtypes = [vp, C.POINTER(HiprCameraState)]
+    lib.hipr_accumulate_samples.argtypes = [vp, c_u32, c_u32, c_u32, vp, c_u32, C.c_int]
     lib.hipr_read_accumulation.argtypes = [vp, C.POINTER(C.c_double), c_u64]
     lib.hipr_scatter_tiles.argtypes = [vp, vp, c_u64, c_u32, c_u32, c_u32, vp, c_u32]
     lib.hipr_synchronize.argtypes = [vp]

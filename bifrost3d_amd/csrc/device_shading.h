@@ -40,7 +40,15 @@ HD Sample sample_none() { return {{0, 0, 0}, 0.0f, {0, 0, 0}}; }
 // --use_fast_math PTX (extensions/OptiXRenderer/CMakeLists.txt:82-83); otherwise the correctly rounded-ish ocml versions.
 #if HIPR_FAST_MATH
 HD void sincos_(float a, float& s, float& c) { s = __sinf(a); c = __cosf(a); }
+#ifndef HIPR_NATIVE_POW
+#define HIPR_NATIVE_POW 1
+#endif
+#if HIPR_NATIVE_POW
+// x^y as exp2(y * log2(x)) on the hardware's v_log_f32 / v_exp_f32, what --use_fast_math makes of powf in the reference's PTX (HIP's __powf is the full ocml pow).
+HD float pow_(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
+#else
 HD float pow_(float x, float y) { return __powf(x, y); }
+#endif
 #else
 HD void sincos_(float a, float& s, float& c) { s = sinf(a); c = cosf(a); }
 HD float pow_(float x, float y) { return powf(x, y); }

@@ -119,6 +119,8 @@ struct HiprContext {
     FrameInfo frame = {};
     bool frame_ready = false;
     uint32_t n_slots = 0;   // owned_tiles * 64 * samples_per_pass
+    uint32_t traced_samples = 0;        // samples the radiance buffer holds since the last hipr_trace_pass
+    float pass_depth_normalizer = 0.0f; // depth entry: far - near of the traced pass's camera
     DeviceBuffer radiance, accumulation, scratch_accumulation, counters, work_counters;
     bool use_scratch = false;
     int entry = HIPR_ENTRY_PATH_TRACING;
@@ -133,7 +135,7 @@ struct HiprContext {
     int active_trace_variant() const { return use_persistent() ? HIPR_TRACE_WIDE_PERSISTENT : (use_exhaustive() ? HIPR_TRACE_EXHAUSTIVE : HIPR_TRACE_BVH2); }
     int cu_count = 256;
     int blocks_per_cu_override = 0;     // HIPR_BLOCKS_PER_CU
-    int shade_blocks_per_cu = 2;        // persistent shade blocks per CU (HIPR_SHADE_BLOCKS_PER_CU)
+    int shade_blocks_per_cu = 0;        // persistent shade blocks per CU = waves per SIMD; 0: 3 (what the kernel is compiled for), 2 for all-Diffuse scenes (HIPR_SHADE_BLOCKS_PER_CU)
     int refill_below = 40;              // persistent kernels refill a wave once fewer lanes than this are busy (HIPR_REFILL_BELOW)
     int persistent_blocks_per_cu[3][3] = {{0, 0, 0}, {0, 0, 0}};   // [shadow][stack bucket]
 
@@ -318,10 +320,42 @@ void launch_trace_fused(HiprContext* c, const Wavefront& w, const PathState& in,
 }
 
 void launch_shade(HiprContext* c, const Wavefront& w, const HiprCameraState& camera, int cur, uint32_t alive, const uint32_t* in_count, uint32_t* out_counts) {
-    // persistent blocks: two per CU stay resident (2 waves per SIMD), each walks the queue with a grid stride
-    ShadeLaunch a = {grid_for(alive, SHADE_BLOCK, uint32_t(c->cu_count) * uint32_t(c->shade_blocks_per_cu)), w.stream, c->scene, camera, c->entry, w.path_state(cur), w.hits.as<float4>(), w.path_state(1 - cur),
+    // persistent blocks: three per CU stay resident (3 waves per SIMD), each walks the queue with a grid stride, one batch ahead on its inputs
+    // measured: the Default / Transmissive kernels gain from a third wave per SIMD (atrium 29.4 -> 25.9 ms of shading per step), the lighter all-Diffuse
+    // kernel loses (Cornell 18 390 -> 17 194 Mrays/s)
+    const uint32_t blocks_per_cu = c->shade_blocks_per_cu > 0 ? uint32_t(c->shade_blocks_per_cu) : (c->shading_models == 2 ? 2u : 3u);
+    ShadeLaunch a = {grid_for(alive, SHADE_BLOCK, uint32_t(c->cu_count) * blocks_per_cu), w.stream, c->scene, camera, c->entry, w.path_state(cur), w.hits.as<float4>(), w.path_state(1 - cur),
                      w.shadow_queue(), c->radiance.as<float4>(), in_count, reinterpret_cast<unsigned long long*>(out_counts), c->counters.as<DeviceCounters>()};
     hipr::launch_shade(c->shading_models, a);
+}
+
+// Splits the path slots of a pass (owned tiles x 64 x samples_per_pass) over the wavefronts on a tile (= wave) boundary and sizes the
+// queues and the per-sample radiance buffer; small passes stay one wavefront. Buffers only ever grow. The accumulation is not touched.
+int partition_path_slots(HiprContext* c) {
+    const FrameInfo& fi = c->frame;
+    const uint64_t slots = uint64_t(fi.owned_tiles) * 64u * fi.samples_per_pass;
+    c->n_slots = uint32_t(slots);
+    int r = 0;
+    c->wavefront_count = int(std::max<uint64_t>(1, std::min<uint64_t>(uint64_t(c->wavefront_limit), slots / 65536u)));
+    const uint64_t share = ((slots + c->wavefront_count - 1) / c->wavefront_count + 63) / 64 * 64;
+    for (int g = 0; g < MAX_WAVEFRONTS; ++g) {
+        Wavefront& w = c->wavefronts[g];
+        const uint64_t first = std::min<uint64_t>(slots, share * g);
+        w.first_slot = uint32_t(first);
+        w.n_slots = g >= c->wavefront_count ? 0u : uint32_t(std::min<uint64_t>(share, slots - first));
+        const size_t bytes = size_t(std::max(w.n_slots, 64u)) * 16;
+        if (g >= c->wavefront_count) {   // queues of wavefronts this pass size does not use go back to the allocator
+            for (auto& buffers : w.path) for (DeviceBuffer& b : buffers) b.release();
+            w.hits.release();
+            for (DeviceBuffer& b : w.shadow) b.release();
+            continue;
+        }
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) r |= w.path[i][j].resize(bytes);
+        r |= w.hits.resize(bytes);
+        for (int j = 0; j < 3; ++j) r |= w.shadow[j].resize(bytes);
+    }
+    r |= c->radiance.resize(slots * 16);
+    return r;
 }
 
 int check_context(HiprContext* c) {
@@ -688,28 +722,7 @@ int hipr_set_frame(HiprContext* c, const HiprFrameDesc* f) {
     const uint64_t slots = uint64_t(fi.owned_tiles) * 64u * fi.samples_per_pass;
     if (slots == 0 || slots > 0x7FFFFFFFull) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_set_frame: %llu path slots per pass", (unsigned long long)slots);
     c->frame = fi;
-    c->n_slots = uint32_t(slots);
-    int r = 0;
-    // Split the slots over the wavefronts on a tile (= wave) boundary; small frames stay one wavefront.
-    c->wavefront_count = int(std::max<uint64_t>(1, std::min<uint64_t>(uint64_t(c->wavefront_limit), slots / 65536u)));
-    const uint64_t share = ((slots + c->wavefront_count - 1) / c->wavefront_count + 63) / 64 * 64;
-    for (int g = 0; g < MAX_WAVEFRONTS; ++g) {
-        Wavefront& w = c->wavefronts[g];
-        const uint64_t first = std::min<uint64_t>(slots, share * g);
-        w.first_slot = uint32_t(first);
-        w.n_slots = g >= c->wavefront_count ? 0u : uint32_t(std::min<uint64_t>(share, slots - first));
-        const size_t bytes = size_t(std::max(w.n_slots, 64u)) * 16;
-        if (g >= c->wavefront_count) {   // queues of wavefronts this frame does not use go back to the allocator
-            for (auto& buffers : w.path) for (DeviceBuffer& b : buffers) b.release();
-            w.hits.release();
-            for (DeviceBuffer& b : w.shadow) b.release();
-            continue;
-        }
-        for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) r |= w.path[i][j].resize(bytes);
-        r |= w.hits.resize(bytes);
-        for (int j = 0; j < 3; ++j) r |= w.shadow[j].resize(bytes);
-    }
-    r |= c->radiance.resize(slots * 16);
+    int r = partition_path_slots(c);
     const size_t acc_bytes = size_t(fi.owned_tiles) * 64 * sizeof(double4);
     c->accumulation.release();
     c->scratch_accumulation.release();
@@ -719,6 +732,7 @@ int hipr_set_frame(HiprContext* c, const HiprFrameDesc* f) {
     HIP_TRY(hipMemsetAsync(c->accumulation.ptr, 0, acc_bytes, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->frame_ready = true;
+    c->traced_samples = 0;
     return HIPR_OK;
 }
 
@@ -756,11 +770,28 @@ int hipr_owned_pixel_count(HiprContext* c, uint32_t* out_count) {
     return HIPR_OK;
 }
 
+int hipr_set_samples_per_pass(HiprContext* c, uint32_t samples_per_pass) {
+    if (int s = check_context(c)) return s;
+    if (!c->frame_ready) return fail(HIPR_ERROR_NOT_READY, "no frame set");
+    const uint64_t slots = uint64_t(c->frame.owned_tiles) * 64u * samples_per_pass;
+    if (samples_per_pass == 0 || slots > 0x7FFFFFFFull) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_set_samples_per_pass: %llu path slots per pass", (unsigned long long)slots);
+    if (samples_per_pass == c->frame.samples_per_pass) return HIPR_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));      // the queues may move
+    c->collect_times();
+    c->frame.samples_per_pass = samples_per_pass;
+    if (partition_path_slots(c)) return HIPR_ERROR_OUT_OF_MEMORY;
+    return HIPR_OK;
+}
+
 int hipr_render_pass(HiprContext* c, const HiprCameraState* camera, void* out_half4_device, uint32_t out_pitch_pixels, int synchronize) {
+    if (int s = hipr_trace_pass(c, camera)) return s;
+    return hipr_accumulate_samples(c, 0, c->frame.samples_per_pass, camera->accumulations, out_half4_device, out_pitch_pixels, synchronize);
+}
+
+int hipr_trace_pass(HiprContext* c, const HiprCameraState* camera) {
     if (int s = check_context(c)) return s;
     if (!camera) return fail(HIPR_ERROR_INVALID_ARGUMENT, "null camera");
     if (!c->tables_ready || !c->scene_ready || !c->frame_ready) return fail(HIPR_ERROR_NOT_READY, "tables, scene and frame must be set before rendering");
-    if (out_half4_device && c->frame.tile_stride == 1 && out_pitch_pixels < c->frame.width) return fail(HIPR_ERROR_INVALID_ARGUMENT, "output pitch smaller than the frame width");
 
     const FrameInfo& f = c->frame;
     const uint32_t n = c->n_slots;
@@ -896,23 +927,39 @@ int hipr_render_pass(HiprContext* c, const HiprCameraState* camera, void* out_ha
         }
     }
 
-    c->begin_timed(HIPR_KERNEL_ACCUMULATE, c->stream);
-    float depth_normalizer = 0.0f;
+    c->pass_depth_normalizer = 0.0f;
     if (c->entry == HIPR_ENTRY_DEPTH) {   // max depth = distance between the near and far plane centres (SimpleRGPs.cu:247-255)
         const float* ip = camera->inverse_projection_matrix;
         const float near_z = (ip[8] * 0.0f + ip[9] * 0.0f + ip[10] * -1.0f + ip[11]) / (ip[12] * 0.0f + ip[13] * 0.0f + ip[14] * -1.0f + ip[15]);
         const float far_z = (ip[8] * 0.0f + ip[9] * 0.0f + ip[10] * 1.0f + ip[11]) / (ip[12] * 0.0f + ip[13] * 0.0f + ip[14] * 1.0f + ip[15]);
-        depth_normalizer = far_z - near_z;
+        c->pass_depth_normalizer = far_z - near_z;
     }
-    hipLaunchKernelGGL(k_accumulate, dim3((f.owned_tiles * 64 + 255) / 256), dim3(256), 0, c->stream, f, camera->accumulations, c->radiance.as<float4>(),
-                       c->active_accumulation().as<double4>(), static_cast<ushort4*>(out_half4_device), out_pitch_pixels, depth_normalizer);
-    c->end_timed(c->stream);
     HIP_TRY(hipGetLastError());
-
+    c->traced_samples = f.samples_per_pass;
     c->total.camera_rays += pass.camera_rays;
     c->total.closest_rays += pass.closest_rays;
     c->total.shadow_rays += pass.shadow_rays;
     c->total.iterations += pass.iterations;
+    if (c->instrument || c->timed.size() > 2048) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->collect_times();
+    }
+    return HIPR_OK;
+}
+
+int hipr_accumulate_samples(HiprContext* c, uint32_t first_sample, uint32_t sample_count, uint32_t first_accumulation, void* out_half4_device, uint32_t out_pitch_pixels,
+                            int synchronize) {
+    if (int s = check_context(c)) return s;
+    if (!c->frame_ready) return fail(HIPR_ERROR_NOT_READY, "no frame set");
+    if (sample_count == 0 || uint64_t(first_sample) + sample_count > c->traced_samples)
+        return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_accumulate_samples: samples [%u, %u) of a traced pass of %u", first_sample, first_sample + sample_count, c->traced_samples);
+    if (out_half4_device && c->frame.tile_stride == 1 && out_pitch_pixels < c->frame.width) return fail(HIPR_ERROR_INVALID_ARGUMENT, "output pitch smaller than the frame width");
+    const FrameInfo& f = c->frame;
+    c->begin_timed(HIPR_KERNEL_ACCUMULATE, c->stream);
+    hipLaunchKernelGGL(k_accumulate, dim3((f.owned_tiles * 64 + 255) / 256), dim3(256), 0, c->stream, f, first_sample, sample_count, first_accumulation, c->radiance.as<float4>(),
+                       c->active_accumulation().as<double4>(), static_cast<ushort4*>(out_half4_device), out_pitch_pixels, c->pass_depth_normalizer);
+    c->end_timed(c->stream);
+    HIP_TRY(hipGetLastError());
     if (synchronize || c->instrument || c->timed.size() > 2048) {
         HIP_TRY(hipStreamSynchronize(c->stream));
         c->collect_times();

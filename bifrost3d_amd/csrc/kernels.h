@@ -925,16 +925,17 @@ HD unsigned short float_to_half_bits(float v) {
     return bits;
 }
 
-__global__ __launch_bounds__(256) void k_accumulate(FrameInfo frame, uint32_t first_accumulation, const float4* radiance, double4* accumulation,
-                                                     ushort4* out, uint32_t out_pitch, float depth_normalizer) {
+// Folds samples [first_sample, first_sample + sample_count) of the traced pass into the running mean as accumulations first_accumulation, + 1, ...
+__global__ __launch_bounds__(256) void k_accumulate(FrameInfo frame, uint32_t first_sample, uint32_t sample_count, uint32_t first_accumulation, const float4* radiance,
+                                                     double4* accumulation, ushort4* out, uint32_t out_pitch, float depth_normalizer) {
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
     const uint32_t per_sample = frame.owned_tiles * 64u;
     if (k >= per_sample) return;
     uint32_t x, y;
     if (!owned_pixel(frame, k, x, y)) return;
     double4 acc = accumulation[k];
-    for (uint32_t s = 0; s < frame.samples_per_pass; ++s) {
-        const float4 r = radiance[s * per_sample + k];
+    for (uint32_t s = 0; s < sample_count; ++s) {
+        const float4 r = radiance[(first_sample + s) * per_sample + k];
         const uint32_t a = first_accumulation + s;
         if (a != 0) {
             const double t = 1.0 / (a + 1.0);

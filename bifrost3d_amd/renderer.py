@@ -63,6 +63,17 @@ class Context:
     def render_pass(self, camera: capi.HiprCameraState, out_ptr: int = 0, out_pitch: int = 0, synchronize: bool = False):
         self._check(self.lib.hipr_render_pass(self.handle, C.byref(camera), C.c_void_p(out_ptr), out_pitch, int(synchronize)), "hipr_render_pass")
 
+    def set_samples_per_pass(self, samples: int):
+        self._check(self.lib.hipr_set_samples_per_pass(self.handle, samples), "hipr_set_samples_per_pass")
+        self.frame.samples_per_pass = samples
+
+    def trace_pass(self, camera: capi.HiprCameraState):
+        self._check(self.lib.hipr_trace_pass(self.handle, C.byref(camera)), "hipr_trace_pass")
+
+    def accumulate_samples(self, first_sample: int, sample_count: int, first_accumulation: int, out_ptr: int = 0, out_pitch: int = 0, synchronize: bool = False):
+        self._check(self.lib.hipr_accumulate_samples(self.handle, first_sample, sample_count, first_accumulation, C.c_void_p(out_ptr), out_pitch, int(synchronize)),
+                    "hipr_accumulate_samples")
+
     def synchronize(self):
         self._check(self.lib.hipr_synchronize(self.handle), "hipr_synchronize")
 

@@ -317,6 +317,20 @@ int hipr_owned_pixel_count(HiprContext* context, uint32_t* out_count);
 int hipr_render_pass(HiprContext* context, const HiprCameraState* camera,
                      void* out_half4_device, uint32_t out_pitch_pixels, int synchronize);
 
+/* hipr_render_pass in its two halves, for hosts that show a progressive image one accumulation at a time (the reference's
+ * render() contract, OR/Renderer.cpp:1250-1265) without giving up batched tracing:
+ *   hipr_trace_pass           traces frame.samples_per_pass accumulations starting at camera->accumulations and leaves the radiance
+ *                             of every sample in the pass's per-sample buffer; the running mean is not touched;
+ *   hipr_accumulate_samples   folds samples [first_sample, first_sample + sample_count) of the traced pass into the f64 running mean
+ *                             as accumulations first_accumulation, first_accumulation + 1, ... and writes the half4 pixels.
+ * Tracing 32 accumulations in one pass and folding them one per frame gives, frame by frame, the bits that 32 one-accumulation
+ * passes give (ORS/SimpleRGPs.cu:74-107 is applied per sample either way), at the throughput of the batched pass.
+ * hipr_set_samples_per_pass changes the batch size of the current frame without resetting the accumulation (queues only grow). */
+int hipr_set_samples_per_pass(HiprContext* context, uint32_t samples_per_pass);
+int hipr_trace_pass(HiprContext* context, const HiprCameraState* camera);
+int hipr_accumulate_samples(HiprContext* context, uint32_t first_sample, uint32_t sample_count, uint32_t first_accumulation,
+                            void* out_half4_device, uint32_t out_pitch_pixels, int synchronize);
+
 /* Copies the f64 accumulation (double4 per owned pixel, compact owned-tile-major order or full
  * frame row-major when tile_stride == 1) to host memory. Blocking. */
 int hipr_read_accumulation(HiprContext* context, double* out_rgba, uint64_t capacity_pixels);

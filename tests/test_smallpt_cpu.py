@@ -72,6 +72,6 @@ def test_bench_cpu_baseline_reports_the_port(oracle):
     from pathlib import Path
     sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
     import bench
-    line = bench.cpu_baseline(0.5)
+    line = bench.cpu_baseline_smallpt(0.5)
     assert line["kind"] == "port" and line["unit"] == "Mrays/s" and line["value"] > 0 and line["cores"] == oracle.lib.oracle_smallpt_threads()
     assert "256x256" in line["sample"]
