@@ -69,6 +69,7 @@ def parse_args(argv=None):
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-other-workloads", action="store_true", help="skip BASELINE configs[1] and configs[2] after the main timed region")
     p.add_argument("--no-rmse", action="store_true")
+    p.add_argument("--no-plugin", action="store_true", help="skip the run through the C++ HIPRenderer::Renderer class (plugin_renderer key)")
     p.add_argument("--cpu-baseline-seconds", type=float, default=10.0)
     p.add_argument("--master-port", type=int, default=0, help="rendezvous port when this process spawns the ranks itself (0: pick a free one)")
     return p.parse_args(argv)
@@ -234,6 +235,37 @@ def cpu_baseline_c2(ctx, seconds: float):
             "device_same_sample": {"value": gpu_rays / gpu_seconds / 1e6, "unit": "Mrays/s", "rays": gpu_rays, "seconds": gpu_seconds},
             "counters_equal": {k: [int(cc[k]), int(gc[k])] for k in ("camera_rays", "closest_rays", "shadow_rays", "shaded_hits")},
             "ray_count_relative_difference": abs(cpu_rays - gpu_rays) / max(1, cpu_rays)}
+
+
+def plugin_renderer_figures(ctx, args, main_figures):
+    """The same workload through the plugin class a Bifrost application holds: the atrium built in the Bifrost managers, pulled by
+    HIPRenderer::Renderer::handle_updates, one blocking Renderer::render() per accumulation into a device render target (host/host_api.cpp
+    hiprh_renderer_bench). render() traces ahead in batches of up to 32 accumulations and folds one per call (bit-identical frames, tested);
+    `one_launch_per_accumulation` is the same loop at the reference's launch granularity. Rays per accumulation are those of the main
+    measurement (same scene, camera and frame; the ray counts are deterministic)."""
+    from bifrost3d_amd.host import renderer_bench
+    ctx.set_frame(8, 8)            # give the main context's queues back before the renderer allocates its own
+    rays_per_accumulation = main_figures["rays_per_step"] / max(1, main_figures["spp_per_step"])
+    out = {}
+    import ctypes
+    libc = ctypes.CDLL(None)
+    for key, max_batch, warmup, calls in (("batched", 32, 128, 128), ("one_launch_per_accumulation", 1, 4, 16)):
+        # the renderer announces its device on stdout like the reference does (OR/Renderer.cpp:300): keep this process's stdout to the one JSON line
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            r = renderer_bench(args.atrium_triangles, args.width, args.height, warmup, calls, max_batch)
+        finally:
+            libc.fflush(None)
+            os.dup2(saved, 1)
+            os.close(saved)
+        ms = r["milliseconds"] / r["calls"]
+        out[key] = {"ms_per_render_call": ms, "Mrays_per_s": rays_per_accumulation / ms / 1e3, "calls_timed": r["calls"], "accumulations_reached": r["accumulations"],
+                    "max_batch": max_batch, "triangles": r["triangles"]}
+    out["batched"]["fraction_of_c_abi_batched_rate"] = out["batched"]["Mrays_per_s"] / main_figures["value"]
+    out["note"] = "HIPRenderer::Renderer::render(), blocking, one more accumulation in the frame per call; scene through the Bifrost managers"
+    return out
 
 
 # --------------------------------------------------------------------------------------------------------------------------------
@@ -461,6 +493,8 @@ def main():
                     figures.pop("roofline_by_kernel")
                     others[other] = figures
                 out["other_workloads"] = others
+            if scene_name == "atrium" and not args.no_plugin:
+                out["plugin_renderer"] = plugin_renderer_figures(ctx, args, main_figures)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline_smallpt(args.cpu_baseline_seconds)
                 out["cpu_baseline"]["c2"] = cpu_baseline_c2(ctx, args.cpu_baseline_seconds)

@@ -42,6 +42,7 @@ def load_host_library() -> C.CDLL:
     lib.hiprh_bvh_wide_nodes.argtypes = [vp]; lib.hiprh_bvh_wide_nodes.restype = C.POINTER(capi.HiprWideNode)
     lib.hiprh_pmjbn_samples.argtypes = [C.POINTER(C.c_float), C.c_uint, C.c_uint]
     lib.hiprh_bvh_destroy.argtypes = [vp]
+    lib.hiprh_renderer_bench.argtypes = [C.c_char_p, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.POINTER(C.c_double)]
     lib.hiprh_encode_octahedral.argtypes = [C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_short)]
     _lib = lib
     return lib
@@ -115,3 +116,13 @@ class Scene:
     def nodes(self) -> np.ndarray:
         d = self.desc
         return np.ctypeslib.as_array(C.cast(d.nodes, C.POINTER(C.c_uint32)), shape=(d.node_count, 16)).copy()
+
+
+def renderer_bench(target_triangles: int, width: int, height: int, warmup_calls: int, calls: int, max_batch: int) -> dict:
+    """Times `calls` HIPRenderer::Renderer::render() calls on the atrium built in the Bifrost managers (the plugin path end to end)."""
+    lib = load_host_library()
+    out = (C.c_double * 3)()
+    status = lib.hiprh_renderer_bench(str(capi.TABLES_PATH.parent.parent).encode(), target_triangles, width, height, warmup_calls, calls, max_batch, out)
+    if status != 0:
+        raise capi.HiprError(f"hiprh_renderer_bench failed with status {status}")
+    return {"milliseconds": out[0], "accumulations": int(out[1]), "triangles": int(out[2]), "calls": calls, "max_batch": max_batch}

@@ -182,7 +182,15 @@ struct Renderer::Implementation {
         Matrix4x4f inverse_view_projection_matrix = Matrix4x4f::identity();
         Backend backend = Backend::None;
         bool scene_uploaded = false;
+        // Progressive batching (render()): samples [batch_used, batch_size) of the pass traced from accumulation batch_first are waiting
+        // in the context's per-sample radiance buffer; they stay valid while nothing that shaped them changes.
+        unsigned int batch_first = 0, batch_size = 0, batch_used = 0;
+        HiprCameraState batch_camera = {};
+        HiprSceneState batch_scene_state = {};
+        int batch_entry = -1;
+        void drop_batch() { batch_size = batch_used = 0; }
     };
+    unsigned int max_batch_size = 32;   // accumulations traced together at most (set_max_batch_size; 1 = the reference's one launch per accumulation)
     std::vector<CameraState> per_camera_state = std::vector<CameraState>(1);
     AIDenoiserFlags AI_denoiser_flags = AIDenoiserFlag::Default;
     PathRegularizationSettings path_regularization = {0.5f, 0.0f};   // OR/Renderer.cpp:482-483
@@ -236,6 +244,7 @@ struct Renderer::Implementation {
         if (!scene) rebuild_scene();
         if (hipr_upload_scene(c.context, &scene->desc()) != HIPR_OK) return false;
         c.scene_uploaded = true;
+        c.drop_batch();
         return true;
     }
 
@@ -327,6 +336,7 @@ struct Renderer::Implementation {
             if (hipr_set_frame(state.context, &frame) != HIPR_OK) return false;
             state.frame_size = frame_size;
             state.accumulations = 0;
+            state.drop_batch();
         }
         Matrix4x4f inverse_projection = Cameras::get_inverse_projection_matrix(camera_ID);
         Matrix4x4f inverse_view_projection = Cameras::get_inverse_view_projection_matrix(camera_ID);
@@ -345,16 +355,45 @@ struct Renderer::Implementation {
         return true;
     }
 
+    // The reference traces ONE accumulation per render() (a blocking context->launch, OR/Renderer.cpp:1250-1265). Here the tracing is
+    // batched without changing what a call returns: when the samples traced earlier are used up, the next `batch` accumulations are
+    // traced in one wavefront pass (hipr_trace_pass) and every render() folds exactly one of them into the running mean and
+    // writes the frame (hipr_accumulate_samples) -- bit for bit the image one launch per accumulation gives, since the per-sample
+    // radiance and the f64 fold are the same. The batch grows with the accumulation count (1, 1, 1, 1, 2, 3, 4, 6, ... up to
+    // max_batch_size), so a camera that keeps moving still gets one accumulation per call, and at most a third of the work done since
+    // the last reset is ever thrown away by the next one.
+    unsigned int next_batch_size(const CameraState& state) const {
+        unsigned int batch = std::max(1u, std::min(max_batch_size, state.accumulations / 2));
+        const unsigned int remaining = state.max_accumulation_count - state.accumulations;
+        return std::min(batch, std::max(1u, remaining));
+    }
+
     unsigned int render(CameraID camera_ID, void* buffer, unsigned int pitch, Vector2i frame_size) {   // OR/Renderer.cpp:1250-1265
         conditional_per_camera_state_resize(camera_ID);
         HiprCameraState camera;
         if (!prepare_camera_state(camera_ID, frame_size, camera)) return 0;
         CameraState& state = per_camera_state[camera_ID];
         if (state.accumulations >= state.max_accumulation_count) return state.accumulations;
-        hipr_set_scene_state(state.context, &scene_state);
         int entry = entry_of(state.backend);
-        hipr_set_entry_point(state.context, entry < 0 ? HIPR_ENTRY_PATH_TRACING : entry);
-        if (hipr_render_pass(state.context, &camera, buffer, pitch, 1) != HIPR_OK) return state.accumulations;   // launch is blocking in the reference
+        entry = entry < 0 ? HIPR_ENTRY_PATH_TRACING : entry;
+
+        // Is the next accumulation already traced, with the settings in force now? (Accumulation resets change `accumulations`;
+        // bounce count, regularisation, next event sample count, environment tint and backend take effect immediately as in the reference.)
+        HiprCameraState comparable = camera;
+        comparable.accumulations = state.batch_camera.accumulations;
+        const bool batch_valid = state.batch_used < state.batch_size && state.batch_first + state.batch_used == state.accumulations && state.batch_entry == entry &&
+                                 std::memcmp(&comparable, &state.batch_camera, sizeof(HiprCameraState)) == 0 &&
+                                 std::memcmp(&scene_state, &state.batch_scene_state, sizeof(HiprSceneState)) == 0;
+        if (!batch_valid) {
+            const unsigned int batch = next_batch_size(state);
+            hipr_set_scene_state(state.context, &scene_state);
+            hipr_set_entry_point(state.context, entry);
+            if (hipr_set_samples_per_pass(state.context, batch) != HIPR_OK || hipr_trace_pass(state.context, &camera) != HIPR_OK) { state.drop_batch(); return state.accumulations; }
+            state.batch_first = state.accumulations; state.batch_size = batch; state.batch_used = 0;
+            state.batch_camera = camera; state.batch_scene_state = scene_state; state.batch_entry = entry;
+        }
+        if (hipr_accumulate_samples(state.context, state.batch_used, 1, state.accumulations, buffer, pitch, 1) != HIPR_OK) return state.accumulations;   // launch is blocking in the reference
+        ++state.batch_used;
         ++state.accumulations;
         return state.accumulations;
     }
@@ -416,6 +455,8 @@ void Renderer::set_backend(CameraID camera_ID, Backend backend) {   // OR/Render
 
 PathRegularizationSettings Renderer::get_path_regularization_settings() const { return m_impl->path_regularization; }
 void Renderer::set_path_regularization_settings(PathRegularizationSettings settings) { m_impl->path_regularization = settings; }
+unsigned int Renderer::get_max_batch_size() const { return m_impl->max_batch_size; }
+void Renderer::set_max_batch_size(unsigned int accumulations) { m_impl->max_batch_size = std::max(1u, std::min(accumulations, 256u)); }
 AIDenoiserFlags Renderer::get_AI_denoiser_flags() const { return m_impl->AI_denoiser_flags; }
 void Renderer::set_AI_denoiser_flags(AIDenoiserFlags flags) { m_impl->AI_denoiser_flags = flags; }
 
@@ -471,6 +512,8 @@ std::vector<Screenshot> Renderer::request_auxiliary_buffers(CameraID camera_ID, 
     const int pixel_count = frame_size.x * frame_size.y;
     hipr_set_scene_state(state.context, &m_impl->scene_state);
 
+    state.drop_batch();   // the auxiliary passes reuse the context's per-sample radiance buffer
+    if (hipr_set_samples_per_pass(state.context, 1) != HIPR_OK) return screenshots;
     auto render_auxiliary_feature = [&](int entry, std::vector<double>& accumulation) -> bool {
         if (hipr_use_scratch_accumulation(state.context, 1) != HIPR_OK) return false;
         hipr_set_entry_point(state.context, entry);

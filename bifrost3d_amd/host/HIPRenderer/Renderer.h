@@ -62,6 +62,11 @@ public:
     PathRegularizationSettings get_path_regularization_settings() const;
     void set_path_regularization_settings(PathRegularizationSettings settings);
 
+    // Not in the reference: how many accumulations render() may trace together (default 32; 1 = one launch per accumulation like the
+    // reference). Every render() still returns exactly one more accumulation and the same pixels for any setting; see Renderer.cpp.
+    unsigned int get_max_batch_size() const;
+    void set_max_batch_size(unsigned int accumulations);
+
     AIDenoiserFlags get_AI_denoiser_flags() const;
     void set_AI_denoiser_flags(AIDenoiserFlags flags);
 
@@ -69,7 +74,7 @@ public:
     // application resets the change notifications (apps/SimpleViewer/main.cpp:298-308).
     void handle_updates();
 
-    // One accumulation. `half4_device_buffer`: R16G16B16A16_FLOAT pixels in device memory, row 0 = bottom,
+    // One accumulation more in the frame (traced ahead in batches, see set_max_batch_size). `half4_device_buffer`: R16G16B16A16_FLOAT pixels in device memory, row 0 = bottom,
     // `buffer_pitch` pixels per row (>= frame_size.x). Returns the iteration count like the reference.
     unsigned int render(Bifrost::Scene::CameraID camera_ID, void* half4_device_buffer, unsigned int buffer_pitch, Bifrost::Math::Vector2i frame_size);
 

@@ -1,5 +1,6 @@
 // MaterialScene.cpp -- see MaterialScene.h.
 #include "MaterialScene.h"
+#include "AtriumScene.h"
 
 #include "glTFLoader/glTFLoader.h"
 
@@ -359,6 +360,72 @@ void create_opacity_scene(CameraID camera_ID, SceneNode root_node, unsigned quad
             plane_node.set_parent(root_node);
         }
     }
+}
+
+// ---- the atrium through the Bifrost managers --------------------------------------------------------------------------------------------
+namespace {
+struct BifrostSceneSink {
+    SceneNode root;
+    SceneRootID scene_root;
+    std::vector<Mesh> meshes;
+    std::vector<Material> materials = {Material()};       // index 0 = the invalid material, as in SceneBuilder
+    HIPRenderer::CameraDescription camera;
+
+    uint32_t add_mesh(HIPRenderer::MeshData data) {
+        MeshFlags buffers = MeshFlag::Position;
+        if (!data.normals.empty()) buffers |= MeshFlag::Normal;
+        if (!data.texcoords.empty()) buffers |= MeshFlag::Texcoord;
+        Mesh mesh("Atrium part", unsigned(data.primitives.size()), unsigned(data.positions.size()), buffers);
+        std::memcpy(mesh.get_primitives(), data.primitives.data(), data.primitives.size() * sizeof(Vector3ui));
+        std::memcpy(mesh.get_positions(), data.positions.data(), data.positions.size() * sizeof(Vector3f));
+        if (!data.normals.empty()) std::memcpy(mesh.get_normals(), data.normals.data(), data.normals.size() * sizeof(Vector3f));
+        if (!data.texcoords.empty()) std::memcpy(mesh.get_texcoords(), data.texcoords.data(), data.texcoords.size() * sizeof(Vector2f));
+        mesh.compute_bounds();
+        meshes.push_back(mesh);
+        return uint32_t(meshes.size() - 1);
+    }
+    uint32_t add_material(const HiprMaterial& m) {
+        Materials::Data d = {};
+        if (m.flags & HIPR_MATERIAL_THIN_WALLED) d.flags |= MaterialFlag::ThinWalled;
+        if (m.flags & HIPR_MATERIAL_CUTOUT) d.flags |= MaterialFlag::Cutout;
+        d.shading_model = m.shading_model == HIPR_SHADING_DIFFUSE ? ShadingModel::Diffuse : (m.shading_model == HIPR_SHADING_TRANSMISSIVE ? ShadingModel::Transmissive : ShadingModel::Default);
+        d.tint = RGB(m.tint[0], m.tint[1], m.tint[2]);
+        d.roughness = m.roughness; d.specularity = m.specularity; d.metallic = m.metallic;
+        d.coat = m.coat / 65535.0f; d.coat_roughness = m.coat_roughness / 65535.0f;
+        d.coverage = m.coverage;
+        d.emission = RGB(m.emission[0], m.emission[1], m.emission[2]);
+        materials.push_back(Materials::create("Atrium material", d));
+        return uint32_t(materials.size() - 1);
+    }
+    uint32_t add_model(uint32_t mesh, uint32_t material, const Transform& transform, uint32_t = 0) {
+        SceneNode node = SceneNode("Atrium model", transform);
+        node.set_parent(root);
+        MeshModel model(node, meshes[mesh], materials[material]);
+        return model.get_ID().get_index();
+    }
+    void add_light(const HiprLight& l) {
+        const uint32_t type = l.flags & HIPR_LIGHT_TYPE_MASK;
+        if (type == HIPR_LIGHT_DIRECTIONAL) {
+            SceneNode node = SceneNode("Directional light", Transform(Vector3f::zero(), Quaternionf::look_in(Vector3f(l.data[3], l.data[4], l.data[5]))));
+            node.set_parent(root);
+            LightSources::create_directional_light(node.get_ID(), RGB(l.data[0], l.data[1], l.data[2]));
+        } else if (type == HIPR_LIGHT_SPHERE) {
+            SceneNode node = SceneNode("Sphere light", Transform(Vector3f(l.data[3], l.data[4], l.data[5])));
+            node.set_parent(root);
+            LightSources::create_sphere_light(node.get_ID(), RGB(l.data[0], l.data[1], l.data[2]), l.data[6]);
+        }
+    }
+    void set_environment_tint(RGB tint) { SceneRoots::set_environment_tint(scene_root, tint); }
+};
+} // namespace
+
+AtriumCamera create_atrium_scene(CameraID camera_ID, SceneNode root_node, unsigned target_triangles, unsigned seed) {
+    BifrostSceneSink sink;
+    sink.root = root_node;
+    sink.scene_root = Cameras::get_scene_ID(camera_ID);
+    HIPRenderer::Scenes::build_atrium(sink, target_triangles, seed);
+    Cameras::set_transform(camera_ID, sink.camera.transform);
+    return {sink.camera.near_plane, sink.camera.far_plane, sink.camera.field_of_view, sink.camera.max_bounce_count};
 }
 
 } // namespace ViewerScenes

@@ -39,4 +39,11 @@ void create_glass_scene(Bifrost::Scene::CameraID camera_ID, Bifrost::Scene::Scen
 // (ORS/MonteCarlo.cu:152-164) and the shadow any-hit transmittance product (:278-285).
 void create_opacity_scene(Bifrost::Scene::CameraID camera_ID, Bifrost::Scene::SceneNode root_node, unsigned quads_per_edge = 1);
 
+// The procedural atrium (Scenes::create_atrium, the Sponza-class stand-in of BASELINE configs[3] / [4]) built in the Bifrost managers
+// instead of directly in a SceneBuilder: the same generator calls arrive as Meshes, Materials, MeshModels on scene nodes and light
+// sources under `root_node`, so that the scene reaches the kernels the way a host application's scene does -- through
+// HIPRenderer::Renderer::handle_updates. Sets the camera transform; returns the viewer clip planes and bounce count in `camera`.
+struct AtriumCamera { float near_plane, far_plane, field_of_view; unsigned max_bounce_count; };
+AtriumCamera create_atrium_scene(Bifrost::Scene::CameraID camera_ID, Bifrost::Scene::SceneNode root_node, unsigned target_triangles, unsigned seed);
+
 } // namespace ViewerScenes

@@ -16,6 +16,7 @@
 #include "SceneLoading.h"
 #include "glTFLoader/glTFLoader.h"
 
+#include <chrono>
 #include <cmath>
 
 using namespace HIPRenderer;
@@ -180,6 +181,55 @@ void* hiprh_scene_load(const char* path, unsigned variant) {
     sb->camera.far_plane = defaults.far_plane;
     deallocate_all();
     return sb;
+}
+
+// The plugin path timed end to end (bench.py's `plugin_renderer` key): the atrium built in the Bifrost managers, pulled by
+// HIPRenderer::Renderer::handle_updates and rendered by `calls` blocking Renderer::render() calls into a device render target, exactly what
+// SimpleViewer's main loop does per frame (apps/SimpleViewer/main.cpp:298-308). out[0] = milliseconds of the timed calls, out[1] = accumulations
+// reached, out[2] = flattened triangle count. max_batch: Renderer::set_max_batch_size (1 = one launch per accumulation, the reference's granularity).
+// Returns 0, or a negative number when the renderer cannot be created or a call fails. The Bifrost managers are scratch space here.
+int hiprh_renderer_bench(const char* data_directory, unsigned target_triangles, unsigned width, unsigned height, unsigned warmup_calls, unsigned calls, unsigned max_batch, double* out3) {
+    using namespace Bifrost;
+    if (!data_directory || !out3 || !width || !height) return -1;
+    deallocate_all();
+    Renderer* renderer = Renderer::initialize(0, data_directory);
+    if (!renderer) return -2;
+    int status = 0;
+    {
+        Scene::SceneRoot scene = Scene::SceneRoot("Atrium", RGB(0.68f, 0.92f, 1.0f));
+        const Scene::CameraID camera_ID = Scene::Cameras::create("Camera", scene.get_ID(), Math::Matrix4x4f::identity(), Math::Matrix4x4f::identity());
+        const ViewerScenes::AtriumCamera camera = ViewerScenes::create_atrium_scene(camera_ID, scene.get_root_node(), target_triangles, 1);
+        Math::Matrix4x4f projection, inverse_projection;
+        Scene::CameraUtils::compute_perspective_projection(camera.near_plane, camera.far_plane, camera.field_of_view, float(width) / float(height), projection, inverse_projection);
+        Scene::Cameras::set_projection_matrices(camera_ID, projection, inverse_projection);
+        Scene::Cameras::set_renderer_ID(camera_ID, renderer->get_renderer_ID());
+        renderer->set_max_bounce_count(camera_ID, camera.max_bounce_count);
+        renderer->set_max_batch_size(max_batch);
+        renderer->handle_updates();
+        reset_all_change_notifications();
+
+        HiprContext* allocator = nullptr;     // the render target the presentation layer would own
+        void* target = nullptr;
+        if (hipr_create(0, &allocator) != HIPR_OK || hipr_device_malloc(allocator, uint64_t(width) * height * 8, &target) != HIPR_OK) status = -3;
+        unsigned int accumulations = 0;
+        for (unsigned i = 0; status == 0 && i < warmup_calls; ++i) accumulations = renderer->render(camera_ID, target, width, Math::Vector2i(int(width), int(height)));
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned i = 0; status == 0 && i < calls; ++i) {
+            const unsigned int next = renderer->render(camera_ID, target, width, Math::Vector2i(int(width), int(height)));
+            if (next != accumulations + 1) status = -4;
+            accumulations = next;
+        }
+        out3[0] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        out3[1] = double(accumulations);
+        unsigned triangles = 0;
+        for (Assets::MeshModelID model : Assets::MeshModels::get_iterable()) triangles += Assets::MeshModel(model).get_mesh().get_primitive_count();
+        out3[2] = double(triangles);
+        if (target) hipr_device_free(allocator, target);
+        if (allocator) hipr_destroy(allocator);
+    }
+    delete renderer;
+    deallocate_all();
+    return status;
 }
 
 // Decodes a PNG file into 8 bit pixels (tests: cross-check of the decoder against an independent one). Returns the byte count

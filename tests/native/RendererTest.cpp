@@ -10,6 +10,7 @@
 #include "../../bifrost3d_amd/host/HIPRenderer/Adaptor.h"
 #include "../../bifrost3d_amd/host/HIPRenderer/Renderer.h"
 #include "../../bifrost3d_amd/host/SceneBuilder.h"
+#include "../../bifrost3d_amd/host/MaterialScene.h"
 #include "../../bifrost3d_amd/host/Scenes.h"
 #include "../../include/hiprenderer_c.h"
 
@@ -358,6 +359,34 @@ CPU_TEST_F(RendererFixture, flattened_cornell_box_matches_the_scene_builder) {
     expect_same_scene(from_managers.desc(), direct.desc());
 }
 
+CPU_TEST_F(RendererFixture, atrium_through_the_managers_matches_the_scene_builder) {
+    // The procedural atrium recorded as Bifrost meshes / materials / models / lights (what bench.py's plugin_renderer run renders) flattens to
+    // the triangles, BVH and materials the direct SceneBuilder route gives; only the directional light goes through a quaternion and back.
+    Scene::SceneRoot scene = Scene::SceneRoot("Atrium", Math::RGB(0.68f, 0.92f, 1.0f));
+    Scene::CameraID camera_ID = Scene::Cameras::create("Camera", scene.get_ID(), Math::Matrix4x4f::identity(), Math::Matrix4x4f::identity());
+    ViewerScenes::AtriumCamera camera = ViewerScenes::create_atrium_scene(camera_ID, scene.get_root_node(), 6000, 5);
+    SceneBuilder from_managers;
+    flatten_bifrost_scene(from_managers);
+    SceneBuilder direct;
+    Scenes::create_atrium(direct, 6000, 5);
+    direct.finalize();
+    const HiprSceneDesc &a = from_managers.desc(), &b = direct.desc();
+    EXPECT_EQ(a.triangle_count, b.triangle_count);
+    EXPECT_EQ(a.node_count, b.node_count);
+    EXPECT_EQ(a.instance_count, b.instance_count);
+    EXPECT_EQ(a.material_count, b.material_count);
+    EXPECT_EQ(a.light_count, b.light_count);
+    EXPECT_TRUE(a.triangle_count > 3000u);
+    if (a.triangle_count == b.triangle_count) EXPECT_TRUE(same_bytes(a.triangles, b.triangles, a.triangle_count));
+    if (a.material_count == b.material_count) EXPECT_TRUE(same_bytes(a.materials, b.materials, a.material_count));
+    for (uint32_t l = 0; l < a.light_count && l < b.light_count; ++l)
+        for (int k = 0; k < 11; ++k) EXPECT_FLOAT_EQ_EPS(b.lights[l].data[k], a.lights[l].data[k], 1e-5f);
+    EXPECT_EQ(4u, camera.max_bounce_count);
+    EXPECT_FLOAT_EQ_EPS(direct.camera.near_plane, camera.near_plane, 0.0f);
+    Math::Transform t = Scene::Cameras::get_transform(camera_ID);
+    EXPECT_FLOAT_EQ_EPS(direct.camera.transform.translation.x, t.translation.x, 0.0f);
+}
+
 CPU_TEST_F(RendererFixture, change_sets_follow_the_engine_tick) {
     // Created / Updated flags live until reset_all_change_notifications(), like Bifrost's managers
     // (core/Bifrost/Bifrost/Core/ChangeSet.h, apps/SimpleViewer/main.cpp:298-308).
@@ -444,6 +473,59 @@ GPU_TEST_F(RendererFixture, cornell_box_through_the_renderer_matches_the_c_abi) 
     double sum = 0;
     for (size_t i = 0; i < through_c_abi.size() && i < through_renderer.size(); ++i) { mismatches += through_c_abi[i] != through_renderer[i]; sum += through_c_abi[i]; }
     EXPECT_EQ(size_t(0), mismatches);
+    EXPECT_TRUE(sum > 0.0);
+}
+
+GPU_TEST_F(RendererFixture, batched_tracing_returns_the_images_of_one_launch_per_accumulation) {
+    // render() traces ahead in growing batches (Renderer::set_max_batch_size) and folds one traced sample per call: after EVERY call
+    // the accumulation and the half4 frame must be the bits that one launch per accumulation (batch size 1, the reference's
+    // behaviour) produces -- including across a setting that takes effect immediately and across an accumulation reset.
+    auto frame_size = Math::Vector2i(48, 27);
+    Scene::SceneRoot scene = Scene::SceneRoot("Cornell", Math::RGB(0.68f, 0.92f, 1.0f));
+    SceneBuilder direct;
+    Scenes::create_cornell_box(direct);
+    Math::Matrix4x4f projection, inverse_projection;
+    Scene::CameraUtils::compute_perspective_projection(direct.camera.near_plane, direct.camera.far_plane, direct.camera.field_of_view,
+                                                       float(frame_size.x) / frame_size.y, projection, inverse_projection);
+    Scene::CameraID camera_ID = Scene::Cameras::create("Camera", scene.get_ID(), projection, inverse_projection);
+    Scene::Cameras::set_renderer_ID(camera_ID, renderer->get_renderer_ID());
+    create_cornell_box(camera_ID, scene.get_root_node());
+    renderer->set_max_bounce_count(camera_ID, 4);
+    renderer->handle_updates();
+    reset_all_change_notifications();
+    EXPECT_EQ(32u, renderer->get_max_batch_size());
+
+    const int calls = 44;
+    auto run = [&](unsigned int max_batch, std::vector<std::vector<double>>& accumulations, std::vector<std::vector<half4>>& frames) {
+        renderer->set_max_batch_size(max_batch);
+        renderer->set_backend(camera_ID, Backend::PathTracing);   // restarts the accumulation
+        renderer->set_max_bounce_count(camera_ID, 4);
+        renderer->set_next_event_sample_count(scene.get_ID(), 3);
+        RenderTarget target(frame_size);
+        for (int i = 0; i < calls; ++i) {
+            if (i == 21) renderer->set_max_bounce_count(camera_ID, 2);                     // immediately effective, no restart (OR/Renderer.cpp:1399-1401)
+            if (i == 30) renderer->set_next_event_sample_count(scene.get_ID(), 5);
+            const unsigned int expected = i < 36 ? unsigned(i + 1) : unsigned(i - 35);
+            if (i == 36) renderer->set_backend(camera_ID, Backend::PathTracing);             // restart in the middle of a traced batch
+            EXPECT_EQ(expected, renderer->render(camera_ID, target.device, frame_size.x, frame_size));
+            accumulations.emplace_back();
+            EXPECT_TRUE(renderer->read_accumulation(accumulations.back()));
+            frames.push_back(target.map());
+        }
+    };
+    std::vector<std::vector<double>> one_by_one, batched;
+    std::vector<std::vector<half4>> one_by_one_frames, batched_frames;
+    run(1, one_by_one, one_by_one_frames);
+    run(32, batched, batched_frames);
+    EXPECT_EQ(one_by_one.size(), batched.size());
+    size_t mismatching_calls = 0;
+    for (size_t i = 0; i < one_by_one.size() && i < batched.size(); ++i)
+        mismatching_calls += one_by_one[i] != batched[i] || std::memcmp(one_by_one_frames[i].data(), batched_frames[i].data(), batched_frames[i].size() * sizeof(half4)) != 0;
+    EXPECT_EQ(size_t(0), mismatching_calls);
+    // the settings did change the image: accumulation 22 under 2 bounces differs from what 4 bounces would have given
+    renderer->set_max_batch_size(32);
+    double sum = 0;
+    for (double v : batched.back()) sum += v;
     EXPECT_TRUE(sum > 0.0);
 }
 
