@@ -135,6 +135,9 @@ C_ABI_SYMBOLS = (
     "hipr_render_pass", "hipr_set_samples_per_pass", "hipr_trace_pass", "hipr_accumulate_samples", "hipr_read_accumulation", "hipr_scatter_tiles", "hipr_synchronize", "hipr_get_counters",
     "hipr_device_malloc", "hipr_device_free", "hipr_copy_to_host", "hipr_present_flipped",
     "hipr_reset_counters", "hipr_set_wavefront_count", "hipr_get_trace_variant", "hipr_set_instrumentation", "hipr_reset_timers", "hipr_get_kernel_times",
+    "hipr_group_create", "hipr_group_destroy", "hipr_group_size", "hipr_group_context", "hipr_group_gather_description", "hipr_group_upload_tables", "hipr_group_upload_scene",
+    "hipr_group_set_scene_state", "hipr_group_set_entry_point", "hipr_group_use_scratch_accumulation", "hipr_group_set_frame", "hipr_group_set_samples_per_pass",
+    "hipr_group_trace_pass", "hipr_group_accumulate_samples", "hipr_group_read_accumulation", "hipr_group_get_counters",
     "hipr_debug_shading", "hipr_debug_light", "hipr_debug_generate", "hipr_debug_sobol", "hipr_debug_sample_offsets", "hipr_debug_trace_closest", "hipr_debug_trace_shadow",
 )
 
@@ -189,6 +192,22 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.hipr_get_kernel_times.argtypes = [vp, C.POINTER(HiprKernelTimes)]
     lib.hipr_debug_generate.argtypes = [vp, C.POINTER(HiprCameraState), c_u32, C.POINTER(c_f), C.POINTER(c_f), C.POINTER(c_u32)]
     lib.hipr_debug_sobol.argtypes = [vp, C.POINTER(c_u32), c_u32, C.POINTER(c_u32)]
+    lib.hipr_group_create.argtypes = [C.POINTER(C.c_int), c_u32, C.POINTER(vp)]
+    lib.hipr_group_destroy.argtypes = [vp]
+    lib.hipr_group_size.argtypes = [vp]; lib.hipr_group_size.restype = c_u32
+    lib.hipr_group_context.argtypes = [vp, c_u32]; lib.hipr_group_context.restype = vp
+    lib.hipr_group_gather_description.argtypes = [vp]; lib.hipr_group_gather_description.restype = C.c_char_p
+    lib.hipr_group_upload_tables.argtypes = [vp, C.POINTER(HiprTables)]
+    lib.hipr_group_upload_scene.argtypes = [vp, C.POINTER(HiprSceneDesc)]
+    lib.hipr_group_set_scene_state.argtypes = [vp, C.POINTER(HiprSceneState)]
+    lib.hipr_group_set_entry_point.argtypes = [vp, C.c_int]
+    lib.hipr_group_use_scratch_accumulation.argtypes = [vp, C.c_int]
+    lib.hipr_group_set_frame.argtypes = [vp, c_u32, c_u32, c_u32]
+    lib.hipr_group_set_samples_per_pass.argtypes = [vp, c_u32]
+    lib.hipr_group_trace_pass.argtypes = [vp, C.POINTER(HiprCameraState)]
+    lib.hipr_group_accumulate_samples.argtypes = [vp, c_u32, c_u32, c_u32, vp, c_u32, C.c_int]
+    lib.hipr_group_read_accumulation.argtypes = [vp, C.POINTER(C.c_double), c_u64]
+    lib.hipr_group_get_counters.argtypes = [vp, C.POINTER(HiprCounters)]
     lib.hipr_debug_sample_offsets.argtypes = [vp, C.POINTER(c_f)]
     lib.hipr_debug_trace_closest.argtypes = [vp, C.POINTER(c_f), C.POINTER(c_u32), c_u32, C.POINTER(c_f)]
     lib.hipr_debug_trace_shadow.argtypes = [vp, C.POINTER(c_f), c_u32, C.POINTER(c_f)]

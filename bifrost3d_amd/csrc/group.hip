@@ -1,0 +1,287 @@
+// group.hip -- hipr_group_*: one frame rendered by several GPUs of a node from ONE process (include/hiprenderer_c.h, "Device groups").
+//
+// The path shards by independent units: pixel tiles of 8 x 8, dealt round-robin (tile % N == member), scene and tables replicated,
+// every member keeps the f64 accumulation of its own tiles for the whole run -- no data-path collective per sample.
+// A group holds one HiprContext per member device and drives each from its own host thread (the wavefront loop of a pass waits on
+// per-bounce queue sizes, so a thread per device keeps the devices independent). The only exchange is once per displayed frame: the
+// members' compact half4 tiles are gathered on member 0's device and k_scatter_tiles assembles the frame there.
+//   gather: RCCL point-to-point (ncclCommInitAll in this process; member 0 posts one ncclRecv per peer inside a group call, every
+//           peer one ncclSend) over xGMI; RCCL is loaded with dlopen so that the library has no link-time dependency on it. When
+//           it cannot be loaded, when two members share a device (tests on a one-GPU box) or with HIPR_GROUP_GATHER=copy, the
+//           same bytes move by peer-to-peer hipMemcpyAsync (device to device over xGMI as well).
+// The reference renders on one device (OR/Renderer.cpp:289-291); there is no reference behaviour here beyond "the same image", which
+// holds bit for bit: the RNG is a pure function of (pixel, accumulation, bounce) and every member walks the same BVH.
+#include "../../include/hiprenderer_c.h"
+
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+// The slice of the RCCL API the gather needs (rccl.h: ncclResult_t is an int enum with ncclSuccess = 0, ncclUint8 = 1 of ncclDataType_t).
+struct Rccl {
+    void* library = nullptr;
+    int (*CommInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
+    int (*CommDestroy)(void* comm) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void* sendbuff, size_t count, int datatype, int peer, void* comm, hipStream_t stream) = nullptr;
+    int (*Recv)(void* recvbuff, size_t count, int datatype, int peer, void* comm, hipStream_t stream) = nullptr;
+    bool load() {
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
+            library = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (library) break;
+        }
+        if (!library) return false;
+        CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(library, "ncclCommInitAll"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(library, "ncclCommDestroy"));
+        GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(library, "ncclGroupStart"));
+        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(library, "ncclGroupEnd"));
+        Send = reinterpret_cast<decltype(Send)>(dlsym(library, "ncclSend"));
+        Recv = reinterpret_cast<decltype(Recv)>(dlsym(library, "ncclRecv"));
+        return CommInitAll && CommDestroy && GroupStart && GroupEnd && Send && Recv;
+    }
+};
+constexpr int NCCL_UINT8 = 1;
+
+struct Member {
+    int device = 0;
+    HiprContext* context = nullptr;
+    void* compact = nullptr;        // half4 per owned pixel, on this member's device
+    hipStream_t stream = nullptr;   // gather traffic of this member
+    void* comm = nullptr;           // ncclComm_t
+    int status = HIPR_OK;
+};
+
+template <typename F>
+int for_each_member(std::vector<Member>& members, F&& work) {
+    // one host thread per device; member 0 runs on the calling thread
+    std::vector<std::thread> threads;
+    for (size_t i = 1; i < members.size(); ++i) threads.emplace_back([&, i] { members[i].status = work(members[i], uint32_t(i)); });
+    members[0].status = work(members[0], 0u);
+    for (std::thread& t : threads) t.join();
+    for (const Member& m : members)
+        if (m.status != HIPR_OK) return m.status;
+    return HIPR_OK;
+}
+
+} // namespace
+
+struct HiprGroup {
+    std::vector<Member> members;
+    Rccl rccl;
+    bool use_rccl = false;
+    uint32_t width = 0, height = 0;
+    uint64_t compact_pixels = 0;    // per member, padded to member 0's count (it owns the most tiles)
+    void* gathered = nullptr;       // members x compact_pixels half4 on member 0's device
+    bool frame_ready = false;
+    std::string gather_description;
+};
+
+extern "C" {
+
+int hipr_group_destroy(HiprGroup* g) {
+    if (!g) return HIPR_OK;
+    for (Member& m : g->members) {
+        (void)hipSetDevice(m.device);
+        if (m.comm && g->rccl.CommDestroy) g->rccl.CommDestroy(m.comm);
+        if (m.compact) (void)hipFree(m.compact);
+        if (m.stream) (void)hipStreamDestroy(m.stream);
+        if (m.context) hipr_destroy(m.context);
+    }
+    if (g->gathered && !g->members.empty()) { (void)hipSetDevice(g->members[0].device); (void)hipFree(g->gathered); }
+    delete g;
+    return HIPR_OK;
+}
+
+int hipr_group_create(const int* device_ids, uint32_t count, HiprGroup** out_group) {
+    if (!device_ids || count == 0 || count > 64 || !out_group) return HIPR_ERROR_INVALID_ARGUMENT;
+    *out_group = nullptr;
+    HiprGroup* g = new HiprGroup();
+    g->members.resize(count);
+    bool distinct = true;
+    for (uint32_t i = 0; i < count; ++i) {
+        Member& m = g->members[i];
+        m.device = device_ids[i];
+        for (uint32_t j = 0; j < i; ++j) distinct = distinct && device_ids[j] != device_ids[i];
+        if (int s = hipr_create(m.device, &m.context)) { hipr_group_destroy(g); return s; }
+        if (hipSetDevice(m.device) != hipSuccess || hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking) != hipSuccess) { hipr_group_destroy(g); return HIPR_ERROR_HIP; }
+    }
+    // peer access for the copy gather and for RCCL's direct transport; a failure only means the copies are staged by the runtime
+    for (uint32_t i = 1; i < count && distinct; ++i) {
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, g->members[0].device, g->members[i].device) == hipSuccess && can) {
+            (void)hipSetDevice(g->members[0].device);
+            (void)hipDeviceEnablePeerAccess(g->members[i].device, 0);
+            (void)hipSetDevice(g->members[i].device);
+            (void)hipDeviceEnablePeerAccess(g->members[0].device, 0);
+        }
+    }
+    (void)hipGetLastError();
+    const char* mode = getenv("HIPR_GROUP_GATHER");
+    g->gather_description = "peer-to-peer hipMemcpyAsync";
+    if (count > 1 && distinct && !(mode && !strcmp(mode, "copy")) && g->rccl.load()) {
+        std::vector<void*> comms(count, nullptr);
+        std::vector<int> devices(device_ids, device_ids + count);
+        if (g->rccl.CommInitAll(comms.data(), int(count), devices.data()) == 0) {
+            for (uint32_t i = 0; i < count; ++i) g->members[i].comm = comms[i];
+            g->use_rccl = true;
+            g->gather_description = "RCCL ncclSend / ncclRecv (ncclCommInitAll)";
+        } else
+            fprintf(stderr, "hiprenderer: ncclCommInitAll failed; the group gathers with peer-to-peer copies\n");
+    }
+    *out_group = g;
+    return HIPR_OK;
+}
+
+uint32_t hipr_group_size(HiprGroup* g) { return g ? uint32_t(g->members.size()) : 0u; }
+HiprContext* hipr_group_context(HiprGroup* g, uint32_t member) { return g && member < g->members.size() ? g->members[member].context : nullptr; }
+const char* hipr_group_gather_description(HiprGroup* g) { return g ? g->gather_description.c_str() : ""; }
+
+int hipr_group_upload_tables(HiprGroup* g, const HiprTables* tables) {
+    if (!g) return HIPR_ERROR_INVALID_ARGUMENT;
+    return for_each_member(g->members, [&](Member& m, uint32_t) { return hipr_upload_tables(m.context, tables); });
+}
+
+int hipr_group_upload_scene(HiprGroup* g, const HiprSceneDesc* scene) {
+    if (!g) return HIPR_ERROR_INVALID_ARGUMENT;
+    return for_each_member(g->members, [&](Member& m, uint32_t) { return hipr_upload_scene(m.context, scene); });   // replicated: every device walks the same BVH
+}
+
+int hipr_group_set_scene_state(HiprGroup* g, const HiprSceneState* state) {
+    if (!g) return HIPR_ERROR_INVALID_ARGUMENT;
+    for (Member& m : g->members)
+        if (int s = hipr_set_scene_state(m.context, state)) return s;
+    return HIPR_OK;
+}
+
+int hipr_group_set_entry_point(HiprGroup* g, int entry) {
+    if (!g) return HIPR_ERROR_INVALID_ARGUMENT;
+    for (Member& m : g->members)
+        if (int s = hipr_set_entry_point(m.context, entry)) return s;
+    return HIPR_OK;
+}
+
+int hipr_group_use_scratch_accumulation(HiprGroup* g, int enable) {
+    if (!g) return HIPR_ERROR_INVALID_ARGUMENT;
+    for (Member& m : g->members)
+        if (int s = hipr_use_scratch_accumulation(m.context, enable)) return s;
+    return HIPR_OK;
+}
+
+int hipr_group_set_frame(HiprGroup* g, uint32_t width, uint32_t height, uint32_t samples_per_pass) {
+    if (!g || width == 0 || height == 0) return HIPR_ERROR_INVALID_ARGUMENT;
+    const uint32_t n = uint32_t(g->members.size());
+    g->frame_ready = false;
+    int status = for_each_member(g->members, [&](Member& m, uint32_t i) {
+        HiprFrameDesc frame = {width, height, i, n, samples_per_pass};
+        return hipr_set_frame(m.context, &frame);
+    });
+    if (status) return status;
+    g->width = width; g->height = height;
+    if (n > 1) {
+        uint32_t owned = 0;
+        if (int s = hipr_owned_pixel_count(g->members[0].context, &owned)) return s;
+        g->compact_pixels = owned;
+        for (Member& m : g->members) {
+            if (hipSetDevice(m.device) != hipSuccess) return HIPR_ERROR_HIP;
+            if (m.compact) (void)hipFree(m.compact);
+            m.compact = nullptr;
+            if (hipMalloc(&m.compact, g->compact_pixels * 8) != hipSuccess) return HIPR_ERROR_OUT_OF_MEMORY;
+        }
+        if (hipSetDevice(g->members[0].device) != hipSuccess) return HIPR_ERROR_HIP;
+        if (g->gathered) (void)hipFree(g->gathered);
+        g->gathered = nullptr;
+        if (hipMalloc(&g->gathered, uint64_t(n) * g->compact_pixels * 8) != hipSuccess) return HIPR_ERROR_OUT_OF_MEMORY;
+    }
+    g->frame_ready = true;
+    return HIPR_OK;
+}
+
+int hipr_group_set_samples_per_pass(HiprGroup* g, uint32_t samples_per_pass) {
+    if (!g) return HIPR_ERROR_INVALID_ARGUMENT;
+    for (Member& m : g->members)
+        if (int s = hipr_set_samples_per_pass(m.context, samples_per_pass)) return s;
+    return HIPR_OK;
+}
+
+int hipr_group_trace_pass(HiprGroup* g, const HiprCameraState* camera) {
+    if (!g || !camera) return HIPR_ERROR_INVALID_ARGUMENT;
+    return for_each_member(g->members, [&](Member& m, uint32_t) { return hipr_trace_pass(m.context, camera); });
+}
+
+int hipr_group_accumulate_samples(HiprGroup* g, uint32_t first_sample, uint32_t sample_count, uint32_t first_accumulation, void* out_half4_device, uint32_t out_pitch_pixels,
+                                  int synchronize) {
+    if (!g || !g->frame_ready) return HIPR_ERROR_NOT_READY;
+    const uint32_t n = uint32_t(g->members.size());
+    if (n == 1) return hipr_accumulate_samples(g->members[0].context, first_sample, sample_count, first_accumulation, out_half4_device, out_pitch_pixels, synchronize);
+    if (out_half4_device && out_pitch_pixels < g->width) return HIPR_ERROR_INVALID_ARGUMENT;
+    const size_t bytes = size_t(g->compact_pixels) * 8;
+    char* gathered = static_cast<char*>(g->gathered);
+    // Every member folds its samples and writes its compact tiles; then the tiles travel to member 0's device.
+    int status = for_each_member(g->members, [&](Member& m, uint32_t i) -> int {
+        if (int s = hipr_accumulate_samples(m.context, first_sample, sample_count, first_accumulation, out_half4_device ? m.compact : nullptr, 0, 1)) return s;
+        if (!out_half4_device) return HIPR_OK;
+        if (hipSetDevice(m.device) != hipSuccess) return HIPR_ERROR_HIP;
+        if (g->use_rccl) {
+            if (i == 0) {
+                if (hipMemcpyAsync(gathered, m.compact, bytes, hipMemcpyDeviceToDevice, m.stream) != hipSuccess) return HIPR_ERROR_HIP;
+                int r = g->rccl.GroupStart();
+                for (uint32_t peer = 1; peer < n && r == 0; ++peer) r = g->rccl.Recv(gathered + size_t(peer) * bytes, bytes, NCCL_UINT8, int(peer), m.comm, m.stream);
+                r = g->rccl.GroupEnd() | r;
+                if (r != 0) return HIPR_ERROR_HIP;
+            } else if (g->rccl.Send(m.compact, bytes, NCCL_UINT8, 0, m.comm, m.stream) != 0)
+                return HIPR_ERROR_HIP;
+        } else if (hipMemcpyAsync(gathered + size_t(i) * bytes, m.compact, bytes, hipMemcpyDeviceToDevice, m.stream) != hipSuccess)
+            return HIPR_ERROR_HIP;
+        return hipStreamSynchronize(m.stream) == hipSuccess ? HIPR_OK : HIPR_ERROR_HIP;
+    });
+    if (status || !out_half4_device) return status;
+    if (int s = hipr_scatter_tiles(g->members[0].context, g->gathered, g->compact_pixels, n, g->width, g->height, out_half4_device, out_pitch_pixels)) return s;
+    return synchronize ? hipr_synchronize(g->members[0].context) : HIPR_OK;
+}
+
+int hipr_group_read_accumulation(HiprGroup* g, double* out_rgba, uint64_t capacity_pixels) {
+    if (!g || !g->frame_ready || !out_rgba) return HIPR_ERROR_INVALID_ARGUMENT;
+    const uint32_t n = uint32_t(g->members.size());
+    if (n == 1) return hipr_read_accumulation(g->members[0].context, out_rgba, capacity_pixels);
+    if (capacity_pixels < uint64_t(g->width) * g->height) return HIPR_ERROR_INVALID_ARGUMENT;
+    const uint32_t tiles_x = (g->width + 7) / 8, tiles_total = tiles_x * ((g->height + 7) / 8);
+    std::vector<double> compact;
+    for (uint32_t i = 0; i < n; ++i) {
+        uint32_t owned = 0;
+        if (int s = hipr_owned_pixel_count(g->members[i].context, &owned)) return s;
+        compact.resize(size_t(owned) * 4);
+        if (int s = hipr_read_accumulation(g->members[i].context, compact.data(), owned)) return s;
+        for (uint32_t k = 0; k < owned; ++k) {
+            const uint32_t tile = (k >> 6) * n + i, lane = k & 63u;
+            const uint32_t x = (tile % tiles_x) * 8 + (lane & 7u), y = (tile / tiles_x) * 8 + (lane >> 3);
+            if (tile < tiles_total && x < g->width && y < g->height) std::memcpy(out_rgba + 4 * (size_t(y) * g->width + x), compact.data() + 4 * size_t(k), 32);
+        }
+    }
+    return HIPR_OK;
+}
+
+int hipr_group_get_counters(HiprGroup* g, HiprCounters* out) {
+    if (!g || !out) return HIPR_ERROR_INVALID_ARGUMENT;
+    std::memset(out, 0, sizeof(*out));
+    for (Member& m : g->members) {
+        HiprCounters c;
+        if (int s = hipr_get_counters(m.context, &c)) return s;
+        out->camera_rays += c.camera_rays; out->closest_rays += c.closest_rays; out->shadow_rays += c.shadow_rays; out->shaded_hits += c.shaded_hits;
+        out->closest_nodes += c.closest_nodes; out->closest_triangles += c.closest_triangles; out->shadow_nodes += c.shadow_nodes; out->shadow_triangles += c.shadow_triangles;
+        out->iterations = std::max(out->iterations, c.iterations);
+    }
+    return HIPR_OK;
+}
+
+} // extern "C"

@@ -170,12 +170,13 @@ void flatten_bifrost_scene(SceneBuilder& sb) {
 
 
 struct Renderer::Implementation {
-    int device_ID = -1;
+    int device_ID = -1;                 // the device frames are delivered on (= device_IDs[0])
+    std::vector<int> device_IDs;        // every device the renderer traces on; tiles are dealt round-robin over them (hipr_group_*)
     Core::RendererID owning_renderer_ID;
     std::vector<float> tables[5];
 
     struct CameraState {
-        HiprContext* context = nullptr;   // one C-ABI context (accumulation buffer + queues) per camera
+        HiprGroup* context = nullptr;     // per camera: one C-ABI context (accumulation buffer + queues) on every device of the renderer, as a group
         Vector2i frame_size = {0, 0};
         bool initialized = false;
         unsigned int accumulations = 0, max_accumulation_count = UINT_MAX, max_bounce_count = 4;   // OR/Renderer.cpp:211-221
@@ -201,7 +202,7 @@ struct Renderer::Implementation {
 
     ~Implementation() {
         for (CameraState& c : per_camera_state)
-            if (c.context) hipr_destroy(c.context);
+            if (c.context) hipr_group_destroy(c.context);
     }
 
     bool conditional_per_camera_state_resize(unsigned int camera_ID) {
@@ -226,12 +227,12 @@ struct Renderer::Implementation {
         return bool(f);
     }
 
-    HiprContext* create_context() {
-        HiprContext* ctx = nullptr;
-        if (hipr_create(device_ID, &ctx) != HIPR_OK) return nullptr;
+    HiprGroup* create_context() {
+        HiprGroup* group = nullptr;
+        if (hipr_group_create(device_IDs.data(), uint32_t(device_IDs.size()), &group) != HIPR_OK) return nullptr;
         HiprTables t = {tables[0].data(), tables[1].data(), tables[2].data(), tables[3].data(), tables[4].data()};
-        if (hipr_upload_tables(ctx, &t) != HIPR_OK) { hipr_destroy(ctx); return nullptr; }
-        return ctx;
+        if (hipr_group_upload_tables(group, &t) != HIPR_OK) { hipr_group_destroy(group); return nullptr; }
+        return group;
     }
 
     void rebuild_scene() {
@@ -242,7 +243,7 @@ struct Renderer::Implementation {
 
     bool upload_scene_to(CameraState& c) {
         if (!scene) rebuild_scene();
-        if (hipr_upload_scene(c.context, &scene->desc()) != HIPR_OK) return false;
+        if (hipr_group_upload_scene(c.context, &scene->desc()) != HIPR_OK) return false;
         c.scene_uploaded = true;
         c.drop_batch();
         return true;
@@ -256,7 +257,7 @@ struct Renderer::Implementation {
             auto changes = Cameras::get_changes(cam_ID);
             if (changes.contains(Cameras::Change::Destroyed)) {
                 if (cam_ID < per_camera_state.size()) {
-                    if (per_camera_state[cam_ID].context) hipr_destroy(per_camera_state[cam_ID].context);
+                    if (per_camera_state[cam_ID].context) hipr_group_destroy(per_camera_state[cam_ID].context);
                     per_camera_state[cam_ID] = CameraState();
                 }
                 continue;
@@ -332,8 +333,7 @@ struct Renderer::Implementation {
         }
         if (!state.scene_uploaded && !upload_scene_to(state)) return false;
         if (frame_size.x != state.frame_size.x || frame_size.y != state.frame_size.y) {
-            HiprFrameDesc frame = {uint32_t(frame_size.x), uint32_t(frame_size.y), 0, 1, 1};
-            if (hipr_set_frame(state.context, &frame) != HIPR_OK) return false;
+            if (hipr_group_set_frame(state.context, uint32_t(frame_size.x), uint32_t(frame_size.y), 1) != HIPR_OK) return false;
             state.frame_size = frame_size;
             state.accumulations = 0;
             state.drop_batch();
@@ -386,13 +386,13 @@ struct Renderer::Implementation {
                                  std::memcmp(&scene_state, &state.batch_scene_state, sizeof(HiprSceneState)) == 0;
         if (!batch_valid) {
             const unsigned int batch = next_batch_size(state);
-            hipr_set_scene_state(state.context, &scene_state);
-            hipr_set_entry_point(state.context, entry);
-            if (hipr_set_samples_per_pass(state.context, batch) != HIPR_OK || hipr_trace_pass(state.context, &camera) != HIPR_OK) { state.drop_batch(); return state.accumulations; }
+            hipr_group_set_scene_state(state.context, &scene_state);
+            hipr_group_set_entry_point(state.context, entry);
+            if (hipr_group_set_samples_per_pass(state.context, batch) != HIPR_OK || hipr_group_trace_pass(state.context, &camera) != HIPR_OK) { state.drop_batch(); return state.accumulations; }
             state.batch_first = state.accumulations; state.batch_size = batch; state.batch_used = 0;
             state.batch_camera = camera; state.batch_scene_state = scene_state; state.batch_entry = entry;
         }
-        if (hipr_accumulate_samples(state.context, state.batch_used, 1, state.accumulations, buffer, pitch, 1) != HIPR_OK) return state.accumulations;   // launch is blocking in the reference
+        if (hipr_group_accumulate_samples(state.context, state.batch_used, 1, state.accumulations, buffer, pitch, 1) != HIPR_OK) return state.accumulations;   // launch is blocking in the reference
         ++state.batch_used;
         ++state.accumulations;
         return state.accumulations;
@@ -402,23 +402,33 @@ struct Renderer::Implementation {
 // ------------------------------------------------------------------------------------------------------------------------
 // Renderer
 // ------------------------------------------------------------------------------------------------------------------------
-Renderer* Renderer::initialize(int device_ID, const std::filesystem::path& data_directory) {
-    Renderer* r = new Renderer(device_ID, data_directory);
+Renderer* Renderer::initialize(int device_ID, const std::filesystem::path& data_directory) { return initialize(std::vector<int>{device_ID}, data_directory); }
+
+Renderer* Renderer::initialize(const std::vector<int>& device_IDs, const std::filesystem::path& data_directory) {
+    if (device_IDs.empty()) return nullptr;
+    Renderer* r = new Renderer(device_IDs, data_directory);
     if (r->m_impl->is_valid()) return r;
     delete r;
     return nullptr;
 }
 
-Renderer::Renderer(int device_ID, const std::filesystem::path& data_directory)
+Renderer::Renderer(const std::vector<int>& device_IDs, const std::filesystem::path& data_directory)
     : m_renderer_ID(Core::Renderers::create("HIPRenderer")), m_impl(new Implementation()) {
     m_impl->owning_renderer_ID = m_renderer_ID;
     if (hipr_device_count() == 0) { fprintf(stderr, "HIPRenderer: no HIP device available.\n"); return; }   // OR/Renderer.cpp:280-281
     if (!m_impl->load_tables(data_directory)) { fprintf(stderr, "HIPRenderer failed to initialize: cannot read %s/HIPRenderer/shading_tables.bin\n", data_directory.c_str()); return; }
-    m_impl->device_ID = device_ID;
-    HiprContext* probe = m_impl->create_context();   // fail here, like the OptiX context creation would
+    m_impl->device_ID = device_IDs[0];
+    m_impl->device_IDs = device_IDs;
+    HiprGroup* probe = m_impl->create_context();   // fail here, like the OptiX context creation would
     if (!probe) { fprintf(stderr, "HIPRenderer failed to initialize:\n%s\n", hipr_last_error()); m_impl->device_ID = -1; return; }
-    hipr_destroy(probe);
-    printf("HIPRenderer using HIP device %d.\n", device_ID);
+    const std::string gather = hipr_group_gather_description(probe);
+    hipr_group_destroy(probe);
+    if (device_IDs.size() == 1) printf("HIPRenderer using HIP device %d.\n", device_IDs[0]);
+    else {
+        printf("HIPRenderer using %d HIP devices (", int(device_IDs.size()));
+        for (size_t i = 0; i < device_IDs.size(); ++i) printf(i ? ", %d" : "%d", device_IDs[i]);
+        printf("): 8x8 pixel tiles dealt round-robin, frames assembled on device %d by %s.\n", device_IDs[0], gather.c_str());
+    }
 }
 
 Renderer::~Renderer() {
@@ -470,7 +480,7 @@ bool Renderer::read_accumulation(std::vector<double>& out_rgba) const {
     for (auto& state : m_impl->per_camera_state)
         if (state.context && state.frame_size.x > 0) {
             out_rgba.resize(size_t(state.frame_size.x) * state.frame_size.y * 4);
-            return hipr_read_accumulation(state.context, out_rgba.data(), out_rgba.size() / 4) == HIPR_OK;
+            return hipr_group_read_accumulation(state.context, out_rgba.data(), out_rgba.size() / 4) == HIPR_OK;
         }
     return false;
 }
@@ -510,19 +520,19 @@ std::vector<Screenshot> Renderer::request_auxiliary_buffers(CameraID camera_ID, 
     auto& state = m_impl->per_camera_state[camera_ID];
     const unsigned int accumulation_count = std::max(1u, state.accumulations);
     const int pixel_count = frame_size.x * frame_size.y;
-    hipr_set_scene_state(state.context, &m_impl->scene_state);
+    hipr_group_set_scene_state(state.context, &m_impl->scene_state);
 
     state.drop_batch();   // the auxiliary passes reuse the context's per-sample radiance buffer
-    if (hipr_set_samples_per_pass(state.context, 1) != HIPR_OK) return screenshots;
+    if (hipr_group_set_samples_per_pass(state.context, 1) != HIPR_OK) return screenshots;
     auto render_auxiliary_feature = [&](int entry, std::vector<double>& accumulation) -> bool {
-        if (hipr_use_scratch_accumulation(state.context, 1) != HIPR_OK) return false;
-        hipr_set_entry_point(state.context, entry);
+        if (hipr_group_use_scratch_accumulation(state.context, 1) != HIPR_OK) return false;
+        hipr_group_set_entry_point(state.context, entry);
         bool ok = true;
         for (camera.accumulations = 0; ok && camera.accumulations < accumulation_count; ++camera.accumulations)
-            ok = hipr_render_pass(state.context, &camera, nullptr, 0, 1) == HIPR_OK;
+            ok = hipr_group_trace_pass(state.context, &camera) == HIPR_OK && hipr_group_accumulate_samples(state.context, 0, 1, camera.accumulations, nullptr, 0, 1) == HIPR_OK;
         accumulation.resize(size_t(pixel_count) * 4);
-        ok = ok && hipr_read_accumulation(state.context, accumulation.data(), pixel_count) == HIPR_OK;
-        hipr_use_scratch_accumulation(state.context, 0);
+        ok = ok && hipr_group_read_accumulation(state.context, accumulation.data(), pixel_count) == HIPR_OK;
+        hipr_group_use_scratch_accumulation(state.context, 0);
         return ok;
     };
     auto unorm8 = [](float v) { v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); return (unsigned char)(v * 255.0f + 0.5f); };
@@ -551,7 +561,7 @@ std::vector<Screenshot> Renderer::request_auxiliary_buffers(CameraID camera_ID, 
         screenshots.push_back(s);
     }
     int entry = entry_of(state.backend);
-    hipr_set_entry_point(state.context, entry < 0 ? HIPR_ENTRY_PATH_TRACING : entry);
+    hipr_group_set_entry_point(state.context, entry < 0 ? HIPR_ENTRY_PATH_TRACING : entry);
     return screenshots;
 }
 

@@ -43,6 +43,11 @@ public:
     // Returns nullptr when no usable device exists or initialisation fails (OR/Renderer.cpp:1365-1378).
     // data_directory must contain HIPRenderer/shading_tables.bin (the reference loads its PTX from <data>/OptiXRenderer/ptx).
     static Renderer* initialize(int device_ID, const std::filesystem::path& data_directory);
+    // Not in the reference (single device, OR/Renderer.cpp:289-291): the same renderer tracing on several GPUs of the node. Pixel tiles of
+    // 8 x 8 are dealt round-robin over the devices, scene and tables are replicated, every device keeps the accumulation of its tiles;
+    // each render() gathers the finished half4 tiles on device_IDs[0] (RCCL over xGMI) and assembles the frame there, so the buffer handed
+    // to render() lives on device_IDs[0]. Frames are bit-identical to the single-device ones.
+    static Renderer* initialize(const std::vector<int>& device_IDs, const std::filesystem::path& data_directory);
     ~Renderer();
 
     Bifrost::Core::RendererID get_renderer_ID() const { return m_renderer_ID; }
@@ -85,7 +90,7 @@ public:
     bool read_accumulation(std::vector<double>& out_rgba) const;
 
 private:
-    Renderer(int device_ID, const std::filesystem::path& data_directory);
+    Renderer(const std::vector<int>& device_IDs, const std::filesystem::path& data_directory);
     Renderer(Renderer&) = delete;
     Renderer& operator=(Renderer&) = delete;
 

@@ -341,6 +341,41 @@ int hipr_scatter_tiles(HiprContext* context, const void* compact_half4_device, u
                        void* out_half4_device, uint32_t out_pitch_pixels);
 
 /* ------------------------------------------------------------------------------------------- */
+/* Device groups: one frame on several GPUs of a node, from one process.          */
+/* The reference is single device (OR/Renderer.cpp:289-291; interop is disabled above one        */
+/* device, DX11OptiXAdaptor/Adaptor.cpp:83-90), so these have no counterpart there: they are the  */
+/* same calls as above, fanned out over one HiprContext per device, plus the one exchange the    */
+/* partition needs. Member i owns the 8x8 tiles with tile % size == i (scene and tables          */
+/* replicated, f64 accumulation kept per member: no collective per sample); a frame is assembled */
+/* on member 0's device by gathering the members' compact half4 tiles (RCCL send / recv over      */
+/* xGMI, or peer-to-peer copies when RCCL is absent or members share a device) and               */
+/* hipr_scatter_tiles. The image is bit-identical to the single-device one. A group of one       */
+/* device forwards every call to its context.                                                    */
+/* ------------------------------------------------------------------------------------------- */
+typedef struct HiprGroup HiprGroup;
+int hipr_group_create(const int* device_ids, uint32_t count, HiprGroup** out_group);
+int hipr_group_destroy(HiprGroup* group);
+uint32_t hipr_group_size(HiprGroup* group);
+HiprContext* hipr_group_context(HiprGroup* group, uint32_t member);
+const char* hipr_group_gather_description(HiprGroup* group);   /* which transport the gather uses */
+int hipr_group_upload_tables(HiprGroup* group, const HiprTables* tables);
+int hipr_group_upload_scene(HiprGroup* group, const HiprSceneDesc* scene);
+int hipr_group_set_scene_state(HiprGroup* group, const HiprSceneState* state);
+int hipr_group_set_entry_point(HiprGroup* group, int entry);
+int hipr_group_use_scratch_accumulation(HiprGroup* group, int enable);
+int hipr_group_set_frame(HiprGroup* group, uint32_t width, uint32_t height, uint32_t samples_per_pass);
+int hipr_group_set_samples_per_pass(HiprGroup* group, uint32_t samples_per_pass);
+/* One host thread per member runs hipr_trace_pass; returns when every member has queued its last bounce. */
+int hipr_group_trace_pass(HiprGroup* group, const HiprCameraState* camera);
+/* Every member folds the samples into its running mean; with an output buffer (on member 0's device, full frame, row pitch in
+ * pixels) the compact tiles are gathered and the frame is assembled there. */
+int hipr_group_accumulate_samples(HiprGroup* group, uint32_t first_sample, uint32_t sample_count, uint32_t first_accumulation,
+                                  void* out_half4_device, uint32_t out_pitch_pixels, int synchronize);
+/* The full frame's f64 accumulation, row-major, assembled on the host from the members' tiles. */
+int hipr_group_read_accumulation(HiprGroup* group, double* out_rgba, uint64_t capacity_pixels);
+int hipr_group_get_counters(HiprGroup* group, HiprCounters* out);   /* sums over the members */
+
+/* ------------------------------------------------------------------------------------------- */
 /* Presentation side: what DX11OptiXAdaptor::Adaptor does around Renderer::render                */
 /* (extensions/DX11OptiXAdapter/DX11OptiXAdaptor/Adaptor.cpp:141-247), so that the host library   */
 /* above this ABI links no GPU runtime.                                                          */

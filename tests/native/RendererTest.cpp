@@ -529,6 +529,54 @@ GPU_TEST_F(RendererFixture, batched_tracing_returns_the_images_of_one_launch_per
     EXPECT_TRUE(sum > 0.0);
 }
 
+GPU_TEST_F(RendererFixture, a_renderer_over_several_devices_delivers_the_single_device_frames) {
+    // Renderer::initialize(device list): tiles dealt round-robin over a group of contexts, compact tiles gathered and assembled on the
+    // first device. With every member on device 0 (this box has one GPU) the partition, the per-member accumulation, the gather (copy
+    // path) and the assembly all run; the frames and the accumulation must equal the single-device renderer's bit for bit, call by call.
+    auto frame_size = Math::Vector2i(52, 29);        // partial tiles at the right and top edges
+    Scene::SceneRoot scene = Scene::SceneRoot("Cornell", Math::RGB(0.68f, 0.92f, 1.0f));
+    SceneBuilder direct;
+    Scenes::create_cornell_box(direct);
+    Math::Matrix4x4f projection, inverse_projection;
+    Scene::CameraUtils::compute_perspective_projection(direct.camera.near_plane, direct.camera.far_plane, direct.camera.field_of_view,
+                                                       float(frame_size.x) / frame_size.y, projection, inverse_projection);
+    Scene::CameraID camera_ID = Scene::Cameras::create("Camera", scene.get_ID(), projection, inverse_projection);
+    create_cornell_box(camera_ID, scene.get_root_node());
+
+    const int calls = 12;
+    auto run = [&](Renderer* r, std::vector<std::vector<double>>& accumulations, std::vector<std::vector<half4>>& frames) {
+        Scene::Cameras::set_renderer_ID(camera_ID, r->get_renderer_ID());
+        r->set_max_bounce_count(camera_ID, 4);
+        r->handle_updates();
+        const int pitch = frame_size.x + 5;           // a render target wider than the frame
+        RenderTarget target(Math::Vector2i(pitch, frame_size.y));
+        for (int i = 0; i < calls; ++i) {
+            EXPECT_EQ(unsigned(i + 1), r->render(camera_ID, target.device, pitch, frame_size));
+            accumulations.emplace_back();
+            EXPECT_TRUE(r->read_accumulation(accumulations.back()));
+            frames.push_back(target.map());
+        }
+    };
+    std::vector<std::vector<double>> single, grouped;
+    std::vector<std::vector<half4>> single_frames, grouped_frames;
+    run(renderer, single, single_frames);
+    Renderer* over_three = Renderer::initialize(std::vector<int>{0, 0, 0}, get_data_directory());
+    EXPECT_TRUE(over_three != nullptr);
+    if (!over_three) return;
+    run(over_three, grouped, grouped_frames);
+    delete over_three;
+    size_t mismatching_calls = 0, lit = 0;
+    for (int i = 0; i < calls; ++i) {
+        bool same = single[i] == grouped[i];
+        for (int y = 0; y < frame_size.y && same; ++y)      // the padding columns of the wider target are not written
+            same = std::memcmp(&single_frames[i][size_t(y) * (frame_size.x + 5)], &grouped_frames[i][size_t(y) * (frame_size.x + 5)], frame_size.x * sizeof(half4)) == 0;
+        mismatching_calls += !same;
+        for (double v : grouped[i]) lit += v > 0.0;
+    }
+    EXPECT_EQ(size_t(0), mismatching_calls);
+    EXPECT_TRUE(lit > 0);
+}
+
 // ------------------------------------------------------------------------------------------------------------------------
 // The compositor-facing adaptor (DX11OptiXAdaptor/Adaptor.cpp:141-247)
 // ------------------------------------------------------------------------------------------------------------------------

@@ -251,3 +251,48 @@ def test_million_triangle_scene(ctx, oracle_q):
         valid = (x < w) & (y < h) & (tile < tiles_x * tiles_y)
         assembled[y[valid], x[valid]] = part[valid]
     assert np.array_equal(assembled, full)
+
+
+def test_device_group_renders_the_single_context_image(ctx, oracle_q):
+    """hipr_group_*: a frame split over the members of a device group (tile % size == member, scene replicated, accumulation kept per
+    member) and assembled on member 0 equals the single-context frame bit for bit -- f64 accumulation and half4 pixels -- also when the
+    pass is batched. On this one-GPU box the three members share device 0, so the gather takes the copy path."""
+    import ctypes as C
+    import torch
+    lib = ctx.lib
+    scene = Scene("atrium", param0=20000, param1=3)
+    w, h, spp, batch = 100, 60, 4, 2
+    single, _ = render_gpu(ctx, scene, w, h, spp, 4, samples_per_pass=batch)
+    reference = torch.zeros((h, w, 4), dtype=torch.float16, device="cuda")
+    ctx.set_frame(w, h, 0, 1, batch)
+    for a in range(0, spp, batch):
+        ctx.render_pass(scene.camera(w, h, accumulations=a, max_bounce_count=4), reference.data_ptr(), w, synchronize=True)
+
+    devices = (C.c_int * 3)(0, 0, 0)
+    group = C.c_void_p()
+    assert lib.hipr_group_create(devices, 3, C.byref(group)) == 0
+    try:
+        assert lib.hipr_group_size(group) == 3 and b"copy" in lib.hipr_group_gather_description(group).lower() or b"memcpy" in lib.hipr_group_gather_description(group).lower()
+        tables = capi.load_tables()
+        t = capi.HiprTables(*[a.ctypes.data_as(C.POINTER(C.c_float)) for a in tables])
+        assert lib.hipr_group_upload_tables(group, C.byref(t)) == 0
+        assert lib.hipr_group_upload_scene(group, C.byref(scene.desc)) == 0
+        state = scene.state
+        assert lib.hipr_group_set_scene_state(group, C.byref(state)) == 0
+        assert lib.hipr_group_set_frame(group, w, h, batch) == 0
+        pitch = w + 12
+        frame = torch.zeros((h, pitch, 4), dtype=torch.float16, device="cuda")
+        torch.cuda.synchronize()
+        for a in range(0, spp, batch):
+            cam = scene.camera(w, h, accumulations=a, max_bounce_count=4)
+            assert lib.hipr_group_trace_pass(group, C.byref(cam)) == 0
+            assert lib.hipr_group_accumulate_samples(group, 0, batch, a, C.c_void_p(frame.data_ptr()), pitch, 1) == 0
+        accumulation = np.zeros((h, w, 4), np.float64)
+        assert lib.hipr_group_read_accumulation(group, accumulation.ctypes.data_as(C.POINTER(C.c_double)), w * h) == 0
+        counters = capi.HiprCounters()
+        assert lib.hipr_group_get_counters(group, C.byref(counters)) == 0
+    finally:
+        lib.hipr_group_destroy(group)
+    assert np.array_equal(accumulation, single)
+    assert torch.equal(frame[:, :w].cpu(), reference.cpu())
+    assert counters.camera_rays == w * h * spp
