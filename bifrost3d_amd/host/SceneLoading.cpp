@@ -1,6 +1,12 @@
 // SceneLoading.cpp -- see SceneLoading.h.
 #include "SceneLoading.h"
 
+#include "ImageIO/ImageLoader.h"
+
+#include <cstdio>
+#include <string>
+#include <vector>
+
 #include <vector>
 
 using namespace Bifrost;
@@ -73,6 +79,51 @@ ViewerDefaults apply_viewer_defaults(SceneNode root_node, CameraID camera_ID, bo
     result.near_plane = result.scene_size / 10000.0f;
     result.far_plane = result.scene_size * 3.0f;
     return result;
+}
+
+Image load_image(const std::string& path) {
+    auto readable = [](const std::string& p) { FILE* f = std::fopen(p.c_str(), "rb"); if (f) std::fclose(f); return f != nullptr; };
+    if (readable(path)) return ImageLoader::load(path);
+    if (path.size() > 4)
+        for (const char* extension : {"png", "jpg"}) {
+            std::string other = path;
+            other.replace(other.size() - 3, 3, extension);
+            if (readable(other)) return ImageLoader::load(other);
+        }
+    printf("No image found at '%s'\n", path.c_str());
+    return Image();
+}
+
+TextureID load_environment_map(const std::string& path) {
+    Image image = ImageLoader::load(path);
+    if (!image.exists()) return TextureID::invalid_UID();
+    const PixelFormat format = image.get_pixel_format();
+    const unsigned width = image.get_width(), height = image.get_height(), channels = unsigned(channel_count(format));
+    if (channels != 4) {      // Image::change_format of the reference: missing colour channels repeat the intensity, alpha is one
+        const bool is_float = format == PixelFormat::Intensity_Float || format == PixelFormat::RGB_Float;
+        const size_t n = size_t(width) * height;
+        Image wide;
+        if (is_float) {
+            std::vector<float> pixels(4 * n);
+            const float* src = image.get_pixels<float>();
+            for (size_t i = 0; i < n; ++i) {
+                for (unsigned c = 0; c < 3; ++c) pixels[4 * i + c] = src[channels * i + (channels == 3 ? c : 0)];
+                pixels[4 * i + 3] = 1.0f;
+            }
+            wide = Image::create2D(image.get_name(), PixelFormat::RGBA_Float, false, width, height, pixels.data());
+        } else {
+            std::vector<unsigned char> pixels(4 * n);
+            const unsigned char* src = image.get_pixels<unsigned char>();
+            for (size_t i = 0; i < n; ++i) {
+                for (unsigned c = 0; c < 3; ++c) pixels[4 * i + c] = src[channels * i + (channels == 3 ? c : 0)];
+                pixels[4 * i + 3] = 255;
+            }
+            wide = Image::create2D(image.get_name(), PixelFormat::RGBA32, Images::is_sRGB(image.get_ID()), width, height, pixels.data());
+        }
+        Images::destroy(image.get_ID());
+        image = wide;
+    }
+    return Textures::create2D(image.get_ID(), MagnificationFilter::Linear, MinificationFilter::Linear, WrapMode::Repeat, WrapMode::Clamp);
 }
 
 } // namespace SceneLoading

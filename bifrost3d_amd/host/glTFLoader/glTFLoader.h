@@ -23,7 +23,7 @@ namespace glTFLoader {
 typedef Bifrost::Assets::Image (*ImageLoader)(const std::string& name, const void* data, size_t byte_count);
 
 // Returns the root node of the default scene (a node named "Scene root" above them when the scene has several roots),
-// SceneNode::invalid() when the file cannot be read or parsed or names no default scene. A null `image_loader` selects PngImage::load_from_memory.
+// SceneNode::invalid() when the file cannot be read or parsed or names no default scene. A null `image_loader` selects ImageLoader::load_from_memory (PNG, JPEG, Radiance HDR).
 Bifrost::Scene::SceneNode load(const std::string& filename, ImageLoader image_loader = nullptr);
 
 bool file_supported(const std::string& filename);

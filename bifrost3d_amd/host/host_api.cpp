@@ -9,6 +9,7 @@
 
 #include "HIPRenderer/PresampledEnvironment.h"
 #include "HIPRenderer/Renderer.h"
+#include "ImageIO/ImageLoader.h"
 #include "ImageIO/PngImage.h"
 #include "MaterialScene.h"
 #include "ObjLoader/ObjLoader.h"
@@ -156,19 +157,29 @@ static void* create_opacity_scene(unsigned quads_per_edge, unsigned variant) {
 // (apps/SimpleViewer/main.cpp:330-429): sky-blue environment tint, cut-out detection, camera placed from the scene bounds,
 // the default directional light when the file brings none. Textures: PNG only (ImageIO/PngImage.h). Null when the file
 // cannot be loaded. The Bifrost managers are scratch space here: whatever they held is dropped.
-void* hiprh_scene_load(const char* path, unsigned variant) {
+void* hiprh_scene_load_with_environment(const char* path, const char* environment_map_path, unsigned variant);
+void* hiprh_scene_load(const char* path, unsigned variant) { return hiprh_scene_load_with_environment(path, nullptr, variant); }
+
+// The same with SimpleViewer's --environment-map (main.cpp:331-341, 533): a latitude-longitude image (Radiance .hdr, PNG or JPEG) that lights the
+// scene and is seen where paths escape; it counts as a light source, so no default directional light is added (main.cpp:419-426).
+void* hiprh_scene_load_with_environment(const char* path, const char* environment_map_path, unsigned variant) {
     using namespace Bifrost;
     if (!path) return nullptr;
     deallocate_all();
     Scene::SceneRoot scene = Scene::SceneRoot("Model scene", RGB(0.68f, 0.92f, 1.0f));
     Scene::SceneNode loaded = Scene::SceneNode::invalid();
-    if (ObjLoader::file_supported(path)) loaded = ObjLoader::load(path, PngImage::load);
+    if (ObjLoader::file_supported(path)) loaded = ObjLoader::load(path, SceneLoading::load_image);
     else if (glTFLoader::file_supported(path)) loaded = glTFLoader::load(path);
     if (loaded == Scene::SceneNode::invalid()) { deallocate_all(); return nullptr; }
     loaded.set_parent(scene.get_root_node());
     SceneLoading::detect_and_flag_cutout_materials();
+    bool has_environment = false;
+    if (environment_map_path && environment_map_path[0]) {
+        const Assets::TextureID environment = SceneLoading::load_environment_map(environment_map_path);
+        if (environment != Assets::TextureID::invalid_UID()) { scene.set_environment_map(environment); has_environment = true; }
+    }
     const Scene::CameraID camera_ID = Scene::Cameras::create("Camera", scene.get_ID(), Math::Matrix4x4f::identity(), Math::Matrix4x4f::identity());
-    const SceneLoading::ViewerDefaults defaults = SceneLoading::apply_viewer_defaults(scene.get_root_node(), camera_ID, true);
+    const SceneLoading::ViewerDefaults defaults = SceneLoading::apply_viewer_defaults(scene.get_root_node(), camera_ID, true, has_environment);
 
     if (variant & 1u)
         for (Assets::MaterialID material_ID : Assets::Materials::get_iterable()) Assets::Material(material_ID).set_shading_model(Assets::ShadingModel::Diffuse);
@@ -230,6 +241,27 @@ int hiprh_renderer_bench(const char* data_directory, unsigned target_triangles, 
     delete renderer;
     deallocate_all();
     return status;
+}
+
+// Decodes any image file the loaders read (PNG, JPEG, Radiance HDR) for the codec tests: returns the byte count of the pixels (8 bit or float, rows
+// top-down unless `flip`), 0 when the file cannot be decoded; format: 0 = 8 bit, 1 = float.
+size_t hiprh_image_load(const char* path, int flip, unsigned* width, unsigned* height, unsigned* channels, int* is_float, void* out, size_t capacity) {
+    using namespace Bifrost::Assets;
+    if (!path) return 0;
+    Image image = ImageLoader::load(path);
+    if (!image.exists()) return 0;
+    const PixelFormat format = image.get_pixel_format();
+    const bool floats = format == PixelFormat::Intensity_Float || format == PixelFormat::RGB_Float || format == PixelFormat::RGBA_Float;
+    const unsigned w = image.get_width(), h = image.get_height(), c = unsigned(channel_count(format));
+    const size_t row = size_t(w) * c * (floats ? 4 : 1), bytes = row * h;
+    if (width) *width = w;
+    if (height) *height = h;
+    if (channels) *channels = c;
+    if (is_float) *is_float = floats;
+    if (out && capacity >= bytes)
+        for (unsigned y = 0; y < h; ++y) std::memcpy(static_cast<char*>(out) + size_t(y) * row, image.get_pixels<char>() + size_t(flip ? y : h - 1 - y) * row, row);
+    Images::destroy(image.get_ID());
+    return bytes;
 }
 
 // Decodes a PNG file into 8 bit pixels (tests: cross-check of the decoder against an independent one). Returns the byte count

@@ -6,7 +6,7 @@
 // Bifrost/Assets/{InfiniteAreaLight,Image,Texture}.cpp with Math/Distribution2D.h. No reference source is copied, patched or
 // stood in for: the files build as they are with clang's -fms-extensions -fdelayed-template-parsing and the standard headers
 // the MSVC dialect gets implicitly (-include cmath ...). What does not build that way (Math/RNG.cpp, Assets/Mesh*.cpp,
-// apps/SmallPT, and everything that includes OptiX headers) stays out, and the oracle keeps being pinned by test vectors there. (Math/Distributions.h builds but is
+// apps/SmallPT, and everything that includes OptiX headers; extensions/StbImageLoader -- the reference's image loader with its vendored stb_image.h -- does build) stays out, and the oracle keeps being pinned by test vectors there. (Math/Distributions.h builds but is
 // not the path's code: the renderer samples with its own differently parameterised OptiXRenderer/Distributions.h.)
 #include <Bifrost/Assets/Image.h>
 #include <Bifrost/Assets/InfiniteAreaLight.h>
@@ -19,6 +19,7 @@
 #include <Bifrost/Math/Utils.h>
 #include <Bifrost/Scene/Camera.h>
 #include <Bifrost/Scene/SceneRoot.h>
+#include <StbImageLoader/StbImageLoader.h>
 
 #include <cstring>
 
@@ -182,6 +183,22 @@ int ref_infinite_area_light(int width, int height, const float* rgba, const floa
     Textures::destroy(texture.get_ID());
     Images::destroy(image.get_ID());
     return status;
+}
+
+// The reference's image loader (extensions/StbImageLoader/StbImageLoader/StbImageLoader.cpp:99-113, stb_image 2.29 underneath): the file's pixels as
+// the reference's Image holds them (bottom row first). Returns the byte count, 0 when the file does not load; info4 = width, height, channels, float flag.
+size_t ref_image_load(const char* path, int* info4, void* out, size_t capacity) {
+    allocate_managers();
+    Image image = StbImageLoader::load(path);
+    if (!image.exists()) return 0;
+    const PixelFormat format = image.get_pixel_format();
+    const bool floats = format == PixelFormat::Intensity_Float || format == PixelFormat::RGB_Float || format == PixelFormat::RGBA_Float;
+    const int channels = channel_count(format);
+    const size_t bytes = size_t(image.get_width()) * image.get_height() * channels * (floats ? 4 : 1);
+    info4[0] = int(image.get_width()); info4[1] = int(image.get_height()); info4[2] = channels; info4[3] = floats;
+    if (out && capacity >= bytes) std::memcpy(out, image.get_pixels(), bytes);
+    Images::destroy(image.get_ID());
+    return bytes;
 }
 
 } // extern "C"

@@ -1,0 +1,205 @@
+"""The JPEG and Radiance HDR decoders of the host library (host/ImageIO/{JpegImage,HdrImage,ImageLoader}.cpp) against the decoder the
+reference loads its textures and environment maps with: StbImageLoader::load (extensions/StbImageLoader/StbImageLoader/
+StbImageLoader.cpp:99-113, stb_image 2.29), compiled from the reference tree into oracle/_ref where that tree is present, and
+against the golden vectors that loader produced (tests/golden/images, written by tests/golden/make_image_goldens.py) everywhere.
+The bar is bit-exact pixels: the decoders use the reference decoder's integer IDCT, chroma interpolation and colour matrix.
+"""
+import ctypes as C
+import struct
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "tests"))
+GOLDEN = ROOT / "tests" / "golden" / "images"
+
+from bifrost3d_amd.host import load_host_library  # noqa: E402
+import reference_bindings  # noqa: E402
+
+
+def host_load(path):
+    lib = load_host_library()
+    lib.hiprh_image_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_int), C.c_void_p, C.c_size_t]
+    lib.hiprh_image_load.restype = C.c_size_t
+    w, h, c, f = C.c_uint(), C.c_uint(), C.c_uint(), C.c_int()
+    size = lib.hiprh_image_load(str(path).encode(), 1, C.byref(w), C.byref(h), C.byref(c), C.byref(f), None, 0)
+    if size == 0:
+        return None
+    out = np.empty(size, np.uint8)
+    lib.hiprh_image_load(str(path).encode(), 1, None, None, None, None, out.ctypes.data_as(C.c_void_p), size)     # flip = 1: rows as the Image holds them, bottom first
+    pixels = out.view(np.float32) if f.value else out
+    return pixels.reshape(h.value, w.value, c.value)
+
+
+def reference_load(path):
+    lib = reference_bindings.lib()
+    lib.ref_image_load.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.c_void_p, C.c_size_t]
+    lib.ref_image_load.restype = C.c_size_t
+    info = (C.c_int * 4)()
+    size = lib.ref_image_load(str(path).encode(), info, None, 0)
+    if size == 0:
+        return None
+    out = np.empty(size, np.uint8)
+    lib.ref_image_load(str(path).encode(), info, out.ctypes.data_as(C.c_void_p), size)
+    pixels = out.view(np.float32) if info[3] else out
+    return pixels.reshape(info[1], info[0], info[2])
+
+
+def make_picture(width, height, seed):
+    """Smooth gradients, hard edges and noise: every quantisation / subsampling path sees signal."""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:height, 0:width]
+    r = 127 + 120 * np.sin(x * 0.21 + seed) * np.cos(y * 0.13)
+    g = (x * 255 / max(1, width - 1) + rng.normal(0, 18, (height, width)))
+    b = np.where(((x // 5) + (y // 7)) % 2 == 0, 230, 25) + rng.normal(0, 6, (height, width))
+    return np.clip(np.stack([r, g, b], axis=-1), 0, 255).astype(np.uint8)
+
+
+JPEG_CASES = [
+    # name, size, mode, save arguments
+    ("q90_444", (37, 23), "RGB", dict(quality=90, subsampling=0)),
+    ("q75_420", (64, 48), "RGB", dict(quality=75, subsampling=2)),
+    ("q50_422_odd", (45, 31), "RGB", dict(quality=50, subsampling=1)),
+    ("q95_420_odd", (33, 17), "RGB", dict(quality=95, subsampling=2, optimize=True)),
+    ("grey", (29, 40), "L", dict(quality=85)),
+    ("progressive_420", (52, 39), "RGB", dict(quality=80, subsampling=2, progressive=True)),
+    ("progressive_444_grey", (24, 24), "L", dict(quality=60, progressive=True)),
+    ("restart_420", (72, 40), "RGB", dict(quality=70, subsampling=2, restart_marker_blocks=3)),
+    ("restart_rows_444", (40, 40), "RGB", dict(quality=88, subsampling=0, restart_marker_rows=1)),
+    ("one_pixel", (1, 1), "RGB", dict(quality=90)),
+    ("block_8x8_q10", (8, 8), "RGB", dict(quality=10, subsampling=2)),
+    ("wide_strip", (200, 3), "RGB", dict(quality=92, subsampling=2)),
+]
+
+
+def write_jpeg(path, size, mode, arguments, seed):
+    from PIL import Image
+    picture = make_picture(size[0], size[1], seed)
+    image = Image.fromarray(picture if mode == "RGB" else picture[..., 1], mode)
+    image.save(path, "JPEG", **arguments)
+
+
+def write_hdr(path, pixels, run_length_encoded=True, magic=b"#?RADIANCE"):
+    """pixels: (h, w, 4) uint8 RGBE. New-style run-length encoding per scanline, or flat quadruples."""
+    h, w, _ = pixels.shape
+    out = bytearray(magic + b"\n# written by the test\nFORMAT=32-bit_rle_rgbe\nEXPOSURE=1.0\n\n" + f"-Y {h} +X {w}\n".encode())
+    for row in pixels:
+        if not run_length_encoded:
+            out += row.tobytes()
+            continue
+        out += bytes([2, 2, w >> 8, w & 255])
+        for channel in range(4):
+            plane = row[:, channel]
+            i = 0
+            while i < w:
+                run = 1
+                while i + run < w and run < 127 and plane[i + run] == plane[i]:
+                    run += 1
+                if run >= 3:
+                    out += bytes([128 + run, plane[i]])
+                    i += run
+                else:
+                    literal = 1
+                    while i + literal < w and literal < 128 and not (i + literal + 2 < w and plane[i + literal] == plane[i + literal + 1] == plane[i + literal + 2]):
+                        literal += 1
+                    out += bytes([literal]) + plane[i:i + literal].tobytes()
+                    i += literal
+    Path(path).write_bytes(bytes(out))
+
+
+def hdr_picture(width, height, seed):
+    rng = np.random.default_rng(seed)
+    rgbe = rng.integers(0, 256, (height, width, 4)).astype(np.uint8)
+    rgbe[..., 3] = rng.integers(118, 140, (height, width))
+    rgbe[:, : width // 3, 0] = 77            # long runs
+    rgbe[height // 2, :, 3] = 0              # a black row (exponent 0)
+    rgbe[0, :, :] = rgbe[0, 0, :]            # a constant scanline
+    return rgbe
+
+
+HDR_CASES = [("rle_64x20", (64, 20), True, b"#?RADIANCE"), ("rle_9x5_rgbe_magic", (9, 5), True, b"#?RGBE"), ("flat_narrow_5x7", (5, 7), False, b"#?RADIANCE"),
+             ("flat_wide_40x6", (40, 6), False, b"#?RADIANCE")]
+
+
+@pytest.mark.skipif(not reference_bindings.available(), reason="oracle/_ref is not built (no /root/reference)")
+@pytest.mark.parametrize("name,size,mode,arguments", JPEG_CASES)
+def test_jpeg_decoder_equals_the_reference_loader(tmp_path, name, size, mode, arguments):
+    pytest.importorskip("PIL.Image")
+    path = tmp_path / f"{name}.jpg"
+    write_jpeg(path, size, mode, arguments, seed=len(name))
+    mine, reference = host_load(path), reference_load(path)
+    assert reference is not None and mine is not None
+    assert mine.shape == reference.shape == (size[1], size[0], 3 if mode == "RGB" else 1)
+    assert np.array_equal(mine, reference), int(np.abs(mine.astype(int) - reference.astype(int)).max())
+
+
+@pytest.mark.skipif(not reference_bindings.available(), reason="oracle/_ref is not built (no /root/reference)")
+@pytest.mark.parametrize("name,size,rle,magic", HDR_CASES)
+def test_hdr_decoder_equals_the_reference_loader(tmp_path, name, size, rle, magic):
+    path = tmp_path / f"{name}.hdr"
+    write_hdr(path, hdr_picture(size[0], size[1], len(name)), rle, magic)
+    mine, reference = host_load(path), reference_load(path)
+    assert reference is not None and mine is not None and mine.dtype == np.float32
+    assert mine.shape == reference.shape == (size[1], size[0], 3)
+    assert np.array_equal(mine.view(np.uint32), reference.view(np.uint32))
+    assert mine.max() > 1.0 and (mine == 0).any()
+
+
+def test_decoders_reproduce_the_golden_vectors():
+    """Files and the pixels the reference's loader made of them, committed (tests/golden/make_image_goldens.py): runs where the reference tree is absent."""
+    expected = np.load(GOLDEN / "expected.npz")
+    files = sorted(p for p in GOLDEN.iterdir() if p.suffix in (".jpg", ".hdr"))
+    assert len(files) >= 8
+    for path in files:
+        mine = host_load(path)
+        assert mine is not None, path.name
+        reference = expected[path.name]
+        assert mine.shape == reference.shape and mine.dtype == reference.dtype, path.name
+        assert np.array_equal(mine.view(np.uint8), reference.view(np.uint8)), path.name
+
+
+def test_loader_rejects_what_it_cannot_decode(tmp_path):
+    bad = tmp_path / "truncated.jpg"
+    bad.write_bytes(b"\xff\xd8\xff\xe0\x00\x10JFIF\x00")
+    assert host_load(bad) is None
+    arithmetic = tmp_path / "arithmetic.jpg"
+    arithmetic.write_bytes(b"\xff\xd8\xff\xc9\x00\x0b\x08\x00\x08\x00\x08\x01\x01\x11\x00\xff\xd9")
+    assert host_load(arithmetic) is None
+    hdr = tmp_path / "bad.hdr"
+    hdr.write_bytes(b"#?RADIANCE\nFORMAT=32-bit_rle_xyze\n\n-Y 2 +X 2\n" + bytes(16))
+    assert host_load(hdr) is None
+    assert host_load(tmp_path / "absent.jpg") is None
+
+
+def test_environment_map_and_jpeg_textures_reach_the_flattened_scene(tmp_path):
+    """SimpleViewer's --environment-map (main.cpp:331-341) with a Radiance file and an OBJ whose material names a .jpg texture: the scene
+    description carries the presampled environment light and the decoded texture."""
+    pytest.importorskip("PIL.Image")
+    from bifrost3d_amd import capi
+    lib = load_host_library()
+    lib.hiprh_scene_load_with_environment.argtypes = [C.c_char_p, C.c_char_p, C.c_uint]
+    lib.hiprh_scene_load_with_environment.restype = C.c_void_p
+    write_jpeg(tmp_path / "wood.jpg", (16, 16), "RGB", dict(quality=90, subsampling=0), seed=3)
+    (tmp_path / "quad.mtl").write_text("newmtl wood\nKd 1 1 1\nmap_Kd wood.jpg\n")
+    (tmp_path / "quad.obj").write_text("mtllib quad.mtl\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nusemtl wood\nf 1/1 2/2 3/3\nf 1/1 3/3 4/4\n")
+    sky = np.zeros((16, 32, 4), np.uint8)
+    sky[..., :3] = 90
+    sky[..., 3] = 128
+    sky[2:4, 5:8] = (250, 240, 200, 134)       # a sun
+    write_hdr(tmp_path / "sky.hdr", sky)
+    handle = lib.hiprh_scene_load_with_environment(str(tmp_path / "quad.obj").encode(), str(tmp_path / "sky.hdr").encode(), 0)
+    assert handle
+    try:
+        desc = lib.hiprh_scene_desc(handle).contents
+        assert desc.triangle_count == 2 and bool(desc.environment)
+        env = desc.environment.contents
+        assert env.sample_count >= 2 and desc.textures[env.environment_map_ID].format == 20 and desc.textures[env.environment_map_ID].width == 32     # RGBA32F
+        assert desc.light_count == 1 and (desc.lights[0].flags & 7) == 4          # only the presampled environment: no default directional light
+        wood = [desc.textures[i] for i in range(1, desc.texture_count) if desc.textures[i].width == 16]
+        assert len(wood) == 1 and wood[0].format == 4 and wood[0].is_sRGB == 1    # RGB24 expanded to RGBA8
+        assert capi.load_library().hipr_validate_scene(C.byref(desc)) == 0
+    finally:
+        lib.hiprh_scene_destroy(handle)
