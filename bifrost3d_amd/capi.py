@@ -130,7 +130,7 @@ assert C.sizeof(HiprTexture) == 24 and C.sizeof(HiprCameraState) == 180 and C.si
 # Every symbol include/hiprenderer_c.h declares; tests check the library exports all of them.
 C_ABI_SYMBOLS = (
     "hipr_create", "hipr_destroy", "hipr_last_error", "hipr_device_count", "hipr_set_stream",
-    "hipr_upload_tables", "hipr_upload_scene", "hipr_validate_scene", "hipr_set_scene_state", "hipr_set_entry_point", "hipr_use_scratch_accumulation",
+    "hipr_upload_tables", "hipr_upload_scene", "hipr_validate_scene", "hipr_update_scene_geometry", "hipr_group_update_scene_geometry", "hipr_set_scene_state", "hipr_set_entry_point", "hipr_use_scratch_accumulation",
     "hipr_set_frame", "hipr_owned_pixel_count",
     "hipr_render_pass", "hipr_set_samples_per_pass", "hipr_trace_pass", "hipr_accumulate_samples", "hipr_read_accumulation", "hipr_scatter_tiles", "hipr_synchronize", "hipr_get_counters",
     "hipr_device_malloc", "hipr_device_free", "hipr_copy_to_host", "hipr_present_flipped",
@@ -173,6 +173,8 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.hipr_upload_tables.argtypes = [vp, C.POINTER(HiprTables)]
     lib.hipr_upload_scene.argtypes = [vp, C.POINTER(HiprSceneDesc)]
     lib.hipr_validate_scene.argtypes = [C.POINTER(HiprSceneDesc)]
+    lib.hipr_update_scene_geometry.argtypes = [vp, C.POINTER(HiprSceneDesc)]
+    lib.hipr_group_update_scene_geometry.argtypes = [vp, C.POINTER(HiprSceneDesc)]
     lib.hipr_set_scene_state.argtypes = [vp, C.POINTER(HiprSceneState)]
     lib.hipr_set_entry_point.argtypes = [vp, C.c_int]
     lib.hipr_use_scratch_accumulation.argtypes = [vp, C.c_int]

@@ -157,6 +157,11 @@ int hipr_group_upload_scene(HiprGroup* g, const HiprSceneDesc* scene) {
     return for_each_member(g->members, [&](Member& m, uint32_t) { return hipr_upload_scene(m.context, scene); });   // replicated: every device walks the same BVH
 }
 
+int hipr_group_update_scene_geometry(HiprGroup* g, const HiprSceneDesc* scene) {
+    if (!g) return HIPR_ERROR_INVALID_ARGUMENT;
+    return for_each_member(g->members, [&](Member& m, uint32_t) { return hipr_update_scene_geometry(m.context, scene); });
+}
+
 int hipr_group_set_scene_state(HiprGroup* g, const HiprSceneState* state) {
     if (!g) return HIPR_ERROR_INVALID_ARGUMENT;
     for (Member& m : g->members)

@@ -112,6 +112,7 @@ struct HiprContext {
     DeviceBuffer ggx_rho, dielectric_rho, alpha, sample_offsets, sobol_tables;
     DeviceScene scene = {};
     bool tables_ready = false, scene_ready = false;
+    size_t uploaded_instance_bytes = 0;
     int stack_size = 16;
     int shading_models = 7;             // bit mask of the shading models the scene's instances reference
 
@@ -464,6 +465,34 @@ float reverse_halton(int prime, int i) {
     return float(h);
 }
 
+// What the kernels read per triangle is derived on the device from the uploaded pools: the shading records (k_build_shade_triangles), the
+// vertex + edges form the trace kernels test (k_build_trace_triangles) and, for scenes searched exhaustively, the items (build_trace_items).
+int build_derived_geometry(HiprContext* c, const HiprSceneDesc* s) {
+    DeviceScene& d = c->scene;
+    hipStream_t st = c->stream;
+    if (s->triangle_count) {   // flatten the per-hit attribute chain into one record per triangle
+        if (c->shade_triangles.resize(size_t(s->triangle_count) * SHADE_TRIANGLE_QUADS * sizeof(float4))) return HIPR_ERROR_OUT_OF_MEMORY;
+        d.shade_triangles = c->shade_triangles.as<float4>();
+        hipLaunchKernelGGL(k_build_shade_triangles, dim3((s->triangle_count + 255) / 256), dim3(256), 0, st, d, c->shade_triangles.as<float4>());
+        if (c->trace_triangles.resize(size_t(s->triangle_count) * 3 * sizeof(float4))) return HIPR_ERROR_OUT_OF_MEMORY;
+        d.trace_triangles = c->trace_triangles.as<float4>();
+        hipLaunchKernelGGL(k_build_trace_triangles, dim3((s->triangle_count + 255) / 256), dim3(256), 0, st, d.triangles, s->triangle_count, c->trace_triangles.as<float4>());
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    d.trace_items = nullptr;
+    d.trace_item_count = 0;
+    if (s->triangle_count && (s->triangle_count <= SMALL_SCENE_TRIANGLES || c->trace_variant == HIPR_TRACE_EXHAUSTIVE)) {
+        std::vector<float> items;
+        build_trace_items(s->triangles, s->triangle_count, items);
+        if (c->trace_items.upload(items.data(), items.size() * sizeof(float), st)) return HIPR_ERROR_OUT_OF_MEMORY;
+        HIP_TRY(hipStreamSynchronize(st));
+        d.trace_items = c->trace_items.as<float4>();
+        d.trace_item_count = uint32_t(items.size() / 16);
+    }
+    return HIPR_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -667,26 +696,7 @@ int hipr_upload_scene(HiprContext* c, const HiprSceneDesc* s) {
     d.node_count = s->node_count;
     d.triangle_count = s->triangle_count;
     d.light_count = s->light_count;
-    if (s->triangle_count) {   // flatten the per-hit attribute chain into one record per triangle
-        if (c->shade_triangles.resize(size_t(s->triangle_count) * SHADE_TRIANGLE_QUADS * sizeof(float4))) return HIPR_ERROR_OUT_OF_MEMORY;
-        d.shade_triangles = c->shade_triangles.as<float4>();
-        hipLaunchKernelGGL(k_build_shade_triangles, dim3((s->triangle_count + 255) / 256), dim3(256), 0, st, d, c->shade_triangles.as<float4>());
-        if (c->trace_triangles.resize(size_t(s->triangle_count) * 3 * sizeof(float4))) return HIPR_ERROR_OUT_OF_MEMORY;
-        d.trace_triangles = c->trace_triangles.as<float4>();
-        hipLaunchKernelGGL(k_build_trace_triangles, dim3((s->triangle_count + 255) / 256), dim3(256), 0, st, d.triangles, s->triangle_count, c->trace_triangles.as<float4>());
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(st));
-    }
-    d.trace_items = nullptr;
-    d.trace_item_count = 0;
-    if (s->triangle_count && (s->triangle_count <= SMALL_SCENE_TRIANGLES || c->trace_variant == HIPR_TRACE_EXHAUSTIVE)) {
-        std::vector<float> items;
-        build_trace_items(s->triangles, s->triangle_count, items);
-        if (c->trace_items.upload(items.data(), items.size() * sizeof(float), st)) return HIPR_ERROR_OUT_OF_MEMORY;
-        HIP_TRY(hipStreamSynchronize(st));
-        d.trace_items = c->trace_items.as<float4>();
-        d.trace_item_count = uint32_t(items.size() / 16);
-    }
+    if (int status = build_derived_geometry(c, s)) return status;
     c->stack_size = s->bvh_max_depth <= 16 ? 16 : (s->bvh_max_depth <= 32 ? 32 : 64);
     int models = 0;
     for (uint32_t i = 0; i < s->instance_count; ++i) {
@@ -695,8 +705,34 @@ int hipr_upload_scene(HiprContext* c, const HiprSceneDesc* s) {
         models |= 1 << std::min<int>(s->materials[m].shading_model, 2);
     }
     c->shading_models = models ? models : 7;
+    c->uploaded_instance_bytes = size_t(s->instance_count) * sizeof(HiprInstance);
     c->scene_ready = true;
     return HIPR_OK;
+}
+
+int hipr_update_scene_geometry(HiprContext* c, const HiprSceneDesc* s) {
+    if (int st = check_context(c)) return st;
+    if (!s) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_update_scene_geometry: null scene");
+    if (!c->scene_ready) return fail(HIPR_ERROR_NOT_READY, "hipr_update_scene_geometry: no scene uploaded");
+    const DeviceScene& d = c->scene;
+    if (s->node_count != d.node_count || s->triangle_count != d.triangle_count || (s->wide_nodes ? s->wide_node_count : 0u) != d.wide_node_count || s->light_count != d.light_count ||
+        size_t(s->instance_count) * sizeof(HiprInstance) != c->uploaded_instance_bytes)
+        return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_update_scene_geometry: node, triangle, instance and light counts must equal the uploaded scene's (a refit keeps the topology)");
+    uint32_t wide_stack_need = 0;
+    char invalid[256];
+    if (validate_scene(s, wide_stack_need, invalid, sizeof(invalid))) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_update_scene_geometry: %s", invalid);
+    if (wide_stack_need != c->wide_stack_entries) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_update_scene_geometry: the wide BVH's topology changed");
+    for (int g = 0; g < MAX_WAVEFRONTS; ++g) if (c->wavefronts[g].stream) HIP_TRY(hipStreamSynchronize(c->wavefronts[g].stream));
+    hipStream_t st = c->stream;
+    int r = 0;
+    r |= c->nodes.upload(s->nodes, size_t(s->node_count) * sizeof(HiprBvhNode), st);
+    if (d.wide_node_count) r |= c->wide_nodes.upload(s->wide_nodes, size_t(s->wide_node_count) * sizeof(HiprWideNode), st);
+    r |= c->triangles.upload(s->triangles, size_t(s->triangle_count) * sizeof(HiprTriangle), st);
+    r |= c->instances.upload(s->instances, size_t(s->instance_count) * sizeof(HiprInstance), st);
+    r |= c->lights.upload(s->lights, size_t(s->light_count) * sizeof(HiprLight), st);
+    if (r) return r < 0 ? r : HIPR_ERROR_HIP;
+    HIP_TRY(hipStreamSynchronize(st));
+    return build_derived_geometry(c, s);
 }
 
 int hipr_set_scene_state(HiprContext* c, const HiprSceneState* state) {

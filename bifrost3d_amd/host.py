@@ -26,6 +26,7 @@ def load_host_library() -> C.CDLL:
     lib.hiprh_png_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_ubyte), C.c_size_t]
     lib.hiprh_png_load.restype = C.c_size_t
     lib.hiprh_make_camera.argtypes = [C.POINTER(C.c_float), C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.POINTER(capi.HiprCameraState)]
+    lib.hiprh_scene_move_model.argtypes = [vp, C.c_uint, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_double]
     lib.hiprh_scene_destroy.argtypes = [vp]
     lib.hiprh_scene_desc.argtypes = [vp]
     lib.hiprh_scene_desc.restype = C.POINTER(capi.HiprSceneDesc)
@@ -108,6 +109,15 @@ class Scene:
             raise capi.HiprError("hiprh_scene_camera failed")
         cam.path_regularization_scale_decay = scale_decay
         return cam
+
+    def move_model(self, model_index: int, translation, rotation=(0.0, 0.0, 0.0, 1.0), scale: float = 1.0, rebuild_threshold: float = 0.0) -> bool:
+        """Transform-only update (BVH refit). True when the topology was kept, False when the scene builder rebuilt the tree."""
+        t = (C.c_float * 3)(*translation)
+        r = (C.c_float * 4)(*rotation)
+        status = self.lib.hiprh_scene_move_model(self.handle, model_index, t, r, scale, rebuild_threshold)
+        if status < 0:
+            raise capi.HiprError("hiprh_scene_move_model failed")
+        return status == 1
 
     def triangles(self) -> np.ndarray:
         d = self.desc

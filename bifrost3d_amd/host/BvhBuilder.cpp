@@ -163,6 +163,38 @@ struct Builder {
     }
 };
 
+// The quantised child boxes of a wide node: origin = the low corner of the union, one power-of-two grid per axis, 8 bit bounds rounded
+// outwards (checked in f64) so that the decoded boxes contain the exact ones. Shared by the build and the refit.
+static void quantise_children(const Box* boxes, size_t count, HiprWideNode& w) {
+    Box all; all.reset();
+    for (size_t k = 0; k < count; ++k) all.grow(boxes[k]);
+    uint32_t q[2][3] = {{0, 0, 0}, {0, 0, 0}};
+    w.exponents = 0;
+    for (int a = 0; a < 3; ++a) {
+        w.origin[a] = all.lo[a];
+        const double origin = all.lo[a], extent = double(all.hi[a]) - origin;
+        int e = extent > 0.0 ? int(std::ceil(std::log2(extent / 255.0))) : -126;
+        e = std::max(e, -126);
+        for (;; ++e) {   // grow the grid until every bound fits in [0, 255] after rounding outwards
+            const double scale = std::ldexp(1.0, e);
+            bool fits = true;
+            uint32_t qa[2] = {0, 0};
+            for (size_t k = 0; k < count && fits; ++k) {
+                double lo = std::floor((double(boxes[k].lo[a]) - origin) / scale), hi = std::ceil((double(boxes[k].hi[a]) - origin) / scale);
+                while (lo > 0.0 && origin + lo * scale > double(boxes[k].lo[a])) lo -= 1.0;
+                while (origin + hi * scale < double(boxes[k].hi[a])) hi += 1.0;
+                lo = std::max(lo, 0.0);
+                if (hi > 255.0) { fits = false; break; }
+                qa[0] |= uint32_t(lo) << (8 * k);
+                qa[1] |= uint32_t(hi) << (8 * k);
+            }
+            if (fits) { q[0][a] = qa[0]; q[1][a] = qa[1]; break; }
+        }
+        w.exponents |= uint32_t(e + 127) << (8 * a);
+    }
+    for (int a = 0; a < 3; ++a) { w.qlo[a] = q[0][a]; w.qhi[a] = q[1][a]; }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Collapse to compressed 4-wide nodes: a node adopts the children of its largest inner child until it has four, then the
 // child boxes are quantised to 8 bits per bound on the node's own grid, rounding outwards.
@@ -218,32 +250,9 @@ struct WideCollapse {
         const uint32_t index = uint32_t(wide.size());
         wide.emplace_back();
         HiprWideNode w = {};
-        Box all; all.reset();
-        for (const Child& ch : children) all.grow(ch.box);
-        uint32_t q[2][3] = {{0, 0, 0}, {0, 0, 0}};
-        for (int a = 0; a < 3; ++a) {
-            w.origin[a] = all.lo[a];
-            const double origin = all.lo[a], extent = double(all.hi[a]) - origin;
-            int e = extent > 0.0 ? int(std::ceil(std::log2(extent / 255.0))) : -126;
-            e = std::max(e, -126);
-            for (;; ++e) {   // grow the grid until every bound fits in [0, 255] after rounding outwards
-                const double scale = std::ldexp(1.0, e);
-                bool fits = true;
-                uint32_t qa[2] = {0, 0};
-                for (size_t k = 0; k < children.size() && fits; ++k) {
-                    double lo = std::floor((double(children[k].box.lo[a]) - origin) / scale), hi = std::ceil((double(children[k].box.hi[a]) - origin) / scale);
-                    while (lo > 0.0 && origin + lo * scale > double(children[k].box.lo[a])) lo -= 1.0;
-                    while (origin + hi * scale < double(children[k].box.hi[a])) hi += 1.0;
-                    lo = std::max(lo, 0.0);
-                    if (hi > 255.0) { fits = false; break; }
-                    qa[0] |= uint32_t(lo) << (8 * k);
-                    qa[1] |= uint32_t(hi) << (8 * k);
-                }
-                if (fits) { q[0][a] = qa[0]; q[1][a] = qa[1]; break; }
-            }
-            w.exponents |= uint32_t(e + 127) << (8 * a);
-        }
-        for (int a = 0; a < 3; ++a) { w.qlo[a] = q[0][a]; w.qhi[a] = q[1][a]; }
+        Box child_boxes[4];
+        for (size_t k = 0; k < children.size(); ++k) child_boxes[k] = children[k].box;
+        quantise_children(child_boxes, children.size(), w);
 
         stack_need = 0;
         for (int k = 0; k < 4; ++k) w.child[k] = HIPR_WIDE_EMPTY;
@@ -304,6 +313,64 @@ BvhBuildResult build_bvh(const std::vector<HiprTriangle>& triangles, uint32_t ma
     result.wide_nodes = std::move(collapse.wide);
     result.max_depth = b.deepest + 1;   // stack entries needed is bounded by the node depth; keep one spare
     return result;
+}
+
+// Refit: same topology and triangle order, new triangle positions (a transform-only scene update; the reference refits its root
+// acceleration structure the same way, OR/Renderer.cpp:472,1010-1041). Nodes are stored parent before children, so one sweep from the
+// last node to the first sees every child box up to date. Returns the sum of the BVH2 child box half-areas, a SAH-style quality
+// figure the caller compares with the build's to decide when a moved scene deserves a new tree.
+double refit_bvh(BvhBuildResult& bvh, const std::vector<HiprTriangle>& triangles) {
+    auto triangle_bounds = [&](int32_t leaf) {
+        const uint32_t code = uint32_t(~leaf), first = code >> 3, count = (code & 7u) + 1u;
+        Box b; b.reset();
+        for (uint32_t t = first; t < first + count; ++t) { b.grow(triangles[t].v0); b.grow(triangles[t].v1); b.grow(triangles[t].v2); }
+        return b;
+    };
+    auto node_bounds = [&](const HiprBvhNode& n) {
+        Box b;
+        b.lo[0] = std::min(n.c0xy[0], n.c1xy[0]); b.hi[0] = std::max(n.c0xy[1], n.c1xy[1]);
+        b.lo[1] = std::min(n.c0xy[2], n.c1xy[2]); b.hi[1] = std::max(n.c0xy[3], n.c1xy[3]);
+        b.lo[2] = std::min(n.cz[0], n.cz[2]); b.hi[2] = std::max(n.cz[1], n.cz[3]);
+        return b;
+    };
+    double area = 0.0;
+    for (size_t i = bvh.nodes.size(); i-- > 0;) {
+        HiprBvhNode& n = bvh.nodes[i];
+        for (int c = 0; c < 2; ++c) {
+            const int32_t ref = n.child[c];
+            const Box box = ref < 0 ? triangle_bounds(ref) : node_bounds(bvh.nodes[size_t(ref)]);
+            Builder::store_child(n, c, box, ref);
+            area += box.half_area();
+        }
+    }
+    std::vector<Box> exact(bvh.wide_nodes.size());
+    for (size_t i = bvh.wide_nodes.size(); i-- > 0;) {
+        HiprWideNode& w = bvh.wide_nodes[i];
+        Box boxes[4];
+        size_t count = 0;
+        int32_t refs[4];
+        for (int k = 0; k < 4; ++k) {
+            if (w.child[k] == HIPR_WIDE_EMPTY) continue;
+            refs[count] = w.child[k];
+            boxes[count++] = w.child[k] < 0 ? triangle_bounds(w.child[k]) : exact[size_t(w.child[k])];
+        }
+        exact[i].reset();
+        for (size_t k = 0; k < count; ++k) exact[i].grow(boxes[k]);
+        quantise_children(boxes, count, w);      // the non-empty children occupy the first `count` slots, as the build left them
+        (void)refs;
+    }
+    return area;
+}
+
+double bvh_child_area(const BvhBuildResult& bvh) {
+    double area = 0.0;
+    for (const HiprBvhNode& n : bvh.nodes) {
+        Box a, b;
+        a.lo[0] = n.c0xy[0]; a.hi[0] = n.c0xy[1]; a.lo[1] = n.c0xy[2]; a.hi[1] = n.c0xy[3]; a.lo[2] = n.cz[0]; a.hi[2] = n.cz[1];
+        b.lo[0] = n.c1xy[0]; b.hi[0] = n.c1xy[1]; b.lo[1] = n.c1xy[2]; b.hi[1] = n.c1xy[3]; b.lo[2] = n.cz[2]; b.hi[2] = n.cz[3];
+        area += a.half_area() + b.half_area();
+    }
+    return area;
 }
 
 } // namespace HIPRenderer

@@ -99,6 +99,23 @@ static ImageData convert_image(ImageID image_ID) {   // OR/Renderer.cpp:650-701:
     return out;
 }
 
+// Dense light array in ID order (light_creation, OR/Renderer.cpp:855-902).
+static std::vector<HiprLight> collect_lights() {
+    std::vector<HiprLight> lights;
+    for (LightSourceID light_ID : LightSources::get_iterable()) {
+        Transform t = SceneNodes::get_global_transform(LightSources::get_node_ID(light_ID));
+        RGB power = LightSources::get_power(light_ID);
+        switch (LightSources::get_type(light_ID)) {
+        case LightSources::Type::Sphere: lights.push_back(SceneBuilder::sphere_light(t.translation, power, LightSources::get_radius(light_ID))); break;
+        case LightSources::Type::Spot:
+            lights.push_back(SceneBuilder::spot_light(t.translation, t.rotation.forward(), power, LightSources::get_radius(light_ID), LightSources::get_cos_angle(light_ID)));
+            break;
+        case LightSources::Type::Directional: lights.push_back(SceneBuilder::directional_light(t.rotation.forward(), power)); break;
+        }
+    }
+    return lights;
+}
+
 void flatten_bifrost_scene(SceneBuilder& sb) {
 
     // Textures and materials keep their Bifrost indices (slot 0 = invalid), like the reference's per-ID arrays.
@@ -139,18 +156,7 @@ void flatten_bifrost_scene(SceneBuilder& sb) {
         sb.add_model(it->second, model.get_material().get_ID().get_index(), model.get_scene_node().get_global_transform(), model_ID.get_index());
     }
 
-    // Dense light array in ID order (light_creation, OR/Renderer.cpp:855-902).
-    for (LightSourceID light_ID : LightSources::get_iterable()) {
-        Transform t = SceneNodes::get_global_transform(LightSources::get_node_ID(light_ID));
-        RGB power = LightSources::get_power(light_ID);
-        switch (LightSources::get_type(light_ID)) {
-        case LightSources::Type::Sphere: sb.add_light(SceneBuilder::sphere_light(t.translation, power, LightSources::get_radius(light_ID))); break;
-        case LightSources::Type::Spot:
-            sb.add_light(SceneBuilder::spot_light(t.translation, t.rotation.forward(), power, LightSources::get_radius(light_ID), LightSources::get_cos_angle(light_ID)));
-            break;
-        case LightSources::Type::Directional: sb.add_light(SceneBuilder::directional_light(t.rotation.forward(), power)); break;
-        }
-    }
+    for (const HiprLight& light : collect_lights()) sb.add_light(light);
     // Environment map of the scene (OR/Renderer.cpp:1136-1160): only four channel images, importance sampled through presampled lights.
     for (SceneRootID scene_ID : SceneRoots::get_iterable()) {
         const TextureID environment_map = SceneRoots::get_environment_map(scene_ID);
@@ -183,6 +189,7 @@ struct Renderer::Implementation {
         Matrix4x4f inverse_view_projection_matrix = Matrix4x4f::identity();
         Backend backend = Backend::None;
         bool scene_uploaded = false;
+        bool geometry_update_pending = false;   // the uploaded scene's instances / lights moved: hipr_update_scene_geometry, not a new upload
         // Progressive batching (render()): samples [batch_used, batch_size) of the pass traced from accumulation batch_first are waiting
         // in the context's per-sample radiance buffer; they stay valid while nothing that shaped them changes.
         unsigned int batch_first = 0, batch_size = 0, batch_used = 0;
@@ -245,6 +252,7 @@ struct Renderer::Implementation {
         if (!scene) rebuild_scene();
         if (hipr_group_upload_scene(c.context, &scene->desc()) != HIPR_OK) return false;
         c.scene_uploaded = true;
+        c.geometry_update_pending = false;
         c.drop_batch();
         return true;
     }
@@ -284,14 +292,24 @@ struct Renderer::Implementation {
             auto changes = Materials::get_changes(material_ID);
             if (changes.any_set(Materials::Change::Created, Materials::Change::Updated, Materials::Change::ShadingModel)) { scene_dirty = true; should_reset_accumulations = true; }
         }
-        if (!LightSources::get_changed_lights().is_empty()) { scene_dirty = true; should_reset_accumulations = true; }   // :852-1008
+        // Lights (:852-1008): created or destroyed lights change the light count (a new scene description); updated ones are replaced in place.
+        bool lights_moved = false;
+        for (LightSourceID light_ID : LightSources::get_changed_lights()) {
+            if (LightSources::get_changes(light_ID).any_set(LightSources::Change::Created, LightSources::Change::Destroyed)) scene_dirty = true;
+            else lights_moved = true;
+            should_reset_accumulations = true;
+        }
 
-        for (SceneNodeID node_ID : SceneNodes::get_changed_nodes()) {   // :1010-1041, only nodes that carry renderables or lights matter
+        // Moved nodes (:1010-1041; only nodes that carry renderables or lights matter). The reference updates the node's transform and
+        // marks the root acceleration structure dirty, which OptiX REFITS (:472); here the scene's world-space triangles of the moved
+        // models are recomputed and the BVH is refitted (SceneBuilder::update_model_transforms), the rest of the scene stays as uploaded.
+        std::vector<std::pair<uint32_t, Transform>> moved_models;
+        for (SceneNodeID node_ID : SceneNodes::get_changed_nodes()) {
             if (!SceneNodes::get_changes(node_ID).contains(SceneNodes::Change::Transform)) continue;
-            bool used = false;
-            for (MeshModelID m : MeshModels::get_iterable()) used |= MeshModels::get_scene_node_ID(m) == node_ID;
-            for (LightSourceID l : LightSources::get_iterable()) used |= LightSources::get_node_ID(l) == node_ID;
-            if (used) { scene_dirty = true; should_reset_accumulations = true; }
+            for (MeshModelID m : MeshModels::get_iterable())
+                if (MeshModels::get_scene_node_ID(m) == node_ID) { moved_models.emplace_back(m.get_index(), SceneNodes::get_global_transform(node_ID)); should_reset_accumulations = true; }
+            for (LightSourceID l : LightSources::get_iterable())
+                if (LightSources::get_node_ID(l) == node_ID) { lights_moved = true; should_reset_accumulations = true; }
         }
         for (MeshModelID model_ID : MeshModels::get_changed_models())   // :1043-1110
             if (MeshModels::get_changes(model_ID).any_set(MeshModels::Change::Created, MeshModels::Change::Destroyed, MeshModels::Change::Material)) {
@@ -317,6 +335,18 @@ struct Renderer::Implementation {
             }
         }
 
+        if (!scene_dirty && scene && (!moved_models.empty() || lights_moved)) {
+            // transform-only tick: refit in place; a tree the motion has stretched too far is rebuilt by the scene builder itself
+            if (lights_moved && !scene->replace_lights(collect_lights())) scene_dirty = true;      // the light count changed after all
+            else {
+                const bool topology_kept = moved_models.empty() || scene->update_model_transforms(moved_models);
+                for (CameraState& c : per_camera_state) {
+                    if (topology_kept) c.geometry_update_pending = c.scene_uploaded;
+                    else c.scene_uploaded = false;
+                    c.drop_batch();
+                }
+            }
+        }
         if (scene_dirty) scene.reset();   // rebuilt lazily by the next render
         if (scene_dirty)
             for (CameraState& c : per_camera_state) c.scene_uploaded = false;
@@ -332,6 +362,11 @@ struct Renderer::Implementation {
             if (!state.context) return false;
         }
         if (!state.scene_uploaded && !upload_scene_to(state)) return false;
+        if (state.geometry_update_pending) {
+            if (!scene || hipr_group_update_scene_geometry(state.context, &scene->desc()) != HIPR_OK) { if (!upload_scene_to(state)) return false; }
+            state.geometry_update_pending = false;
+            state.drop_batch();
+        }
         if (frame_size.x != state.frame_size.x || frame_size.y != state.frame_size.y) {
             if (hipr_group_set_frame(state.context, uint32_t(frame_size.x), uint32_t(frame_size.y), 1) != HIPR_OK) return false;
             state.frame_size = frame_size;

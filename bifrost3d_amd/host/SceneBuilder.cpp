@@ -179,7 +179,9 @@ void SceneBuilder::finalize(uint32_t bvh_max_depth) {
         }
     }
 
+    m_bvh_max_depth_limit = bvh_max_depth;
     m_bvh = build_bvh(world, bvh_max_depth);
+    m_built_bvh_area = bvh_child_area(m_bvh);
     m_triangles.resize(world.size());
     for (size_t k = 0; k < world.size(); ++k) m_triangles[k] = world[m_bvh.order[k]];
 
@@ -203,6 +205,47 @@ void SceneBuilder::finalize(uint32_t bvh_max_depth) {
     m_environment.per_pixel_PDF = m_environment_PDF.data();
     m_environment.samples = m_environment_samples.data();
     d.environment = m_has_environment ? &m_environment : nullptr;
+}
+
+bool SceneBuilder::update_model_transforms(const std::vector<std::pair<uint32_t, Transform>>& model_transforms, double rebuild_threshold) {
+    std::vector<bool> moved(m_instances.size(), false);
+    for (const auto& update : model_transforms)
+        for (size_t i = 0; i < m_instances.size(); ++i)
+            if (uint32_t(m_instances[i].instance_id) == ((1u << 30) | update.first)) {
+                Matrix3x4f m = to_matrix3x4(update.second);
+                std::memcpy(m_instances[i].object_to_world, m.begin(), sizeof(m_instances[i].object_to_world));
+                moved[i] = true;
+            }
+    m_bounds = AABB::invalid();
+    for (HiprTriangle& t : m_triangles) {
+        if (moved[t.instance_index]) {
+            const HiprInstance& inst = m_instances[t.instance_index];
+            const MeshRecord& mesh = m_meshes[m_instance_mesh[t.instance_index]];
+            const float* M = inst.object_to_world;
+            const uint32_t* idx = &m_indices[3 * size_t(mesh.index_offset + t.primitive_index)];
+            float* corners[3] = {t.v0, t.v1, t.v2};
+            for (int k = 0; k < 3; ++k) {
+                const float* p = m_geometry[mesh.vertex_offset + idx[k]].position;
+                for (int r = 0; r < 3; ++r) corners[k][r] = M[4 * r] * p[0] + M[4 * r + 1] * p[1] + M[4 * r + 2] * p[2] + M[4 * r + 3];
+            }
+        }
+        m_bounds.grow_to_contain(Vector3f(t.v0[0], t.v0[1], t.v0[2]));
+        m_bounds.grow_to_contain(Vector3f(t.v1[0], t.v1[1], t.v1[2]));
+        m_bounds.grow_to_contain(Vector3f(t.v2[0], t.v2[1], t.v2[2]));
+    }
+    const double area = refit_bvh(m_bvh, m_triangles);
+    if (m_built_bvh_area > 0.0 && area > rebuild_threshold * m_built_bvh_area) {
+        finalize(m_bvh_max_depth_limit);      // the instances already carry the new transforms
+        return false;
+    }
+    return true;
+}
+
+bool SceneBuilder::replace_lights(const std::vector<HiprLight>& lights) {
+    const size_t environment_lights = m_has_environment && m_environment_samples.size() > 1 ? 1 : 0;
+    if (lights.size() + environment_lights != m_lights.size()) return false;
+    std::copy(lights.begin(), lights.end(), m_lights.begin());      // the presampled environment light, if any, stays last
+    return true;
 }
 
 HiprCameraState make_camera_state(const CameraDescription& camera, float aspect_ratio, uint32_t accumulations, float path_regularization_PDF_scale) {

@@ -9,6 +9,7 @@
 
 #include <cstdint>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace HIPRenderer {
@@ -67,6 +68,15 @@ public:
     // Transforms every model to world space, builds the BVH and fills desc().
     void finalize(uint32_t bvh_max_depth = 62);
 
+    // Transform-only update after finalize(): the models named by their model index (add_model's return value) get new object-to-world
+    // transforms; their world-space triangles are recomputed in place (BVH leaf order kept) and the BVH is REFIT, not rebuilt -- what the
+    // reference does when a node moves (root acceleration refit, OR/Renderer.cpp:472,1010-1041). When the refit tree's box area has grown
+    // past `rebuild_threshold` times the built tree's (a badly stretched tree traverses slowly) the scene is rebuilt instead. Returns true when
+    // the topology was kept (nodes, triangle order and counts unchanged: hipr_update_scene_geometry suffices), false after a rebuild.
+    bool update_model_transforms(const std::vector<std::pair<uint32_t, Transform>>& model_transforms, double rebuild_threshold = 1.5);
+    // The lights of a finalized scene replaced one for one (moved or re-coloured lights; the count must match).
+    bool replace_lights(const std::vector<HiprLight>& lights);
+
     const HiprSceneDesc& desc() const { return m_desc; }
     const HiprSceneState& state() const { return m_state; }
     HiprSceneState& state() { return m_state; }
@@ -91,6 +101,8 @@ private:
     std::vector<uint32_t> m_instance_mesh;
     std::vector<HiprTriangle> m_triangles;
     BvhBuildResult m_bvh;
+    double m_built_bvh_area = 0.0;
+    uint32_t m_bvh_max_depth_limit = 62;
     std::vector<float> m_environment_PDF;
     std::vector<HiprLightSample> m_environment_samples;
     HiprEnvironment m_environment = {};

@@ -283,6 +283,15 @@ size_t hiprh_png_load(const char* path, int flip, unsigned* width, unsigned* hei
     return bytes;
 }
 
+// Transform-only update of a built scene (SceneBuilder::update_model_transforms): model `model_index` (1-based, in creation order for the
+// built-in scenes) gets the transform translation[3], rotation quaternion xyzw[4], uniform scale. Returns 1 when the BVH was refitted in
+// place (topology kept: hipr_update_scene_geometry suffices), 0 when the builder rebuilt the tree (upload the scene again), -1 on error.
+int hiprh_scene_move_model(void* scene, unsigned model_index, const float* translation3, const float* rotation4, float scale, double rebuild_threshold) {
+    if (!scene || !translation3 || !rotation4) return -1;
+    const Transform t(Vector3f(translation3[0], translation3[1], translation3[2]), Bifrost::Math::Quaternionf(rotation4[0], rotation4[1], rotation4[2], rotation4[3]), scale);
+    return static_cast<SceneBuilder*>(scene)->update_model_transforms({{model_index, t}}, rebuild_threshold > 0.0 ? rebuild_threshold : 1.5) ? 1 : 0;
+}
+
 void hiprh_scene_destroy(void* scene) { delete static_cast<SceneBuilder*>(scene); }
 
 const HiprSceneDesc* hiprh_scene_desc(void* scene) { return scene ? &static_cast<SceneBuilder*>(scene)->desc() : nullptr; }

@@ -41,6 +41,10 @@ class Context:
         state = scene.state
         self._check(self.lib.hipr_set_scene_state(self.handle, C.byref(state)), "hipr_set_scene_state")
 
+    def update_scene_geometry(self, scene):
+        self._scene = scene
+        self._check(self.lib.hipr_update_scene_geometry(self.handle, C.byref(scene.desc)), "hipr_update_scene_geometry")
+
     def set_scene_state(self, state: capi.HiprSceneState):
         self._check(self.lib.hipr_set_scene_state(self.handle, C.byref(state)), "hipr_set_scene_state")
 

@@ -287,6 +287,11 @@ int hipr_upload_scene(HiprContext* context, const HiprSceneDesc* scene);
  * texture extents inside the texel pool, BVH2 and wide BVH child and leaf ranges -- must be in range; HIPR_ERROR_INVALID_ARGUMENT
  * and a message in hipr_last_error() otherwise. (OptiX validates its node graph in rtContextValidate; this is the counterpart.) */
 int hipr_validate_scene(const HiprSceneDesc* scene);
+/* Transform-only update: the same scene after its host refitted the BVH to moved instances (the reference refits its root acceleration
+ * structure when a node moves, OR/Renderer.cpp:472,1010-1041). Re-uploads nodes, wide nodes, triangles, instances and lights, whose
+ * counts and tree topology must equal the uploaded scene's, and rebuilds the per-triangle records derived from them; meshes,
+ * materials, textures, environment and tables stay as uploaded. */
+int hipr_update_scene_geometry(HiprContext* context, const HiprSceneDesc* scene);
 int hipr_set_scene_state(HiprContext* context, const HiprSceneState* state);
 
 /* Entry points, numbered like OR/Types.h:33-44. set_backend() of the host renderer maps Backend values onto them
@@ -360,6 +365,7 @@ HiprContext* hipr_group_context(HiprGroup* group, uint32_t member);
 const char* hipr_group_gather_description(HiprGroup* group);   /* which transport the gather uses */
 int hipr_group_upload_tables(HiprGroup* group, const HiprTables* tables);
 int hipr_group_upload_scene(HiprGroup* group, const HiprSceneDesc* scene);
+int hipr_group_update_scene_geometry(HiprGroup* group, const HiprSceneDesc* scene);
 int hipr_group_set_scene_state(HiprGroup* group, const HiprSceneState* state);
 int hipr_group_set_entry_point(HiprGroup* group, int entry);
 int hipr_group_use_scratch_accumulation(HiprGroup* group, int enable);

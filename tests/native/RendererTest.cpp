@@ -577,6 +577,69 @@ GPU_TEST_F(RendererFixture, a_renderer_over_several_devices_delivers_the_single_
     EXPECT_TRUE(lit > 0);
 }
 
+GPU_TEST_F(RendererFixture, a_moved_node_refits_the_scene_and_restarts_the_accumulation) {
+    // OR/Renderer.cpp:1010-1041: a transform change updates the model's transform, marks the root acceleration structure dirty (refit) and
+    // resets the accumulation. Here the tick refits the flattened BVH in place; the frames that follow must be those of a renderer that was
+    // given the scene at the new pose from the start, up to hits on coincident surfaces (the two trees visit triangles in another order).
+    auto frame_size = Math::Vector2i(64, 36);
+    Scene::SceneRoot scene = Scene::SceneRoot("Cornell", Math::RGB(0.68f, 0.92f, 1.0f));
+    SceneBuilder direct;
+    Scenes::create_cornell_box(direct);
+    Math::Matrix4x4f projection, inverse_projection;
+    Scene::CameraUtils::compute_perspective_projection(direct.camera.near_plane, direct.camera.far_plane, direct.camera.field_of_view,
+                                                       float(frame_size.x) / frame_size.y, projection, inverse_projection);
+    Scene::CameraID camera_ID = Scene::Cameras::create("Camera", scene.get_ID(), projection, inverse_projection);
+    Scene::Cameras::set_renderer_ID(camera_ID, renderer->get_renderer_ID());
+    create_cornell_box(camera_ID, scene.get_root_node());
+    renderer->set_max_bounce_count(camera_ID, 4);
+    RenderTarget target(frame_size);
+    auto tick = [&](Renderer* r) {
+        r->handle_updates();
+        unsigned int iteration = r->render(camera_ID, target.device, frame_size.x, frame_size);
+        reset_all_change_notifications();
+        return iteration;
+    };
+    EXPECT_EQ(1u, tick(renderer));
+    EXPECT_EQ(2u, tick(renderer));
+    std::vector<double> before;
+    EXPECT_TRUE(renderer->read_accumulation(before));
+
+    // move the small box (the model created sixth)
+    Scene::SceneNode box_node;
+    unsigned int index = 0;
+    for (Assets::MeshModelID model_ID : Assets::MeshModels::get_iterable())
+        if (++index == 6) box_node = Assets::MeshModel(model_ID).get_scene_node();
+    const Math::Transform pose(Math::Vector3f(0.05f, -0.30f, 0.10f), Math::Quaternionf::from_angle_axis(0.8f, Math::Vector3f::up()), 0.3f);
+    box_node.set_global_transform(pose);
+    EXPECT_EQ(1u, tick(renderer));                       // restarted
+    EXPECT_EQ(2u, tick(renderer));
+    EXPECT_EQ(3u, tick(renderer));
+    std::vector<double> refitted;
+    EXPECT_TRUE(renderer->read_accumulation(refitted));
+    EXPECT_TRUE(before != refitted);
+
+    // a second renderer meets the scene at the new pose: a fresh flatten + build
+    Renderer* fresh = Renderer::initialize(0, get_data_directory());
+    EXPECT_TRUE(fresh != nullptr);
+    if (!fresh) return;
+    Scene::Cameras::set_renderer_ID(camera_ID, fresh->get_renderer_ID());
+    scene.set_environment_tint(Math::RGB(0.68f, 0.92f, 1.0f));      // renderers learn the tint from the scene root's change set, which the ticks above have cleared
+    fresh->set_max_bounce_count(camera_ID, 4);
+    for (int i = 0; i < 3; ++i) tick(fresh);
+    std::vector<double> rebuilt;
+    EXPECT_TRUE(fresh->read_accumulation(rebuilt));
+    delete fresh;
+    EXPECT_EQ(refitted.size(), rebuilt.size());
+    // The two trees hold the triangles in another order, so the exhaustive search pairs other triangles into parallelogram items and the
+    // barycentrics differ in the last ulp: the pixels agree to 1e-3 relative, up to a per cent of paths that took another discrete decision.
+    size_t different_pixels = 0;
+    for (size_t i = 0; i + 3 < refitted.size() && i + 3 < rebuilt.size(); i += 4)
+        for (int c = 0; c < 3; ++c)
+            if (std::abs(refitted[i + c] - rebuilt[i + c]) > 1e-3 * (std::abs(rebuilt[i + c]) + 1e-3)) { ++different_pixels; break; }
+    if (different_pixels * 100 > refitted.size() / 4) fprintf(stderr, "refit vs fresh build: %zu of %zu pixels differ\n", different_pixels, refitted.size() / 4);
+    EXPECT_TRUE(different_pixels * 100 <= refitted.size() / 4);      // <= 1 % of the pixels
+}
+
 // ------------------------------------------------------------------------------------------------------------------------
 // The compositor-facing adaptor (DX11OptiXAdaptor/Adaptor.cpp:141-247)
 // ------------------------------------------------------------------------------------------------------------------------

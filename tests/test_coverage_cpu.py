@@ -277,3 +277,73 @@ def test_deep_chain_scene_needs_more_than_the_lds_stack(oracle, tmp_path):
     assert np.array_equal(brute.view(np.uint32), wide.view(np.uint32))
     assert 0.4 < (brute[:, 3].view(np.uint32) != 0xFFFFFFFF).mean() < 0.6
     assert nodes / len(rays) > 20          # the grazing half walks the whole chain
+
+
+# ---- transform-only updates: the BVH is refitted, not rebuilt (OR/Renderer.cpp:472, 1010-1041) ------------------------------------------------
+
+def cornell_box_rays(n, seed):
+    rng = np.random.default_rng(seed)
+    rays = np.zeros((n, 8), np.float32)
+    rays[:, 0:3] = rng.uniform(-0.45, 0.45, (n, 3))
+    d = rng.normal(size=(n, 3))
+    rays[:, 4:7] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    rays[:, 7] = np.inf
+    return rays
+
+
+def hit_records(scene, hits):
+    """(t, u, v, instance, primitive) per ray: comparable between two trees over the same triangles (leaf order differs)."""
+    tris = scene.triangles()
+    ids = hits[:, 3].view(np.uint32)
+    hit = (ids != 0xFFFFFFFF) & ((ids & 0x80000000) == 0)
+    instance = np.where(hit, tris[np.where(hit, ids, 0), 9], 0xFFFFFFFF)
+    primitive = np.where(hit, tris[np.where(hit, ids, 0), 10], 0xFFFFFFFF)
+    return hits[:, :3].view(np.uint32), instance, primitive, ids
+
+
+@pytest.mark.parametrize("quads", [1, 3, 12])
+def test_refit_after_a_model_moved_keeps_the_topology_and_finds_the_same_hits(oracle, quads):
+    """The short box of the Cornell scene (model 6) moves and turns: nodes, leaf order and counts stay, every box is refitted, and all
+    three searches of the oracle find on the refitted tree what exhaustive search finds -- and what a scene BUILT at that pose finds."""
+    scene = Scene("cornell", param0=quads)
+    before_nodes, before_tris = scene.nodes(), scene.triangles()
+    rays = cornell_box_rays(20000, 31)
+    pose = dict(translation=(0.05, -0.30, 0.10), rotation=(0.0, float(np.sin(0.4)), 0.0, float(np.cos(0.4))), scale=0.3)
+    assert scene.move_model(6, **pose) is True
+    d = scene.desc
+    assert capi.load_library().hipr_validate_scene(C.byref(d)) == 0
+    after_nodes, after_tris = scene.nodes(), scene.triangles()
+    assert np.array_equal(before_nodes[:, 12:14], after_nodes[:, 12:14])                       # children unchanged
+    assert np.array_equal(before_tris[:, 9:12], after_tris[:, 9:12])                           # leaf order unchanged
+    moved = (before_tris[:, :9] != after_tris[:, :9]).any(axis=1)
+    assert moved.sum() == 12 and set(after_tris[moved, 9].tolist()) == {5}                      # exactly the box's triangles (instance index 5)
+    brute, _ = oracle.trace_closest(d, rays, use_bvh=0, with_lights=False)
+    two, _ = oracle.trace_closest(d, rays, use_bvh=1, with_lights=False)
+    wide, _ = oracle.trace_closest(d, rays, use_bvh=2, with_lights=False)
+    assert np.array_equal(two.view(np.uint32), wide.view(np.uint32))
+    # against exhaustive search: the same triangle (coincident surfaces -- boxes on the floor -- aside) at the same place; the 34-triangle scene's
+    # exhaustive search tests parallelogram items, whose barycentrics differ from the per-triangle solve in the last ulp
+    assert (two[:, 3].view(np.uint32) != brute[:, 3].view(np.uint32)).mean() <= 2e-3
+    same = two[:, 3].view(np.uint32) == brute[:, 3].view(np.uint32)
+    finite = same & np.isfinite(brute[:, 0])
+    assert np.abs(two[finite, :3] - brute[finite, :3]).max() <= 1e-5
+    if quads > 1:
+        assert (two.view(np.uint32) != brute.view(np.uint32)).any(axis=1).mean() <= 2e-3
+    # the refitted boxes are tight: a second refit to the same pose changes nothing
+    again = scene.nodes().copy()
+    assert scene.move_model(6, **pose) is True and np.array_equal(again, scene.nodes())
+    # moving back restores the built boxes bit for bit
+    assert scene.move_model(6, translation=(0.2, -0.35, -0.2), rotation=(0.0, float(np.sin(np.pi / 12)), 0.0, float(np.cos(np.pi / 12))), scale=0.3) is True
+    assert np.array_equal(scene.triangles(), before_tris) and np.array_equal(scene.nodes(), before_nodes)
+
+
+def test_a_far_move_makes_the_builder_rebuild(oracle):
+    scene = Scene("cornell", param0=3)
+    node_count = scene.desc.node_count
+    assert scene.move_model(6, translation=(0.0, 40.0, 0.0), scale=0.3) is False                  # the root box grew 80-fold: rebuilt
+    assert scene.desc.triangle_count == 114 and capi.load_library().hipr_validate_scene(C.byref(scene.desc)) == 0
+    rays = cornell_box_rays(4000, 5)
+    brute, _ = oracle.trace_closest(scene.desc, rays, use_bvh=0, with_lights=False)
+    wide, _ = oracle.trace_closest(scene.desc, rays, use_bvh=2, with_lights=False)
+    assert (wide.view(np.uint32) != brute.view(np.uint32)).any(axis=1).mean() <= 2e-3
+    assert scene.desc.node_count > 0 and node_count > 0

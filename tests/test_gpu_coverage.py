@@ -296,3 +296,47 @@ def test_device_group_renders_the_single_context_image(ctx, oracle_q):
     assert np.array_equal(accumulation, single)
     assert torch.equal(frame[:, :w].cpu(), reference.cpu())
     assert counters.camera_rays == w * h * spp
+
+
+@pytest.mark.parametrize("quads", [1, 3, 12])
+def test_refitted_scene_on_the_device_bit_exact(ctx, oracle_q, quads):
+    """hipr_update_scene_geometry after SceneBuilder::update_model_transforms moved a model (BVH refit, topology kept): closest hits, shadow
+    transmittance and counters equal the oracle's on the refitted description for all three searches, and the image equals the image
+    of the pose reached by moving back and forth (the refit is exact: the same boxes either way)."""
+    from test_coverage_cpu import cornell_box_rays
+    scene = Scene("cornell", param0=quads)
+    ctx.upload_scene(scene)
+    variant = ctx.trace_variant()
+    pose = dict(translation=(0.05, -0.30, 0.10), rotation=(0.0, float(np.sin(0.4)), 0.0, float(np.cos(0.4))), scale=0.3)
+    assert scene.move_model(6, **pose) is True
+    ctx.update_scene_geometry(scene)
+    assert ctx.trace_variant() == variant
+    ctx.set_instrumentation(True)
+    rays = cornell_box_rays(40000, 8)
+    skip = np.full(len(rays), 0xFFFFFFFF, np.uint32)
+    gpu = ctx.debug_trace_closest(rays, skip)
+    counters = ctx.counters()
+    cpu, (nodes, tris) = oracle_q.trace_closest(scene.desc, rays, skip, use_bvh=ctx.oracle_search(), with_lights=True)
+    assert np.array_equal(gpu.view(np.uint32), cpu.view(np.uint32))
+    assert counters["closest_nodes"] == nodes and counters["closest_triangles"] == tris
+    rays[:, 7] = np.random.default_rng(3).uniform(0.05, 2.0, len(rays))
+    gpu_s = ctx.debug_trace_shadow(rays)
+    counters = ctx.counters()
+    ctx.set_instrumentation(False)
+    cpu_s, (nodes, tris) = oracle_q.trace_shadow(scene.desc, rays, use_bvh=ctx.oracle_search())
+    assert np.array_equal(gpu_s, cpu_s) and counters["shadow_nodes"] == nodes and counters["shadow_triangles"] == tris
+
+    w, h, spp = 64, 36, 4
+    ctx.set_frame(w, h)
+    for a in range(spp):
+        ctx.render_pass(scene.camera(w, h, accumulations=a, max_bounce_count=4), synchronize=True)
+    moved_image = ctx.read_accumulation()
+    reference, _, _ = oracle_q.render(scene.desc, scene.state, scene.camera(w, h, max_bounce_count=4), w, h, spp, use_bvh=ctx.oracle_search())
+    close, rmse = image_metrics(moved_image, reference)
+    assert close >= 0.97 and rmse <= 0.01, (close, rmse)
+    untouched = Scene("cornell", param0=quads)
+    still, _ = render_gpu(ctx, untouched, w, h, spp, 4)
+    assert not np.array_equal(still, moved_image)      # the box did move in the picture
+    # a wrong-sized description is refused, the uploaded scene stays usable
+    other = Scene("cornell", param0=quads + 1)
+    assert ctx.lib.hipr_update_scene_geometry(ctx.handle, __import__("ctypes").byref(other.desc)) == -1
