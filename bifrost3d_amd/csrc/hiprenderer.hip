@@ -1122,6 +1122,13 @@ int hipr_device_free(HiprContext* c, void* device_pointer) {
     return HIPR_OK;
 }
 
+int hipr_device_memset(HiprContext* c, void* device_pointer, int byte_value, uint64_t bytes) {
+    if (int s = check_context(c)) return s;
+    if (!device_pointer) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_device_memset: null pointer");
+    HIP_TRY(hipMemsetAsync(device_pointer, byte_value, bytes, c->stream));
+    return HIPR_OK;
+}
+
 int hipr_copy_to_host(HiprContext* c, void* host, const void* device_pointer, uint64_t bytes) {
     if (int s = check_context(c)) return s;
     if (!host || !device_pointer) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_copy_to_host: bad argument");

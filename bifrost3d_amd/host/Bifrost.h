@@ -560,6 +560,14 @@ public:
     static void set_projection_matrices(CameraID id, Matrix4x4f p, Matrix4x4f ip) { m()[id].projection = p; m()[id].inverse_projection = ip; }
     static Matrix4x4f get_inverse_view_projection_matrix(CameraID id) { return to_matrix4x4(m()[id].transform) * m()[id].inverse_projection; }   // Camera.h:112-114
     // The part of the window the camera renders to, normalised (Camera.h:116-124); the whole window by default.
+    static int get_z_index(CameraID id) { return m()[id].z_index; }
+    static void set_z_index(CameraID id, int z_index) { m()[id].z_index = z_index; }
+    static std::vector<CameraID> get_z_sorted_IDs() {      // BF/Scene/Camera.cpp:171-178
+        std::vector<CameraID> IDs;
+        for (CameraID id : get_iterable()) IDs.push_back(id);
+        std::stable_sort(IDs.begin(), IDs.end(), [](CameraID lhs, CameraID rhs) { return get_z_index(lhs) < get_z_index(rhs); });
+        return IDs;
+    }
     static void set_viewport(CameraID id, float x, float y, float width, float height) { Record& r = m()[id]; r.viewport[0] = x; r.viewport[1] = y; r.viewport[2] = width; r.viewport[3] = height; }
     static void get_window_viewport(CameraID id, Vector2i window_size, int& x, int& y, int& width, int& height) {
         const Record& r = m()[id];
@@ -575,6 +583,7 @@ private:
         std::string name; SceneRootID scene; Core::RendererID renderer; Transform transform = Transform::identity();
         Matrix4x4f projection = Matrix4x4f::identity(), inverse_projection = Matrix4x4f::identity();
         float viewport[4] = {0.0f, 0.0f, 1.0f, 1.0f};
+        int z_index = 0;                                                   // Camera.h: cameras composite in ascending z-index
         Math::CameraEffects::Settings effects_settings = Math::CameraEffects::Settings::preset();
     };
     static Core::Manager<CameraID, Record, Change>& m() { static Core::Manager<CameraID, Record, Change> s; return s; }

@@ -99,8 +99,11 @@ unsigned HeadlessCompositor::render(float delta_time) {
     for (auto& renderer : m_impl->renderers)
         if (renderer) renderer->handle_updates();
 
+    // The back buffer starts black every frame (the swap chain's target is cleared before the cameras draw): regions no viewport covers must not
+    // show last frame's pixels. Cameras composite in ascending z-index, so an overlay camera lands on top (DX11Renderer/Compositor.cpp:268).
+    hipr_device_memset(m_impl->context, m_impl->backbuffer, 0, uint64_t(m_impl->window_size.x) * m_impl->window_size.y * 4);
     unsigned composited = 0;
-    for (CameraID camera_ID : Cameras::get_iterable()) {
+    for (CameraID camera_ID : Cameras::get_z_sorted_IDs()) {
         Recti viewport;
         Cameras::get_window_viewport(camera_ID, m_impl->window_size, viewport.x, viewport.y, viewport.width, viewport.height);
         const Vector2i frame_size = Vector2i(viewport.width, viewport.height);

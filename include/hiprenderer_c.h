@@ -389,6 +389,7 @@ int hipr_group_get_counters(HiprGroup* group, HiprCounters* out);   /* sums over
 /* The render target / back buffer the adaptor owns (Adaptor.cpp:227-247 resize_render_target). */
 int hipr_device_malloc(HiprContext* context, uint64_t bytes, void** out_device_pointer);
 int hipr_device_free(HiprContext* context, void* device_pointer);   /* waits for the context stream first */
+int hipr_device_memset(HiprContext* context, void* device_pointer, int byte_value, uint64_t bytes);   /* on the context stream: the clear of the back buffer before the cameras composite */
 /* optix::Buffer::map() of the non-interop path (Adaptor.cpp:159-166). Blocking. */
 int hipr_copy_to_host(HiprContext* context, void* host, const void* device_pointer, uint64_t bytes);
 /* The adaptor's full-screen blit (Adaptor.cpp:96-100): backbuffer[x + y * backbuffer_pitch] =

@@ -119,3 +119,47 @@ GPU_TEST_F(CompositorFixture, composites_two_cameras_into_their_viewports) {
     }
     delete compositor;
 }
+
+GPU_TEST_F(CompositorFixture, overlapping_cameras_composite_in_z_order_over_a_cleared_back_buffer) {
+    // DX11Renderer/Compositor.cpp:268 iterates Cameras::get_z_sorted_IDs(): the camera with the larger z-index is drawn later and ends on top,
+    // whatever the creation order; what no viewport covers is the cleared back buffer, not last frame's pixels.
+    const Vector2i window_size(64, 36);
+    HIPRenderer::HeadlessCompositor* compositor = HIPRenderer::HeadlessCompositor::initialize(0, data_directory(), window_size);
+    EXPECT_TRUE(compositor != nullptr);
+    if (!compositor) return;
+    const Core::RendererID renderer_ID = compositor->add_renderer(HIPRenderer::HeadlessAdaptor::initialize);
+    if (renderer_ID == Core::RendererID::invalid_UID()) { EXPECT_TRUE(false); delete compositor; return; }
+    const RGB tint(0.2f, 0.4f, 0.8f);
+    SceneRoot scene = SceneRoot("Test", tint);
+    // created first but drawn last: an inset that applies the preset (brighter than the linear main view)
+    const CameraID inset = create_ortho_camera(Vector2i(16, 18), scene), main_view = create_ortho_camera(Vector2i(32, 36), scene);
+    Cameras::set_renderer_ID(inset, renderer_ID); Cameras::set_renderer_ID(main_view, renderer_ID);
+    Cameras::set_viewport(main_view, 0.0f, 0.0f, 0.5f, 1.0f);
+    Cameras::set_viewport(inset, 0.25f, 0.5f, 0.25f, 0.5f);
+    Cameras::set_z_index(main_view, 0); Cameras::set_z_index(inset, 5);
+    Cameras::set_effects_settings(main_view, Math::CameraEffects::Settings::linear());
+    Math::CameraEffects::Settings preset = Math::CameraEffects::Settings::preset();
+    preset.exposure.eye_adaptation_enabled = false; preset.vignette = 0.0f; preset.film_grain = 0.0f;
+    Cameras::set_effects_settings(inset, preset);
+    const std::vector<CameraID> order = Cameras::get_z_sorted_IDs();
+    EXPECT_EQ(size_t(2), order.size());
+    if (order.size() == 2) { EXPECT_TRUE(order[0] == main_view); EXPECT_TRUE(order[1] == inset); }
+
+    EXPECT_EQ(2u, compositor->render(1.0f / 60.0f));
+    std::vector<unsigned char> pixels;
+    EXPECT_TRUE(compositor->read_back_buffer(pixels));
+    if (pixels.size() == size_t(64 * 36 * 4)) {
+        const unsigned char* main_pixel = pixels.data() + 4 * (4 + 64 * 4);          // main view only
+        const unsigned char* inset_pixel = pixels.data() + 4 * (24 + 64 * 27);       // inside both viewports: the inset is on top
+        const unsigned char* uncovered = pixels.data() + 4 * (50 + 64 * 10);         // right half: no camera
+        EXPECT_TRUE(std::abs(main_pixel[1] - to_sRGB8(tint.g)) <= 1);
+        EXPECT_TRUE(inset_pixel[1] > to_sRGB8(tint.g) + 10);
+        EXPECT_EQ(0, int(uncovered[0])); EXPECT_EQ(0, int(uncovered[1])); EXPECT_EQ(0, int(uncovered[2]));
+    }
+    // swap the order: the main view now covers the inset
+    Cameras::set_z_index(inset, -1);
+    EXPECT_EQ(2u, compositor->render(1.0f / 60.0f));
+    EXPECT_TRUE(compositor->read_back_buffer(pixels));
+    if (pixels.size() == size_t(64 * 36 * 4)) EXPECT_TRUE(std::abs(pixels[4 * (24 + 64 * 27) + 1] - to_sRGB8(tint.g)) <= 1);
+    delete compositor;
+}

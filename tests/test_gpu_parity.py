@@ -156,6 +156,18 @@ def rmse(a, b):
     return float(np.sqrt(np.mean((a[..., :3] - b[..., :3]) ** 2)))
 
 
+def image_bar(name, gpu, cpu, close_at_least, rmse_at_most, band=1e-3):
+    """The statistical image bar: the share of pixels within `band` relative of the oracle's and the RMSE, both stated per test from what
+    was measured on the MI355X (gpurun_out/r02_image_metrics.txt: the bars sit a factor of a few above the measured figures)."""
+    rel = np.abs(gpu[..., :3] - cpu[..., :3]) / (np.abs(cpu[..., :3]) + 1e-3)
+    close = float((rel.max(axis=-1) <= band).mean())
+    value = rmse(gpu, cpu)
+    print(f"IMAGE-METRIC {name}: close({band:g}) {close:.4f} rmse {value:.3e} mean {float(cpu[..., :3].mean()):.3f}")
+    assert np.isfinite(gpu).all()
+    assert close >= close_at_least, (name, close)
+    assert value <= rmse_at_most, (name, value)
+
+
 def test_background_colour_G10(ctx):
     """RendererFixture.render_background_color, tests/OptiXRendererTests/RendererTest.h:142-153: 16x12, +-1e-4 (half output)."""
     import torch
@@ -173,14 +185,11 @@ def test_background_colour_G10(ctx):
 def test_cornell_image_matches_oracle(ctx, oracle_q, cornell):
     """Full path: 8 accumulations of the Cornell box (reference materials), bounces 4. Shading uses sin/cos/pow whose
     last ulp differs between glibc and ocml, so individual paths may take different discrete decisions: the bar is
-    statistical. Tolerances: >= 97 % of the pixels within 1e-3 relative, image RMSE <= 0.03 (pixel noise at 8 spp is ~0.3)."""
+    statistical, but tight: measured on the MI355X (round 2) every pixel is within 1e-3 relative and the RMSE is 1e-6; the bar is >= 99.9 % of the pixels and RMSE <= 1e-4."""
     w, h, spp = 64, 36, 8
     gpu, gc = render_gpu(ctx, cornell, w, h, spp, 4)
-    cpu, cc, _ = oracle_q.render(cornell.desc, cornell.state, cornell.camera(w, h, max_bounce_count=4), w, h, spp)
-    rel = np.abs(gpu[..., :3] - cpu[..., :3]) / (np.abs(cpu[..., :3]) + 1e-3)
-    close = (rel.max(axis=-1) <= 1e-3).mean()
-    assert close >= 0.97, close
-    assert rmse(gpu, cpu) <= 0.03
+    cpu, cc, _ = oracle_q.render(cornell.desc, cornell.state, cornell.camera(w, h, max_bounce_count=4), w, h, spp, use_bvh=ctx.oracle_search())
+    image_bar("cornell", gpu, cpu, 0.999, 1e-4)
     assert gc["camera_rays"] == cc["camera_rays"] == w * h * spp
     for key in ("closest_rays", "shadow_rays", "shaded_hits"):
         assert abs(gc[key] - cc[key]) <= 0.002 * cc[key], (key, gc[key], cc[key])
@@ -191,20 +200,16 @@ def test_diffuse_cornell_image_matches_oracle(ctx, oracle_q):
     scene = Scene("cornell", diffuse_only=True)
     w, h, spp = 64, 36, 8
     gpu, _ = render_gpu(ctx, scene, w, h, spp, 4)
-    cpu, _, _ = oracle_q.render(scene.desc, scene.state, scene.camera(w, h, max_bounce_count=4), w, h, spp)
-    rel = np.abs(gpu[..., :3] - cpu[..., :3]) / (np.abs(cpu[..., :3]) + 1e-3)
-    assert (rel.max(axis=-1) <= 1e-3).mean() >= 0.97
-    assert rmse(gpu, cpu) <= 0.03
+    cpu, _, _ = oracle_q.render(scene.desc, scene.state, scene.camera(w, h, max_bounce_count=4), w, h, spp, use_bvh=ctx.oracle_search())
+    image_bar("cornell_diffuse", gpu, cpu, 0.999, 1e-4)
 
 
 def test_atrium_image_matches_oracle(ctx, oracle_q, atrium):
     """DefaultShading with coat + metals + directional and sphere light, 20 k triangles."""
     w, h, spp = 48, 27, 4
     gpu, _ = render_gpu(ctx, atrium, w, h, spp, 4)
-    cpu, _, _ = oracle_q.render(atrium.desc, atrium.state, atrium.camera(w, h, max_bounce_count=4), w, h, spp)
-    rel = np.abs(gpu[..., :3] - cpu[..., :3]) / (np.abs(cpu[..., :3]) + 1e-3)
-    assert (rel.max(axis=-1) <= 2e-3).mean() >= 0.95
-    assert np.isfinite(gpu).all()
+    cpu, _, _ = oracle_q.render(atrium.desc, atrium.state, atrium.camera(w, h, max_bounce_count=4), w, h, spp, use_bvh=ctx.oracle_search())
+    image_bar("atrium_20k", gpu, cpu, 0.99, 1e-3, band=2e-3)
 
 
 def test_tiling_and_batching_are_bit_invariant(ctx, cornell):
@@ -325,10 +330,8 @@ def test_tessellated_cornell_renders_the_same_image(ctx, oracle_q, cornell_tesse
     of it under the usual statistical bar."""
     w, h, spp = 64, 36, 8
     gpu, _ = render_gpu(ctx, cornell_tessellated, w, h, spp, 4)
-    cpu, _, _ = oracle_q.render(cornell_tessellated.desc, cornell_tessellated.state, cornell_tessellated.camera(w, h, max_bounce_count=4), w, h, spp)
-    rel = np.abs(gpu[..., :3] - cpu[..., :3]) / (np.abs(cpu[..., :3]) + 1e-3)
-    assert (rel.max(axis=-1) <= 1e-3).mean() >= 0.97
-    assert rmse(gpu, cpu) <= 0.03
+    cpu, _, _ = oracle_q.render(cornell_tessellated.desc, cornell_tessellated.state, cornell_tessellated.camera(w, h, max_bounce_count=4), w, h, spp, use_bvh=ctx.oracle_search())
+    image_bar("cornell_tessellated", gpu, cpu, 0.999, 1e-4)
 
 
 @pytest.mark.parametrize("scene_name", ["cornell", "atrium"])
@@ -341,10 +344,7 @@ def test_environment_map_image_matches_oracle(ctx, oracle_q, scene_name):
     w, h, spp = 64, 36, 8
     gpu, gc = render_gpu(ctx, scene, w, h, spp, 4)
     cpu, cc, _ = oracle_q.render(scene.desc, scene.state, scene.camera(w, h, max_bounce_count=4), w, h, spp, use_bvh=ctx.oracle_search())
-    assert np.isfinite(gpu).all()
-    rel = np.abs(gpu[..., :3] - cpu[..., :3]) / (np.abs(cpu[..., :3]) + 1e-3)
-    assert (rel.max(axis=-1) <= 2e-3).mean() >= 0.95, float((rel.max(axis=-1) <= 2e-3).mean())
-    assert rmse(gpu, cpu) <= 0.05 * max(1.0, float(cpu[..., :3].mean()))
+    image_bar("environment_" + scene_name, gpu, cpu, 0.99, (1e-4 if scene_name == "cornell" else 0.03) * max(1.0, float(cpu[..., :3].mean())), band=2e-3)
     for key in ("closest_rays", "shadow_rays"):
         assert abs(gc[key] - cc[key]) <= 0.003 * cc[key], (key, gc[key], cc[key])
     # the environment changes the picture: brighter than the constant-tint render of the same scene
@@ -364,9 +364,7 @@ def test_loaded_gltf_image_matches_oracle(ctx, oracle_q, tmp_path, binary_contai
     w, h, spp = 64, 36, 8
     gpu, gc = render_gpu(ctx, scene, w, h, spp, 4)
     cpu, cc, _ = oracle_q.render(scene.desc, scene.state, scene.camera(w, h, max_bounce_count=4), w, h, spp, use_bvh=ctx.oracle_search())
-    assert np.isfinite(gpu).all()
-    rel = np.abs(gpu[..., :3] - cpu[..., :3]) / (np.abs(cpu[..., :3]) + 1e-3)
-    assert (rel.max(axis=-1) <= 2e-3).mean() >= 0.95, float((rel.max(axis=-1) <= 2e-3).mean())
+    image_bar("gltf_binary" if binary_container else "gltf_text", gpu, cpu, 0.999, 1e-4, band=2e-3)
     assert gc["closest_rays"] == cc["closest_rays"] or abs(gc["closest_rays"] - cc["closest_rays"]) <= 0.003 * cc["closest_rays"]
     # the camera placed from the scene bounds (a scene size away from its centre) sees the model: part of the frame is not the sky-blue environment
     sky = np.array([0.68, 0.92, 1.0])
@@ -384,9 +382,7 @@ def test_material_scene_image_matches_oracle(ctx, oracle_q, coat):
     gpu, gc = render_gpu(ctx, scene, w, h, spp, 32)
     assert ctx.trace_variant() == capi.TRACE_WIDE_PERSISTENT
     cpu, cc, _ = oracle_q.render(scene.desc, scene.state, scene.camera(w, h, max_bounce_count=32), w, h, spp, use_bvh=ctx.oracle_search())
-    assert np.isfinite(gpu).all()
-    rel = np.abs(gpu[..., :3] - cpu[..., :3]) / (np.abs(cpu[..., :3]) + 1e-3)
-    assert (rel.max(axis=-1) <= 2e-3).mean() >= 0.95, float((rel.max(axis=-1) <= 2e-3).mean())
+    image_bar("material_coat" if coat else "material", gpu, cpu, 0.995, 1e-3, band=2e-3)
     for key in ("closest_rays", "shadow_rays"):
         assert abs(gc[key] - cc[key]) <= 0.003 * cc[key], (key, gc[key], cc[key])
     # the floor's checker is there: neighbouring texels of very different brightness below the horizon
@@ -404,13 +400,9 @@ def test_glass_scene_image_matches_oracle(ctx, oracle_q):
     w, h, spp = 96, 54, 4
     gpu, gc = render_gpu(ctx, scene, w, h, spp, 32)
     cpu, cc, _ = oracle_q.render(scene.desc, scene.state, scene.camera(w, h, max_bounce_count=32), w, h, spp, use_bvh=ctx.oracle_search())
-    assert np.isfinite(gpu).all()
-    rel = np.abs(gpu[..., :3] - cpu[..., :3]) / (np.abs(cpu[..., :3]) + 1e-3)
-    assert (rel.max(axis=-1) <= 2e-3).mean() >= 0.93, float((rel.max(axis=-1) <= 2e-3).mean())
+    image_bar("glass", gpu, cpu, 0.99, 1e-3, band=2e-3)
     for key in ("closest_rays", "shadow_rays"):
         assert abs(gc[key] - cc[key]) <= 0.003 * cc[key], (key, gc[key], cc[key])
-    # the glass is seen: some pixels of the lower half differ clearly from an empty floor render of the same frame
-    assert rmse(gpu, cpu) <= 0.05 * float(cpu[..., :3].mean())
 
 
 def test_spot_light_image_matches_oracle(ctx, oracle_q):
@@ -421,8 +413,7 @@ def test_spot_light_image_matches_oracle(ctx, oracle_q):
     w, h, spp = 64, 36, 8
     gpu, gc = render_gpu(ctx, scene, w, h, spp, 4)
     cpu, cc, _ = oracle_q.render(scene.desc, scene.state, scene.camera(w, h, max_bounce_count=4), w, h, spp, use_bvh=ctx.oracle_search())
-    rel = np.abs(gpu[..., :3] - cpu[..., :3]) / (np.abs(cpu[..., :3]) + 1e-3)
-    assert np.isfinite(gpu).all() and (rel.max(axis=-1) <= 2e-3).mean() >= 0.95, float((rel.max(axis=-1) <= 2e-3).mean())
+    image_bar("spot", gpu, cpu, 0.999, 1e-4, band=2e-3)
     for key in ("closest_rays", "shadow_rays"):
         assert abs(gc[key] - cc[key]) <= 0.003 * cc[key], (key, gc[key], cc[key])
     dark, _ = render_gpu(ctx, plain, w, h, spp, 4)
