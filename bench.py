@@ -60,9 +60,10 @@ def parse_args(argv=None):
     p.add_argument("--atrium-triangles", type=int, default=260000)
     p.add_argument("--bounces", type=int, default=None, help="max_bounce_count; default 4, and 32 for the viewer's built-in scenes (apps/SimpleViewer/main.cpp:353)")
     p.add_argument("--spp-per-pass", type=int, default=32, help="accumulations traced together per step and GPU (HiprFrameDesc::samples_per_pass)")
-    p.add_argument("--wavefronts", type=int, default=2, choices=[1, 2, 3, 4],
-                   help="2 (default): a pass runs as two half-frame wavefronts on two streams, one shades while the other traces (bit-identical image); "
-                        "the per-kernel durations are then those of co-running kernels")
+    p.add_argument("--wavefronts", type=int, default=0, choices=[0, 1, 2, 3, 4],
+                   help="0 (default): the library's choice by scene -- one wavefront for the persistent wide-BVH kernels (atrium, material scene: kernel durations are "
+                        "those of kernels running alone), two half-frame wavefronts on two streams for the small-scene kernels (Cornell box: one shades while the other "
+                        "traces, +9 ... +27 %%; per-kernel durations are then co-running durations)")
     p.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                    help="gloo + --share-device runs the N > 1 code path with every rank on GPU 0 (functional test of tiling / gather / scatter on a 1-GPU box)")
     p.add_argument("--share-device", action="store_true")
@@ -394,6 +395,7 @@ def measure(ctx, scene, scene_name, bounces, args, rank, world, device, steps, w
         result["frame_ok"] = bool(torch.isfinite(frame.float()).all().item()) and float(frame[..., :3].float().mean()) > 0
         result["small"] = ctx.trace_variant() == capi.TRACE_EXHAUSTIVE
         result["fused"] = ctx.trace_is_fused()
+    result["wavefronts"] = args.wavefronts if args.wavefronts else (1 if ctx.trace_is_fused() else 2)
     return result
 
 
@@ -403,13 +405,13 @@ def summarise(result, scene_name, scene_text, bounces, args, world, steps):
     key = f"{scene_name}:{W}x{H}:spp{args.spp_per_pass}:bounces{bounces}"
     if scene_name == "atrium":
         key += f":tris{args.atrium_triangles}"
-    key += f":wf{args.wavefronts}"
+    key += f":wf{result['wavefronts']}"
     traffic, traffic_source = load_measured_traffic(key) if world == 1 else ({}, None)
     rooflines, kernel_times = rooflines_of(result["counters"], result["times"], result["per_ray"], result["small"], result["fused"], S, traffic)
     dominant = max(rooflines, key=lambda n: rooflines[n]["total_ms"])
     roofline = dict(rooflines[dominant])
     roofline["traffic_source"] = traffic_source
-    if args.wavefronts > 1:
+    if result["wavefronts"] > 1:
         roofline["co_running"] = "two half-frame wavefronts on two streams: this kernel's launches overlap the other wavefront's kernels, so avg_launch_ms is a co-running duration"
     limiter = load_observed_limiter(scene_name)
     roofline["observed_limiter"] = limiter if limiter else "see DESIGN.md 'What bounds the kernels': the counters put these kernels on VALU issue and gather latency, not on HBM bytes"
@@ -470,7 +472,7 @@ def main():
             "metric": METRIC, "value": main_figures["value"], "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": main_figures["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": main_figures["workload"], "frame": [args.width, args.height], "spp_per_step": main_figures["spp_per_step"], "spp_total": main_figures["spp_total"],
-                       "parallelism": f"tiles8x8-round-robin-x{world}" if world > 1 else "single-gpu", "wavefronts": args.wavefronts,
+                       "parallelism": f"tiles8x8-round-robin-x{world}" if world > 1 else "single-gpu", "wavefronts": result["wavefronts"],
                        "ms_per_256spp_frame": main_figures["ms_per_256spp_frame"], "rays_per_step": main_figures["rays_per_step"],
                        "closest_rays": main_figures["closest_rays"], "shadow_rays": main_figures["shadow_rays"], "pixel_samples": main_figures["pixel_samples"],
                        "frame_finite_and_lit": main_figures["frame_finite_and_lit"], "library_sha16": library_sha16(),

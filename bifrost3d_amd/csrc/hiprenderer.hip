@@ -103,8 +103,9 @@ struct HiprContext {
     hipStream_t own_stream = nullptr, stream = nullptr, copy_stream = nullptr;
     hipEvent_t pass_start = nullptr;
     Wavefront wavefronts[MAX_WAVEFRONTS];
-    int wavefront_limit = 2;                // hipr_set_wavefront_count / HIPR_WAVEFRONTS: 2 overlaps one half-frame's shading with the other's tracing (never slower, measured)
-    int wavefront_count = 1;                // set by hipr_set_frame: small frames run as one wavefront
+    int wavefront_limit = 0;                // hipr_set_wavefront_count / HIPR_WAVEFRONTS; 0 = by scene: see wavefronts_wanted()
+    int wavefront_count = 1;                // set by partition_path_slots: small frames run as one wavefront
+    int partitioned_for = 0;                // the wavefronts_wanted() the current partition was made for
 
     // scene
     DeviceBuffer shade_triangles, trace_triangles, trace_items, wide_nodes, environment_PDF, environment_samples;
@@ -130,6 +131,10 @@ struct HiprContext {
     int trace_variant = -1;             // 1: persistent kernels, 0: one ray per lane, -1: pick by BVH size (HIPR_TRACE_VARIANT)
     uint32_t wide_stack_entries = 0;
     // persistent kernels walk the compressed 4-wide BVH; without one (HiprSceneDesc::wide_nodes == NULL) the plain BVH2 kernels serve every scene
+    // Two half-frame wavefronts on two streams overlap one half's shading with the other's tracing. That pays where the trace kernels are short
+    // and light (exhaustive search / BVH2: Cornell +9 % ... +27 %); the persistent wide-BVH kernels fill the register file on their own, the
+    // other wavefront's blocks then wait for residency and nothing is gained (atrium 88.4 vs 88.8 ms, material 24.9 vs 25.1 ms per step): one.
+    int wavefronts_wanted() const { return wavefront_limit > 0 ? wavefront_limit : (scene_ready && use_persistent() ? 1 : 2); }
     bool use_persistent() const { return scene.wide_node_count > 0 && (trace_variant < 0 ? scene.node_count > 64 : trace_variant == HIPR_TRACE_WIDE_PERSISTENT); }
     // tiny scenes: exhaustive search over the triangles (k_trace_*_small)
     bool use_exhaustive() const { return trace_variant < 0 ? (scene.triangle_count <= SMALL_SCENE_TRIANGLES && !use_persistent()) : trace_variant == HIPR_TRACE_EXHAUSTIVE; }
@@ -337,7 +342,8 @@ int partition_path_slots(HiprContext* c) {
     const uint64_t slots = uint64_t(fi.owned_tiles) * 64u * fi.samples_per_pass;
     c->n_slots = uint32_t(slots);
     int r = 0;
-    c->wavefront_count = int(std::max<uint64_t>(1, std::min<uint64_t>(uint64_t(c->wavefront_limit), slots / 65536u)));
+    c->partitioned_for = c->wavefronts_wanted();
+    c->wavefront_count = int(std::max<uint64_t>(1, std::min<uint64_t>(uint64_t(c->partitioned_for), slots / 65536u)));
     const uint64_t share = ((slots + c->wavefront_count - 1) / c->wavefront_count + 63) / 64 * 64;
     for (int g = 0; g < MAX_WAVEFRONTS; ++g) {
         Wavefront& w = c->wavefronts[g];
@@ -541,7 +547,7 @@ int hipr_create(int device_id, HiprContext** out_context) {
     if (const char* v = getenv("HIPR_REFILL_BELOW")) c->refill_below = atoi(v);
     if (const char* v = getenv("HIPR_SHADE_BLOCKS_PER_CU")) c->shade_blocks_per_cu = std::max(1, atoi(v));
     if (const char* v = getenv("HIPR_BLOCKS_PER_CU")) c->blocks_per_cu_override = atoi(v);
-    if (const char* v = getenv("HIPR_WAVEFRONTS")) c->wavefront_limit = std::max(1, std::min(MAX_WAVEFRONTS, atoi(v)));
+    if (const char* v = getenv("HIPR_WAVEFRONTS")) c->wavefront_limit = std::max(0, std::min(MAX_WAVEFRONTS, atoi(v)));
     if (const char* v = getenv("HIPR_TRACE_LOG")) c->trace_log = atoi(v) != 0;
     HIP_TRY(hipMemsetAsync(c->counters.ptr, 0, sizeof(DeviceCounters), c->stream));
 
@@ -828,6 +834,11 @@ int hipr_trace_pass(HiprContext* c, const HiprCameraState* camera) {
     if (int s = check_context(c)) return s;
     if (!camera) return fail(HIPR_ERROR_INVALID_ARGUMENT, "null camera");
     if (!c->tables_ready || !c->scene_ready || !c->frame_ready) return fail(HIPR_ERROR_NOT_READY, "tables, scene and frame must be set before rendering");
+    if (c->partitioned_for != c->wavefronts_wanted()) {      // the scene uploaded since hipr_set_frame wants another split of the path slots
+        for (int g = 0; g < MAX_WAVEFRONTS; ++g) if (c->wavefronts[g].stream) HIP_TRY(hipStreamSynchronize(c->wavefronts[g].stream));
+        c->collect_times();
+        if (partition_path_slots(c)) return HIPR_ERROR_OUT_OF_MEMORY;
+    }
 
     const FrameInfo& f = c->frame;
     const uint32_t n = c->n_slots;
@@ -1038,8 +1049,8 @@ int hipr_reset_counters(HiprContext* c) {
 
 int hipr_set_wavefront_count(HiprContext* c, int count) {
     if (!c) return fail(HIPR_ERROR_INVALID_ARGUMENT, "null context");
-    if (count < 1 || count > MAX_WAVEFRONTS) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_set_wavefront_count: %d is outside [1, %d]", count, MAX_WAVEFRONTS);
-    c->wavefront_limit = count;   // takes effect with the next hipr_set_frame
+    if (count < 0 || count > MAX_WAVEFRONTS) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_set_wavefront_count: %d is outside [0, %d]", count, MAX_WAVEFRONTS);
+    c->wavefront_limit = count;   // 0: by scene; takes effect with the next pass
     return HIPR_OK;
 }
 

@@ -630,7 +630,12 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(5))
     const uint32_t chunk_size = min(TRACE_CHUNK_MAX, max(64u, (n / (gridDim.x * (TRACE_BLOCK / 64u) * 2u)) & ~63u));
 
     uint32_t chunk_next = 0, chunk_end = 0;   // wave uniform
-    uint32_t shard = blockIdx.x % TRACE_SHARDS;
+    // Blocks that share an XCD (blockIdx % 8: dispatch deals blocks round-robin over the XCDs) start on eight NEIGHBOURING shards, so one XCD's L2
+    // serves one contiguous eighth of the ray queue -- rays of neighbouring pixels, which walk the same part of the BVH (HIPR_SHARD_MAP=0: blockIdx % 64).
+#ifndef HIPR_XCD_SHARDS
+#define HIPR_XCD_SHARDS 1
+#endif
+    uint32_t shard = HIPR_XCD_SHARDS ? ((blockIdx.x & 7u) * (TRACE_SHARDS / 8u) + ((blockIdx.x >> 3) % (TRACE_SHARDS / 8u))) : blockIdx.x % TRACE_SHARDS;
     bool exhausted = false;
 
     bool active = false, finished = false;    // finished: traversal done, result still in registers

@@ -401,10 +401,10 @@ int hipr_synchronize(HiprContext* context);
 int hipr_get_counters(HiprContext* context, HiprCounters* out);
 int hipr_reset_counters(HiprContext* context);
 /* Enables per-ray node / triangle visit counting in the trace kernels (slower, off by default). */
-/* Number of independent wavefronts a pass is split into (1..4; default 2, or HIPR_WAVEFRONTS; at most one per 65536
- * path slots of the frame). Each share of the path slots runs its bounces on its own stream, so one shades while another
- * traces; results are bit-identical and it is never slower (+24 % on the Cornell box at 32 samples per pass,
- * +10 % at 1). Applies to the next hipr_set_frame. Kernel timers then overlap (their sum exceeds the wall time). */
+/* Number of independent wavefronts a pass is split into (0..4; at most one per 65536 path slots of the frame). Each share of the path
+ * slots runs its bounces on its own stream, so one shades while another traces; results are bit-identical for any count. 0 (the default, or
+ * HIPR_WAVEFRONTS) chooses by scene: two for scenes traced by the exhaustive / BVH2 kernels (+9 % ... +27 % on the Cornell box), one for the
+ * persistent wide-BVH kernels, which fill the machine alone (measured: no gain, and per-kernel timers then time kernels that ran alone). */
 int hipr_set_wavefront_count(HiprContext* context, int count);
 /* How the uploaded scene is traced (chosen from its size; HIPR_TRACE_VARIANT overrides for experiments):
  *   HIPR_TRACE_BVH2             BVH2 kernels, one ray per lane (k_trace_closest / k_trace_shadow)

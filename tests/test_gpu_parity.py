@@ -317,7 +317,7 @@ def test_wavefront_count_does_not_change_the_image(ctx, cornell, atrium, scene_n
             ctx.set_wavefront_count(count)
             images[count], counters[count] = render_gpu(ctx, scene, w, h, spp, 4)
     finally:
-        ctx.set_wavefront_count(2)
+        ctx.set_wavefront_count(0)
         ctx.set_frame(w, h)
     for count in (2, 3, 4):
         assert np.array_equal(images[1], images[count]), count
