@@ -276,9 +276,12 @@ void launch_persistent(HiprContext* c, const Wavefront& w, const PathState& in, 
 
 template <int MODE, bool INSTRUMENT>
 void launch_persistent_for_stack(HiprContext* c, const Wavefront& w, const PathState& in, const uint32_t* closest_count, const uint32_t* shadow_count, uint32_t upper_bound) {
-    // LDS stack entries by the worst case of the wide tree; beyond 32 the LDS stack is backed by a scratch array
+    // LDS stack entries by the worst case of the wide tree. Trees that need up to 32 entries run with 16 in LDS and the rest in a per-lane scratch
+    // array (traversals rarely get past 16): 4 KB of LDS per wave instead of 8 lets a sixth wave per SIMD stay resident, and the kernel is bound by
+    // the latency of its dependent gathers (atrium, 260 k triangles: 61.0 -> 57.7 ms of trace time per step). Deeper trees (the 10 M triangle
+    // atrium) spill often enough that 32 LDS entries + scratch is the faster split (116.7 vs 119.9 ms).
     if (c->wide_stack_entries <= 16) launch_persistent<16, MODE, INSTRUMENT, false>(c, w, in, closest_count, shadow_count, upper_bound, 0);
-    else if (c->wide_stack_entries <= 32) launch_persistent<32, MODE, INSTRUMENT, false>(c, w, in, closest_count, shadow_count, upper_bound, 1);
+    else if (c->wide_stack_entries <= 32) launch_persistent<16, MODE, INSTRUMENT, true>(c, w, in, closest_count, shadow_count, upper_bound, 1);
     else launch_persistent<32, MODE, INSTRUMENT, true>(c, w, in, closest_count, shadow_count, upper_bound, 2);
 }
 

@@ -613,8 +613,12 @@ constexpr int TRACE_SPILL_ENTRIES = 96;       // stack entries beyond the LDS st
 //                  from whatever is left, and the long-ray tail of one kind is filled with work of the other.
 enum { TRACE_CLOSEST = 0, TRACE_SHADOW = 1, TRACE_FUSED = 2 };
 
+// Waves per SIMD the persistent kernels are compiled for. With 16 LDS stack entries (4 KB per wave) the register file is the limit: measured on the
+// atrium, 5 waves 60.4 ms of trace time per step, 6 waves (<= 80 VGPRs) 57.7, 7 waves (72 VGPRs) 57.8, 8 waves (64 VGPRs, spills) 60.3. With 32
+// entries LDS holds five waves and the registers of a sixth are better spent (10 M triangle atrium: 116.7 ms at 93 VGPRs, 121.0 at 80).
+HD constexpr int trace_waves_per_simd(int stack_entries) { return stack_entries <= 16 ? 6 : 5; }
 template <int STACK, int MODE, bool INSTRUMENT, bool OVERFLOW>
-__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) void k_trace_persistent(DeviceScene sc, PathState in, float4* hits, ShadowQueue q, float4* radiance,
+__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(trace_waves_per_simd(STACK)))) void k_trace_persistent(DeviceScene sc, PathState in, float4* hits, ShadowQueue q, float4* radiance,
                                                                   const uint32_t* closest_count_ptr, const uint32_t* shadow_count_ptr, uint32_t* work_counter,
                                                                   int refill_below, DeviceCounters* counters) {
     __shared__ int s_stack[STACK * TRACE_BLOCK];

@@ -302,18 +302,39 @@ HD HiprMaterial shade_fetch_material(const DeviceScene& sc, const ShadeInputs& i
 #ifndef HIPR_SHADE_WAVES
 #define HIPR_SHADE_WAVES 3
 #endif
+#ifndef HIPR_SHADE_LDS_TABLES
+#define HIPR_SHADE_LDS_TABLES 1
+#endif
+constexpr uint32_t SHADE_LDS_LIGHTS = 32;   // light arrays up to this size are copied to LDS (1.5 KB); larger ones are read from global memory
 template <int MODELS, bool AOV>
 __global__ __launch_bounds__(SHADE_BLOCK, HIPR_SHADE_WAVES) void k_shade(DeviceScene sc, HiprCameraState cam, int entry, PathState in, const float4* hits, PathState out,
                                                         ShadowQueue shadows, float4* radiance, const uint32_t* count_ptr, unsigned long long* out_counts,
                                                         DeviceCounters* counters) {
     __shared__ uint32_t s_cont[SHADE_BLOCK / 64], s_shad[SHADE_BLOCK / 64], s_base[2];
     __shared__ uint32_t s_sobol[SOBOL_TABLE_WORDS];
+#if HIPR_SHADE_LDS_TABLES
+    // The two small lookup tables every Default / Transmissive hit reads with data-dependent indices (GGX rho 32 x 32 ushort2, alpha-from-PDF 32 x 32
+    // ushort: 6 KB) and the light array (RIS picks a random light per candidate) live in LDS: three to six dependent global round trips per hit become
+    // LDS reads. The 32 KB dielectric table (Transmissive only) stays in global memory.
+    __shared__ ushort2 s_ggx_rho[32 * 32];
+    __shared__ unsigned short s_alpha[32 * 32];
+    __shared__ HiprLight s_lights[SHADE_LDS_LIGHTS];
+#endif
     const uint32_t n = *count_ptr;
     if (blockIdx.x * SHADE_BLOCK >= n) return;
     const uint32_t stride = gridDim.x * SHADE_BLOCK;
     uint32_t base = blockIdx.x * SHADE_BLOCK;
     ShadeInputs cur = shade_fetch_inputs(in, hits, base + threadIdx.x, n);
     for (uint32_t w = threadIdx.x; w < SOBOL_TABLE_WORDS; w += SHADE_BLOCK) s_sobol[w] = sc.sobol_tables[w];
+#if HIPR_SHADE_LDS_TABLES
+    for (uint32_t w = threadIdx.x; w < 32 * 32; w += SHADE_BLOCK) { s_ggx_rho[w] = sc.tables.ggx_rho[w]; s_alpha[w] = sc.tables.alpha[w]; }
+    const bool lights_in_lds = sc.light_count <= SHADE_LDS_LIGHTS;
+    if (lights_in_lds)
+        for (uint32_t w = threadIdx.x; w < sc.light_count * 12u; w += SHADE_BLOCK) reinterpret_cast<uint32_t*>(s_lights)[w] = reinterpret_cast<const uint32_t*>(sc.lights)[w];
+    sc.tables.ggx_rho = s_ggx_rho;
+    sc.tables.alpha = s_alpha;
+    if (lights_in_lds) sc.lights = s_lights;
+#endif
     ShadeGeometry geo = shade_fetch_geometry(sc, cur);
     HiprMaterial mat = shade_fetch_material(sc, cur, geo);
     __syncthreads();
@@ -354,15 +375,16 @@ __global__ __launch_bounds__(SHADE_BLOCK, HIPR_SHADE_WAVES) void k_shade(DeviceS
         }
         mat = shade_fetch_material(sc, next, geo);
         __syncthreads();
+        const uint32_t cont_slot = s_base[0] + s_cont[wave] + __popcll(cont_mask & lt), shad_base = s_base[1] + s_shad[wave];
         if (so.continues) {
-            const uint32_t j = s_base[0] + s_cont[wave] + __popcll(cont_mask & lt);
+            const uint32_t j = cont_slot;
             out.o_tmin[j] = make_float4(so.o.x, so.o.y, so.o.z, so.tmin);
             out.d_pdf[j] = make_float4(so.d.x, so.d.y, so.d.z, so.bsdf_pdf);
             out.thr_bounces[j] = make_float4(so.throughput.x, so.throughput.y, so.throughput.z, __uint_as_float(so.bounces));
             out.meta[j] = make_uint4(slot, so.last_triangle, pixel_hash, accumulation);
         }
         if (so.shadow) {
-            const uint32_t j = s_base[1] + s_shad[wave] + __popcll(shad_mask & lt);
+            const uint32_t j = shad_base + __popcll(shad_mask & lt);
             shadows.o_tmax[j] = make_float4(so.so.x, so.so.y, so.so.z, so.stmax);
             shadows.d_slot[j] = make_float4(so.sd.x, so.sd.y, so.sd.z, __uint_as_float(slot));
             shadows.radiance[j] = make_float4(so.sradiance.x, so.sradiance.y, so.sradiance.z, 0.0f);
