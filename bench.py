@@ -261,6 +261,34 @@ def plugin_renderer_figures(ctx, args, main_figures):
     return out
 
 
+def denoiser_figures(args, device):
+    """The filter stage of Backend::AIDenoisedPathTracing at the bench's frame size (csrc/denoiser.hip, include/hipr_denoiser_c.h): milliseconds
+    per hipr_denoiser_process call on synthetic half4 frames already on the device, and the HBM roofline of the image work. Algorithmic bytes
+    per pixel: prepare 16 read + 32 written, each of the 5 passes 32 read + 16 written, finish 32 + 16, output 16 + 8 = 360 B."""
+    import torch
+    from bifrost3d_amd import denoiser
+    W, H = args.width, args.height
+    generator = torch.Generator(device=device).manual_seed(1)
+    noisy = (torch.rand((H, W, 4), generator=generator, device=device) * 2.0).to(torch.float16)
+    albedo = torch.rand((H, W, 4), generator=generator, device=device).to(torch.float16)
+    out = torch.empty_like(noisy)
+    d = denoiser.Denoiser(device.index or 0)
+    settings = denoiser.default_settings()
+    for _ in range(3):
+        d.process(noisy, albedo, out, W, H, settings)
+    calls = 20
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        d.process(noisy, albedo, out, W, H, settings)      # synchronises the denoiser's stream
+    ms = (time.perf_counter() - t0) / calls * 1e3
+    d.close()
+    bytes_per_frame = 360.0 * W * H
+    achieved = bytes_per_frame / (ms * 1e-3) / 1e9
+    return {"ms_per_frame": ms, "frame": [W, H], "iterations": settings.iterations, "bytes_per_pixel_algorithmic": 360,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None},
+            "note": "host-timed, launch + synchronise included; 25 taps per pixel per pass come from L1 / L2, the algorithmic bytes count each plane once per pass"}
+
+
 # --------------------------------------------------------------------------------------------------------------------------------
 # Rooflines. Algorithmic HBM bytes per unit of work, DESIGN.md "Kernels" / SURVEY.md 8d:
 #   generate       80 B per path        (64 B path state + 16 B radiance slot written)
@@ -497,6 +525,7 @@ def main():
                 out["other_workloads"] = others
             if scene_name == "atrium" and not args.no_plugin:
                 out["plugin_renderer"] = plugin_renderer_figures(ctx, args, main_figures)
+                out["denoiser_stage"] = denoiser_figures(args, device)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline_smallpt(args.cpu_baseline_seconds)
                 out["cpu_baseline"]["c2"] = cpu_baseline_c2(ctx, args.cpu_baseline_seconds)

@@ -116,7 +116,7 @@ class HiprCounters(C.Structure):
 
 TRACE_BVH2, TRACE_WIDE_PERSISTENT, TRACE_EXHAUSTIVE = 0, 1, 2
 SHADING_DEFAULT, SHADING_DIFFUSE, SHADING_TRANSMISSIVE = 0, 1, 2
-ENTRY_PATH_TRACING, ENTRY_DEPTH, ENTRY_ALBEDO, ENTRY_TINT, ENTRY_ROUGHNESS, ENTRY_SHADING_NORMAL, ENTRY_PRIMITIVE_ID = 0, 3, 4, 5, 6, 7, 8
+ENTRY_PATH_TRACING, ENTRY_DEPTH, ENTRY_ALBEDO, ENTRY_TINT, ENTRY_ROUGHNESS, ENTRY_SHADING_NORMAL, ENTRY_PRIMITIVE_ID, ENTRY_DENOISER_ALBEDO = 0, 3, 4, 5, 6, 7, 8, 9
 HIPR_KERNEL_NAMES = ("generate", "trace_closest", "shade", "trace_shadow", "accumulate")
 
 

@@ -785,11 +785,12 @@ int hipr_set_entry_point(HiprContext* c, int entry) {
     if (!c) return fail(HIPR_ERROR_INVALID_ARGUMENT, "null context");
     switch (entry) {
     case HIPR_ENTRY_PATH_TRACING: case HIPR_ENTRY_DEPTH: case HIPR_ENTRY_ALBEDO: case HIPR_ENTRY_TINT: case HIPR_ENTRY_ROUGHNESS:
-    case HIPR_ENTRY_SHADING_NORMAL: case HIPR_ENTRY_PRIMITIVE_ID:
+    case HIPR_ENTRY_SHADING_NORMAL: case HIPR_ENTRY_PRIMITIVE_ID: case HIPR_ENTRY_DENOISER_ALBEDO:
         c->entry = entry;
         return HIPR_OK;
     case 1: case 2:
-        return fail(HIPR_ERROR_UNSUPPORTED, "entry point %d wraps the NVIDIA DL denoiser and has no equivalent here", entry);
+        return fail(HIPR_ERROR_UNSUPPORTED, "entry point %d is one of the two launches of the reference's AIDenoisedBackend command list; here that backend is a path tracing pass, "
+                    "a HIPR_ENTRY_DENOISER_ALBEDO pass and hipr_denoiser_process (include/hipr_denoiser_c.h)", entry);
     }
     return fail(HIPR_ERROR_INVALID_ARGUMENT, "unknown entry point %d", entry);
 }
@@ -801,8 +802,9 @@ int hipr_use_scratch_accumulation(HiprContext* c, int enable) {
     c->collect_times();
     if (enable) {
         const size_t bytes = size_t(c->frame.owned_tiles) * 64 * sizeof(double4);
+        const bool keep = enable == 2 && c->scratch_accumulation.ptr && c->scratch_accumulation.bytes >= bytes;   // a running mean kept across calls
         if (int s = c->scratch_accumulation.resize(bytes)) return s;
-        HIP_TRY(hipMemset(c->scratch_accumulation.ptr, 0, bytes));
+        if (!keep) HIP_TRY(hipMemset(c->scratch_accumulation.ptr, 0, bytes));
     }
     c->use_scratch = enable != 0;
     return HIPR_OK;

@@ -66,6 +66,10 @@ HD void shade_path(const DeviceScene& sc, const HiprCameraState& cam, int entry,
     if (id & HIPR_HIT_LIGHT) {
         if (AOV) {
             if (entry == HIPR_ENTRY_DEPTH) out.add_radiance = mk3(length(ro - (rd * hit.x + ro)));
+            if (entry == HIPR_ENTRY_DENOISER_ALBEDO) {   // the light's radiance brought into [0, 1) (SimpleRGPs.cu:180-182)
+                const f3 L = light_evaluate_intersection(sc.lights[id & ~HIPR_HIT_LIGHT], ro, rd, bsdf_pdf);
+                out.add_radiance = L / (mk3(1.0f) + L);
+            }
             return;
         }
         f3 L = light_evaluate_intersection(sc.lights[id & ~HIPR_HIT_LIGHT], ro, rd, bsdf_pdf);
@@ -170,14 +174,16 @@ HD void shade_path(const DeviceScene& sc, const HiprCameraState& cam, int entry,
                 return v;
             };
             value = mk3(float(compact_by_2(code >> 2)), float(compact_by_2(code >> 1)), float(compact_by_2(code))) / 1023.0f;
-        } else if (entry == HIPR_ENTRY_ALBEDO) {
+        } else if (entry == HIPR_ENTRY_ALBEDO || entry == HIPR_ENTRY_DENOISER_ALBEDO) {
             const float abs_cos = fabsf(dot(rd, shading_normal));
             const f4 trq = base * qscale;
             MaterialInputs ai = in;
             ai.tint = {trq.x, trq.y, trq.z};
             ai.roughness = trq.w;
-            if (mp.shading_model == HIPR_SHADING_DIFFUSE) value = ai.tint;
-            else if (transmissive) {
+            // the denoiser's feature image takes every material as DefaultShading (SimpleRGPs.cu:171-178)
+            const bool by_model = entry == HIPR_ENTRY_ALBEDO;
+            if (by_model && mp.shading_model == HIPR_SHADING_DIFFUSE) value = ai.tint;
+            else if (by_model && transmissive) {
                 const Shading t = make_transmissive(sc.tables, ai, abs_cos, -1.0f);
                 const f2 rho = fetch_dielectric_rho(sc.tables, abs_cos, sqrtf(t.s1), t.s2);
                 const float reflection = rho.y / rho.x;

@@ -14,6 +14,7 @@
 #include "PresampledEnvironment.h"
 #include "../SceneBuilder.h"
 #include "../../../include/hiprenderer_c.h"
+#include "../../../include/hipr_denoiser_c.h"
 
 #include <climits>
 #include <cmath>
@@ -197,6 +198,10 @@ struct Renderer::Implementation {
         HiprSceneState batch_scene_state = {};
         int batch_entry = -1;
         void drop_batch() { batch_size = batch_used = 0; }
+        // Backend::AIDenoisedPathTracing (OR/IBackend.cpp:19-80): the filter object and the two half4 frames it reads, on the device frames are delivered on
+        HiprDenoiser* denoiser = nullptr;
+        void *noisy_frame = nullptr, *albedo_frame = nullptr;
+        size_t feature_frame_pixels = 0;
     };
     unsigned int max_batch_size = 32;   // accumulations traced together at most (set_max_batch_size; 1 = the reference's one launch per accumulation)
     std::vector<CameraState> per_camera_state = std::vector<CameraState>(1);
@@ -208,8 +213,15 @@ struct Renderer::Implementation {
     bool is_valid() const { return device_ID >= 0; }
 
     ~Implementation() {
-        for (CameraState& c : per_camera_state)
-            if (c.context) hipr_group_destroy(c.context);
+        for (CameraState& c : per_camera_state) {
+            if (c.denoiser) hipr_denoiser_destroy(c.denoiser);
+            if (c.context) {
+                HiprContext* root = hipr_group_context(c.context, 0);
+                if (c.noisy_frame) hipr_device_free(root, c.noisy_frame);
+                if (c.albedo_frame) hipr_device_free(root, c.albedo_frame);
+                hipr_group_destroy(c.context);
+            }
+        }
     }
 
     bool conditional_per_camera_state_resize(unsigned int camera_ID) {
@@ -403,12 +415,56 @@ struct Renderer::Implementation {
         return std::min(batch, std::max(1u, remaining));
     }
 
+    // AIDenoisedBackend::render (OR/IBackend.cpp:62-80) with the reference's command list spelled out: the path tracing launch, whose ray
+    // generation program also accumulates the albedo feature image (ORS/SimpleRGPs.cu:149-201) -- here a second, one-segment pass of the
+    // HIPR_ENTRY_DENOISER_ALBEDO entry into the context's second running mean --, the filter (the presenting list only: every frame, or the
+    // power-of-two and every 32nd frame under LogarithmicFeedback), and copy_to_output with its two debug views. One accumulation per
+    // call, not batched: the albedo pass between two folds would overwrite the samples a batch keeps in the path slots.
+    unsigned int render_denoised(CameraState& state, const HiprCameraState& camera, void* buffer, unsigned int pitch, Vector2i frame_size) {
+        HiprContext* root = hipr_group_context(state.context, 0);
+        const size_t pixels = size_t(frame_size.x) * size_t(frame_size.y);
+        if (!state.denoiser && hipr_denoiser_create(device_ID, &state.denoiser) != HIPR_OK) { printf("HIPRenderer: cannot create the denoiser.\n"); return state.accumulations; }
+        if (pixels > state.feature_frame_pixels) {
+            if (state.noisy_frame) hipr_device_free(root, state.noisy_frame);
+            if (state.albedo_frame) hipr_device_free(root, state.albedo_frame);
+            state.noisy_frame = state.albedo_frame = nullptr; state.feature_frame_pixels = 0;
+            if (hipr_device_malloc(root, pixels * 8, &state.noisy_frame) != HIPR_OK || hipr_device_malloc(root, pixels * 8, &state.albedo_frame) != HIPR_OK) return state.accumulations;
+            state.feature_frame_pixels = pixels;
+        }
+        state.drop_batch();
+        const uint32_t width = uint32_t(frame_size.x), height = uint32_t(frame_size.y);
+        hipr_group_set_scene_state(state.context, &scene_state);
+        hipr_group_set_entry_point(state.context, HIPR_ENTRY_PATH_TRACING);
+        if (hipr_group_set_samples_per_pass(state.context, 1) != HIPR_OK || hipr_group_trace_pass(state.context, &camera) != HIPR_OK ||
+            hipr_group_accumulate_samples(state.context, 0, 1, state.accumulations, state.noisy_frame, width, 1) != HIPR_OK) return state.accumulations;
+        hipr_group_set_entry_point(state.context, HIPR_ENTRY_DENOISER_ALBEDO);
+        bool albedo_ok = hipr_group_use_scratch_accumulation(state.context, 2) == HIPR_OK && hipr_group_trace_pass(state.context, &camera) == HIPR_OK &&
+                         hipr_group_accumulate_samples(state.context, 0, 1, state.accumulations, state.albedo_frame, width, 1) == HIPR_OK;
+        hipr_group_use_scratch_accumulation(state.context, 0);
+        hipr_group_set_entry_point(state.context, HIPR_ENTRY_PATH_TRACING);
+        if (!albedo_ok) return state.accumulations;
+
+        const unsigned int frame_number = state.accumulations + 1;
+        const bool presenting = (frame_number & (frame_number - 1)) == 0 || frame_number % 32 == 0 || !AI_denoiser_flags.is_set(AIDenoiserFlag::LogarithmicFeedback);
+        const int show = AI_denoiser_flags.is_set(AIDenoiserFlag::VisualizeNoise) ? HIPR_DENOISER_SHOW_NOISE
+                       : AI_denoiser_flags.is_set(AIDenoiserFlag::VisualizeAlbedo) ? HIPR_DENOISER_SHOW_ALBEDO : HIPR_DENOISER_SHOW_FILTERED;
+        HiprDenoiserSettings settings;
+        hipr_denoiser_default_settings(&settings);
+        if (hipr_denoiser_process(state.denoiser, &settings, state.noisy_frame, width, state.albedo_frame, width, width, height, presenting ? 1 : 0, show, buffer, pitch) != HIPR_OK ||
+            hipr_denoiser_synchronize(state.denoiser) != HIPR_OK) {
+            printf("HIPRenderer: denoising failed: %s\n", hipr_denoiser_last_error(state.denoiser));
+            return state.accumulations;
+        }
+        return ++state.accumulations;
+    }
+
     unsigned int render(CameraID camera_ID, void* buffer, unsigned int pitch, Vector2i frame_size) {   // OR/Renderer.cpp:1250-1265
         conditional_per_camera_state_resize(camera_ID);
         HiprCameraState camera;
         if (!prepare_camera_state(camera_ID, frame_size, camera)) return 0;
         CameraState& state = per_camera_state[camera_ID];
         if (state.accumulations >= state.max_accumulation_count) return state.accumulations;
+        if (state.backend == Backend::AIDenoisedPathTracing) return render_denoised(state, camera, buffer, pitch, frame_size);
         int entry = entry_of(state.backend);
         entry = entry < 0 ? HIPR_ENTRY_PATH_TRACING : entry;
 
@@ -488,9 +544,7 @@ void Renderer::set_backend(CameraID camera_ID, Backend backend) {   // OR/Render
     if (backend == Backend::None) return;
     m_impl->conditional_per_camera_state_resize(camera_ID);
     auto& state = m_impl->per_camera_state[camera_ID];
-    if (backend == Backend::AIDenoisedPathTracing)
-        printf("HIPRenderer: the AI denoised backend wraps NVIDIA's DL denoiser and is not available; rendering plain path tracing.\n");
-    else if (entry_of(backend) < 0) {
+    if (backend != Backend::AIDenoisedPathTracing && entry_of(backend) < 0) {
         printf("HIPRenderer: Backend %u not supported.\n", unsigned(backend));
         backend = Backend::AlbedoVisualization;
     }

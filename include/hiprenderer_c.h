@@ -298,10 +298,14 @@ int hipr_set_scene_state(HiprContext* context, const HiprSceneState* state);
  * (OR/Renderer.cpp:1417-1455). The two AI denoiser entries (1, 2) wrap NVIDIA's proprietary DL denoiser and are not
  * provided: hipr_set_entry_point returns HIPR_ERROR_UNSUPPORTED for them. */
 enum { HIPR_ENTRY_PATH_TRACING = 0, HIPR_ENTRY_DEPTH = 3, HIPR_ENTRY_ALBEDO = 4, HIPR_ENTRY_TINT = 5, HIPR_ENTRY_ROUGHNESS = 6,
-       HIPR_ENTRY_SHADING_NORMAL = 7, HIPR_ENTRY_PRIMITIVE_ID = 8 };
+       HIPR_ENTRY_SHADING_NORMAL = 7, HIPR_ENTRY_PRIMITIVE_ID = 8,
+       /* The feature image the reference accumulates next to the radiance for its denoiser (AIDenoiser::path_tracing_RPG, ORS/SimpleRGPs.cu:149-201): at the
+        * first accepted surface hit DefaultShading::rho of the material whatever its shading model, at a light hit radiance / (1 + radiance), black on a miss. */
+       HIPR_ENTRY_DENOISER_ALBEDO = 9 };
 int hipr_set_entry_point(HiprContext* context, int entry);
 /* request_auxiliary_buffers (OR/Renderer.cpp:1267-1358) renders AOVs into scratch buffers so the camera's accumulation
- * survives: enable != 0 redirects hipr_render_pass / hipr_read_accumulation to a zeroed scratch accumulation buffer. */
+ * survives: enable != 0 redirects hipr_render_pass / hipr_read_accumulation to a scratch accumulation buffer. enable == 1 zeroes it;
+ * enable == 2 keeps what it holds (a second running mean next to the camera's: the denoiser's albedo feature image). */
 int hipr_use_scratch_accumulation(HiprContext* context, int enable);
 
 /* (Re)allocates the f64 accumulation buffer and the wavefront queues for the owned tiles;

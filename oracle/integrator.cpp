@@ -898,6 +898,10 @@ float3 aov_pixel(const HiprSceneDesc& scene, const HiprSceneState& state, const 
             payload.throughput = {0, 0, 0};
             payload.position = 1e30f * payload.direction;
         } else if (hit.id & HIT_LIGHT_BIT) {
+            if (entry == HIPR_ENTRY_DENOISER_ALBEDO) {   // AIDenoiser::path_tracing_RPG, SimpleRGPs.cu:180-182: radiance / (1 + radiance) of the light the path hit
+                const float3 L = Lights::evaluate_intersection(scene.lights[hit.id & ~HIT_LIGHT_BIT], ray.origin, ray.direction, payload.bsdf_PDF);
+                return L / (make_float3(1) + L);
+            }
             payload.throughput = {0, 0, 0};
             payload.position = ray.direction * hit.t + ray.origin;
         } else
@@ -922,12 +926,13 @@ float3 aov_pixel(const HiprSceneDesc& scene, const HiprSceneState& state, const 
         uint32_t code = instance_encoding ^ primitive_encoding;
         return make_float3(float(compact_by_2(code >> 2)), float(compact_by_2(code >> 1)), float(compact_by_2(code))) / 1023.0f;
     }
-    case HIPR_ENTRY_ALBEDO: {
+    case HIPR_ENTRY_ALBEDO: case HIPR_ENTRY_DENOISER_ALBEDO: {
         float abs_cos_theta = fabsf(dot(last_ray_direction, payload.shading_normal));
         float4 trq = tr * scale;
         MaterialInputs in = {make_float3(trq), trq.w, mp.specularity, material_metallic(scene, mp, payload.texcoord), unorm16(mp.coat), unorm16(mp.coat_roughness)};
-        if (mp.shading_model == HIPR_SHADING_DIFFUSE) return in.tint;
-        if (mp.shading_model == HIPR_SHADING_TRANSMISSIVE) return TransmissiveShading(in, abs_cos_theta).rho(abs_cos_theta);
+        // the denoiser's feature image takes every material as DefaultShading (SimpleRGPs.cu:171-178)
+        if (entry == HIPR_ENTRY_ALBEDO && mp.shading_model == HIPR_SHADING_DIFFUSE) return in.tint;
+        if (entry == HIPR_ENTRY_ALBEDO && mp.shading_model == HIPR_SHADING_TRANSMISSIVE) return TransmissiveShading(in, abs_cos_theta).rho(abs_cos_theta);
         return DefaultShading(in, abs_cos_theta).rho(abs_cos_theta);
     }
     }

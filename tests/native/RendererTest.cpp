@@ -645,6 +645,92 @@ GPU_TEST_F(RendererFixture, a_moved_node_refits_the_scene_and_restarts_the_accum
 // ------------------------------------------------------------------------------------------------------------------------
 static float half_bits_to_float(unsigned short bits) { _Float16 h; std::memcpy(&h, &bits, 2); return float(h); }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Backend::AIDenoisedPathTracing (OR/IBackend.cpp:19-80, ORS/SimpleRGPs.cu:145-221): the path tracing frame, the albedo
+// feature image and the filtered frame, selected by the AIDenoiserFlags; the filter runs on the presenting frames only.
+// ------------------------------------------------------------------------------------------------------------------------
+GPU_TEST_F(RendererFixture, denoised_backend_follows_the_reference_command_lists) {
+    auto frame_size = Math::Vector2i(96, 54);
+    Scene::SceneRoot scene = Scene::SceneRoot("Cornell", Math::RGB(0.68f, 0.92f, 1.0f));
+    SceneBuilder direct;
+    Scenes::create_cornell_box(direct);
+    Math::Matrix4x4f projection, inverse_projection;
+    Scene::CameraUtils::compute_perspective_projection(direct.camera.near_plane, direct.camera.far_plane, direct.camera.field_of_view,
+                                                       float(frame_size.x) / frame_size.y, projection, inverse_projection);
+    Scene::CameraID camera_ID = Scene::Cameras::create("Camera", scene.get_ID(), projection, inverse_projection);
+    Scene::Cameras::set_renderer_ID(camera_ID, renderer->get_renderer_ID());
+    create_cornell_box(camera_ID, scene.get_root_node());
+    renderer->handle_updates();
+    const size_t pixel_count = size_t(frame_size.x) * frame_size.y;
+    RenderTarget target(frame_size);
+
+    // frames of the plain path tracer, one launch per accumulation: what VisualizeNoise has to show
+    renderer->set_max_batch_size(1);
+    renderer->set_backend(camera_ID, Backend::PathTracing);
+    std::vector<std::vector<half4>> plain;
+    for (int i = 0; i < 4; ++i) { renderer->render(camera_ID, target.device, frame_size.x, frame_size); plain.push_back(target.map()); }
+
+    auto run = [&](AIDenoiserFlags flags, int frames) {
+        renderer->set_AI_denoiser_flags(flags);
+        renderer->set_backend(camera_ID, Backend::AIDenoisedPathTracing);   // restarts the accumulation
+        std::vector<std::vector<half4>> out;
+        for (int i = 0; i < frames; ++i) {
+            EXPECT_EQ(unsigned(i + 1), renderer->render(camera_ID, target.device, frame_size.x, frame_size));
+            out.push_back(target.map());
+        }
+        return out;
+    };
+    EXPECT_TRUE(renderer->get_AI_denoiser_flags().is_set(AIDenoiserFlag::LogarithmicFeedback));   // AIDenoiserFlag::Default
+
+    // VisualizeNoise: bit for bit the path traced frames
+    auto noise = run({AIDenoiserFlag::LogarithmicFeedback, AIDenoiserFlag::VisualizeNoise}, 4);
+    for (int i = 0; i < 4; ++i) {
+        size_t different = 0;
+        for (size_t p = 0; p < pixel_count; ++p) different += noise[i][p].r != plain[i][p].r || noise[i][p].g != plain[i][p].g || noise[i][p].b != plain[i][p].b;
+        EXPECT_EQ(size_t(0), different);
+    }
+
+    // VisualizeAlbedo: in [0, 1], not black where the camera sees the box, and steadier from frame to frame than the radiance
+    auto albedo = run({AIDenoiserFlag::LogarithmicFeedback, AIDenoiserFlag::VisualizeAlbedo}, 2);
+    size_t lit = 0, out_of_range = 0;
+    for (size_t p = 0; p < pixel_count; ++p) {
+        const float r = float(albedo[1][p].r), g = float(albedo[1][p].g), b = float(albedo[1][p].b);
+        lit += (r + g + b) > 0.05f;
+        out_of_range += r < 0.0f || g < 0.0f || b < 0.0f || r > 1.001f || g > 1.001f || b > 1.001f;
+    }
+    EXPECT_TRUE(lit > pixel_count / 2);
+    EXPECT_EQ(size_t(0), out_of_range);
+
+    // the filtered frames: frame 3 is not a presenting frame under logarithmic feedback (3 is neither a power of two nor a multiple
+    // of 32), so it shows the filtered image of frame 2 again; frame 4 filters anew. Without the flag every frame filters.
+    auto logarithmic = run(AIDenoiserFlag::LogarithmicFeedback, 4);
+    auto same = [&](const std::vector<half4>& a, const std::vector<half4>& b) { return std::memcmp(a.data(), b.data(), pixel_count * sizeof(half4)) == 0; };
+    EXPECT_TRUE(same(logarithmic[1], logarithmic[2]));
+    EXPECT_FALSE(same(logarithmic[2], logarithmic[3]));
+    auto every_frame = run(AIDenoiserFlag::None, 3);
+    EXPECT_TRUE(same(every_frame[1], logarithmic[1]));
+    EXPECT_FALSE(same(every_frame[1], every_frame[2]));
+
+    // and the filter does what it is there for: the filtered 4 spp frame is closer to a converged image than the noisy one
+    renderer->set_max_batch_size(32);
+    renderer->set_backend(camera_ID, Backend::PathTracing);
+    for (int i = 0; i < 512; ++i) renderer->render(camera_ID, target.device, frame_size.x, frame_size);
+    std::vector<half4> converged = target.map();
+    auto squared_error = [&](const std::vector<half4>& a) {
+        double sum = 0;
+        for (size_t p = 0; p < pixel_count; ++p) {
+            // tone-compressed so the light source itself does not decide the comparison
+            auto c = [](float v) { return v / (1.0f + v); };
+            const double dr = c(float(a[p].r)) - c(float(converged[p].r)), dg = c(float(a[p].g)) - c(float(converged[p].g)), db = c(float(a[p].b)) - c(float(converged[p].b));
+            sum += dr * dr + dg * dg + db * db;
+        }
+        return sum / double(pixel_count);
+    };
+    const double noisy_error = squared_error(plain[3]), filtered_error = squared_error(logarithmic[3]);
+    printf("    4 spp against 512 spp, mean squared error (tone compressed): noisy %.5f, filtered %.5f\n", noisy_error, filtered_error);
+    EXPECT_TRUE(filtered_error < 0.5 * noisy_error);
+}
+
 GPU_TEST_F(RendererFixture, adaptor_presents_the_flipped_viewport) {
     delete renderer;   // the adaptor owns its own renderer, like the compositor's unique_ptr<IRenderer>
     renderer = nullptr;

@@ -258,7 +258,7 @@ def test_errors_are_reported_not_swallowed(ctx):
 
 
 AOV_ENTRIES = [("depth", capi.ENTRY_DEPTH), ("albedo", capi.ENTRY_ALBEDO), ("tint", capi.ENTRY_TINT), ("roughness", capi.ENTRY_ROUGHNESS),
-               ("shading_normal", capi.ENTRY_SHADING_NORMAL), ("primitive_id", capi.ENTRY_PRIMITIVE_ID)]
+               ("shading_normal", capi.ENTRY_SHADING_NORMAL), ("primitive_id", capi.ENTRY_PRIMITIVE_ID), ("denoiser_albedo", capi.ENTRY_DENOISER_ALBEDO)]
 
 
 @pytest.mark.parametrize("name,entry", AOV_ENTRIES)
@@ -266,7 +266,8 @@ AOV_ENTRIES = [("depth", capi.ENTRY_DEPTH), ("albedo", capi.ENTRY_ALBEDO), ("tin
 def test_aov_entry_points_match_oracle(ctx, oracle_q, cornell, atrium, scene_name, name, entry):
     """The visualisation backends (SimpleRGPs.cu:227-340): depth, tint, roughness, normals and primitive ids are one
     closest hit + attribute fetch (tolerance 1e-5 absolute: the camera ray and hit are bit-exact, the colour is a few
-    f32 operations); albedo goes through the rho tables and pow (tolerance 2e-3)."""
+    f32 operations); albedo goes through the rho tables and pow (tolerance 2e-3). denoiser_albedo is the feature image of the reference's
+    denoising backend (SimpleRGPs.cu:149-201): every material as DefaultShading, light hits as radiance / (1 + radiance)."""
     scene = cornell if scene_name == "cornell" else atrium
     w, h, spp = 48, 27, 2
     ctx.set_entry_point(entry)
@@ -275,7 +276,7 @@ def test_aov_entry_points_match_oracle(ctx, oracle_q, cornell, atrium, scene_nam
     finally:
         ctx.set_entry_point(capi.ENTRY_PATH_TRACING)
     cpu, _, _ = oracle_q.render(scene.desc, scene.state, scene.camera(w, h, max_bounce_count=4), w, h, spp, entry=entry)
-    tol = 2e-3 if name == "albedo" else 1e-5
+    tol = 2e-3 if "albedo" in name else 1e-5
     if name == "depth":   # world units, scaled by the scene size on both sides
         tol = 1e-5 * max(1.0, float(np.nanmax(np.where(np.isfinite(cpu[..., 0]), cpu[..., 0], 0.0))))
     g, c = gpu[..., :3], cpu[..., :3]
