@@ -7,7 +7,9 @@
 Scenes: cornell, cornell_diffuse, atrium, material, material_coat, glass, or a model file (.gltf / .glb / .obj with PNG textures)
 set up the way the viewer sets up its command-line scene. `--effects preset` applies the camera's default post-process
 (histogram exposure, vignette, filmic tonemapping, film grain; eye adaptation off so that a single frame is fully adapted),
-`linear` only converts to sRGB. Python here is plumbing around the two C-ABIs (hiprenderer_c.h, hipr_camera_effects_c.h).
+`linear` only converts to sRGB. `--denoise` runs the denoising backend's data flow before the effects: an albedo feature pass of the
+same accumulations (HIPR_ENTRY_DENOISER_ALBEDO into the second running mean) and the filter of hipr_denoiser_c.h. Python here is
+plumbing around the C-ABIs (hiprenderer_c.h, hipr_camera_effects_c.h, hipr_denoiser_c.h).
 """
 import argparse
 import struct
@@ -19,7 +21,7 @@ from pathlib import Path
 import numpy as np
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
-from bifrost3d_amd import camera_effects  # noqa: E402
+from bifrost3d_amd import camera_effects, capi, denoiser  # noqa: E402
 from bifrost3d_amd.host import Scene  # noqa: E402
 from bifrost3d_amd.renderer import Context  # noqa: E402
 
@@ -45,6 +47,7 @@ def main():
     p.add_argument("--spp-per-pass", type=int, default=8)
     p.add_argument("--bounces", type=int, default=-1, help="max_bounce_count; -1 keeps the scene's own (4, or 32 for the viewer's test scenes)")
     p.add_argument("--effects", choices=["preset", "linear"], default="preset")
+    p.add_argument("--denoise", action="store_true", help="filter the frame with the denoising backend's filter (albedo feature pass + edge-avoiding a-trous wavelets)")
     p.add_argument("--out", default="render.png")
     args = p.parse_args()
     width, height = (int(v) for v in args.size.lower().split("x"))
@@ -76,6 +79,18 @@ def main():
         done += n
     seconds = time.time() - started
     counters = ctx.counters()
+
+    if args.denoise:
+        albedo = torch.zeros_like(frame)
+        ctx.set_entry_point(capi.ENTRY_DENOISER_ALBEDO)
+        ctx.use_scratch_accumulation(2)
+        for first in range(0, args.spp, batch):
+            ctx.render_pass(scene.camera(width, height, accumulations=first, max_bounce_count=args.bounces), albedo.data_ptr(), width, synchronize=True)
+        ctx.use_scratch_accumulation(0)
+        ctx.set_entry_point(capi.ENTRY_PATH_TRACING)
+        dn = denoiser.Denoiser(0)
+        dn.process(frame, albedo, frame, width, height)      # in place: the output kernel reads the filtered plane, not the noisy frame
+        dn.close()
 
     fx = camera_effects.CameraEffects(0)
     settings = camera_effects.Settings.preset() if args.effects == "preset" else camera_effects.Settings.linear()
