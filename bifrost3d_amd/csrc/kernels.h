@@ -26,7 +26,10 @@ namespace hipr {
 #define HIPR_NO_TRIANGLE 0xFFFFFFFFu
 
 constexpr int TRACE_BLOCK = 128;   // 2 waves; LDS stack = STACK * 128 * 4 B
-constexpr int SHADE_BLOCK = 256;
+#ifndef HIPR_SHADE_BLOCK_THREADS
+#define HIPR_SHADE_BLOCK_THREADS 256
+#endif
+constexpr int SHADE_BLOCK = HIPR_SHADE_BLOCK_THREADS;
 constexpr int SHADE_TRIANGLE_QUADS = 6;   // float4 per shading record (96 B), see k_build_shade_triangles
 
 struct DeviceScene {

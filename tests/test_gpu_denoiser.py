@@ -143,3 +143,29 @@ def test_denoised_cornell_is_closer_to_the_converged_image(ctx, dn, cornell):
     print(f"DENOISER-METRIC cornell {w}x{h}, 4 spp against 1024 spp: noisy mse {mse(noisy):.5f}, filtered mse {mse(filtered):.5f}")
     assert mse(filtered) < 0.4 * mse(noisy)
     assert np.isfinite(filtered).all()
+
+
+def test_second_running_mean_survives_between_feature_passes(ctx, cornell):
+    """hipr_use_scratch_accumulation(ctx, 2): the albedo feature image is a running mean NEXT to the camera's, kept across calls while path tracing
+    passes run in between (the backend alternates the two every frame). Interleaved, both means must equal the ones accumulated alone."""
+    w, h = 64, 36
+    radiance_alone, _ = render_gpu(ctx, cornell, w, h, 3, 4)
+    ctx.set_entry_point(capi.ENTRY_DENOISER_ALBEDO)
+    albedo_alone, _ = render_gpu(ctx, cornell, w, h, 3, 4)
+    ctx.set_entry_point(capi.ENTRY_PATH_TRACING)
+
+    ctx.set_frame(w, h)
+    for a in range(3):
+        cam = cornell.camera(w, h, accumulations=a, max_bounce_count=4)
+        ctx.render_pass(cam, synchronize=True)
+        ctx.set_entry_point(capi.ENTRY_DENOISER_ALBEDO)
+        ctx.use_scratch_accumulation(2)
+        ctx.render_pass(cam, synchronize=True)
+        if a == 2:
+            albedo_interleaved = ctx.read_accumulation()
+        ctx.use_scratch_accumulation(0)
+        ctx.set_entry_point(capi.ENTRY_PATH_TRACING)
+    radiance_interleaved = ctx.read_accumulation()
+    assert np.array_equal(radiance_interleaved, radiance_alone)
+    assert np.array_equal(albedo_interleaved, albedo_alone)
+    assert not np.array_equal(albedo_alone, radiance_alone)
