@@ -1,0 +1,44 @@
+"""bench.py end to end on the GPU box, small: the N = 1 line's contract, and the N = 2 path (ranks spawned by bench.py itself, tiles dealt round-robin,
+gather to rank 0, scatter into the frame) with both ranks on the one device of the box and the gloo backend, since RCCL wants one device per rank."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+SMALL = ["--width", "640", "--height", "360", "--atrium-triangles", "20000", "--steps", "2", "--warmup", "1", "--spp-per-pass", "4",
+         "--no-other-workloads", "--no-rmse", "--no-plugin", "--no-cpu-baseline"]
+
+
+def run_bench(extra):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    done = subprocess.run([sys.executable, str(ROOT / "bench.py")] + SMALL + extra, capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
+    assert done.returncode == 0, done.stderr[-2000:]
+    lines = [text for text in done.stdout.splitlines() if text.strip()]
+    assert len(lines) == 1, lines          # ONE JSON line on stdout, everything else on stderr
+    return json.loads(lines[0])
+
+
+def test_bench_line_contract_single_gpu():
+    line = run_bench([])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["steps"] == 2 and line["warmup"] == 1 and line["unit"] == "Mrays/s" and line["value"] > 0
+    assert line["config"]["frame_finite_and_lit"] and "workload" in line["config"]
+    roofline = line["roofline"]
+    assert roofline["bound"] in ("hbm", "mfma") and roofline["unit"] == "GB/s" and roofline["peak"] == 8000.0
+    assert roofline["frac"] == pytest.approx(roofline["achieved"] / roofline["peak"])
+
+
+def test_bench_two_ranks_on_one_device():
+    one = run_bench([])
+    two = run_bench(["--gpus", "2", "--share-device", "--dist-backend", "gloo"])
+    assert two["n_gpus"] == 2 and two["config"]["frame_finite_and_lit"]
+    assert two["config"]["parallelism"].endswith("x2")
+    # weak scaling: each rank traces the per-GPU share of one rank alone, on its half of the tiles -> twice the paths, and (same scene, same camera,
+    # deterministic sampling) about twice the rays of the single-rank step
+    assert two["config"]["rays_per_step"] == pytest.approx(2.0 * one["config"]["rays_per_step"], rel=0.02)
