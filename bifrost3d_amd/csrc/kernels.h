@@ -277,6 +277,11 @@ HD void traverse(const DeviceScene& sc, f3 o, f3 d, float tmin, const float& tma
     }
 }
 
+// Wave votes on a predicate the compiler already holds as a lane mask: __builtin_amdgcn_ballot_w64 is one scalar AND with exec, where HIP's
+// __ballot(int) / __any(int) first materialise the predicate as 0 / 1 in a VGPR and compare it again (two VALU instructions per vote).
+__device__ __forceinline__ unsigned long long wave_ballot(bool predicate) { return __builtin_amdgcn_ballot_w64(predicate); }
+__device__ __forceinline__ bool wave_any(bool predicate) { return __builtin_amdgcn_ballot_w64(predicate) != 0ull; }
+
 HD void wave_add(unsigned long long* dst, uint32_t v) {
     // one atomic per wave: butterfly reduction over the 64 lanes
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
@@ -523,7 +528,7 @@ __global__ __launch_bounds__(256) void k_trace_closest_small(DeviceScene sc, Pat
             const bool second_half = quad & (test.us < test.vs);
             const uint32_t id = second_half ? __float_as_uint(m.y) : __float_as_uint(m.x);
             inside &= id != skip;
-            if (!__any(inside)) continue;       // wave-uniform: most items are missed by every ray of the wave
+            if (!wave_any(inside)) continue;       // wave-uniform: most items are missed by every ray of the wave
             const float inv = 1.0f / test.det;
             const float tt = dot_fma(mk3(b.z, b.w, c.x), test.q) * inv;
             const bool closer = inside & (tt > tmin) & ((tt < best_t) | ((tt == best_t) & (id < best_id)));
@@ -560,13 +565,13 @@ __global__ __launch_bounds__(256) void k_trace_shadow_small(DeviceScene sc, Shad
         bool blocked = false;
         const ConstantFloat4Pointer items = as_constant(sc.trace_items);
         for (uint32_t t = 0; t < sc.trace_item_count; ++t) {
-            if (!__any(!blocked)) break;
+            if (!wave_any(!blocked)) break;
             const ScalarFloat4 a = items[4 * t], b = items[4 * t + 1], c = items[4 * t + 2], m = items[4 * t + 3];
             if (INSTRUMENT) tris += blocked ? 0u : 1u;
             const bool quad = (__float_as_uint(c.w) & HIPR_ITEM_QUAD) != 0;
             ItemTest test;
             const bool inside = item_inside(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), quad, o, d, test) & !blocked;
-            if (!__any(inside)) continue;
+            if (!wave_any(inside)) continue;
             const float inv = 1.0f / test.det;
             const float tt = dot_fma(mk3(b.z, b.w, c.x), test.q) * inv;
             if (inside && tt > 0.0f && tt < tmax) {
@@ -687,7 +692,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(tra
             finished = false;
         }
         // ---- refill idle lanes from the wave's private range -------------------------------------------------------
-        const unsigned long long idle = __ballot(!active);
+        const unsigned long long idle = wave_ballot(!active);
         if (INSTRUMENT && lane == 0 && idle && !exhausted) ++diag_refills;
         if (idle && !exhausted) {
             while (chunk_next >= chunk_end && !exhausted) {
@@ -702,7 +707,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(tra
                     // and move to the next one that still has rays, instead of walking the shards one dependent load at a time.
                     const uint32_t my_size = uint32_t((unsigned long long)n * (lane + 1u) / TRACE_SHARDS) - uint32_t((unsigned long long)n * lane / TRACE_SHARDS);
                     const uint32_t claimed = __hip_atomic_load(work_counter + lane * TRACE_SHARD_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned long long open = __ballot(claimed < my_size);
+                    const unsigned long long open = wave_ballot(claimed < my_size);
                     if (!open) exhausted = true;
                     else {
                         const unsigned long long rotated = shard ? ((open >> shard) | (open << (64u - shard))) : open;
@@ -750,9 +755,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(tra
                 chunk_next = min(chunk_next + uint32_t(__popcll(idle)), chunk_end);
             }
         }
-        unsigned long long busy = __ballot(active);
+        unsigned long long busy = wave_ballot(active);
         if (!busy) {
-            if (__ballot(finished)) continue;
+            if (wave_ballot(finished)) continue;
             if (exhausted) break;
             continue;
         }
@@ -762,7 +767,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(tra
         do {
             const bool tri_mode = active & (tri_cur < tri_end);
             const bool node_mode = active & !tri_mode;
-            const unsigned long long tmask = __ballot(tri_mode), nmask = __ballot(node_mode);
+            const unsigned long long tmask = wave_ballot(tri_mode), nmask = wave_ballot(node_mode);
             int next_item = TRACE_DONE;     // the item this lane continues with; selects only, no divergent state updates
             bool take_next = false, need_pop = false;
             if (INSTRUMENT && lane == 0) {
@@ -790,7 +795,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(tra
                     TriangleTest test;
                     const bool hit = triangle_inside(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), o, d, test);
                     float t = 0.0f, u = 0.0f, v = 0.0f;
-                    if (__any(hit)) triangle_hit_values(test, mk3(b.z, b.w, c.x), t, u, v);     // the lanes in this branch agree to skip the division
+                    if (wave_any(hit)) triangle_hit_values(test, mk3(b.z, b.w, c.x), t, u, v);     // the lanes in this branch agree to skip the division
                     need_pop = tri_cur == tri_end;
                     if constexpr (MODE != TRACE_CLOSEST) {
                         if (is_shadow && hit && t > tmin && t < tmax) {
@@ -874,7 +879,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(tra
                 active = !done;
                 finished = done;
             }
-            busy = __ballot(active);
+            busy = wave_ballot(active);
         } while (busy && (exhausted || __popcll(busy) >= refill_below));
     }
 

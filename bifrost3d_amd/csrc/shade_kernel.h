@@ -390,7 +390,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, HIPR_SHADE_WAVES) void k_shade(DeviceS
         // ONE 64-bit global atomic (low word = paths that continue, high word = shadow rays) and publishes its base: one block barrier per batch.
         // The counters alternate between two LDS words by batch parity; the last wave of a batch clears the word of the next one, which no wave
         // can have reached before the barrier below.
-        const unsigned long long cont_mask = __ballot(so.continues), shad_mask = __ballot(so.shadow);
+        const unsigned long long cont_mask = wave_ballot(so.continues), shad_mask = wave_ballot(so.shadow);
         const unsigned long long lt = (1ull << lane) - 1ull;
         shaded_total += so.shaded ? 1u : 0u;
         const uint32_t parity = batch & 1u;
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, HIPR_SHADE_WAVES) void k_shade(DeviceS
         ++batch;
 #else
         // ---- compaction: ballot + prefix popcount in the wave, LDS scan over the block's waves, one atomic for both queues
-        const unsigned long long cont_mask = __ballot(so.continues), shad_mask = __ballot(so.shadow);
+        const unsigned long long cont_mask = wave_ballot(so.continues), shad_mask = wave_ballot(so.shadow);
         const unsigned long long lt = (1ull << lane) - 1ull;
         if (lane == 0) { s_cont[wave] = __popcll(cont_mask); s_shad[wave] = __popcll(shad_mask); }
         shaded_total += so.shaded ? 1u : 0u;
