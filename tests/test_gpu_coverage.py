@@ -5,8 +5,11 @@
     -- ORS/MonteCarlo.cu:152-164,278-285, OR/Types.h:405-414, apps/SimpleViewer/Scenes/Opacity.h:27-104;
   * next_event_sample_count in {1, 8, 64, 256} (clamp to 256, OR/Renderer.cpp:1390) and the 256 sample offsets themselves (:323-336);
   * path regularisation with scale_decay != 0 (OR/PublicTypes.h:38-45);
-  * a tree that needs more than the 32 entry LDS stack (the OVERFLOW kernels) and a 1 M-triangle scene (BASELINE config 5's shape).
+  * a tree that needs more than the 32 entry LDS stack (the OVERFLOW kernels) and a 1 M-triangle scene (BASELINE config 5's shape);
+  * light arrays on both sides of the 32 lights the shade kernel keeps in LDS.
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -340,3 +343,47 @@ def test_refitted_scene_on_the_device_bit_exact(ctx, oracle_q, quads):
     # a wrong-sized description is refused, the uploaded scene stays usable
     other = Scene("cornell", param0=quads + 1)
     assert ctx.lib.hipr_update_scene_geometry(ctx.handle, __import__("ctypes").byref(other.desc)) == -1
+
+
+class SceneWithOtherLights:
+    """A scene's description with the light array replaced (same geometry, materials, BVH): what a host with many lights uploads."""
+
+    def __init__(self, scene, lights):
+        self.scene = scene                      # keeps the arrays the description points at alive
+        self.lights = (capi.HiprLight * len(lights))(*lights)
+        self.desc = capi.HiprSceneDesc()
+        C.memmove(C.byref(self.desc), C.byref(scene.desc), C.sizeof(capi.HiprSceneDesc))
+        self.desc.lights = C.cast(self.lights, C.POINTER(capi.HiprLight))
+        self.desc.light_count = len(lights)
+        self.state = scene.state
+        self.camera = scene.camera
+
+
+@pytest.mark.parametrize("light_count", [32, 33, 48])
+def test_many_lights(ctx, oracle_q, light_count):
+    """The shade kernel keeps light arrays of up to 32 entries in LDS and reads longer ones from global memory: the Cornell box lit by a ring of
+    `light_count` small sphere lights that share the power of its one lamp, on both sides of that limit, against the oracle."""
+    scene = Scene("cornell")
+    original = scene.desc.lights[0]
+    lights = []
+    for k in range(light_count):
+        light = capi.HiprLight()
+        C.memmove(C.byref(light), C.byref(original), C.sizeof(capi.HiprLight))
+        angle = 2.0 * np.pi * k / light_count
+        for c in range(3):
+            light.data[c] = original.data[c] / light_count                  # power
+        light.data[3] = original.data[3] + 0.25 * np.cos(angle)               # position: a ring under the ceiling
+        light.data[5] = original.data[5] + 0.25 * np.sin(angle)
+        light.data[6] = 0.02                                                   # radius
+        lights.append(light)
+    many = SceneWithOtherLights(scene, lights)
+    w, h, spp = 64, 36, 8
+    gpu, gc = render_gpu(ctx, many, w, h, spp, 4)
+    cpu, cc, _ = oracle_q.render(many.desc, many.state, many.camera(w, h, max_bounce_count=4), w, h, spp, use_bvh=ctx.oracle_search())
+    close, rmse = image_metrics(gpu, cpu)
+    print(f"cornell with {light_count} lights: pixels within 1e-3: {close:.4f}, RMSE {rmse:.3e}")
+    assert np.isfinite(gpu).all() and close >= 0.995, close
+    assert rmse <= 1e-3
+    for key in ("closest_rays", "shadow_rays"):
+        assert abs(gc[key] - cc[key]) <= 0.003 * cc[key], (key, gc[key], cc[key])
+    assert float(gpu[..., :3].mean()) > 0.05
