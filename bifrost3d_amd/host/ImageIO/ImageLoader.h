@@ -1,5 +1,5 @@
-// ImageLoader.h -- one entry point for every image format the loaders read, by file signature: PNG (PngImage), JPEG (JpegImage)
-// and Radiance HDR (HdrImage). Takes the place of StbImageLoader::load / load_from_memory (extensions/StbImageLoader/
+// ImageLoader.h -- one entry point for every image format the loaders read, by file signature: PNG (PngImage), JPEG (JpegImage),
+// Radiance HDR (HdrImage) and, by a plausible header, TGA (TgaImage). Takes the place of StbImageLoader::load / load_from_memory (extensions/StbImageLoader/
 // StbImageLoader/StbImageLoader.cpp:99-124) as the ImageLoader callback of the OBJ and glTF loaders and for --environment-map.
 #pragma once
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Writes tests/golden/images: small JPEG / Radiance HDR files and, in expected.npz, the pixels the REFERENCE's loader
+"""Writes tests/golden/images: small JPEG / Radiance HDR / TGA files and, in expected.npz, the pixels the REFERENCE's loader
 (StbImageLoader::load, built from /root/reference into oracle/_ref) makes of them. Run in the build container; the files and
 vectors are data, committed so that the codec test also runs where the reference tree is absent."""
 import sys
@@ -25,5 +25,10 @@ for name, size, rle, magic in codecs.HDR_CASES[:3]:
     path = out / f"{name}.hdr"
     codecs.write_hdr(path, codecs.hdr_picture(size[0], size[1], len(name)), rle, magic)
     expected[path.name] = codecs.reference_load(path)
+for name, size, arguments, channels in codecs.TGA_CASES:
+    if name in ("colour24_bottom_up", "colour32_rle_top_down", "colour15_rle", "grey16_alpha", "mapped8_32_rle", "mapped16_16_skip", "grey8_rle_top_down"):
+        path = out / f"{name}.tga"
+        codecs.write_tga(path, size, seed=len(name), **arguments)
+        expected[path.name] = codecs.reference_load(path)
 np.savez_compressed(out / "expected.npz", **expected)
 print({k: v.shape for k, v in expected.items()})

@@ -1,4 +1,4 @@
-"""The JPEG and Radiance HDR decoders of the host library (host/ImageIO/{JpegImage,HdrImage,ImageLoader}.cpp) against the decoder the
+"""The JPEG, Radiance HDR and TGA decoders of the host library (host/ImageIO/{JpegImage,HdrImage,TgaImage,ImageLoader}.cpp) against the decoder the
 reference loads its textures and environment maps with: StbImageLoader::load (extensions/StbImageLoader/StbImageLoader/
 StbImageLoader.cpp:99-113, stb_image 2.29), compiled from the reference tree into oracle/_ref where that tree is present, and
 against the golden vectors that loader produced (tests/golden/images, written by tests/golden/make_image_goldens.py) everywhere.
@@ -124,6 +124,101 @@ HDR_CASES = [("rle_64x20", (64, 20), True, b"#?RADIANCE"), ("rle_9x5_rgbe_magic"
              ("flat_wide_40x6", (40, 6), False, b"#?RADIANCE")]
 
 
+def write_tga(path, size, kind, bits, run_length=False, top_down=False, id_bytes=b"", map_entries=0, map_bits=24, map_skip=0, seed=1):
+    """A TGA 2.0 file without footer. kind: "colour" (type 2 / 10), "grey" (3 / 11) or "mapped" (1 / 9, `bits` = index size).
+    Run-length packets are cut at random lengths and run across row ends; pixels are stored bottom row first unless top_down."""
+    width, height = size
+    rng = np.random.default_rng(seed)
+    picture = make_picture(width, height, seed)
+    alpha = ((np.mgrid[0:height, 0:width][1] * 7 + seed * 13) % 256).astype(np.uint8)
+
+    def pack_colour(rgb, a, entry_bits):          # one pixel / map entry as stored
+        r, g, b = (int(v) for v in rgb)
+        if entry_bits in (15, 16):
+            v = ((r >> 3) << 10) | ((g >> 3) << 5) | (b >> 3) | ((0x8000 if a > 127 else 0) if entry_bits == 16 else 0)
+            return struct.pack("<H", v)
+        if entry_bits == 24:
+            return bytes([b, g, r])
+        if entry_bits == 32:
+            return bytes([b, g, r, int(a)])
+        return bytes([(r + g + b) // 3])          # 8 bit map entries: grey
+
+    colour_map = b""
+    if kind == "mapped":
+        palette = rng.integers(0, 256, (map_entries, 3), dtype=np.uint8)
+        colour_map = bytes(map_skip) + b"".join(pack_colour(palette[i], 255 - i, map_bits) for i in range(map_entries))
+        indices = rng.integers(0, map_entries + (3 if bits == 16 else 0), (height, width))      # a few indices past the map with 16 bit indices
+        indices[:, : width // 3] = indices[:, :1]                                               # runs for the encoder
+        pixels = [struct.pack("<H" if bits == 16 else "<B", int(min(v, 255) if bits == 8 else v)) for v in indices.reshape(-1)]
+        image_type = 1
+    elif kind == "grey":
+        grey = picture[..., 1].copy()
+        grey[:, : width // 3] = grey[:, :1]
+        pixels = [bytes([int(g)]) if bits == 8 else bytes([int(g), int(a)]) for g, a in zip(grey.reshape(-1), alpha.reshape(-1))]
+        image_type = 3
+    else:
+        picture[:, : width // 3] = picture[:, :1]
+        pixels = [pack_colour(rgb, a, bits) for rgb, a in zip(picture.reshape(-1, 3), alpha.reshape(-1))]
+        image_type = 2
+    if not top_down:      # stored bottom row first
+        rows = [pixels[y * width:(y + 1) * width] for y in range(height)][::-1]
+        pixels = [p for row in rows for p in row]
+
+    body = bytearray()
+    if run_length:
+        image_type += 8
+        i = 0
+        while i < len(pixels):
+            run = 1
+            while i + run < len(pixels) and pixels[i + run] == pixels[i] and run < 128:
+                run += 1
+            if run >= 2:
+                run = min(run, int(rng.integers(2, 129)))
+                body += bytes([0x80 | (run - 1)]) + pixels[i]
+                i += run
+            else:
+                literal = 1
+                while i + literal < len(pixels) and literal < 128 and pixels[i + literal] != pixels[i + literal - 1]:
+                    literal += 1
+                literal = min(literal, int(rng.integers(1, 129)))
+                body += bytes([literal - 1]) + b"".join(pixels[i:i + literal])
+                i += literal
+    else:
+        body += b"".join(pixels)
+    descriptor = (0x20 if top_down else 0) | (8 if (kind == "colour" and bits == 32) or (kind == "grey" and bits == 16) else 0)
+    header = struct.pack("<BBBHHBHHHHBB", len(id_bytes), 1 if kind == "mapped" else 0, image_type, map_skip, map_entries, map_bits if kind == "mapped" else 0,
+                         0, 0, width, height, bits, descriptor)
+    Path(path).write_bytes(header + id_bytes + colour_map + bytes(body))
+
+
+# name, size, keyword arguments of write_tga, channels of the decoded image (grey + alpha is expanded to RGBA by the loader)
+TGA_CASES = [("colour24_bottom_up", (37, 21), dict(kind="colour", bits=24), 3),
+             ("colour32_top_down_id", (16, 9), dict(kind="colour", bits=32, top_down=True, id_bytes=b"made by the test"), 4),
+             ("colour24_rle", (64, 33), dict(kind="colour", bits=24, run_length=True), 3),
+             ("colour32_rle_top_down", (31, 17), dict(kind="colour", bits=32, run_length=True, top_down=True), 4),
+             ("colour16", (20, 11), dict(kind="colour", bits=16), 3),
+             ("colour15_rle", (25, 13), dict(kind="colour", bits=15, run_length=True), 3),
+             ("grey8", (19, 23), dict(kind="grey", bits=8), 1),
+             ("grey8_rle_top_down", (40, 10), dict(kind="grey", bits=8, run_length=True, top_down=True), 1),
+             ("grey16_alpha", (12, 14), dict(kind="grey", bits=16), 4),
+             ("mapped8_24", (33, 12), dict(kind="mapped", bits=8, map_entries=200, map_bits=24), 3),
+             ("mapped8_32_rle", (28, 15), dict(kind="mapped", bits=8, map_entries=17, map_bits=32, run_length=True), 4),
+             ("mapped16_16_skip", (21, 9), dict(kind="mapped", bits=16, map_entries=300, map_bits=16, map_skip=5), 3),
+             ("mapped8_grey_entries", (10, 6), dict(kind="mapped", bits=8, map_entries=64, map_bits=8), 1)]
+
+
+@pytest.mark.skipif(not reference_bindings.available(), reason="oracle/_ref is not built (no /root/reference)")
+@pytest.mark.parametrize("name,size,arguments,channels", TGA_CASES)
+def test_tga_decoder_equals_the_reference_loader(tmp_path, name, size, arguments, channels):
+    path = tmp_path / f"{name}.tga"
+    write_tga(path, size, seed=len(name), **arguments)
+    mine, reference = host_load(path), reference_load(path)
+    assert reference is not None and mine is not None
+    assert mine.shape == reference.shape == (size[1], size[0], channels)
+    assert np.array_equal(mine, reference), int(np.abs(mine.astype(int) - reference.astype(int)).max())
+    assert len(np.unique(mine)) > 4
+
+
 @pytest.mark.skipif(not reference_bindings.available(), reason="oracle/_ref is not built (no /root/reference)")
 @pytest.mark.parametrize("name,size,mode,arguments", JPEG_CASES)
 def test_jpeg_decoder_equals_the_reference_loader(tmp_path, name, size, mode, arguments):
@@ -151,8 +246,8 @@ def test_hdr_decoder_equals_the_reference_loader(tmp_path, name, size, rle, magi
 def test_decoders_reproduce_the_golden_vectors():
     """Files and the pixels the reference's loader made of them, committed (tests/golden/make_image_goldens.py): runs where the reference tree is absent."""
     expected = np.load(GOLDEN / "expected.npz")
-    files = sorted(p for p in GOLDEN.iterdir() if p.suffix in (".jpg", ".hdr"))
-    assert len(files) >= 8
+    files = sorted(p for p in GOLDEN.iterdir() if p.suffix in (".jpg", ".hdr", ".tga"))
+    assert len(files) >= 14 and sum(p.suffix == ".tga" for p in files) >= 6
     for path in files:
         mine = host_load(path)
         assert mine is not None, path.name
@@ -172,6 +267,12 @@ def test_loader_rejects_what_it_cannot_decode(tmp_path):
     hdr.write_bytes(b"#?RADIANCE\nFORMAT=32-bit_rle_xyze\n\n-Y 2 +X 2\n" + bytes(16))
     assert host_load(hdr) is None
     assert host_load(tmp_path / "absent.jpg") is None
+    tga = tmp_path / "map_without_entries.tga"
+    tga.write_bytes(struct.pack("<BBBHHBHHHHBB", 0, 1, 1, 0, 0, 24, 0, 0, 4, 4, 8, 0) + bytes(16))
+    assert host_load(tga) is None
+    text = tmp_path / "notes.tga"
+    text.write_bytes(b"this is not an image at all, whatever the extension says")
+    assert host_load(text) is None
 
 
 def test_environment_map_and_jpeg_textures_reach_the_flattened_scene(tmp_path):
@@ -203,3 +304,21 @@ def test_environment_map_and_jpeg_textures_reach_the_flattened_scene(tmp_path):
         assert capi.load_library().hipr_validate_scene(C.byref(desc)) == 0
     finally:
         lib.hiprh_scene_destroy(handle)
+
+
+def test_tga_textures_reach_the_flattened_scene(tmp_path):
+    """An OBJ in the style of the Crytek Sponza distribution: materials naming .tga textures, one of them with an alpha channel (a cut-out,
+    apps/SimpleViewer/main.cpp:222-268). The flattened scene carries both textures with the decoded size and format."""
+    from bifrost3d_amd import capi
+    from bifrost3d_amd.host import Scene
+    write_tga(tmp_path / "bricks.tga", (16, 8), kind="colour", bits=24, run_length=True, seed=4)
+    write_tga(tmp_path / "leaf.tga", (8, 8), kind="colour", bits=32, seed=5)
+    (tmp_path / "wall.mtl").write_text("newmtl bricks\nKd 1 1 1\nmap_Kd bricks.tga\nnewmtl leaf\nKd 1 1 1\nmap_Kd leaf.tga\n")
+    (tmp_path / "wall.obj").write_text("mtllib wall.mtl\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 2 0 0\nv 2 1 0\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\n"
+                                       "usemtl bricks\nf 1/1 2/2 3/3\nf 1/1 3/3 4/4\nusemtl leaf\nf 2/1 5/2 6/3\nf 2/1 6/3 3/4\n")
+    scene = Scene("file:" + str(tmp_path / "wall.obj"))
+    desc = scene.desc
+    assert desc.triangle_count == 4
+    sizes = sorted((desc.textures[i].width, desc.textures[i].height) for i in range(1, desc.texture_count))
+    assert (16, 8) in sizes and (8, 8) in sizes
+    assert capi.load_library().hipr_validate_scene(C.byref(desc)) == 0

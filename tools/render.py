@@ -4,7 +4,7 @@
     python tools/render.py --scene material --spp 256 --size 1280x720 --out material.png
     python tools/render.py --scene-file model.glb --spp 64 --effects linear --out model.png
 
-Scenes: cornell, cornell_diffuse, atrium, material, material_coat, glass, or a model file (.gltf / .glb / .obj with PNG textures)
+Scenes: cornell, cornell_diffuse, atrium, material, material_coat, glass, or a model file (.gltf / .glb / .obj with PNG, JPEG or TGA textures)
 set up the way the viewer sets up its command-line scene. `--effects preset` applies the camera's default post-process
 (histogram exposure, vignette, filmic tonemapping, film grain; eye adaptation off so that a single frame is fully adapted),
 `linear` only converts to sRGB. `--denoise` runs the denoising backend's data flow before the effects: an albedo feature pass of the
