@@ -7,13 +7,20 @@
 //   * every triangle is referenced by exactly one leaf, leaves hold 1..4 triangles;
 //   * the deepest leaf is at most `max_depth` levels below the root (median splits take over when
 //     the SAH tree would exceed the LDS stack of the kernels);
-//   * the result depends only on the input order and values (single threaded, stable partition).
+//   * the result depends only on the input order and values: the build runs on several host threads for large scenes (the top levels
+//     bin and partition in parallel, the subtrees below them build side by side) and produces the tree the single-threaded build does,
+//     node for node -- bounds and bin counts are order-independent reductions, the partition is stable, and subtrees are stitched in
+//     depth-first order. HIPR_BVH_THREADS overrides the thread count (1 = single threaded).
 #include "BvhBuilder.h"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <cfloat>
 #include <cstdlib>
 #include <cmath>
+#include <thread>
 
 namespace HIPRenderer {
 
@@ -39,19 +46,60 @@ static uint32_t leaf_max() {
 }
 #define LEAF_MAX leaf_max()
 
+static unsigned build_threads() {
+    static const unsigned value = [] {
+        if (const char* v = std::getenv("HIPR_BVH_THREADS")) return unsigned(std::max(1, std::atoi(v)));
+        const unsigned n = std::thread::hardware_concurrency();
+        return n == 0 ? 1u : std::min(n, 16u);
+    }();
+    return value;
+}
+
+// f(chunk, begin, end) over `chunks` equal slices of [begin, end), on as many threads; chunk 0 runs on the caller.
+template <typename F>
+static void for_chunks(uint32_t begin, uint32_t end, unsigned chunks, F f) {
+    const uint64_t count = end - begin;
+    auto slice = [&](unsigned c) { return uint32_t(begin + count * c / chunks); };
+    std::vector<std::thread> workers;
+    workers.reserve(chunks > 0 ? chunks - 1 : 0);
+    for (unsigned c = 1; c < chunks; ++c) workers.emplace_back([&, c] { f(c, slice(c), slice(c + 1)); });
+    f(0u, slice(0), slice(1));
+    for (std::thread& w : workers) w.join();
+}
+
+constexpr uint32_t PARALLEL_RANGE = 1u << 17;      // ranges at least this long are binned and partitioned on several threads
+constexpr int32_t SUBTREE_MARK = 0x40000000;       // child reference of the top tree: a subtree built as its own task (| task index)
+
 struct Builder {
     const std::vector<HiprTriangle>& tris;
-    std::vector<Box> boxes;
-    std::vector<float> centroids;   // 3 per triangle
-    std::vector<uint32_t> order;
+    const Box* boxes = nullptr;           // per input triangle
+    const float* centroids = nullptr;     // 3 per input triangle
+    uint32_t* order = nullptr;            // the permutation being built; a (sub)builder touches only its own range
     std::vector<HiprBvhNode> nodes;
     uint32_t max_depth_limit;
     uint32_t deepest = 0;
+    unsigned threads = 1;                 // worker threads of the build (the top builder only)
+    unsigned range_threads = 1;           // > 1: long ranges are binned and partitioned in this many slices (measured: beyond 8 the top levels get slower)
 
-    explicit Builder(const std::vector<HiprTriangle>& t, uint32_t limit) : tris(t), max_depth_limit(limit) {}
+    // Subtrees handed to worker threads (top builder only): ranges at most `subtree_cutoff` long.
+    struct Task { uint32_t begin, end, depth; std::vector<HiprBvhNode> nodes; uint32_t deepest = 0; };
+    std::vector<Task> tasks;
+    uint32_t subtree_cutoff = 0;          // 0: build everything here
+
+    Builder(const std::vector<HiprTriangle>& t, uint32_t limit) : tris(t), max_depth_limit(limit) {}
 
     Box bounds_of(uint32_t begin, uint32_t end) const {
         Box b; b.reset();
+        if (range_threads > 1 && end - begin >= PARALLEL_RANGE) {
+            std::vector<Box> partial(range_threads);
+            for_chunks(begin, end, range_threads, [&](unsigned c, uint32_t cb, uint32_t ce) {
+                Box p; p.reset();
+                for (uint32_t i = cb; i < ce; ++i) p.grow(boxes[order[i]]);
+                partial[c] = p;
+            });
+            for (const Box& p : partial) b.grow(p);      // min / max: the same box in any order
+            return b;
+        }
         for (uint32_t i = begin; i < end; ++i) b.grow(boxes[order[i]]);
         return b;
     }
@@ -62,11 +110,44 @@ struct Builder {
         return levels;
     }
 
+    struct Bins {
+        Box box[3][BIN_COUNT];
+        uint32_t n[3][BIN_COUNT];
+        void reset() { for (int a = 0; a < 3; ++a) for (int b = 0; b < BIN_COUNT; ++b) { box[a][b].reset(); n[a][b] = 0; } }
+    };
+    static int bin_of(float centroid, float lo, float scale) {
+        int b = int((centroid - lo) * scale);
+        return std::min(std::max(b, 0), BIN_COUNT - 1);
+    }
+    // The triangles of [begin, end) sorted into the bins of every axis with an extent (scale[axis] > 0).
+    void fill_bins(uint32_t begin, uint32_t end, const Box& cb, const float scale[3], Bins& bins) const {
+        bins.reset();
+        for (uint32_t i = begin; i < end; ++i) {
+            const uint32_t t = order[i];
+            for (int axis = 0; axis < 3; ++axis) {
+                if (!(scale[axis] > 0.0f)) continue;
+                const int b = bin_of(centroids[3 * t + axis], cb.lo[axis], scale[axis]);
+                bins.box[axis][b].grow(boxes[t]);
+                bins.n[axis][b]++;
+            }
+        }
+    }
+
     // Returns the split position in [begin+1, end-1].
     uint32_t split(uint32_t begin, uint32_t end, uint32_t depth) {
         const uint32_t count = end - begin;
+        const bool parallel = range_threads > 1 && count >= PARALLEL_RANGE;
         Box cb; cb.reset();
-        for (uint32_t i = begin; i < end; ++i) cb.grow(&centroids[3 * order[i]]);
+        if (parallel) {
+            std::vector<Box> partial(range_threads);
+            for_chunks(begin, end, range_threads, [&](unsigned c, uint32_t b, uint32_t e) {
+                Box p; p.reset();
+                for (uint32_t i = b; i < e; ++i) p.grow(&centroids[3 * order[i]]);
+                partial[c] = p;
+            });
+            for (const Box& p : partial) cb.grow(p);
+        } else
+            for (uint32_t i = begin; i < end; ++i) cb.grow(&centroids[3 * order[i]]);
 
         // Depth budget: once only enough levels remain for a balanced tree, split at the median.
         const bool force_median = depth + levels_needed(count) >= max_depth_limit;
@@ -74,20 +155,25 @@ struct Builder {
         int best_axis = -1, best_bin = -1;
         float best_cost = FLT_MAX;
         if (!force_median) {
+            float scale[3];
             for (int axis = 0; axis < 3; ++axis) {
                 const float extent = cb.hi[axis] - cb.lo[axis];
-                if (!(extent > 0.0f)) continue;
-                Box bin_box[BIN_COUNT];
-                uint32_t bin_n[BIN_COUNT] = {};
-                for (auto& b : bin_box) b.reset();
-                const float scale = BIN_COUNT / extent;
-                for (uint32_t i = begin; i < end; ++i) {
-                    const uint32_t t = order[i];
-                    int b = int((centroids[3 * t + axis] - cb.lo[axis]) * scale);
-                    b = std::min(std::max(b, 0), BIN_COUNT - 1);
-                    bin_box[b].grow(boxes[t]);
-                    bin_n[b]++;
-                }
+                scale[axis] = extent > 0.0f ? BIN_COUNT / extent : 0.0f;
+            }
+            Bins bins;
+            if (parallel) {
+                std::vector<Bins> partial(range_threads);
+                for_chunks(begin, end, range_threads, [&](unsigned c, uint32_t b, uint32_t e) { fill_bins(b, e, cb, scale, partial[c]); });
+                bins.reset();
+                for (const Bins& p : partial)
+                    for (int a = 0; a < 3; ++a)
+                        for (int b = 0; b < BIN_COUNT; ++b) { if (p.n[a][b]) bins.box[a][b].grow(p.box[a][b]); bins.n[a][b] += p.n[a][b]; }
+            } else
+                fill_bins(begin, end, cb, scale, bins);
+            for (int axis = 0; axis < 3; ++axis) {
+                if (!(scale[axis] > 0.0f)) continue;
+                const Box* bin_box = bins.box[axis];
+                const uint32_t* bin_n = bins.n[axis];
                 float right_area[BIN_COUNT];
                 uint32_t right_n[BIN_COUNT];
                 Box acc; acc.reset();
@@ -114,12 +200,34 @@ struct Builder {
             const float extent = cb.hi[best_axis] - cb.lo[best_axis];
             const float scale = BIN_COUNT / extent;
             const float lo = cb.lo[best_axis];
-            auto mid = std::stable_partition(order.begin() + begin, order.begin() + end, [&](uint32_t t) {
-                int b = int((centroids[3 * t + best_axis] - lo) * scale);
-                b = std::min(std::max(b, 0), BIN_COUNT - 1);
-                return b <= best_bin;
-            });
-            const uint32_t m = uint32_t(mid - order.begin());
+            auto left = [&](uint32_t t) { return bin_of(centroids[3 * t + best_axis], lo, scale) <= best_bin; };
+            uint32_t m;
+            if (parallel) {
+                // stable partition in two passes: count the left elements of every slice, then scatter both sides in slice order
+                std::vector<uint32_t> lefts(range_threads, 0u);
+                for_chunks(begin, end, range_threads, [&](unsigned c, uint32_t b, uint32_t e) {
+                    uint32_t k = 0;
+                    for (uint32_t i = b; i < e; ++i) k += left(order[i]) ? 1u : 0u;
+                    lefts[c] = k;
+                });
+                uint32_t total_left = 0;
+                for (uint32_t k : lefts) total_left += k;
+                std::vector<uint32_t> left_at(range_threads), right_at(range_threads);
+                uint32_t l = 0, r = total_left;
+                for (unsigned c = 0; c < range_threads; ++c) {
+                    const uint32_t slice = uint32_t(begin + uint64_t(count) * (c + 1) / range_threads) - uint32_t(begin + uint64_t(count) * c / range_threads);
+                    left_at[c] = l; right_at[c] = r;
+                    l += lefts[c]; r += slice - lefts[c];
+                }
+                std::vector<uint32_t> moved(count);
+                for_chunks(begin, end, range_threads, [&](unsigned c, uint32_t b, uint32_t e) {
+                    uint32_t lw = left_at[c], rw = right_at[c];
+                    for (uint32_t i = b; i < e; ++i) { const uint32_t t = order[i]; if (left(t)) moved[lw++] = t; else moved[rw++] = t; }
+                });
+                for_chunks(begin, end, range_threads, [&](unsigned, uint32_t b, uint32_t e) { std::copy(moved.begin() + (b - begin), moved.begin() + (e - begin), order + b); });
+                m = begin + total_left;
+            } else
+                m = uint32_t(std::stable_partition(order + begin, order + end, left) - order);
             if (m > begin && m < end) return m;
         }
 
@@ -128,8 +236,7 @@ struct Builder {
         for (int a = 1; a < 3; ++a)
             if (cb.hi[a] - cb.lo[a] > cb.hi[axis] - cb.lo[axis]) axis = a;
         const uint32_t m = begin + count / 2;
-        std::stable_sort(order.begin() + begin, order.begin() + end,
-                         [&](uint32_t a, uint32_t b) { return centroids[3 * a + axis] < centroids[3 * b + axis]; });
+        std::stable_sort(order + begin, order + end, [&](uint32_t a, uint32_t b) { return centroids[3 * a + axis] < centroids[3 * b + axis]; });
         return m;
     }
 
@@ -142,7 +249,8 @@ struct Builder {
         n.child[c] = ref;
     }
 
-    // Builds the node covering order[begin, end) (count > LEAF_MAX) and returns its index.
+    // Builds the node covering order[begin, end) (count > LEAF_MAX) and returns its index. With a subtree cutoff (the top builder of a
+    // parallel build), a child range at most that long becomes a task instead and its reference carries SUBTREE_MARK.
     uint32_t build(uint32_t begin, uint32_t end, uint32_t depth) {
         const uint32_t index = uint32_t(nodes.size());
         nodes.emplace_back();
@@ -155,11 +263,89 @@ struct Builder {
             if (e - b <= LEAF_MAX) {
                 store_child(scratch, c, box, leaf_ref(b, e - b));
                 deepest = std::max(deepest, depth + 1);
+            } else if (subtree_cutoff && e - b <= subtree_cutoff) {
+                store_child(scratch, c, box, SUBTREE_MARK | int32_t(tasks.size()));
+                tasks.push_back({b, e, depth + 1, {}, 0});
             } else
                 store_child(scratch, c, box, int32_t(build(b, e, depth + 1)));
         }
         nodes[index] = scratch;
         return index;
+    }
+
+    // The top tree and the finished subtrees laid out in the depth-first order the single-threaded build produces: a layout pass gives every
+    // top node and every subtree its place, then the subtrees are copied to theirs side by side.
+    void layout(uint32_t top_index, const std::vector<HiprBvhNode>& top, std::vector<uint32_t>& top_at, std::vector<uint32_t>& task_at, uint32_t& next) const {
+        top_at[top_index] = next++;
+        for (int c = 0; c < 2; ++c) {
+            const int32_t ref = top[top_index].child[c];
+            if (ref < 0) continue;                                     // a leaf
+            if (ref & SUBTREE_MARK) { task_at[size_t(ref & ~SUBTREE_MARK)] = next; next += uint32_t(tasks[size_t(ref & ~SUBTREE_MARK)].nodes.size()); }
+            else layout(uint32_t(ref), top, top_at, task_at, next);
+        }
+    }
+
+    void build_all(uint32_t n) {
+        threads = n >= 2 * PARALLEL_RANGE ? build_threads() : 1u;
+        range_threads = std::min(threads, 8u);
+        if (threads == 1) { nodes.reserve(n); build(0, n, 1); return; }
+        subtree_cutoff = std::max<uint32_t>(n / (threads * 8u), 4096u);
+        const auto x0 = std::chrono::steady_clock::now();
+        build(0, n, 1);
+        const auto x1 = std::chrono::steady_clock::now();
+        // the subtrees, longest first, pulled from a shared counter
+        std::vector<size_t> by_size(tasks.size());
+        for (size_t i = 0; i < by_size.size(); ++i) by_size[i] = i;
+        std::stable_sort(by_size.begin(), by_size.end(), [&](size_t a, size_t b) { return tasks[a].end - tasks[a].begin > tasks[b].end - tasks[b].begin; });
+        std::atomic<size_t> next{0};
+        auto worker = [&] {
+            for (size_t k = next.fetch_add(1); k < by_size.size(); k = next.fetch_add(1)) {
+                Task& task = tasks[by_size[k]];
+                Builder sub(tris, max_depth_limit);
+                sub.boxes = boxes; sub.centroids = centroids; sub.order = order;
+                sub.nodes.reserve(task.end - task.begin);
+                sub.build(task.begin, task.end, task.depth);
+                task.nodes = std::move(sub.nodes);
+                task.deepest = sub.deepest;
+            }
+        };
+        std::vector<std::thread> workers;
+        for (unsigned t = 1; t < threads; ++t) workers.emplace_back(worker);
+        worker();
+        for (std::thread& w : workers) w.join();
+        const auto x2 = std::chrono::steady_clock::now();
+        for (const Task& task : tasks) deepest = std::max(deepest, task.deepest);
+        std::vector<HiprBvhNode> top = std::move(nodes);
+        std::vector<uint32_t> top_at(top.size()), task_at(tasks.size());
+        uint32_t total = 0;
+        layout(0, top, top_at, task_at, total);
+        std::vector<HiprBvhNode> out(total);
+        for (size_t i = 0; i < top.size(); ++i) {
+            HiprBvhNode node = top[i];
+            for (int c = 0; c < 2; ++c)
+                if (node.child[c] >= 0) node.child[c] = int32_t((node.child[c] & SUBTREE_MARK) ? task_at[size_t(node.child[c] & ~SUBTREE_MARK)] : top_at[size_t(node.child[c])]);
+            out[top_at[i]] = node;
+        }
+        std::atomic<size_t> next_copy{0};
+        auto copier = [&] {
+            for (size_t k = next_copy.fetch_add(1); k < tasks.size(); k = next_copy.fetch_add(1)) {
+                const int32_t offset = int32_t(task_at[k]);
+                HiprBvhNode* target = out.data() + offset;
+                for (HiprBvhNode node : tasks[k].nodes) {
+                    for (int c = 0; c < 2; ++c) if (node.child[c] >= 0) node.child[c] += offset;
+                    *target++ = node;
+                }
+                std::vector<HiprBvhNode>().swap(tasks[k].nodes);
+            }
+        };
+        std::vector<std::thread> copiers;
+        for (unsigned t = 1; t < threads; ++t) copiers.emplace_back(copier);
+        copier();
+        for (std::thread& w : copiers) w.join();
+        nodes = std::move(out);
+        if (std::getenv("HIPR_BVH_TIMING"))
+            fprintf(stderr, "[hipr]   top tree %.3f s (%zu subtree tasks of <= %u triangles), subtrees %.3f s, stitch %.3f s\n", std::chrono::duration<double>(x1 - x0).count(), tasks.size(), subtree_cutoff,
+                    std::chrono::duration<double>(x2 - x1).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - x2).count());
     }
 };
 
@@ -203,16 +389,33 @@ struct WideCollapse {
     const std::vector<HiprBvhNode>& nodes;
     std::vector<HiprWideNode> wide;
     std::vector<uint32_t> binary_need;   // stack entries the BVH2 subtree of a node needs when nothing below it is widened
+    std::vector<uint32_t> subtree_size;  // BVH2 nodes in the subtree of a node
+    const uint32_t* need = nullptr;      // = binary_need.data() of the collapse that computed it (shared with the subtree collapses)
 
-    uint32_t compute_binary_need(uint32_t node_index) {
-        uint32_t need = 0;
-        for (int c = 0; c < 2; ++c) {
-            const int32_t ref = nodes[node_index].child[c];
-            need = std::max(need, 1u + (ref >= 0 ? compute_binary_need(uint32_t(ref)) : 0u));
+    // Subtrees collapsed as tasks of their own (the top collapse of a parallel run): BVH2 subtrees of at most `subtree_cutoff` nodes.
+    struct Task { uint32_t node_index, budget; std::vector<HiprWideNode> wide; uint32_t stack_need = 0; };
+    std::vector<Task> tasks;
+    uint32_t subtree_cutoff = 0;
+    static bool is_task(int32_t ref) { return ref >= SUBTREE_MARK && ref != int32_t(HIPR_WIDE_EMPTY); }
+    explicit WideCollapse(const std::vector<HiprBvhNode>& n, const uint32_t* shared_need = nullptr) : nodes(n), need(shared_need) {}
+
+    // Nodes are stored parent before children: one sweep from the last node to the first sees every child done.
+    uint32_t compute_binary_need() {
+        binary_need.assign(nodes.size(), 0u);
+        subtree_size.assign(nodes.size(), 1u);
+        for (size_t i = nodes.size(); i-- > 0;) {
+            uint32_t deepest = 0;
+            for (int c = 0; c < 2; ++c) {
+                const int32_t ref = nodes[i].child[c];
+                deepest = std::max(deepest, 1u + (ref >= 0 ? binary_need[size_t(ref)] : 0u));
+                if (ref >= 0) subtree_size[i] += subtree_size[size_t(ref)];
+            }
+            binary_need[i] = deepest;
         }
-        return binary_need[node_index] = need;
+        need = binary_need.data();
+        return binary_need[0];
     }
-    uint32_t need_of(int32_t ref) const { return ref >= 0 ? binary_need[ref] : 0u; }
+    uint32_t need_of(int32_t ref) const { return ref >= 0 ? need[ref] : 0u; }
 
     struct Child { Box box; int32_t ref; };
 
@@ -259,11 +462,94 @@ struct WideCollapse {
         for (size_t k = 0; k < children.size(); ++k) {
             uint32_t below = 0;
             const uint32_t held = uint32_t(children.size() - 1);
-            w.child[k] = children[k].ref >= 0 ? int32_t(collapse(uint32_t(children[k].ref), budget > held ? budget - held : 0u, below)) : children[k].ref;
+            const uint32_t child_budget = budget > held ? budget - held : 0u;
+            if (children[k].ref < 0) w.child[k] = children[k].ref;
+            else if (subtree_cutoff && subtree_size[size_t(children[k].ref)] <= subtree_cutoff) {
+                w.child[k] = SUBTREE_MARK | int32_t(tasks.size());      // its stack need joins in finish()
+                tasks.push_back({uint32_t(children[k].ref), child_budget, {}, 0u});
+            } else
+                w.child[k] = int32_t(collapse(uint32_t(children[k].ref), child_budget, below));
             stack_need = std::max(stack_need, uint32_t(children.size() - 1) + below);
         }
         wide[index] = w;
         return index;
+    }
+
+    // ---- the parallel run: top collapse here, subtrees on worker threads, then the depth-first layout the sequential collapse produces ----
+    void layout(uint32_t top_index, const std::vector<HiprWideNode>& top, std::vector<uint32_t>& top_at, std::vector<uint32_t>& task_at, uint32_t& next, uint32_t& stack_need) const {
+        top_at[top_index] = next++;
+        uint32_t children = 0;
+        for (int k = 0; k < 4; ++k) children += top[top_index].child[k] != int32_t(HIPR_WIDE_EMPTY);
+        stack_need = 0;
+        for (int k = 0; k < 4; ++k) {
+            const int32_t ref = top[top_index].child[k];
+            if (ref == int32_t(HIPR_WIDE_EMPTY)) continue;
+            uint32_t below = 0;
+            if (is_task(ref)) {
+                const Task& task = tasks[size_t(ref - SUBTREE_MARK)];
+                task_at[size_t(ref - SUBTREE_MARK)] = next;
+                next += uint32_t(task.wide.size());
+                below = task.stack_need;
+            } else if (ref >= 0)
+                layout(uint32_t(ref), top, top_at, task_at, next, below);
+            stack_need = std::max(stack_need, children - 1u + below);
+        }
+    }
+
+    void run(uint32_t budget, unsigned threads, uint32_t& stack_need) {
+        if (threads <= 1 || nodes.size() < PARALLEL_RANGE) { wide.reserve(nodes.size() / 2 + 1); collapse(0, budget, stack_need); return; }
+        subtree_cutoff = std::max<uint32_t>(uint32_t(nodes.size() / (threads * 8u)), 2048u);
+        uint32_t ignored = 0;
+        collapse(0, budget, ignored);
+        std::vector<size_t> by_size(tasks.size());
+        for (size_t i = 0; i < by_size.size(); ++i) by_size[i] = i;
+        std::stable_sort(by_size.begin(), by_size.end(), [&](size_t a, size_t b) { return subtree_size[tasks[a].node_index] > subtree_size[tasks[b].node_index]; });
+        std::atomic<size_t> next{0};
+        auto worker = [&] {
+            for (size_t k = next.fetch_add(1); k < by_size.size(); k = next.fetch_add(1)) {
+                Task& task = tasks[by_size[k]];
+                WideCollapse sub(nodes, need);
+                sub.wide.reserve(subtree_size[task.node_index] / 2 + 1);
+                sub.collapse(task.node_index, task.budget, task.stack_need);
+                task.wide = std::move(sub.wide);
+            }
+        };
+        std::vector<std::thread> workers;
+        for (unsigned t = 1; t < threads; ++t) workers.emplace_back(worker);
+        worker();
+        for (std::thread& w : workers) w.join();
+
+        std::vector<HiprWideNode> top = std::move(wide);
+        std::vector<uint32_t> top_at(top.size()), task_at(tasks.size());
+        uint32_t total = 0;
+        layout(0, top, top_at, task_at, total, stack_need);
+        std::vector<HiprWideNode> out(total);
+        for (size_t i = 0; i < top.size(); ++i) {
+            HiprWideNode node = top[i];
+            for (int k = 0; k < 4; ++k) {
+                const int32_t ref = node.child[k];
+                if (is_task(ref)) node.child[k] = int32_t(task_at[size_t(ref - SUBTREE_MARK)]);
+                else if (ref >= 0 && ref != int32_t(HIPR_WIDE_EMPTY)) node.child[k] = int32_t(top_at[size_t(ref)]);
+            }
+            out[top_at[i]] = node;
+        }
+        std::atomic<size_t> next_copy{0};
+        auto copier = [&] {
+            for (size_t k = next_copy.fetch_add(1); k < tasks.size(); k = next_copy.fetch_add(1)) {
+                const int32_t offset = int32_t(task_at[k]);
+                HiprWideNode* target = out.data() + offset;
+                for (HiprWideNode node : tasks[k].wide) {
+                    for (int c = 0; c < 4; ++c) if (node.child[c] >= 0 && node.child[c] != int32_t(HIPR_WIDE_EMPTY)) node.child[c] += offset;
+                    *target++ = node;
+                }
+                std::vector<HiprWideNode>().swap(tasks[k].wide);
+            }
+        };
+        std::vector<std::thread> copiers;
+        for (unsigned t = 1; t < threads; ++t) copiers.emplace_back(copier);
+        copier();
+        for (std::thread& w : copiers) w.join();
+        wide = std::move(out);
     }
 };
 
@@ -275,18 +561,20 @@ BvhBuildResult build_bvh(const std::vector<HiprTriangle>& triangles, uint32_t ma
     result.max_depth = 0;
     if (n == 0) return result;
 
+    const auto t_start = std::chrono::steady_clock::now();
     Builder b(triangles, std::max(max_depth, 8u));
-    b.boxes.resize(n);
-    b.centroids.resize(3 * size_t(n));
-    b.order.resize(n);
+    std::vector<Box> boxes(n);
+    std::vector<float> centroids(3 * size_t(n));
+    result.order.resize(n);
     for (uint32_t i = 0; i < n; ++i) {
         const HiprTriangle& t = triangles[i];
-        Box& box = b.boxes[i];
+        Box& box = boxes[i];
         box.reset();
         box.grow(t.v0); box.grow(t.v1); box.grow(t.v2);
-        for (int a = 0; a < 3; ++a) b.centroids[3 * i + a] = 0.5f * (box.lo[a] + box.hi[a]);
-        b.order[i] = i;
+        for (int a = 0; a < 3; ++a) centroids[3 * i + a] = 0.5f * (box.lo[a] + box.hi[a]);
+        result.order[i] = i;
     }
+    b.boxes = boxes.data(); b.centroids = centroids.data(); b.order = result.order.data();
 
     if (n <= LEAF_MAX) {
         // A single leaf: both children reference it (the duplicate test cannot change the result).
@@ -296,22 +584,23 @@ BvhBuildResult build_bvh(const std::vector<HiprTriangle>& triangles, uint32_t ma
         Builder::store_child(root, 1, box, Builder::leaf_ref(0, n));
         b.nodes.push_back(root);
         b.deepest = 1;
-    } else {
-        b.nodes.reserve(n);
-        b.build(0, n, 1);
-    }
+    } else
+        b.build_all(n);
+    const auto t_built = std::chrono::steady_clock::now();
 
     result.nodes = std::move(b.nodes);
-    result.order = std::move(b.order);
-    WideCollapse collapse{result.nodes, {}, {}};
-    collapse.wide.reserve(result.nodes.size() / 2 + 1);
-    collapse.binary_need.assign(result.nodes.size(), 0u);
+    WideCollapse collapse(result.nodes);
     // Keep the worst case within the 32 entry LDS stack of the traversal kernels whenever the BVH2 itself allows it; deeper
     // trees are collapsed freely and traversed by the kernels that back the LDS stack with scratch memory.
-    const uint32_t budget = collapse.compute_binary_need(0) <= 32u ? 32u : 0xFFFFu;
-    collapse.collapse(0, budget, result.wide_stack_entries);
+    const uint32_t budget = collapse.compute_binary_need() <= 32u ? 32u : 0xFFFFu;
+    collapse.run(budget, b.threads, result.wide_stack_entries);
     result.wide_nodes = std::move(collapse.wide);
     result.max_depth = b.deepest + 1;   // stack entries needed is bounded by the node depth; keep one spare
+    if (std::getenv("HIPR_BVH_TIMING")) {
+        const auto t_end = std::chrono::steady_clock::now();
+        fprintf(stderr, "[hipr] build_bvh: %u triangles, %u threads: BVH2 %.3f s, wide collapse %.3f s\n", n, b.threads, std::chrono::duration<double>(t_built - t_start).count(),
+                std::chrono::duration<double>(t_end - t_built).count());
+    }
     return result;
 }
 

@@ -347,3 +347,23 @@ def test_a_far_move_makes_the_builder_rebuild(oracle):
     wide, _ = oracle.trace_closest(scene.desc, rays, use_bvh=2, with_lights=False)
     assert (wide.view(np.uint32) != brute.view(np.uint32)).any(axis=1).mean() <= 2e-3
     assert scene.desc.node_count > 0 and node_count > 0
+
+
+def test_parallel_bvh_build_is_the_sequential_build():
+    """The host BVH build runs its top levels and its subtrees on several threads for large scenes (host/BvhBuilder.cpp); the tree, the wide tree
+    and the triangle order must be the single-threaded ones byte for byte (the oracle and the kernels' counters are pinned on that tree)."""
+    import os
+    import subprocess
+    import sys
+    probe = str(ROOT / "tools" / "bvh_build_probe.py")
+    lines = {}
+    for threads in ("1", "3", "8"):
+        env = dict(os.environ, HIPR_BVH_THREADS=threads, HIPR_BVH_TIMING="1")
+        done = subprocess.run([sys.executable, probe, "400000"], capture_output=True, text=True, env=env, timeout=600)
+        assert done.returncode == 0, done.stderr[-1000:]
+        assert f"{threads} threads" in done.stderr, done.stderr[-500:]          # the thread count took effect
+        lines[threads] = done.stdout.strip().split()
+    triangles, nodes, wide_nodes, _, digest = lines["1"]
+    assert int(triangles) > 262144 and int(nodes) > 0 and int(wide_nodes) > 0
+    for threads in ("3", "8"):
+        assert lines[threads][:3] == [triangles, nodes, wide_nodes] and lines[threads][4] == digest, (threads, lines[threads], lines["1"])
