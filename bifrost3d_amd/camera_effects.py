@@ -65,7 +65,7 @@ class Times(C.Structure):
 C_ABI_SYMBOLS = [
     "hipr_camera_effects_create", "hipr_camera_effects_destroy", "hipr_camera_effects_last_error", "hipr_camera_effects_set_stream", "hipr_camera_effects_synchronize",
     "hipr_camera_effects_process", "hipr_camera_effects_get_linear_exposure", "hipr_camera_effects_set_linear_exposure", "hipr_camera_effects_reduce_histogram",
-    "hipr_camera_effects_exposure_from_histogram", "hipr_camera_effects_log_average", "hipr_camera_effects_exposure_from_log_average", "hipr_camera_effects_bloom",
+    "hipr_camera_effects_exposure_from_histogram", "hipr_camera_effects_log_average", "hipr_camera_effects_exposure_from_log_average", "hipr_camera_effects_bloom", "hipr_camera_effects_dual_kawase_bloom",
     "hipr_camera_effects_set_instrumentation", "hipr_camera_effects_reset_timers", "hipr_camera_effects_get_times",
 ]
 
@@ -85,6 +85,7 @@ def declare(lib) -> None:
     lib.hipr_camera_effects_log_average.argtypes = [vp, FP, C.POINTER(C.c_float)]
     lib.hipr_camera_effects_exposure_from_log_average.argtypes = [vp, SP, C.c_float, FP, C.POINTER(C.c_float)]
     lib.hipr_camera_effects_bloom.argtypes = [vp, C.c_float, C.c_int32, FP, vp]
+    lib.hipr_camera_effects_dual_kawase_bloom.argtypes = [vp, C.c_float, C.c_uint32, FP, vp]
     lib.hipr_camera_effects_set_instrumentation.argtypes = [vp, C.c_int]
     lib.hipr_camera_effects_reset_timers.argtypes = [vp]
     lib.hipr_camera_effects_get_times.argtypes = [vp, C.POINTER(Times)]
@@ -158,6 +159,13 @@ class CameraEffects:
         view = self.view(frame, viewport)
         out = self.torch.empty((view.viewport.height, view.viewport.width, 4), dtype=self.torch.float16, device=self.device)
         self._check(self.lib.hipr_camera_effects_bloom(self.handle, threshold, support, C.byref(view), out.data_ptr()), "bloom")
+        self._check(self.lib.hipr_camera_effects_synchronize(self.handle), "synchronize")
+        return out.cpu().numpy()
+
+    def dual_kawase_bloom(self, threshold: float, half_passes: int, frame, viewport=None) -> np.ndarray:
+        view = self.view(frame, viewport)
+        out = self.torch.empty((view.viewport.height, view.viewport.width, 4), dtype=self.torch.float16, device=self.device)
+        self._check(self.lib.hipr_camera_effects_dual_kawase_bloom(self.handle, threshold, half_passes, C.byref(view), out.data_ptr()), "dual_kawase_bloom")
         self._check(self.lib.hipr_camera_effects_synchronize(self.handle), "synchronize")
         return out.cpu().numpy()
 

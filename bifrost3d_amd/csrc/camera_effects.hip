@@ -9,6 +9,7 @@
 //   k_exposure_from_bias        fixed exposure with eye adaptation
 //   k_bloom_horizontal / k_bloom_vertical (+ _tiled)   separable Gaussian through bilinearly placed taps, half4 intermediates; the tiled
 //                               forms stage a block's texel neighbourhood in LDS
+//   k_kawase_extract / _downsample / _upsample   the dual Kawase bloom the reference tests next to the Gaussian one
 //   k_tonemap<MODE>             exposure * (clamped pixel + bloom), vignette, operator, film grain -> RGBA16F / RGBA32F / RGBA8 sRGB
 #include "../../include/hipr_camera_effects_c.h"
 
@@ -247,6 +248,67 @@ __global__ __launch_bounds__(256) void k_bloom_vertical(const uint2* __restrict_
     out[uint32_t(x) + size_t(y) * uint32_t(width)] = pack_rgba(sum.x, sum.y, sum.z, 1.0f);
 }
 
+// ---- Dual Kawase bloom (Bloom.hlsl:69-119, CameraEffects.cpp:140-232): extract, `half_passes` levels down, the same levels up -------------
+struct float4_ { float x, y, z, w; };
+__device__ __forceinline__ float4_ unpack_rgba(uint2 p) {
+    const __half2 rg = *reinterpret_cast<const __half2*>(&p.x), ba = *reinterpret_cast<const __half2*>(&p.y);
+    return {__low2float(rg), __high2float(rg), __low2float(ba), __high2float(ba)};
+}
+// SampleLevel(bilinear_sampler, uv, 0) on a width x height half4 image: clamped addressing, exact fractional weights.
+__device__ __forceinline__ float4_ sample_bilinear(const uint2* __restrict__ pixels, int width, int height, float u, float v) {
+    const float px = u * float(width) - 0.5f, py = v * float(height) - 0.5f;
+    const float fx = floorf(px), fy = floorf(py);
+    const float tx = px - fx, ty = py - fy;
+    const int x0 = min(max(int(fx), 0), width - 1), x1 = min(max(int(fx) + 1, 0), width - 1);
+    const int y0 = min(max(int(fy), 0), height - 1), y1 = min(max(int(fy) + 1, 0), height - 1);
+    const float4_ a = unpack_rgba(pixels[x0 + size_t(y0) * width]), b = unpack_rgba(pixels[x1 + size_t(y0) * width]);
+    const float4_ c = unpack_rgba(pixels[x0 + size_t(y1) * width]), d = unpack_rgba(pixels[x1 + size_t(y1) * width]);
+    auto mix = [](float p, float q, float t) { return p + t * (q - p); };
+    return {mix(mix(a.x, b.x, tx), mix(c.x, d.x, tx), ty), mix(mix(a.y, b.y, tx), mix(c.y, d.y, tx), ty), mix(mix(a.z, b.z, tx), mix(c.z, d.z, tx), ty),
+            mix(mix(a.w, b.w, tx), mix(c.w, d.w, tx), ty)};
+}
+__device__ __forceinline__ void accumulate(float4_& sum, float4_ v, float weight) { sum.x += v.x * weight; sum.y += v.y * weight; sum.z += v.z * weight; sum.w += v.w * weight; }
+
+__global__ __launch_bounds__(256) void k_kawase_extract(DeviceFrame frame, float threshold, uint2* __restrict__ out) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= frame.width || y >= frame.height) return;
+    const float4_ pixel = unpack_rgba(frame.pixels[uint32_t(x + frame.x) + size_t(y + frame.y) * frame.pitch]);
+    out[uint32_t(x) + size_t(y) * uint32_t(frame.width)] = pack_rgba(fmaxf(0.0f, pixel.x - threshold), fmaxf(0.0f, pixel.y - threshold), fmaxf(0.0f, pixel.z - threshold), pixel.w);
+}
+
+__global__ __launch_bounds__(256) void k_kawase_downsample(const uint2* __restrict__ in, int in_width, int in_height, uint2* __restrict__ out, int width, int height) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= width || y >= height) return;
+    const float inverse_width = 1.0f / float(width), inverse_height = 1.0f / float(height);
+    const float half_x = 0.5f * inverse_width, half_y = 0.5f * inverse_height;
+    const float u = float(x) * inverse_width + half_x, v = float(y) * inverse_height + half_y;
+    float4_ sum = {0.0f, 0.0f, 0.0f, 0.0f};
+    accumulate(sum, sample_bilinear(in, in_width, in_height, u, v), 4.0f);
+    accumulate(sum, sample_bilinear(in, in_width, in_height, u + half_x, v + half_y), 1.0f);
+    accumulate(sum, sample_bilinear(in, in_width, in_height, u + half_x, v - half_y), 1.0f);
+    accumulate(sum, sample_bilinear(in, in_width, in_height, u - half_x, v + half_y), 1.0f);
+    accumulate(sum, sample_bilinear(in, in_width, in_height, u - half_x, v - half_y), 1.0f);
+    out[uint32_t(x) + size_t(y) * uint32_t(width)] = pack_rgba(sum.x / 8.0f, sum.y / 8.0f, sum.z / 8.0f, sum.w / 8.0f);
+}
+
+__global__ __launch_bounds__(256) void k_kawase_upsample(const uint2* __restrict__ in, int in_width, int in_height, uint2* __restrict__ out, int width, int height) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= width || y >= height) return;
+    const float inverse_width = 1.0f / float(width), inverse_height = 1.0f / float(height);
+    const float half_x = 0.5f * inverse_width, half_y = 0.5f * inverse_height;
+    const float u = float(x) * inverse_width + half_x, v = float(y) * inverse_height + half_y;
+    float4_ sum = {0.0f, 0.0f, 0.0f, 0.0f};
+    accumulate(sum, sample_bilinear(in, in_width, in_height, u - half_x * 2.0f, v), 1.0f);
+    accumulate(sum, sample_bilinear(in, in_width, in_height, u - half_x, v + half_y), 2.0f);
+    accumulate(sum, sample_bilinear(in, in_width, in_height, u, v + half_y * 2.0f), 1.0f);
+    accumulate(sum, sample_bilinear(in, in_width, in_height, u + half_x, v + half_y), 2.0f);
+    accumulate(sum, sample_bilinear(in, in_width, in_height, u + half_x * 2.0f, v), 1.0f);
+    accumulate(sum, sample_bilinear(in, in_width, in_height, u + half_x, v - half_y), 2.0f);
+    accumulate(sum, sample_bilinear(in, in_width, in_height, u, v - half_y * 2.0f), 1.0f);
+    accumulate(sum, sample_bilinear(in, in_width, in_height, u - half_x, v - half_y), 2.0f);
+    out[uint32_t(x) + size_t(y) * uint32_t(width)] = pack_rgba(sum.x / 12.0f, sum.y / 12.0f, sum.z / 12.0f, sum.w / 12.0f);
+}
+
 // The same two passes with the texels a block needs staged in LDS first. A tap reads two neighbouring texels on either side of
 // the pixel, so a pixel touches the 4 * sample_count texels around it: from global memory that is 108 loads per pixel and pass
 // at 1080p (support 54), all L1 / L2 hits but each an instruction; staged, a block of 256 pixels loads every texel of its
@@ -460,6 +522,8 @@ struct HiprCameraEffects {
     float taps_std_dev = INFINITY;
 
     uint2* ping = nullptr; uint2* pong = nullptr;   // viewport-sized half4 intermediates, grow only (CameraEffects.cpp:78-98)
+    uint2* kawase_chain = nullptr;                   // the levels of the dual Kawase filter back to back, grow only (CameraEffects.cpp:150-199)
+    size_t kawase_capacity = 0;
     size_t intermediate_pixels = 0;
 
     bool direct_bloom = false;              // HIPR_BLOOM_DIRECT=1: the kernels without LDS staging (comparison runs)
@@ -610,6 +674,34 @@ int enqueue_bloom(HiprCameraEffects* fx, float threshold, int support, const Hip
     return HIPR_OK;
 }
 
+int enqueue_dual_kawase(HiprCameraEffects* fx, float threshold, uint32_t half_passes, const HiprFrameView& frame, uint2* out) {
+    const int width = frame.viewport.width, height = frame.viewport.height;
+    uint32_t level_count = 1;      // levels until both dimensions have collapsed (CameraEffects.cpp:166-168)
+    while ((width >> level_count) > 0 || (height >> level_count) > 0) ++level_count;
+    half_passes = std::min(half_passes, level_count - 1);
+    std::vector<size_t> offset(half_passes + 2, 0);
+    auto level_width = [&](uint32_t m) { return std::max(1, width >> m); };
+    auto level_height = [&](uint32_t m) { return std::max(1, height >> m); };
+    for (uint32_t m = 0; m <= half_passes; ++m) offset[m + 1] = offset[m] + size_t(level_width(m)) * level_height(m);
+    if (offset[half_passes + 1] > fx->kawase_capacity) {
+        FX_HIP(hipStreamSynchronize(fx->stream));
+        if (fx->kawase_chain) (void)hipFree(fx->kawase_chain);
+        fx->kawase_chain = nullptr; fx->kawase_capacity = 0;
+        FX_HIP(hipMalloc(&fx->kawase_chain, offset[half_passes + 1] * sizeof(uint2)));
+        fx->kawase_capacity = offset[half_passes + 1];
+    }
+    auto level = [&](uint32_t m) { return m == 0 && half_passes == 0 ? out : fx->kawase_chain + offset[m]; };
+    auto grid_of = [](int w, int h) { return dim3((w + 63) / 64, (h + 3) / 4); };
+    const dim3 block(256);
+    hipLaunchKernelGGL(k_kawase_extract, grid_of(width, height), block, 0, fx->stream, device_frame(frame), threshold, level(0));
+    for (uint32_t p = 0; p < half_passes; ++p)
+        hipLaunchKernelGGL(k_kawase_downsample, grid_of(level_width(p + 1), level_height(p + 1)), block, 0, fx->stream, level(p), level_width(p), level_height(p), level(p + 1), level_width(p + 1), level_height(p + 1));
+    for (uint32_t p = half_passes; p > 0; --p)
+        hipLaunchKernelGGL(k_kawase_upsample, grid_of(level_width(p - 1), level_height(p - 1)), block, 0, fx->stream, level(p), level_width(p), level_height(p), p == 1 ? out : level(p - 1), level_width(p - 1), level_height(p - 1));
+    FX_HIP(hipGetLastError());
+    return HIPR_OK;
+}
+
 void multiply3x3(const float a[9], const float b[9], float out[9]) {
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) out[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
@@ -645,7 +737,7 @@ void hipr_camera_effects_destroy(HiprCameraEffects* fx) {
     if (!fx) return;
     (void)hipSetDevice(fx->device);
     if (fx->stream) (void)hipStreamSynchronize(fx->stream);
-    for (void* p : {(void*)fx->histogram, (void*)fx->block_histograms, (void*)fx->linear_exposure, (void*)fx->partials, (void*)fx->scratch_scalar, (void*)fx->taps, (void*)fx->ping, (void*)fx->pong})
+    for (void* p : {(void*)fx->histogram, (void*)fx->block_histograms, (void*)fx->linear_exposure, (void*)fx->partials, (void*)fx->scratch_scalar, (void*)fx->taps, (void*)fx->ping, (void*)fx->pong, (void*)fx->kawase_chain})
         if (p) (void)hipFree(p);
     if (fx->event_begin) (void)hipEventDestroy(fx->event_begin);
     if (fx->event_end) (void)hipEventDestroy(fx->event_end);
@@ -734,6 +826,12 @@ int hipr_camera_effects_bloom(HiprCameraEffects* fx, float threshold, int32_t su
     if (!fx || !out_half4_device || !valid_frame(frame) || support < 0) return fail(fx, HIPR_ERROR_INVALID_ARGUMENT, "hipr_camera_effects_bloom: null argument, negative support or viewport outside the frame");
     FX_HIP(hipSetDevice(fx->device));
     return enqueue_bloom(fx, threshold, support, *frame, static_cast<uint2*>(out_half4_device));
+}
+
+int hipr_camera_effects_dual_kawase_bloom(HiprCameraEffects* fx, float threshold, uint32_t half_passes, const HiprFrameView* frame, void* out_half4_device) {
+    if (!fx || !out_half4_device || !valid_frame(frame)) return fail(fx, HIPR_ERROR_INVALID_ARGUMENT, "hipr_camera_effects_dual_kawase_bloom: null argument or viewport outside the frame");
+    FX_HIP(hipSetDevice(fx->device));
+    return enqueue_dual_kawase(fx, threshold, half_passes, *frame, static_cast<uint2*>(out_half4_device));
 }
 
 int hipr_camera_effects_process(HiprCameraEffects* fx, const HiprCameraEffectsSettings* settings, float delta_time, const HiprFrameView* frame, void* target, int target_format,

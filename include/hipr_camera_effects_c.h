@@ -92,6 +92,12 @@ int hipr_camera_effects_exposure_from_log_average(HiprCameraEffects* effects, co
 /* GaussianBloom::filter (CameraEffects.cpp:39-112, Bloom.hlsl:24-67): max(0, pixel - threshold) blurred by a separable Gaussian
  * of `support` pixels (standard deviation support / 4) through bilinearly placed taps. out: viewport width x height half4, tightly packed, device. */
 int hipr_camera_effects_bloom(HiprCameraEffects* effects, float threshold, int32_t support, const HiprFrameView* frame, void* out_half4_device);
+/* DualKawaseBloom::filter (CameraEffects.cpp:140-232, Bloom.hlsl:69-119): what exceeds the threshold (alpha kept), `half_passes` times down a chain
+ * of half-sized half4 images (5 bilinear taps each) and back up (8 taps each); half_passes 0 only extracts. The reference tests this filter
+ * (tests/DX11RendererTests/BloomTest.h:218-245) and its CameraEffects::process uses the Gaussian one. out_half4_device: viewport-sized, tightly packed.
+ * Level m is max(1, width >> m) x max(1, height >> m) of the VIEWPORT (the reference sizes its chain by a grow-only buffer and leaves levels that
+ * collapse to zero rows unwritten); bilinear weights are exact fractions, addressing is clamped. */
+int hipr_camera_effects_dual_kawase_bloom(HiprCameraEffects* effects, float threshold, uint32_t half_passes, const HiprFrameView* frame, void* out_half4_device);
 
 int hipr_camera_effects_set_instrumentation(HiprCameraEffects* effects, int time_stages);
 int hipr_camera_effects_reset_timers(HiprCameraEffects* effects);

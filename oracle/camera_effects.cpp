@@ -229,6 +229,84 @@ void bloom(float threshold, int support, const HiprFrameView& frame, std::vector
         }
 }
 
+// ---- Dual Kawase bloom: DualKawaseBloom::filter (CameraEffects.cpp:140-232) over extract_high_intensity / dual_kawase_downsample /
+// dual_kawase_upsample (Bloom.hlsl:69-119). Levels are half4 images (rounded to half when stored), level m is max(1, w >> m) x max(1, h >> m)
+// of the viewport; SampleLevel(bilinear_sampler) = clamped addressing, exact fractional weights.
+struct float4v { float x, y, z, w; };
+struct HalfImage {
+    int width = 0, height = 0;
+    std::vector<uint16_t> texels;      // 4 per pixel
+    void resize(int w, int h) { width = w; height = h; texels.assign(size_t(w) * h * 4, 0); }
+    float4v at(int x, int y) const {
+        x = std::min(std::max(x, 0), width - 1); y = std::min(std::max(y, 0), height - 1);
+        const uint16_t* p = &texels[4 * (size_t(x) + size_t(y) * width)];
+        return {half_to_float(p[0]), half_to_float(p[1]), half_to_float(p[2]), half_to_float(p[3])};
+    }
+    void store(int x, int y, float4v v) {
+        uint16_t* p = &texels[4 * (size_t(x) + size_t(y) * width)];
+        p[0] = float_to_half(v.x); p[1] = float_to_half(v.y); p[2] = float_to_half(v.z); p[3] = float_to_half(v.w);
+    }
+    float4v sample(float u, float v) const {
+        const float px = u * float(width) - 0.5f, py = v * float(height) - 0.5f;
+        const float fx = std::floor(px), fy = std::floor(py);
+        const float tx = px - fx, ty = py - fy;
+        const float4v a = at(int(fx), int(fy)), b = at(int(fx) + 1, int(fy)), c = at(int(fx), int(fy) + 1), d = at(int(fx) + 1, int(fy) + 1);
+        return {lerp1(lerp1(a.x, b.x, tx), lerp1(c.x, d.x, tx), ty), lerp1(lerp1(a.y, b.y, tx), lerp1(c.y, d.y, tx), ty), lerp1(lerp1(a.z, b.z, tx), lerp1(c.z, d.z, tx), ty),
+                lerp1(lerp1(a.w, b.w, tx), lerp1(c.w, d.w, tx), ty)};
+    }
+};
+inline void accumulate(float4v& sum, float4v v, float weight) { sum.x += v.x * weight; sum.y += v.y * weight; sum.z += v.z * weight; sum.w += v.w * weight; }
+
+void dual_kawase_bloom(float threshold, unsigned half_passes, const HiprFrameView& frame, HalfImage& result) {
+    const int width = frame.viewport.width, height = frame.viewport.height;
+    unsigned level_count = 1;
+    while ((width >> level_count) > 0 || (height >> level_count) > 0) ++level_count;
+    half_passes = std::min(half_passes, level_count - 1);
+    std::vector<HalfImage> level(half_passes + 1);
+    for (unsigned m = 0; m <= half_passes; ++m) level[m].resize(std::max(1, width >> m), std::max(1, height >> m));
+    for (int y = 0; y < height; ++y)
+        for (int x = 0; x < width; ++x) {
+            const uint16_t* p = static_cast<const uint16_t*>(frame.pixels) + 4 * (size_t(x + frame.viewport.x) + size_t(y + frame.viewport.y) * frame.pitch);
+            level[0].store(x, y, {std::fmax(0.0f, half_to_float(p[0]) - threshold), std::fmax(0.0f, half_to_float(p[1]) - threshold), std::fmax(0.0f, half_to_float(p[2]) - threshold), half_to_float(p[3])});
+        }
+    for (unsigned p = 0; p < half_passes; ++p) {
+        const HalfImage& in = level[p];
+        HalfImage& out = level[p + 1];
+        const float inverse_width = 1.0f / float(out.width), inverse_height = 1.0f / float(out.height), half_x = 0.5f * inverse_width, half_y = 0.5f * inverse_height;
+        for (int y = 0; y < out.height; ++y)
+            for (int x = 0; x < out.width; ++x) {
+                const float u = float(x) * inverse_width + half_x, v = float(y) * inverse_height + half_y;
+                float4v sum = {0, 0, 0, 0};
+                accumulate(sum, in.sample(u, v), 4.0f);
+                accumulate(sum, in.sample(u + half_x, v + half_y), 1.0f);
+                accumulate(sum, in.sample(u + half_x, v - half_y), 1.0f);
+                accumulate(sum, in.sample(u - half_x, v + half_y), 1.0f);
+                accumulate(sum, in.sample(u - half_x, v - half_y), 1.0f);
+                out.store(x, y, {sum.x / 8.0f, sum.y / 8.0f, sum.z / 8.0f, sum.w / 8.0f});
+            }
+    }
+    for (unsigned p = half_passes; p > 0; --p) {
+        const HalfImage& in = level[p];
+        HalfImage& out = level[p - 1];
+        const float inverse_width = 1.0f / float(out.width), inverse_height = 1.0f / float(out.height), half_x = 0.5f * inverse_width, half_y = 0.5f * inverse_height;
+        for (int y = 0; y < out.height; ++y)
+            for (int x = 0; x < out.width; ++x) {
+                const float u = float(x) * inverse_width + half_x, v = float(y) * inverse_height + half_y;
+                float4v sum = {0, 0, 0, 0};
+                accumulate(sum, in.sample(u - half_x * 2.0f, v), 1.0f);
+                accumulate(sum, in.sample(u - half_x, v + half_y), 2.0f);
+                accumulate(sum, in.sample(u, v + half_y * 2.0f), 1.0f);
+                accumulate(sum, in.sample(u + half_x, v + half_y), 2.0f);
+                accumulate(sum, in.sample(u + half_x * 2.0f, v), 1.0f);
+                accumulate(sum, in.sample(u + half_x, v - half_y), 2.0f);
+                accumulate(sum, in.sample(u, v - half_y * 2.0f), 1.0f);
+                accumulate(sum, in.sample(u - half_x, v - half_y), 2.0f);
+                out.store(x, y, {sum.x / 12.0f, sum.y / 12.0f, sum.z / 12.0f, sum.w / 12.0f});
+            }
+    }
+    result = std::move(level[0]);
+}
+
 void histogram(const HiprCameraEffectsSettings& s, const HiprFrameView& frame, uint32_t* bins) {     // ReduceExposureHistogram.hlsl:27-70
     std::fill(bins, bins + HIPR_EXPOSURE_HISTOGRAM_BINS, 0u);
     for (int y = 0; y < frame.viewport.height; ++y)
@@ -297,6 +375,12 @@ void oracle_ce_bloom(float threshold, int support, const HiprFrameView* frame, f
     std::vector<float3> result;
     bloom(threshold, support, *frame, result);
     std::memcpy(out_rgb, result.data(), result.size() * sizeof(float3));
+}
+// out: viewport-sized half4 pixels (4 x uint16 each), as the device writes them
+void oracle_ce_dual_kawase_bloom(float threshold, unsigned half_passes, const HiprFrameView* frame, uint16_t* out_half4) {
+    HalfImage result;
+    dual_kawase_bloom(threshold, half_passes, *frame, result);
+    std::memcpy(out_half4, result.texels.data(), result.texels.size() * sizeof(uint16_t));
 }
 void oracle_ce_tonemap(const HiprCameraEffectsSettings* settings, const float* rgb_in, int count, float* rgb_out) {
     for (int i = 0; i < count; ++i) {

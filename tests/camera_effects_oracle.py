@@ -22,6 +22,7 @@ def lib():
         _lib.oracle_ce_exposure_from_log_average.argtypes = [SP, C.c_float, FP, C.c_float]; _lib.oracle_ce_exposure_from_log_average.restype = C.c_float
         _lib.oracle_ce_gaussian_taps.argtypes = [C.c_float, C.c_int, fp, fp]
         _lib.oracle_ce_bloom.argtypes = [C.c_float, C.c_int, FP, fp]
+        _lib.oracle_ce_dual_kawase_bloom.argtypes = [C.c_float, C.c_uint, FP, C.POINTER(C.c_uint16)]
         _lib.oracle_ce_tonemap.argtypes = [SP, fp, C.c_int, fp]
         _lib.oracle_ce_vignette.argtypes = [C.c_float] * 3; _lib.oracle_ce_vignette.restype = C.c_float
         _lib.oracle_ce_film_grain.argtypes = [C.c_float] * 4; _lib.oracle_ce_film_grain.restype = C.c_float
@@ -69,6 +70,14 @@ def bloom(threshold: float, support: int, half_pixels, viewport=None) -> np.ndar
     view = view_of(half_pixels, viewport)
     out = np.zeros((view.viewport.height, view.viewport.width, 3), dtype=np.float32)
     lib().oracle_ce_bloom(threshold, support, C.byref(view), out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def dual_kawase_bloom(threshold: float, half_passes: int, half_pixels, viewport=None) -> np.ndarray:
+    """(height, width, 4) float16, the viewport-sized level 0 of the filter."""
+    view = view_of(half_pixels, viewport)
+    out = np.zeros((view.viewport.height, view.viewport.width, 4), dtype=np.float16)
+    lib().oracle_ce_dual_kawase_bloom(threshold, half_passes, C.byref(view), out.ctypes.data_as(C.POINTER(C.c_uint16)))
     return out
 
 

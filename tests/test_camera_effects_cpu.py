@@ -188,6 +188,43 @@ def test_bloom_mirroring():
     assert np.allclose(oracle.bloom(0.0, 11, pixels), oracle.bloom(0.0, 11, mirrored)[::-1, ::-1], atol=1e-3)
 
 
+# ---- BloomTest.h:218-245, the dual Kawase filter (tested by the reference, not used by its CameraEffects::process) --------------------------
+
+def test_dual_kawase_energy_conservation():
+    pixels = np.ones((64, 64, 4), dtype=np.float16)
+    filtered = oracle.dual_kawase_bloom(0.0, 1, pixels).astype(np.float64)
+    assert np.allclose(filtered[..., :3].sum(axis=(0, 1)), pixels[..., :3].astype(np.float64).sum(axis=(0, 1)), rtol=1e-6)
+
+
+def test_dual_kawase_mirroring():
+    """BloomTest.h test_mirroring with four half passes, as it was meant: filtering the point-mirrored image gives the point-mirrored result."""
+    pixels = np.zeros((64, 64, 4), dtype=np.float16)
+    pixels[..., 3] = 1
+    pixels[:32, :32, 0] = 1; pixels[32:, :32, 1] = 1; pixels[:32, 32:, 2] = 1
+    mirrored = np.ascontiguousarray(pixels[::-1, ::-1])
+    a, b = oracle.dual_kawase_bloom(0.0, 4, pixels).astype(np.float32), oracle.dual_kawase_bloom(0.0, 4, mirrored).astype(np.float32)[::-1, ::-1]
+    assert np.allclose(a, b, atol=1e-3)
+    assert 0.05 < float(a[31, 31, 0]) < 0.95          # the colours have bled across the quadrant borders
+
+
+def test_dual_kawase_thresholding():
+    pixels = threshold_image()
+    extracted = oracle.dual_kawase_bloom(5.0, 0, pixels).astype(np.float64)
+    expected = np.maximum(pixels[..., :3].astype(np.float64) - 5.0, 0.0)
+    assert np.allclose(extracted[..., :3].sum(axis=(0, 1)), expected.sum(axis=(0, 1)), rtol=1e-3)          # the bar of BloomTest.h:238-245; the level is stored as half
+    assert np.array_equal(extracted[..., 3], pixels[..., 3].astype(np.float64))       # alpha is carried
+
+
+def test_dual_kawase_levels_and_viewport():
+    """More half passes than the image has levels are clamped (CameraEffects.cpp:211); a viewport is filtered on its own pixels only."""
+    rng = np.random.default_rng(5)
+    pixels = rng.uniform(0, 4, (20, 37, 4)).astype(np.float16)
+    assert np.array_equal(oracle.dual_kawase_bloom(1.0, 40, pixels), oracle.dual_kawase_bloom(1.0, 6, pixels))      # 37 -> 6 levels
+    inside = oracle.dual_kawase_bloom(1.0, 2, pixels, viewport=(5, 3, 16, 8))
+    alone = oracle.dual_kawase_bloom(1.0, 2, np.ascontiguousarray(pixels[3:11, 5:21]))
+    assert inside.shape == (8, 16, 4) and np.array_equal(inside, alone)
+
+
 def test_bloom_reads_the_frame_around_the_viewport_horizontally():
     pixels = np.zeros((8, 32, 4), dtype=np.float16)
     pixels[:, 10, :3] = 8.0        # a bright column just left of the viewport

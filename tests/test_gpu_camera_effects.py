@@ -141,6 +141,37 @@ def test_bloom_matches_oracle(fx, support, viewport):
     assert np.all(gpu[..., 3] == 1.0)
 
 
+# ---- the dual Kawase filter (BloomTest.h:218-245; Bloom.hlsl:69-119) ------------------------------------------------------------------
+
+@pytest.mark.parametrize("half_passes,viewport", [(0, None), (1, None), (3, None), (4, (12, 5, 100, 40)), (2, (7, 3, 33, 21)), (40, None)])
+def test_dual_kawase_matches_oracle(fx, half_passes, viewport):
+    """Odd level sizes (the half-sized grid does not sit on texel pairs), viewports inside a larger frame, more passes than levels."""
+    pixels = random_frame(72, 161, 9, stops=3.0)
+    pixels[..., 3] = np.random.default_rng(2).uniform(0, 1, pixels.shape[:2]).astype(np.float16)
+    gpu = fx.dual_kawase_bloom(1.5, half_passes, fx.upload(pixels), viewport).astype(np.float32)
+    cpu = oracle.dual_kawase_bloom(1.5, half_passes, pixels, viewport).astype(np.float32)
+    assert gpu.shape == cpu.shape
+    # every level is rounded to half on both sides: a half ulp per level each way
+    assert np.allclose(gpu, cpu, rtol=4e-3, atol=2e-4)
+    assert float(np.abs(gpu - cpu).max()) <= 4e-3 * float(np.abs(cpu).max())
+
+
+def test_dual_kawase_reference_cases_on_the_device(fx):
+    white = np.ones((64, 64, 4), dtype=np.float16)
+    filtered = fx.dual_kawase_bloom(0.0, 1, fx.upload(white)).astype(np.float64)
+    assert np.allclose(filtered[..., :3].sum(axis=(0, 1)), 64.0 * 64.0, rtol=1e-6)                                   # energy conservation
+    quadrants = np.zeros((64, 64, 4), dtype=np.float16)
+    quadrants[..., 3] = 1
+    quadrants[:32, :32, 0] = 1; quadrants[32:, :32, 1] = 1; quadrants[:32, 32:, 2] = 1
+    a = fx.dual_kawase_bloom(0.0, 4, fx.upload(quadrants)).astype(np.float32)
+    b = fx.dual_kawase_bloom(0.0, 4, fx.upload(np.ascontiguousarray(quadrants[::-1, ::-1]))).astype(np.float32)[::-1, ::-1]
+    assert np.allclose(a, b, atol=1e-3)                                                                               # mirroring
+    ramp = threshold_image()
+    extracted = fx.dual_kawase_bloom(5.0, 0, fx.upload(ramp)).astype(np.float64)
+    expected = np.maximum(ramp[..., :3].astype(np.float64) - 5.0, 0.0)
+    assert np.allclose(extracted[..., :3].sum(axis=(0, 1)), expected.sum(axis=(0, 1)), rtol=1e-3)                    # thresholding
+
+
 # ---- process: exposure -> bloom -> tonemapping (CameraEffects.cpp:412-507) ----------------------------------------------------------
 
 def settings_for(mode, exposure_mode=camera_effects.EXPOSURE_HISTOGRAM, bloom_threshold=math.inf, film_grain=0.0):
