@@ -126,7 +126,7 @@ struct RenderersTag;
 typedef UID<RenderersTag> RendererID;
 class Renderers {
 public:
-    static RendererID create(const std::string& name) { names().push_back(name); return RendererID((unsigned int)names().size() - 1); }
+    static RendererID create(std::string name) { names().push_back(name); return RendererID((unsigned int)names().size() - 1); }
     static void destroy(RendererID) {}
     static const std::string& get_name(RendererID id) { return names()[id]; }
 private:
@@ -155,7 +155,7 @@ struct ImagesTag; typedef Core::UID<ImagesTag> ImageID;
 class Images {
 public:
     enum class Change : unsigned char { None = 0, Created = 1, Destroyed = 2, PixelsUpdated = 4 };
-    static ImageID create2D(const std::string& name, PixelFormat format, bool is_sRGB, unsigned width, unsigned height, const void* pixels, size_t byte_count) {
+    static ImageID create2D(std::string name, PixelFormat format, bool is_sRGB, unsigned width, unsigned height, const void* pixels, size_t byte_count) {
         ImageID id = m().allocate();
         Record& r = m()[id];
         r.name = name; r.format = format; r.is_sRGB = is_sRGB; r.width = width; r.height = height;
@@ -267,7 +267,7 @@ public:
         }
         static Data create_transmissive(RGB tint, float roughness, float specularity = 0.04f) { Data d = create_dielectric(tint, roughness, specularity); d.shading_model = ShadingModel::Transmissive; return d; }
     };
-    static MaterialID create(const std::string& name, const Data& data) {
+    static MaterialID create(std::string name, Data data) {
         MaterialID id = m().allocate();
         m()[id] = {name, data};
         m().flag(id, Change::Created);
@@ -348,7 +348,7 @@ struct MeshesTag; typedef Core::UID<MeshesTag> MeshID;
 class Meshes {
 public:
     enum class Change : unsigned char { None = 0, Created = 1, Destroyed = 2 };
-    static MeshID create(const std::string& name, unsigned primitive_count, unsigned vertex_count, MeshFlags buffers = MeshFlag::AllBuffers) {
+    static MeshID create(std::string name, unsigned primitive_count, unsigned vertex_count, MeshFlags buffers = MeshFlag::AllBuffers) {
         MeshID id = m().allocate();
         Record& r = m()[id];
         r.name = name;
@@ -431,10 +431,12 @@ namespace Scene {
 using namespace Math;
 
 struct SceneNodesTag; typedef Core::UID<SceneNodesTag> SceneNodeID;
+// Names are taken BY VALUE by every create(): the caller may pass a reference into the very storage that create() is about to grow
+// (SceneNode(other.get_name(), ...): found by the address sanitizer run of the CPU suite).
 class SceneNodes {
 public:
     enum class Change : unsigned char { None = 0, Created = 1, Destroyed = 2, Transform = 4 };
-    static SceneNodeID create(const std::string& name, Transform transform = Transform::identity()) {
+    static SceneNodeID create(std::string name, Transform transform = Transform::identity()) {
         SceneNodeID id = m().allocate();
         m()[id] = {name, transform, SceneNodeID::invalid_UID()};
         m().flag(id, Change::Created);
@@ -487,7 +489,7 @@ struct SceneRootsTag; typedef Core::UID<SceneRootsTag> SceneRootID;
 class SceneRoots {
 public:
     enum class Change : unsigned char { None = 0, Created = 1, Destroyed = 2, EnvironmentTint = 4, EnvironmentMap = 8 };
-    static SceneRootID create(const std::string& name, RGB environment_tint) {
+    static SceneRootID create(std::string name, RGB environment_tint) {
         SceneRootID id = m().allocate();
         m()[id] = {name, environment_tint, SceneNodes::create(name + " root"), {}};
         m().flag(id, Change::Created);
@@ -537,7 +539,7 @@ class Cameras {
 public:
     enum class Change : unsigned char { None = 0, Created = 1, Destroyed = 2, Renderer = 4 };
     typedef Core::Bitmask<Screenshot::Content> ScreenshotContent;
-    static CameraID create(const std::string& name, SceneRootID scene, Matrix4x4f projection, Matrix4x4f inverse_projection) {
+    static CameraID create(std::string name, SceneRootID scene, Matrix4x4f projection, Matrix4x4f inverse_projection) {
         CameraID id = m().allocate();
         Record& r = m()[id];
         r.name = name; r.scene = scene; r.projection = projection; r.inverse_projection = inverse_projection; r.transform = Transform::identity();

@@ -25,7 +25,7 @@ struct LightSample {
 
 class InfiniteAreaLight {
 public:
-    static const unsigned int MINIMUM_PDF_HEIGHT = 128;
+    static constexpr unsigned int MINIMUM_PDF_HEIGHT = 128;      // constexpr: an inline variable, std::max binds a reference to it
 
     explicit InfiniteAreaLight(TextureID latlong);
 

@@ -584,7 +584,7 @@ SceneNode load(const std::string& filename, ImageLoader image_loader) {
         printf("glTFLoader::load error: '%s' not a glTF file\n", filename.c_str());
         return SceneNode::invalid();
     }
-    if (!image_loader) image_loader = ImageLoader::load_from_memory;
+    if (!image_loader) image_loader = ::ImageLoader::load_from_memory;
 
     Document doc;
     if (!open_document(filename, doc)) {
