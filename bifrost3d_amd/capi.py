@@ -12,7 +12,7 @@ from pathlib import Path
 
 PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("HIPR_LIBRARY", PKG_DIR / "csrc" / "libhiprenderer.so"))   # HIPR_LIBRARY: A/B builds of the kernels
-HOST_LIB_PATH = PKG_DIR / "host" / "libhiprenderer_host.so"
+HOST_LIB_PATH = Path(os.environ.get("HIPR_HOST_LIBRARY", PKG_DIR / "host" / "libhiprenderer_host.so"))   # HIPR_HOST_LIBRARY: A/B builds of the host side (BVH builder)
 TABLES_PATH = PKG_DIR / "data" / "HIPRenderer" / "shading_tables.bin"
 
 HIPR_OK = 0

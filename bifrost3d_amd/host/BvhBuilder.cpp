@@ -37,7 +37,10 @@ struct Box {
     }
 };
 
-constexpr int BIN_COUNT = 16;
+#ifndef HIPR_BVH_BINS
+#define HIPR_BVH_BINS 16
+#endif
+constexpr int BIN_COUNT = HIPR_BVH_BINS;
 // Triangles per leaf. The traversal kernels spend one loop iteration per node AND per triangle, so a leaf is worth splitting
 // as long as the split culls triangles; HIPR_BVH_LEAF_SIZE overrides for experiments.
 static uint32_t leaf_max() {
