@@ -261,6 +261,28 @@ def plugin_renderer_figures(ctx, args, main_figures):
     return out
 
 
+def measured_copy_bandwidth(device):
+    """next to the nominal 8 TB/s, what a plain device-to-device copy reaches on this box (bytes read + bytes written per second):
+    the practical ceiling of a streaming kernel. 1 GiB buffers, the best of five copies."""
+    import torch
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=device)
+    b = torch.empty(n, dtype=torch.uint8, device=device)
+    a.zero_()
+    b.copy_(a)
+    torch.cuda.synchronize(device)
+    best = float("inf")
+    for _ in range(5):
+        start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        b.copy_(a)
+        stop.record()
+        stop.synchronize()
+        best = min(best, start.elapsed_time(stop))
+    del a, b
+    return 2.0 * n / (best * 1e-3) / 1e9
+
+
 def denoiser_figures(args, device):
     """The filter stage of Backend::AIDenoisedPathTracing at the bench's frame size (csrc/denoiser.hip, include/hipr_denoiser_c.h): milliseconds
     per hipr_denoiser_process call on synthetic half4 frames already on the device, and the HBM roofline of the image work. Algorithmic bytes
@@ -508,6 +530,10 @@ def main():
             "roofline": main_figures["roofline"], "roofline_by_kernel": main_figures["roofline_by_kernel"], "kernel_ms_per_step": main_figures["kernel_ms_per_step"],
         }
         if world == 1:
+            copy_gbs = measured_copy_bandwidth(device)
+            out["roofline"]["measured_copy_bandwidth"] = {"GB/s": copy_gbs, "what": "1 GiB device-to-device copy, bytes read + written, best of five (torch)",
+                                                          "frac_counter_of_copy": out["roofline"]["achieved_counter"] / copy_gbs if out["roofline"].get("achieved_counter") else None,
+                                                          "frac_of_copy": out["roofline"]["achieved"] / copy_gbs}
             if not args.no_rmse and scene.desc.triangle_count <= 300000:
                 out["config"]["rmse_vs_oracle"] = rmse_against_oracle(ctx, scene, bounces)
             if not args.no_other_workloads and not args.scene_file:
