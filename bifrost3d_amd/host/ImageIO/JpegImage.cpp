@@ -1,5 +1,5 @@
 // JpegImage.cpp -- see JpegImage.h. A JPEG (ITU-T T.81) decoder for the texture loaders: baseline and extended sequential
-// Huffman (SOF0 / SOF1, 8 bit) and progressive (SOF2) scans, restart intervals, 1 or 3 components with any of the usual chroma
+// Huffman (SOF0 / SOF1, 8 bit) and progressive (SOF2) scans, restart intervals, 1, 3 or 4 (Adobe CMYK / YCCK) components with any of the usual chroma
 // subsamplings, JFIF YCbCr and Adobe RGB. The container and entropy decoding follow the standard; the three stages whose
 // arithmetic the standard leaves to the implementation -- inverse DCT, chroma upsampling, YCbCr -> RGB -- use the integer
 // arithmetic of the decoder the reference loads its textures with (stb_image 2.29 inside extensions/StbImageLoader): the
@@ -56,13 +56,13 @@ struct Decoder {
     uint32_t bit_buffer = 0; int bit_count = 0; int marker = -1; bool hit_marker = false;
     uint16_t quantization[4][64];
     HuffmanTable dc_tables[4], ac_tables[4];
-    Component components[3];
+    Component components[4];
     int component_count = 0, width = 0, height = 0, h_max = 1, v_max = 1, mcu_w = 0, mcu_h = 0, mcus_x = 0, mcus_y = 0;
     bool progressive = false, jfif = false, frame_seen = false;
     int adobe_transform = -1;
     int restart_interval = 0;
     // scan state
-    int scan_components = 0, scan_order[3], spectral_start = 0, spectral_end = 63, successive_high = 0, successive_low = 0, eob_run = 0;
+    int scan_components = 0, scan_order[4], spectral_start = 0, spectral_end = 63, successive_high = 0, successive_low = 0, eob_run = 0;
     const char* error = nullptr;
 
     bool fail(const char* message) { if (!error) error = message; return false; }
@@ -145,7 +145,7 @@ struct Decoder {
         height = read_u16(); width = read_u16();
         component_count = read_u8();
         if (width == 0 || height == 0) return fail("empty image");
-        if (component_count != 1 && component_count != 3) return fail("only 1 or 3 components are supported");     // CMYK / YCCK: not what textures use
+        if (component_count != 1 && component_count != 3 && component_count != 4) return fail("only 1, 3 or 4 components are supported");
         if (length != 8 + 3 * component_count) return fail("bad SOF length");
         progressive = is_progressive;
         h_max = v_max = 1;
@@ -499,13 +499,13 @@ struct Decoder {
     }
 
     void convert(std::vector<uint8_t>& pixels, unsigned& channels) const {
-        channels = component_count == 3 ? 3u : 1u;
+        channels = component_count >= 3 ? 3u : 1u;      // four components (CMYK / YCCK) come out as RGB
         pixels.assign(size_t(width) * height * channels, 0);
         const bool named_rgb = component_count == 3 && components[0].id == 'R' && components[1].id == 'G' && components[2].id == 'B';
         const bool is_rgb = component_count == 3 && (named_rgb || (adobe_transform == 0 && !jfif));      // component ids R, G, B, or an Adobe marker that says "no transform"
         struct RowState { int hs, vs, step, y, lores_w; size_t near_offset, far_offset; };      // far_offset: the row the interpolation leans towards
-        RowState state[3];
-        std::vector<uint8_t> line[3];
+        RowState state[4];
+        std::vector<uint8_t> line[4];
         for (int c = 0; c < component_count; ++c) {
             const Component& comp = components[c];
             state[c] = {h_max / comp.h, v_max / comp.v, (v_max / comp.v) >> 1, 0, (width + h_max / comp.h - 1) / (h_max / comp.h), 0, 0};
@@ -532,6 +532,13 @@ struct Decoder {
                 for (int i = 0; i < width; ++i) { out[3 * i] = line[0][i]; out[3 * i + 1] = line[1][i]; out[3 * i + 2] = line[2][i]; }
                 continue;
             }
+            // Four components (Adobe): transform 0 = CMYK stored inverted, every ink times black; 2 = YCCK, the YCbCr conversion below gives inverted
+            // CMY which is then inverted and multiplied by black; anything else: YCbCr with a fourth channel that is ignored.
+            auto times = [](unsigned x, unsigned y) { const unsigned t = x * y + 128u; return uint8_t((t + (t >> 8)) >> 8); };     // (x * y) / 255, rounded
+            if (component_count == 4 && adobe_transform == 0) {
+                for (int i = 0; i < width; ++i) { const unsigned k = line[3][i]; out[3 * i] = times(line[0][i], k); out[3 * i + 1] = times(line[1][i], k); out[3 * i + 2] = times(line[2][i], k); }
+                continue;
+            }
             for (int i = 0; i < width; ++i) {      // 20 bit fixed point; the Cb term of green is truncated to 16 bits as in the reference's SIMD-exact scalar kernel
                 const int y_fixed = (line[0][i] << 20) + (1 << 19), cb = line[1][i] - 128, cr = line[2][i] - 128;
                 const int kr = int(1.40200f * 4096.0f + 0.5f) << 8, kg_cr = int(0.71414f * 4096.0f + 0.5f) << 8, kg_cb = int(0.34414f * 4096.0f + 0.5f) << 8, kb = int(1.77200f * 4096.0f + 0.5f) << 8;
@@ -540,6 +547,8 @@ struct Decoder {
                 const int b = (y_fixed + cb * kb) >> 20;
                 out[3 * i] = clamp_u8(r); out[3 * i + 1] = clamp_u8(g); out[3 * i + 2] = clamp_u8(b);
             }
+            if (component_count == 4 && adobe_transform == 2)
+                for (int i = 0; i < width; ++i) { const unsigned k = line[3][i]; out[3 * i] = times(255u - out[3 * i], k); out[3 * i + 1] = times(255u - out[3 * i + 1], k); out[3 * i + 2] = times(255u - out[3 * i + 2], k); }
         }
     }
 };

@@ -16,7 +16,7 @@ out = ROOT / "tests" / "golden" / "images"
 out.mkdir(parents=True, exist_ok=True)
 expected = {}
 for name, size, mode, arguments in codecs.JPEG_CASES:
-    if name in ("wide_strip", "restart_rows_444", "q75_420"):
+    if name in ("wide_strip", "restart_rows_444", "q75_420", "four_components_transform_1", "cmyk_progressive"):
         continue      # keep the committed set small
     path = out / f"{name}.jpg"
     codecs.write_jpeg(path, size, mode, arguments, seed=len(name))

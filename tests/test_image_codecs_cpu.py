@@ -72,14 +72,29 @@ JPEG_CASES = [
     ("one_pixel", (1, 1), "RGB", dict(quality=90)),
     ("block_8x8_q10", (8, 8), "RGB", dict(quality=10, subsampling=2)),
     ("wide_strip", (200, 3), "RGB", dict(quality=92, subsampling=2)),
+    ("cmyk", (35, 22), "CMYK", dict(quality=90)),
+    ("ycck", (27, 31), "CMYK", dict(quality=85, adobe_transform=2)),
+    ("four_components_transform_1", (16, 16), "CMYK", dict(quality=80, adobe_transform=1)),
+    ("cmyk_progressive", (40, 24), "CMYK", dict(quality=75, progressive=True)),
 ]
 
 
 def write_jpeg(path, size, mode, arguments, seed):
     from PIL import Image
     picture = make_picture(size[0], size[1], seed)
-    image = Image.fromarray(picture if mode == "RGB" else picture[..., 1], mode)
+    arguments = dict(arguments)
+    adobe_transform = arguments.pop("adobe_transform", None)
+    if mode == "CMYK":      # four components with an Adobe marker (transform 0: CMYK, stored inverted)
+        black = ((np.mgrid[0:size[1], 0:size[0]][0] * 9 + seed * 31) % 256).astype(np.uint8)
+        image = Image.fromarray(np.concatenate([picture, black[..., None]], axis=-1), "CMYK")
+    else:
+        image = Image.fromarray(picture if mode == "RGB" else picture[..., 1], mode)
     image.save(path, "JPEG", **arguments)
+    if adobe_transform is not None:      # the same entropy-coded data declared as YCCK (2) or as "YCbCr plus a fourth channel" (1)
+        data = bytearray(Path(path).read_bytes())
+        at = data.index(b"Adobe")
+        data[at + 11] = adobe_transform
+        Path(path).write_bytes(bytes(data))
 
 
 def write_hdr(path, pixels, run_length_encoded=True, magic=b"#?RADIANCE"):
@@ -227,7 +242,7 @@ def test_jpeg_decoder_equals_the_reference_loader(tmp_path, name, size, mode, ar
     write_jpeg(path, size, mode, arguments, seed=len(name))
     mine, reference = host_load(path), reference_load(path)
     assert reference is not None and mine is not None
-    assert mine.shape == reference.shape == (size[1], size[0], 3 if mode == "RGB" else 1)
+    assert mine.shape == reference.shape == (size[1], size[0], 1 if mode == "L" else 3)
     assert np.array_equal(mine, reference), int(np.abs(mine.astype(int) - reference.astype(int)).max())
 
 
