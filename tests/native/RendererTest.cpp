@@ -544,9 +544,10 @@ GPU_TEST_F(RendererFixture, a_renderer_over_several_devices_delivers_the_single_
     create_cornell_box(camera_ID, scene.get_root_node());
 
     const int calls = 12;
-    auto run = [&](Renderer* r, std::vector<std::vector<double>>& accumulations, std::vector<std::vector<half4>>& frames) {
+    auto run = [&](Renderer* r, std::vector<std::vector<double>>& accumulations, std::vector<std::vector<half4>>& frames, Backend backend = Backend::PathTracing) {
         Scene::Cameras::set_renderer_ID(camera_ID, r->get_renderer_ID());
         r->set_max_bounce_count(camera_ID, 4);
+        r->set_backend(camera_ID, backend);
         r->handle_updates();
         const int pitch = frame_size.x + 5;           // a render target wider than the frame
         RenderTarget target(Math::Vector2i(pitch, frame_size.y));
@@ -564,7 +565,22 @@ GPU_TEST_F(RendererFixture, a_renderer_over_several_devices_delivers_the_single_
     EXPECT_TRUE(over_three != nullptr);
     if (!over_three) return;
     run(over_three, grouped, grouped_frames);
+    // the denoising backend over the group: noisy and albedo frames are assembled on the first device and filtered there
+    std::vector<std::vector<double>> single_denoised, grouped_denoised;
+    std::vector<std::vector<half4>> single_denoised_frames, grouped_denoised_frames;
+    run(renderer, single_denoised, single_denoised_frames, Backend::AIDenoisedPathTracing);
+    run(over_three, grouped_denoised, grouped_denoised_frames, Backend::AIDenoisedPathTracing);
     delete over_three;
+    size_t mismatching_denoised_calls = 0, filtered_differs_from_noisy = 0;
+    for (int i = 0; i < calls; ++i) {
+        bool same = single_denoised[i] == grouped_denoised[i];
+        for (int y = 0; y < frame_size.y && same; ++y)
+            same = std::memcmp(&single_denoised_frames[i][size_t(y) * (frame_size.x + 5)], &grouped_denoised_frames[i][size_t(y) * (frame_size.x + 5)], frame_size.x * sizeof(half4)) == 0;
+        mismatching_denoised_calls += !same;
+        filtered_differs_from_noisy += std::memcmp(single_denoised_frames[i].data(), single_frames[i].data(), size_t(frame_size.x) * sizeof(half4)) != 0;
+    }
+    EXPECT_EQ(size_t(0), mismatching_denoised_calls);
+    EXPECT_TRUE(filtered_differs_from_noisy > 0);
     size_t mismatching_calls = 0, lit = 0;
     for (int i = 0; i < calls; ++i) {
         bool same = single[i] == grouped[i];
