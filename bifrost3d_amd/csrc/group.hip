@@ -3,7 +3,8 @@
 // The path shards by independent units: pixel tiles of 8 x 8, dealt round-robin (tile % N == member), scene and tables replicated,
 // every member keeps the f64 accumulation of its own tiles for the whole run -- no data-path collective per sample.
 // A group holds one HiprContext per member device and drives each from its own host thread (the wavefront loop of a pass waits on
-// per-bounce queue sizes, so a thread per device keeps the devices independent). The only exchange is once per displayed frame: the
+// per-bounce queue sizes, so a thread per device keeps the devices independent): member 0 on the calling thread, the others on worker
+// threads that live as long as the group (a render() on 8 GPUs is a few milliseconds: no thread is created on the frame path). The only exchange is once per displayed frame: the
 // members' compact half4 tiles are gathered on member 0's device and k_scatter_tiles assembles the frame there.
 //   gather: RCCL point-to-point (ncclCommInitAll in this process; member 0 posts one ncclRecv per peer inside a group call, every
 //           peer one ncclSend) over xGMI; RCCL is loaded with dlopen so that the library has no link-time dependency on it. When
@@ -18,12 +19,17 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
+
+extern "C" void hipr_internal_set_last_error(const char* message);   // hiprenderer.hip: hipr_last_error() is per thread; a worker's message is handed to the caller's
 
 namespace {
 
@@ -60,19 +66,19 @@ struct Member {
     hipStream_t stream = nullptr;   // gather traffic of this member
     void* comm = nullptr;           // ncclComm_t
     int status = HIPR_OK;
+    std::string message;            // hipr_last_error() of the thread that ran this member's share of the last call
 };
 
-template <typename F>
-int for_each_member(std::vector<Member>& members, F&& work) {
-    // one host thread per device; member 0 runs on the calling thread
+// One worker thread per member beyond the first, parked on a condition variable between calls.
+struct Workers {
     std::vector<std::thread> threads;
-    for (size_t i = 1; i < members.size(); ++i) threads.emplace_back([&, i] { members[i].status = work(members[i], uint32_t(i)); });
-    members[0].status = work(members[0], 0u);
-    for (std::thread& t : threads) t.join();
-    for (const Member& m : members)
-        if (m.status != HIPR_OK) return m.status;
-    return HIPR_OK;
-}
+    std::mutex mutex;
+    std::condition_variable start, done;
+    unsigned long long generation = 0;
+    uint32_t pending = 0;
+    bool stop = false;
+    std::function<int(Member&, uint32_t)> work;
+};
 
 } // namespace
 
@@ -85,12 +91,83 @@ struct HiprGroup {
     void* gathered = nullptr;       // members x compact_pixels half4 on member 0's device
     bool frame_ready = false;
     std::string gather_description;
+    Workers workers;
 };
+
+namespace {
+
+void worker_loop(HiprGroup* g, uint32_t index) {
+    Workers& w = g->workers;
+    unsigned long long seen = 0;
+    for (;;) {
+        std::function<int(Member&, uint32_t)> work;
+        {
+            std::unique_lock<std::mutex> lock(w.mutex);
+            w.start.wait(lock, [&] { return w.stop || w.generation != seen; });
+            if (w.stop) return;
+            seen = w.generation;
+            work = w.work;
+        }
+        Member& m = g->members[index];
+        m.status = work(m, index);
+        m.message = m.status != HIPR_OK ? hipr_last_error() : "";
+        {
+            std::lock_guard<std::mutex> lock(w.mutex);
+            if (--w.pending == 0) w.done.notify_one();
+        }
+    }
+}
+
+// Runs work(member, index) for every member, member 0 on the calling thread, and returns the first failure; the failing member's message becomes
+// the calling thread's hipr_last_error().
+int for_each_member(HiprGroup* g, std::function<int(Member&, uint32_t)> work) {
+    std::vector<Member>& members = g->members;
+    Workers& w = g->workers;
+    const uint32_t others = uint32_t(w.threads.size());
+    if (others) {
+        std::lock_guard<std::mutex> lock(w.mutex);
+        w.work = work;
+        w.pending = others;
+        ++w.generation;
+        w.start.notify_all();
+    }
+    members[0].status = work(members[0], 0u);
+    members[0].message = members[0].status != HIPR_OK ? hipr_last_error() : "";
+    for (size_t i = 1 + others; i < members.size(); ++i) {   // no worker (the group is being built or torn down): in line
+        members[i].status = work(members[i], uint32_t(i));
+        members[i].message = members[i].status != HIPR_OK ? hipr_last_error() : "";
+    }
+    if (others) {
+        std::unique_lock<std::mutex> lock(w.mutex);
+        w.done.wait(lock, [&] { return w.pending == 0; });
+    }
+    for (size_t i = 0; i < members.size(); ++i)
+        if (members[i].status != HIPR_OK) {
+            const std::string text = "device group member " + std::to_string(i) + " (device " + std::to_string(members[i].device) + "): " + members[i].message;
+            hipr_internal_set_last_error(text.c_str());
+            return members[i].status;
+        }
+    return HIPR_OK;
+}
+
+void stop_workers(HiprGroup* g) {
+    Workers& w = g->workers;
+    {
+        std::lock_guard<std::mutex> lock(w.mutex);
+        w.stop = true;
+        w.start.notify_all();
+    }
+    for (std::thread& t : w.threads) t.join();
+    w.threads.clear();
+}
+
+} // namespace
 
 extern "C" {
 
 int hipr_group_destroy(HiprGroup* g) {
     if (!g) return HIPR_OK;
+    stop_workers(g);
     for (Member& m : g->members) {
         (void)hipSetDevice(m.device);
         if (m.comm && g->rccl.CommDestroy) g->rccl.CommDestroy(m.comm);
@@ -139,6 +216,7 @@ int hipr_group_create(const int* device_ids, uint32_t count, HiprGroup** out_gro
         } else
             fprintf(stderr, "hiprenderer: ncclCommInitAll failed; the group gathers with peer-to-peer copies\n");
     }
+    for (uint32_t i = 1; i < count; ++i) g->workers.threads.emplace_back(worker_loop, g, i);
     *out_group = g;
     return HIPR_OK;
 }
@@ -149,17 +227,17 @@ const char* hipr_group_gather_description(HiprGroup* g) { return g ? g->gather_d
 
 int hipr_group_upload_tables(HiprGroup* g, const HiprTables* tables) {
     if (!g) return HIPR_ERROR_INVALID_ARGUMENT;
-    return for_each_member(g->members, [&](Member& m, uint32_t) { return hipr_upload_tables(m.context, tables); });
+    return for_each_member(g, [&](Member& m, uint32_t) { return hipr_upload_tables(m.context, tables); });
 }
 
 int hipr_group_upload_scene(HiprGroup* g, const HiprSceneDesc* scene) {
     if (!g) return HIPR_ERROR_INVALID_ARGUMENT;
-    return for_each_member(g->members, [&](Member& m, uint32_t) { return hipr_upload_scene(m.context, scene); });   // replicated: every device walks the same BVH
+    return for_each_member(g, [&](Member& m, uint32_t) { return hipr_upload_scene(m.context, scene); });   // replicated: every device walks the same BVH
 }
 
 int hipr_group_update_scene_geometry(HiprGroup* g, const HiprSceneDesc* scene) {
     if (!g) return HIPR_ERROR_INVALID_ARGUMENT;
-    return for_each_member(g->members, [&](Member& m, uint32_t) { return hipr_update_scene_geometry(m.context, scene); });
+    return for_each_member(g, [&](Member& m, uint32_t) { return hipr_update_scene_geometry(m.context, scene); });
 }
 
 int hipr_group_set_scene_state(HiprGroup* g, const HiprSceneState* state) {
@@ -187,7 +265,7 @@ int hipr_group_set_frame(HiprGroup* g, uint32_t width, uint32_t height, uint32_t
     if (!g || width == 0 || height == 0) return HIPR_ERROR_INVALID_ARGUMENT;
     const uint32_t n = uint32_t(g->members.size());
     g->frame_ready = false;
-    int status = for_each_member(g->members, [&](Member& m, uint32_t i) {
+    int status = for_each_member(g, [&](Member& m, uint32_t i) {
         HiprFrameDesc frame = {width, height, i, n, samples_per_pass};
         return hipr_set_frame(m.context, &frame);
     });
@@ -221,7 +299,7 @@ int hipr_group_set_samples_per_pass(HiprGroup* g, uint32_t samples_per_pass) {
 
 int hipr_group_trace_pass(HiprGroup* g, const HiprCameraState* camera) {
     if (!g || !camera) return HIPR_ERROR_INVALID_ARGUMENT;
-    return for_each_member(g->members, [&](Member& m, uint32_t) { return hipr_trace_pass(m.context, camera); });
+    return for_each_member(g, [&](Member& m, uint32_t) { return hipr_trace_pass(m.context, camera); });
 }
 
 int hipr_group_accumulate_samples(HiprGroup* g, uint32_t first_sample, uint32_t sample_count, uint32_t first_accumulation, void* out_half4_device, uint32_t out_pitch_pixels,
@@ -232,25 +310,29 @@ int hipr_group_accumulate_samples(HiprGroup* g, uint32_t first_sample, uint32_t 
     if (out_half4_device && out_pitch_pixels < g->width) return HIPR_ERROR_INVALID_ARGUMENT;
     const size_t bytes = size_t(g->compact_pixels) * 8;
     char* gathered = static_cast<char*>(g->gathered);
-    // Every member folds its samples and writes its compact tiles; then the tiles travel to member 0's device.
-    int status = for_each_member(g->members, [&](Member& m, uint32_t i) -> int {
-        if (int s = hipr_accumulate_samples(m.context, first_sample, sample_count, first_accumulation, out_half4_device ? m.compact : nullptr, 0, 1)) return s;
-        if (!out_half4_device) return HIPR_OK;
-        if (hipSetDevice(m.device) != hipSuccess) return HIPR_ERROR_HIP;
+    // Phase 1: every member folds its samples and writes its compact tiles. Phase 2, only when every member got there: the tiles travel to
+    // member 0's device. (A member that failed before posting its send or receive would leave its peer waiting in the exchange for ever.)
+    int status = for_each_member(g, [&](Member& m, uint32_t) -> int {
+        return hipr_accumulate_samples(m.context, first_sample, sample_count, first_accumulation, out_half4_device ? m.compact : nullptr, 0, 1);
+    });
+    if (status || !out_half4_device) return status;
+    status = for_each_member(g, [&](Member& m, uint32_t i) -> int {
+        auto hip_failed = [&](const char* what) { hipr_internal_set_last_error(what); return HIPR_ERROR_HIP; };
+        if (hipSetDevice(m.device) != hipSuccess) return hip_failed("hipSetDevice failed in the tile gather");
         if (g->use_rccl) {
             if (i == 0) {
-                if (hipMemcpyAsync(gathered, m.compact, bytes, hipMemcpyDeviceToDevice, m.stream) != hipSuccess) return HIPR_ERROR_HIP;
+                if (hipMemcpyAsync(gathered, m.compact, bytes, hipMemcpyDeviceToDevice, m.stream) != hipSuccess) return hip_failed("copy of member 0's own tiles failed");
                 int r = g->rccl.GroupStart();
                 for (uint32_t peer = 1; peer < n && r == 0; ++peer) r = g->rccl.Recv(gathered + size_t(peer) * bytes, bytes, NCCL_UINT8, int(peer), m.comm, m.stream);
                 r = g->rccl.GroupEnd() | r;
-                if (r != 0) return HIPR_ERROR_HIP;
+                if (r != 0) return hip_failed("ncclRecv of the members' tiles failed");
             } else if (g->rccl.Send(m.compact, bytes, NCCL_UINT8, 0, m.comm, m.stream) != 0)
-                return HIPR_ERROR_HIP;
+                return hip_failed("ncclSend of a member's tiles failed");
         } else if (hipMemcpyAsync(gathered + size_t(i) * bytes, m.compact, bytes, hipMemcpyDeviceToDevice, m.stream) != hipSuccess)
-            return HIPR_ERROR_HIP;
-        return hipStreamSynchronize(m.stream) == hipSuccess ? HIPR_OK : HIPR_ERROR_HIP;
+            return hip_failed("peer-to-peer copy of a member's tiles failed");
+        return hipStreamSynchronize(m.stream) == hipSuccess ? HIPR_OK : hip_failed("the gather stream failed");
     });
-    if (status || !out_half4_device) return status;
+    if (status) return status;
     if (int s = hipr_scatter_tiles(g->members[0].context, g->gathered, g->compact_pixels, n, g->width, g->height, out_half4_device, out_pitch_pixels)) return s;
     return synchronize ? hipr_synchronize(g->members[0].context) : HIPR_OK;
 }

@@ -114,6 +114,8 @@ struct HiprContext {
     DeviceScene scene = {};
     bool tables_ready = false, scene_ready = false;
     size_t uploaded_instance_bytes = 0;
+    uint32_t uploaded_material_count = 0, uploaded_texture_count = 0, uploaded_vertex_count = 0, uploaded_index_count = 0;   // pools a geometry update leaves in place
+    uint64_t uploaded_texel_bytes = 0;
     int stack_size = 16;
     int shading_models = 7;             // bit mask of the shading models the scene's instances reference
 
@@ -280,8 +282,11 @@ void launch_persistent_for_stack(HiprContext* c, const Wavefront& w, const PathS
     // array (traversals rarely get past 16): 4 KB of LDS per wave instead of 8 lets a sixth wave per SIMD stay resident, and the kernel is bound by
     // the latency of its dependent gathers (atrium, 260 k triangles: 61.0 -> 57.7 ms of trace time per step). Deeper trees (the 10 M triangle
     // atrium) spill often enough that 32 LDS entries + scratch is the faster split (116.7 vs 119.9 ms).
+#ifndef HIPR_STACK_MID
+#define HIPR_STACK_MID 16
+#endif
     if (c->wide_stack_entries <= 16) launch_persistent<16, MODE, INSTRUMENT, false>(c, w, in, closest_count, shadow_count, upper_bound, 0);
-    else if (c->wide_stack_entries <= 32) launch_persistent<16, MODE, INSTRUMENT, true>(c, w, in, closest_count, shadow_count, upper_bound, 1);
+    else if (c->wide_stack_entries <= 32) launch_persistent<HIPR_STACK_MID, MODE, INSTRUMENT, true>(c, w, in, closest_count, shadow_count, upper_bound, 1);
     else launch_persistent<32, MODE, INSTRUMENT, true>(c, w, in, closest_count, shadow_count, upper_bound, 2);
 }
 
@@ -344,6 +349,7 @@ int partition_path_slots(HiprContext* c) {
     const FrameInfo& fi = c->frame;
     const uint64_t slots = uint64_t(fi.owned_tiles) * 64u * fi.samples_per_pass;
     c->n_slots = uint32_t(slots);
+    c->traced_samples = 0;   // the radiance buffer may move and its sample layout changes: nothing traced before can be folded any more
     int r = 0;
     c->partitioned_for = c->wavefronts_wanted();
     c->wavefront_count = int(std::max<uint64_t>(1, std::min<uint64_t>(uint64_t(c->partitioned_for), slots / 65536u)));
@@ -507,6 +513,8 @@ int build_derived_geometry(HiprContext* c, const HiprSceneDesc* s) {
 extern "C" {
 
 const char* hipr_last_error(void) { return g_last_error.c_str(); }
+// Not part of the public header: group.hip hands the message of a member that failed on a worker thread to the calling thread.
+void hipr_internal_set_last_error(const char* message) { g_last_error = message ? message : ""; }
 
 int hipr_device_count(void) {
     int n = 0;
@@ -715,6 +723,8 @@ int hipr_upload_scene(HiprContext* c, const HiprSceneDesc* s) {
     }
     c->shading_models = models ? models : 7;
     c->uploaded_instance_bytes = size_t(s->instance_count) * sizeof(HiprInstance);
+    c->uploaded_material_count = s->material_count; c->uploaded_texture_count = s->texture_count; c->uploaded_vertex_count = s->vertex_count;
+    c->uploaded_index_count = s->index_count; c->uploaded_texel_bytes = s->texel_bytes;
     c->scene_ready = true;
     return HIPR_OK;
 }
@@ -723,6 +733,13 @@ int hipr_update_scene_geometry(HiprContext* c, const HiprSceneDesc* s) {
     if (int st = check_context(c)) return st;
     if (!s) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_update_scene_geometry: null scene");
     if (!c->scene_ready) return fail(HIPR_ERROR_NOT_READY, "hipr_update_scene_geometry: no scene uploaded");
+    if (s->triangle_count && (!s->nodes || !s->triangles || !s->instances || !s->indices || !s->geometry || !s->materials))
+        return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_update_scene_geometry: missing geometry arrays");
+    // Meshes, materials and textures stay on the device as uploaded: the description is validated against ITS pools below, so those must be the
+    // uploaded ones in size -- an index that is in range for a larger pool of the description would read out of bounds on the device.
+    if (s->material_count != c->uploaded_material_count || s->texture_count != c->uploaded_texture_count || s->vertex_count != c->uploaded_vertex_count ||
+        s->index_count != c->uploaded_index_count || s->texel_bytes != c->uploaded_texel_bytes)
+        return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_update_scene_geometry: material, texture, vertex, index and texel pool sizes must equal the uploaded scene's (those pools are not re-uploaded)");
     const DeviceScene& d = c->scene;
     if (s->node_count != d.node_count || s->triangle_count != d.triangle_count || (s->wide_nodes ? s->wide_node_count : 0u) != d.wide_node_count || s->light_count != d.light_count ||
         size_t(s->instance_count) * sizeof(HiprInstance) != c->uploaded_instance_bytes)
@@ -741,6 +758,9 @@ int hipr_update_scene_geometry(HiprContext* c, const HiprSceneDesc* s) {
     r |= c->lights.upload(s->lights, size_t(s->light_count) * sizeof(HiprLight), st);
     if (r) return r < 0 ? r : HIPR_ERROR_HIP;
     HIP_TRY(hipStreamSynchronize(st));
+    int models = 0;   // the instances were re-uploaded: a changed material_index may reference another shading model
+    for (uint32_t i = 0; i < s->instance_count; ++i) models |= 1 << std::min<int>(s->materials[s->instances[i].material_index].shading_model, 2);
+    c->shading_models = models ? models : 7;
     return build_derived_geometry(c, s);
 }
 
@@ -930,6 +950,10 @@ int hipr_trace_pass(HiprContext* c, const HiprCameraState* camera) {
                 fprintf(stderr, "[hipr]     wave iterations: %.0f node (%.1f lanes working) + %.0f triangle (%.1f lanes working); %.1f lanes busy on average; %llu refills\n", ni,
                         double(dc.node_lanes - p.node_lanes) / ni, ti, ti > 0 ? double(dc.triangle_lanes - p.triangle_lanes) / ti : 0.0,
                         double(dc.busy_lanes - p.busy_lanes) / (ni + ti), dc.refills - p.refills);
+                const double pushes = double(dc.pushes - p.pushes);
+                if (pushes > 0)
+                    fprintf(stderr, "[hipr]     stack pushes: %.0f, of which %.3f %% onto entry 16 or deeper and %.3f %% onto entry 24 or deeper\n", pushes,
+                            100.0 * double(dc.pushes_past_16 - p.pushes_past_16) / pushes, 100.0 * double(dc.pushes_past_24 - p.pushes_past_24) / pushes);
             }
             c->trace_log_previous = dc;
         }

@@ -97,6 +97,7 @@ struct DeviceCounters {
     unsigned long long shaded_hits, closest_nodes, closest_triangles, shadow_nodes, shadow_triangles;
     // diagnostics of the persistent kernels (instrumented builds): wave iterations by kind and the lanes that did work in them
     unsigned long long node_iterations, node_lanes, triangle_iterations, triangle_lanes, busy_lanes, refills;
+    unsigned long long pushes, pushes_past_16, pushes_past_24;   // stack pushes of the persistent kernels, and those that landed on entry 16 / 24 or deeper
 };
 
 // Blocks that share an XCD (blockIdx % 8) get a contiguous range of chunks so that spatially
@@ -624,7 +625,10 @@ enum { TRACE_CLOSEST = 0, TRACE_SHADOW = 1, TRACE_FUSED = 2 };
 // Waves per SIMD the persistent kernels are compiled for. With 16 LDS stack entries (4 KB per wave) the register file is the limit: measured on the
 // atrium, 5 waves 60.4 ms of trace time per step, 6 waves (<= 80 VGPRs) 57.7, 7 waves (72 VGPRs) 57.8, 8 waves (64 VGPRs, spills) 60.3. With 32
 // entries LDS holds five waves and the registers of a sixth are better spent (10 M triangle atrium: 116.7 ms at 93 VGPRs, 121.0 at 80).
-HD constexpr int trace_waves_per_simd(int stack_entries) { return stack_entries <= 16 ? 6 : 5; }
+#ifndef HIPR_TRACE_WAVES_SHALLOW
+#define HIPR_TRACE_WAVES_SHALLOW 6
+#endif
+HD constexpr int trace_waves_per_simd(int stack_entries) { return stack_entries <= 24 ? HIPR_TRACE_WAVES_SHALLOW : 5; }
 template <int STACK, int MODE, bool INSTRUMENT, bool OVERFLOW>
 __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(trace_waves_per_simd(STACK)))) void k_trace_persistent(DeviceScene sc, PathState in, float4* hits, ShadowQueue q, float4* radiance,
                                                                   const uint32_t* closest_count_ptr, const uint32_t* shadow_count_ptr, uint32_t* work_counter,
@@ -664,6 +668,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(tra
     uint32_t tri_cur = 0, tri_end = 0;
     uint32_t nodes = 0, tris = 0, shadow_nodes = 0, shadow_tris = 0;
     uint32_t diag_node_iterations = 0, diag_node_lanes = 0, diag_triangle_iterations = 0, diag_triangle_lanes = 0, diag_busy_lanes = 0, diag_refills = 0;   // lane 0 only
+    uint32_t diag_pushes = 0, diag_pushes_16 = 0, diag_pushes_24 = 0;   // per lane
 
     // Work item encoding: >= 0 inner node index, < 0 leaf ~((first << 3) | (count - 1)), TRACE_DONE = nothing left.
     constexpr int TRACE_DONE = 0x7FFFFFFF;
@@ -855,6 +860,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(tra
                     if (key[k] != 0xFFFFFFFFu) {
                         if (!OVERFLOW || sp < STACK) stack[sp * TRACE_BLOCK] = child[k];
                         else spill[sp - STACK] = child[k];
+                        if (INSTRUMENT) { ++diag_pushes; diag_pushes_16 += sp >= 16; diag_pushes_24 += sp >= 24; }
                         ++sp;
                     }
                 }
@@ -887,6 +893,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(tra
         wave_add(&counters->node_iterations, diag_node_iterations); wave_add(&counters->node_lanes, diag_node_lanes);
         wave_add(&counters->triangle_iterations, diag_triangle_iterations); wave_add(&counters->triangle_lanes, diag_triangle_lanes);
         wave_add(&counters->busy_lanes, diag_busy_lanes); wave_add(&counters->refills, diag_refills);
+        wave_add(&counters->pushes, diag_pushes); wave_add(&counters->pushes_past_16, diag_pushes_16); wave_add(&counters->pushes_past_24, diag_pushes_24);
         if (MODE != TRACE_SHADOW) { wave_add(&counters->closest_nodes, nodes); wave_add(&counters->closest_triangles, tris); }
         if (MODE != TRACE_CLOSEST) { wave_add(&counters->shadow_nodes, shadow_nodes); wave_add(&counters->shadow_triangles, shadow_tris); }
     }

@@ -101,7 +101,13 @@ unsigned HeadlessCompositor::render(float delta_time) {
 
     // The back buffer starts black every frame (the swap chain's target is cleared before the cameras draw): regions no viewport covers must not
     // show last frame's pixels. Cameras composite in ascending z-index, so an overlay camera lands on top (DX11Renderer/Compositor.cpp:268).
-    hipr_device_memset(m_impl->context, m_impl->backbuffer, 0, uint64_t(m_impl->window_size.x) * m_impl->window_size.y * 4);
+    // The clear runs on the compositor context's stream, the camera effects write the same buffer on a stream of their own: the clear is
+    // waited for here, so no viewport composited below can be overwritten by it.
+    if (hipr_device_memset(m_impl->context, m_impl->backbuffer, 0, uint64_t(m_impl->window_size.x) * m_impl->window_size.y * 4) != HIPR_OK ||
+        hipr_synchronize(m_impl->context) != HIPR_OK) {
+        fprintf(stderr, "HIPRenderer compositor: clearing the back buffer failed: %s\n", hipr_last_error());
+        return 0;
+    }
     unsigned composited = 0;
     for (CameraID camera_ID : Cameras::get_z_sorted_IDs()) {
         Recti viewport;

@@ -15,6 +15,7 @@ namespace {
 struct Reader {
     const unsigned char* data; size_t size, pos = 0;
     bool at_end() const { return pos >= size; }
+    size_t remaining() const { return size - pos; }
     int byte() { return pos < size ? data[pos++] : 0; }
     std::string line() {     // up to the next newline, without it
         std::string s;
@@ -53,6 +54,12 @@ bool decode(const void* data, size_t byte_count, unsigned& width, unsigned& heig
     const std::string resolution = r.line();
     int h = 0, w = 0;
     if (std::sscanf(resolution.c_str(), "-Y %d +X %d", &h, &w) != 2 || w <= 0 || h <= 0) return fail("unsupported data layout (only -Y h +X w)");
+    // Nothing is allocated from header figures alone: at most 1 << 24 pixels a side (the bound of the decoder the reference loads textures with),
+    // and even a run-length encoded file spends at least 4 bytes a scanline and, flat, 4 bytes a pixel.
+    if (w > (1 << 24) || h > (1 << 24)) return fail("image too large");
+    const size_t remaining = r.remaining();
+    if (size_t(h) * 4 > remaining || ((w < 8 || w >= 32768) && size_t(w) * size_t(h) * 4 > remaining)) return fail("truncated pixel data");
+    if (size_t(w) * size_t(h) > (size_t(1) << 28)) return fail("image too large");
     width = unsigned(w); height = unsigned(h);
     rgb.assign(size_t(w) * h * 3, 0.0f);
     std::vector<unsigned char> scanline(size_t(w) * 4);

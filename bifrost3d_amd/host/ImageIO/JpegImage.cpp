@@ -161,6 +161,9 @@ struct Decoder {
             if (h_max % components[c].h || v_max % components[c].v) return fail("fractional sampling ratios are not supported");
         mcu_w = 8 * h_max; mcu_h = 8 * v_max;
         mcus_x = (width + mcu_w - 1) / mcu_w; mcus_y = (height + mcu_h - 1) / mcu_h;
+        // Planes are sized from the header: a frame that claims more blocks than the file has bits (every block costs a scan at least one) is refused
+        // before anything is allocated.
+        if (uint64_t(mcus_x) * uint64_t(mcus_y) > uint64_t(size) * 8u) return fail("frame dimensions exceed what the file can hold");
         for (int c = 0; c < component_count; ++c) {
             Component& comp = components[c];
             comp.x = (width * comp.h + h_max - 1) / h_max; comp.y = (height * comp.v + v_max - 1) / v_max;
@@ -204,7 +207,8 @@ struct Decoder {
         const int t = decode_symbol(dc);
         if (t < 0 || t > 15) return fail("bad DC code");
         comp.dc_predictor += receive_extend(t);
-        block[0] = int16_t(comp.dc_predictor * q[0]);
+        if (comp.dc_predictor < -(1 << 20) || comp.dc_predictor > (1 << 20)) return fail("DC predictor out of range");      // corrupt stream: no signed overflow below
+        block[0] = int16_t(int64_t(comp.dc_predictor) * q[0]);
         for (int k = 1; k < 64;) {
             const int rs = decode_symbol(ac);
             if (rs < 0) return false;
@@ -227,7 +231,8 @@ struct Decoder {
             const int t = decode_symbol(dc);
             if (t < 0 || t > 15) return fail("bad DC code");
             comp.dc_predictor += receive_extend(t);
-            block[0] = int16_t(comp.dc_predictor * (1 << successive_low));
+            if (comp.dc_predictor < -(1 << 20) || comp.dc_predictor > (1 << 20)) return fail("DC predictor out of range");
+            block[0] = int16_t(int64_t(comp.dc_predictor) * (1 << successive_low));
         } else if (get_bit())           // refinement: one more bit of precision
             block[0] = int16_t(block[0] + (1 << successive_low));
         return true;

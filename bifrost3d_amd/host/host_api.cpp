@@ -4,6 +4,8 @@
 // The scene a handle owns is exactly what a Bifrost host would hand to hipr_upload_scene().
 #include "Scenes.h"
 
+#include <cstdio>
+#include <exception>
 #include <cstring>
 #include <string>
 
@@ -162,7 +164,13 @@ void* hiprh_scene_load(const char* path, unsigned variant) { return hiprh_scene_
 
 // The same with SimpleViewer's --environment-map (main.cpp:331-341, 533): a latitude-longitude image (Radiance .hdr, PNG or JPEG) that lights the
 // scene and is seen where paths escape; it counts as a light source, so no default directional light is added (main.cpp:419-426).
+static void* scene_load_with_environment(const char* path, const char* environment_map_path, unsigned variant);
 void* hiprh_scene_load_with_environment(const char* path, const char* environment_map_path, unsigned variant) {
+    // No exception crosses the C boundary: a crafted or truncated asset that exhausts memory inside a decoder costs the load, not the process.
+    try { return scene_load_with_environment(path, environment_map_path, variant); }
+    catch (const std::exception& e) { fprintf(stderr, "hiprh_scene_load: %s\n", e.what()); Bifrost::deallocate_all(); return nullptr; }
+}
+static void* scene_load_with_environment(const char* path, const char* environment_map_path, unsigned variant) {
     using namespace Bifrost;
     if (!path) return nullptr;
     deallocate_all();
@@ -245,7 +253,12 @@ int hiprh_renderer_bench(const char* data_directory, unsigned target_triangles, 
 
 // Decodes any image file the loaders read (PNG, JPEG, Radiance HDR) for the codec tests: returns the byte count of the pixels (8 bit or float, rows
 // top-down unless `flip`), 0 when the file cannot be decoded; format: 0 = 8 bit, 1 = float.
+static size_t image_load(const char* path, int flip, unsigned* width, unsigned* height, unsigned* channels, int* is_float, void* out, size_t capacity);
 size_t hiprh_image_load(const char* path, int flip, unsigned* width, unsigned* height, unsigned* channels, int* is_float, void* out, size_t capacity) {
+    try { return image_load(path, flip, width, height, channels, is_float, out, capacity); }
+    catch (const std::exception& e) { fprintf(stderr, "hiprh_image_load: %s\n", e.what()); return 0; }
+}
+static size_t image_load(const char* path, int flip, unsigned* width, unsigned* height, unsigned* channels, int* is_float, void* out, size_t capacity) {
     using namespace Bifrost::Assets;
     if (!path) return 0;
     Image image = ImageLoader::load(path);

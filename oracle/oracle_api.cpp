@@ -336,26 +336,33 @@ double oracle_render_entry(const HiprSceneDesc* scene, const HiprSceneState* sta
 #ifdef _OPENMP
     double t0 = omp_get_wtime();
 #endif
-    for (uint32_t a = 0; a < accumulation_count; ++a) {
-        uint32_t accumulation = cam->accumulations + a;
+    // Pixels are independent (the running mean of a pixel only sees that pixel's samples in accumulation order), so the parallel loop runs over
+    // blocks of 16 pixels with the accumulations inside: the same image bit for bit as a pass per accumulation, and every host core stays busy
+    // on small frames (a 160 x 90 frame has 900 blocks; a row-parallel loop kept 23 threads busy).
+    {
 #pragma omp parallel
         {
             RenderCounters local;
-#pragma omp for schedule(dynamic, 4)
-            for (int y = 0; y < height; ++y)
-                for (int x = 0; x < width; ++x) {
-                    float3 r = entry == HIPR_ENTRY_PATH_TRACING ? path_trace_pixel(*scene, *state, *cam, offsets.data(), x, y, width, height, accumulation, settings, &local)
-                                                                : aov_pixel(*scene, *state, *cam, offsets.data(), x, y, width, height, accumulation, entry, settings);
+            const long long pixels = (long long)width * height;
+#pragma omp for schedule(dynamic, 1)
+            for (long long block = 0; block < (pixels + 15) / 16; ++block)
+                for (long long i = block * 16; i < std::min(pixels, block * 16 + 16); ++i) {
+                    const int x = int(i % width), y = int(i / width);
                     double* px = accum_rgba + 4 * (size_t(y) * width + x);
-                    if (accumulation != 0) {
-                        double t = 1.0 / (accumulation + 1.0);
-                        px[0] = px[0] + (double(r.x) - px[0]) * t;
-                        px[1] = px[1] + (double(r.y) - px[1]) * t;
-                        px[2] = px[2] + (double(r.z) - px[2]) * t;
-                    } else {
-                        px[0] = r.x; px[1] = r.y; px[2] = r.z;
+                    for (uint32_t a = 0; a < accumulation_count; ++a) {
+                        const uint32_t accumulation = cam->accumulations + a;
+                        float3 r = entry == HIPR_ENTRY_PATH_TRACING ? path_trace_pixel(*scene, *state, *cam, offsets.data(), x, y, width, height, accumulation, settings, &local)
+                                                                    : aov_pixel(*scene, *state, *cam, offsets.data(), x, y, width, height, accumulation, entry, settings);
+                        if (accumulation != 0) {
+                            double t = 1.0 / (accumulation + 1.0);
+                            px[0] = px[0] + (double(r.x) - px[0]) * t;
+                            px[1] = px[1] + (double(r.y) - px[1]) * t;
+                            px[2] = px[2] + (double(r.z) - px[2]) * t;
+                        } else {
+                            px[0] = r.x; px[1] = r.y; px[2] = r.z;
+                        }
+                        px[3] = 1.0;
                     }
-                    px[3] = 1.0;
                 }
 #pragma omp critical
             {

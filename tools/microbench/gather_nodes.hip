@@ -3,6 +3,9 @@
 //   B  quad gather : the 4 lanes of a quad fetch the 4 quarters of ONE node per instruction (4 instructions serve the
 //                    quad's 4 nodes); 64 B contiguous per quad and instruction
 //   C  quad gather + LDS transpose so that every lane ends up with its own node (the usable form of B)
+//   D  quad gather + a 4 x 4 transpose inside the quad through DPP (two butterfly stages of v_cndmask_b32 with a quad_perm source: 32 VALU, no LDS)
+//   E  like D, but only `ACTIVE` of the 64 lanes want a node (the trace kernel averages 38 working lanes per node iteration): lane gather with
+//      the idle lanes masked against quad gather with the loads of idle quad-mates masked
 // Build: hipcc -O3 --offload-arch=gfx950 -o gather_nodes gather_nodes.hip ; run: ./gather_nodes
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -35,6 +38,44 @@ __global__ __launch_bounds__(128) void k_gather(const float4* nodes, uint32_t no
                 v[i] = nodes[4 * size_t(leader_node) + j];
             }
             acc += v[0].x + v[1].y + v[2].z + v[3].w;
+        } else if (MODE == 3 || MODE == 4 || MODE == 5) {
+            const bool want = MODE == 3 || ((hash(seed ^ 0x9E3779B9u) & 63u) < 38u);   // E: 38 of 64 lanes on average, scattered
+            const uint32_t j = lane & 3u;
+            if (MODE == 4) {   // masked lane gather
+                if (want) {
+                    const uint4* p = reinterpret_cast<const uint4*>(nodes) + 4 * size_t(node);
+                    const uint4 v[4] = {p[0], p[1], p[2], p[3]};
+                    uint32_t x = 0; for (int k = 0; k < 4; ++k) x += v[k].x ^ (v[k].y + (v[k].z ^ v[k].w));
+                    acc += __uint_as_float(x);
+                }
+            } else {
+                uint4 v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    // node index and request flag of quad-mate i, broadcast inside the quad (one DPP move each)
+                    const uint32_t packed = (node << 1) | (want ? 1u : 0u);
+                    const uint32_t mate = i == 0 ? __builtin_amdgcn_mov_dpp(packed, 0x00, 0xF, 0xF, false) : i == 1 ? __builtin_amdgcn_mov_dpp(packed, 0x55, 0xF, 0xF, false)
+                                        : i == 2 ? __builtin_amdgcn_mov_dpp(packed, 0xAA, 0xF, 0xF, false) : __builtin_amdgcn_mov_dpp(packed, 0xFF, 0xF, 0xF, false);
+                    v[i] = make_uint4(0, 0, 0, 0);
+                    if (mate & 1u) v[i] = reinterpret_cast<const uint4*>(nodes)[4 * size_t(mate >> 1) + j];
+                }
+                // lane j holds quarter j of the nodes of mates 0..3; two butterfly stages leave quarter k of the lane's OWN node in register k
+                const bool odd = (lane & 1u) != 0, upper = (lane & 2u) != 0;
+                uint4 s[4];
+#define XCHG1(x) uint32_t(__builtin_amdgcn_mov_dpp(int(x), 0xB1, 0xF, 0xF, false))   /* quad_perm [1, 0, 3, 2] */
+#define XCHG2(x) uint32_t(__builtin_amdgcn_mov_dpp(int(x), 0x4E, 0xF, 0xF, false))   /* quad_perm [2, 3, 0, 1] */
+#define STAGE(out0, out1, in0, in1, sel, X) \
+                out0.x = sel ? X(in1.x) : in0.x; out0.y = sel ? X(in1.y) : in0.y; out0.z = sel ? X(in1.z) : in0.z; out0.w = sel ? X(in1.w) : in0.w; \
+                out1.x = sel ? in1.x : X(in0.x); out1.y = sel ? in1.y : X(in0.y); out1.z = sel ? in1.z : X(in0.z); out1.w = sel ? in1.w : X(in0.w);
+                STAGE(s[0], s[1], v[0], v[1], odd, XCHG1)
+                STAGE(s[2], s[3], v[2], v[3], odd, XCHG1)
+                STAGE(v[0], v[2], s[0], s[2], upper, XCHG2)
+                STAGE(v[1], v[3], s[1], s[3], upper, XCHG2)
+#undef STAGE
+#undef XCHG1
+#undef XCHG2
+                if (want) { uint32_t x = 0; for (int k = 0; k < 4; ++k) x += v[k].x ^ (v[k].y + (v[k].z ^ v[k].w)); acc += __uint_as_float(x); }   // every dword is used: the transpose cannot be pruned
+            }
         } else {
             const uint32_t j = lane & 3u;
             float4* tile = s_tile + wave * 256;
@@ -68,7 +109,7 @@ double run(const float4* nodes, uint32_t mask, float* out, int blocks, int itera
 }
 
 int main() {
-    const int blocks = 256 * 10, iterations = 256;   // 10 blocks of 2 waves per CU = 5 waves per SIMD, like the trace kernel
+    const int blocks = 256 * 12, iterations = 256;   // 12 blocks of 2 waves per CU = 6 waves per SIMD, like the trace kernel
     float* out;
     CHECK(hipMalloc(&out, size_t(blocks) * 128 * 4));
     for (uint32_t log_nodes : {12u, 14u, 17u, 20u, 23u}) {   // 256 KB, 1 MB, 8 MB, 64 MB, 512 MB of nodes
@@ -80,8 +121,13 @@ int main() {
         const double a = run<0>(nodes, uint32_t(count - 1), out, blocks, iterations);
         const double b = run<1>(nodes, uint32_t(count - 1), out, blocks, iterations);
         const double c = run<2>(nodes, uint32_t(count - 1), out, blocks, iterations);
+        const double d = run<3>(nodes, uint32_t(count - 1), out, blocks, iterations);
+        const double e_lane = run<4>(nodes, uint32_t(count - 1), out, blocks, iterations);
+        const double e_quad = run<5>(nodes, uint32_t(count - 1), out, blocks, iterations);
         printf("nodes %8zu (%7.1f MB): lane gather %7.3f ms = %6.1f Gnodes/s (%5.0f GB/s) | quad gather %7.3f ms = %6.1f Gnodes/s | quad + LDS transpose %7.3f ms = %6.1f Gnodes/s\n",
                count, count * 64 / 1e6, a, fetches / a / 1e6, fetches * 64 / a / 1e6, b, fetches / b / 1e6, c, fetches / c / 1e6);
+        printf("                             quad + DPP transpose %7.3f ms = %6.1f Gnodes/s | 38 of 64 lanes: lane gather %7.3f ms = %6.1f Gnodes/s, quad + DPP %7.3f ms = %6.1f Gnodes/s\n",
+               d, fetches / d / 1e6, e_lane, fetches * (38.0 / 64.0) / e_lane / 1e6, e_quad, fetches * (38.0 / 64.0) / e_quad / 1e6);
         CHECK(hipFree(nodes));
     }
     return 0;
