@@ -19,14 +19,18 @@ N > 1: tiles of 8 x 8 pixels are dealt round-robin to the ranks and a step trace
 tiles to rank 0 and the scatter kernel that assembles the frame.
 
 The ONE JSON line rank 0 prints carries the contract keys plus
-  roofline          the kernel with the largest total time in the timed region: algorithmic bytes / HIP-event duration (`achieved`,
-                    `frac`, SURVEY.md 8d's model) AND the counter view (`traffic` = PMC HBM bytes per launch from profiles/pmc_traffic.json,
-                    `frac_counter` = traffic / duration / peak), `observed_limiter` from the SQ counter passes under profiles/;
+  roofline          the kernel with the largest total time in the timed region. `traffic` = bytes that crossed the L2's memory side per launch, from
+                    rocprofv3 counters: (2 * FETCH_SIZE + WRITE_SIZE) * 1024, measured by two child runs of this workload under `rocprofv3 --pmc` before the
+                    timed run (fallback: profiles/pmc_traffic.json), calibrated on this renderer's access patterns (profiles/r03_fetch_calibration.txt);
+                    `achieved` = traffic / HIP-event launch duration, `frac` = achieved / 8 TB/s -- always <= 1. `achieved_model` / `frac_model` price
+                    SURVEY.md 8d's ALGORITHMIC bytes (every node visit 64 B, ...) the same way: an upper bound that counts cache hits and may pass 1.
+                    `observed_limiter` from the SQ / TA counter passes under profiles/;
   cpu_baseline      the SmallPT restatement (BASELINE config 1) on the host cores, plus `c2`: the oracle's render of config 2 (Cornell,
                     all Diffuse) at reduced size next to the device's, equal ray counters, like-for-like Mrays/s (N = 1 only);
   other_workloads   BASELINE configs[1] (Cornell, all Diffuse) and configs[2] (material scene, 32 bounces) measured the same way after
                     the main timed region, each with value / ms per 256 spp / roofline / rmse (N = 1 only; --no-other-workloads skips);
-  config.rmse_vs_oracle   RMSE against the CPU oracle at equal spp and seed, 8 and 256 spp on a 160 x 90 frame.
+  config.rmse_vs_oracle   RMSE against the CPU oracle at equal spp and seed, 8 and 256 spp on a 160 x 90 frame, both definitions of SURVEY.md 8d, the bias
+                    statistics of the difference, and each image's distance to a converged (16 x spp, disjoint accumulations) oracle image.
 """
 from __future__ import annotations
 
@@ -73,6 +77,14 @@ def parse_args(argv=None):
     p.add_argument("--no-plugin", action="store_true", help="skip the run through the C++ HIPRenderer::Renderer class (plugin_renderer key)")
     p.add_argument("--cpu-baseline-seconds", type=float, default=10.0)
     p.add_argument("--master-port", type=int, default=0, help="rendezvous port when this process spawns the ranks itself (0: pick a free one)")
+    p.add_argument("--pmc-traffic", default="auto", choices=["auto", "file", "off"],
+                   help="where roofline.traffic (bytes that crossed the L2's memory side per launch) comes from: auto = two rocprofv3 --pmc child runs of this workload "
+                        "(FETCH_SIZE, then WRITE_SIZE; 2 steps each) started BEFORE this process touches the GPU, falling back to the committed profiles/pmc_traffic.json; "
+                        "file = that file only; off = none")
+    p.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # this process is one of the counter passes: timed region only, no extras
+    p.add_argument("--spawn-deadline", type=float, default=900.0, help="seconds the self-spawned ranks get before they are stopped (well under the driver's own timeout)")
+    p.add_argument("--fixed-frame", action="store_true", help="N > 1: split the SAME job over the ranks (a step is spp-per-pass accumulations of the whole frame, every rank "
+                   "traces its tiles of them: 1/N of the paths per GPU and step, 'strong' scaling) instead of N x spp-per-pass accumulations per step ('weak', the default)")
     return p.parse_args(argv)
 
 
@@ -94,11 +106,42 @@ def spawn_ranks(args) -> int:
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this pool
         children.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env,
                                          stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
-    out, _ = children[0].communicate()
-    codes = [children[0].returncode] + [c.wait() for c in children[1:]]
-    sys.stdout.write(out.decode())
+    # Fail fast: every child is polled; the first one that exits non-zero (a rank that died at init would leave the others in the rendezvous until the
+    # driver's timeout) ends the rest, and so does the overall deadline. Rank 0's stdout is drained by a thread so that its pipe never fills.
+    import threading
+    captured = []
+    reader = threading.Thread(target=lambda: captured.append(children[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.monotonic() + args.spawn_deadline
+    failed = None
+    while failed is None and any(c.poll() is None for c in children):
+        for rank, c in enumerate(children):
+            code = c.poll()
+            if code is not None and code != 0:
+                failed = (rank, code)
+                break
+        if failed is None and time.monotonic() > deadline:
+            failed = (-1, 124)
+        if failed is None:
+            time.sleep(0.2)
+    if failed is not None:
+        sys.stderr.write(f"bench.py: rank {failed[0]} exited with {failed[1]}; stopping the other ranks\n" if failed[0] >= 0 else
+                         f"bench.py: the ranks did not finish within {args.spawn_deadline:.0f} s; stopping them\n")
+        for c in children:
+            if c.poll() is None:
+                c.terminate()
+        for c in children:
+            try:
+                c.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                c.kill()
+                c.wait()
+    reader.join(timeout=10)
+    sys.stdout.write(b"".join(captured).decode())
     sys.stdout.flush()
-    return max(abs(c) for c in codes)
+    if failed is not None:
+        return abs(failed[1]) or 1
+    return max(abs(c.returncode) for c in children)
 
 
 # --------------------------------------------------------------------------------------------------------------------------------
@@ -124,6 +167,84 @@ def make_scene(name, args):
 def library_sha16() -> str:
     from bifrost3d_amd import capi
     return hashlib.sha256(Path(capi.LIB_PATH).read_bytes()).hexdigest()[:16]
+
+
+def kernel_bench_name(kernel: str):
+    """Bench key of a kernel name as rocprofv3 prints it (the keys of kernel_ms_per_step / roofline_by_kernel)."""
+    k = kernel.split("(")[0]
+    for needle, name in (("k_generate", "generate"), ("k_shade", "shade"), ("k_accumulate", "accumulate"), ("k_trace_shadow", "trace_shadow"), ("k_trace_closest", "trace_closest")):
+        if needle in k:
+            return name
+    if "k_trace_persistent" in k:   # template arguments <STACK, MODE, ...>; MODE 0 closest, 1 shadow, 2 fused
+        args = k[k.index("<") + 1:k.rindex(">")].split(",") if "<" in k else []
+        mode = args[1].strip() if len(args) > 1 else "2"
+        return {"0": "trace_closest", "1": "trace_shadow"}.get(mode, "trace")
+    return None
+
+
+def measure_traffic_live(argv):
+    """roofline.traffic measured by THIS run: two child processes, `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (TCC has four counter slots: the two
+    cannot share a pass, MI355X_MICROARCH.md "rocprofv3 PMC slots"), each running this script's workload for 2 steps, started before this process has
+    initialised the GPU (fresh children; nothing is exec'ed over a process that touched the device). Per kernel and launch:
+        bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024
+    FETCH_SIZE counts the L2's memory-side read requests (TCC_EA0_RDREQ) at 64 B each while every such request on gfx950 moves a 128 B line: calibrated
+    for this renderer's access patterns (16 B per lane gathers of 64 B nodes and 48 B triangles, dword-per-lane spills, 16 B per lane streams) by
+    tools/microbench/fetch_calibration.hip -> profiles/r03_fetch_calibration.txt: 2 * FETCH_SIZE * 1024 = RDREQ * 128 B for every pattern, WRITE_SIZE exact.
+    The figure is FABRIC-side: Infinity Cache hits are counted (TCC_EA0_RDREQ_DRAM reads the same), no DRAM-side counter is exposed.
+    Returns ({bench kernel name: bytes per launch}, source description) or ({}, reason)."""
+    import csv
+    import shutil
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return {}, {"error": "rocprofv3 not found"}
+    passthrough = []
+    skip = 0
+    for i, a in enumerate(argv):        # the workload arguments, without the ones that shape the parent run
+        if skip:
+            skip -= 1
+            continue
+        if a in ("--steps", "--warmup", "--gpus", "--pmc-traffic", "--cpu-baseline-seconds", "--master-port", "--spawn-deadline"):
+            skip = 1
+            continue
+        if a.split("=")[0] in ("--steps", "--warmup", "--gpus", "--pmc-traffic", "--cpu-baseline-seconds", "--master-port", "--spawn-deadline"):
+            continue
+        passthrough.append(a)
+    totals = {"FETCH_SIZE": {}, "WRITE_SIZE": {}}
+    t0 = time.perf_counter()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="hipr_pmc_")
+        cmd = [rocprof, "--pmc", counter, "--output-format", "csv", "-d", tmp, "--", sys.executable, str(Path(__file__).resolve())] + passthrough + \
+              ["--pmc-child", "--steps", "2", "--warmup", "1", "--gpus", "1"]
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=600, cwd=tmp, env=dict(os.environ, TMPDIR=tmp))
+        except (subprocess.TimeoutExpired, OSError) as e:
+            shutil.rmtree(tmp, ignore_errors=True)
+            return {}, {"error": f"rocprofv3 --pmc {counter}: {e}"}
+        sums, launches = {}, {}
+        for f in Path(tmp).rglob("*counter_collection.csv"):
+            with open(f, newline="") as fh:
+                for row in csv.DictReader(fh):
+                    if row["Counter_Name"] != counter:
+                        continue
+                    name = kernel_bench_name(row["Kernel_Name"])
+                    if name is None:
+                        continue
+                    sums[name] = sums.get(name, 0.0) + float(row["Counter_Value"])
+                    launches.setdefault(name, set()).add(row["Dispatch_Id"])
+        shutil.rmtree(tmp, ignore_errors=True)
+        if r.returncode != 0 or not sums:
+            return {}, {"error": f"rocprofv3 --pmc {counter} exited with {r.returncode}: {r.stderr.decode(errors='replace')[-300:]}"}
+        totals[counter] = {n: (sums[n] / len(launches[n]), len(launches[n])) for n in sums}
+    traffic, detail = {}, {}
+    for name in set(totals["FETCH_SIZE"]) | set(totals["WRITE_SIZE"]):
+        f_kib, f_n = totals["FETCH_SIZE"].get(name, (0.0, 0))
+        w_kib, w_n = totals["WRITE_SIZE"].get(name, (0.0, 0))
+        traffic[name] = (2.0 * f_kib + w_kib) * 1024.0
+        detail[name] = {"FETCH_SIZE_KiB_per_launch": f_kib, "WRITE_SIZE_KiB_per_launch": w_kib, "launches_fetch_pass": f_n, "launches_write_pass": w_n}
+    return traffic, {"measured": "live: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child runs of this workload (2 steps each) before the timed run",
+                     "formula": "(2 * FETCH_SIZE + WRITE_SIZE) * 1024 bytes per launch; calibration profiles/r03_fetch_calibration.txt", "side": "fabric (L2 memory side: Infinity Cache + HBM)",
+                     "seconds": time.perf_counter() - t0, "counters": detail, "stale": False}
 
 
 def load_measured_traffic(key):
@@ -157,16 +278,25 @@ def load_observed_limiter(scene_name):
     return None
 
 
-def rmse_against_oracle(ctx, scene, bounces, spps=(8, 256), width=160, height=90):
-    """BASELINE.json's third figure, per-pixel RMSE at equal spp and seed. No OptiX image can exist here, so the comparand is the CPU
-    oracle (same scene, camera, accumulations 0..spp-1, the search the GPU uses) on a frame small enough for the CPU: (i) sqrt(mean
-    over pixels and channels of (a - b)^2), (ii) the reference's ImageOperations::Compare::rms (extensions/ImageOperations/
-    ImageOperations/Compare.h:23-43): sqrt(mean(luminance(|a - b|)^2)). Runs after the timed region."""
+def rmse_against_oracle(ctx, scene, bounces, spps=(8, 256), width=160, height=90, converged_name=None):
+    """BASELINE.json's third figure, per-pixel RMSE at equal spp and seed, as SURVEY.md 8(d) writes the protocol. No OptiX image can exist here, so the
+    comparand is the CPU oracle (same scene, camera, accumulations 0..spp-1, the search the GPU uses) on a frame small enough for the CPU:
+    (i) sqrt(mean over pixels and channels of (a - b)^2), (ii) the reference's ImageOperations::Compare::rms (extensions/ImageOperations/ImageOperations/
+    Compare.h:23-43): sqrt(mean(luminance(|a - b|)^2)); plus, to separate bias from noise, the distance of EACH of the two images to a converged oracle
+    image of 16 x the spp from disjoint accumulations (profiles/converged/<scene>_<w>x<h>_acc<spp>_<17 spp>.npy, tools/converged_reference.py: the oracle is
+    deterministic, the file is its output on host cores) and the mean signed difference with its standard error. The full protocol with the per-sample
+    breakdown of the worst pixels is tools/rmse_protocol.py -> profiles/r03_rmse_protocol_*.json. Runs after the timed region."""
     sys.path.insert(0, str(ROOT / "tests"))
     import numpy as np
     from oracle_bindings import get_oracle
     oracle = get_oracle(True)   # unorm16 tables, as uploaded to the device
     ctx.set_wavefront_count(1)
+
+    def both(a, b):
+        diff = np.abs(a - b)
+        luminance = 0.2126 * diff[..., 0] + 0.7152 * diff[..., 1] + 0.0722 * diff[..., 2]   # BF/Math/Color.h luminance()
+        return {"rmse_rgb": float(np.sqrt(np.mean(diff ** 2))), "rmse_reference_compare_rms": float(np.sqrt(np.mean(luminance ** 2)))}
+
     out = {"frame": [width, height], "comparand": "CPU oracle (oracle/integrator.cpp), same seed and search", "north_star_bound": 1e-3}
     for spp in spps:
         batch = min(spp, 32)
@@ -177,10 +307,20 @@ def rmse_against_oracle(ctx, scene, bounces, spps=(8, 256), width=160, height=90
         gpu = ctx.read_accumulation()[..., :3]
         cpu, _, seconds = oracle.render(scene.desc, scene.state, scene.camera(width, height, max_bounce_count=bounces), width, height, spp, use_bvh=ctx.oracle_search())
         cpu = cpu[..., :3]
-        diff = np.abs(gpu - cpu)
-        luminance = 0.2126 * diff[..., 0] + 0.7152 * diff[..., 1] + 0.0722 * diff[..., 2]   # BF/Math/Color.h luminance()
-        out[f"spp{spp}"] = {"rmse_rgb": float(np.sqrt(np.mean(diff ** 2))), "rmse_reference_compare_rms": float(np.sqrt(np.mean(luminance ** 2))),
-                            "mean_radiance": float(cpu.mean()), "oracle_seconds": float(seconds)}
+        entry = dict(both(gpu, cpu), mean_radiance=float(cpu.mean()), oracle_seconds=float(seconds))
+        d = (gpu - cpu).reshape(-1, 3)
+        worst = np.sort((d ** 2).sum(axis=-1))[::-1][:8].sum()
+        entry["bias"] = {"mean_signed_difference_rgb": [float(v) for v in d.mean(axis=0)], "standard_error_rgb": [float(v) for v in d.std(axis=0) / np.sqrt(len(d))],
+                         "share_of_squared_error_in_8_worst_pixels": float(worst / max((d ** 2).sum(), 1e-300)),
+                         "rmse_rgb_without_8_worst_pixels": float(np.sqrt(max((d ** 2).sum() - worst, 0.0) / (3.0 * (len(d) - 8))))}
+        stem = ROOT / "profiles" / "converged" / f"{converged_name}_{width}x{height}_acc{spp}_{17 * spp}" if converged_name else None
+        if stem is not None and Path(str(stem) + ".npy").exists() and Path(str(stem) + ".json").exists():
+            meta = json.loads(Path(str(stem) + ".json").read_text())
+            if meta.get("triangles") == int(scene.desc.triangle_count) and meta.get("bounces") == bounces and meta.get("search") == ctx.oracle_search():
+                converged = np.load(str(stem) + ".npy").astype(np.float64)
+                entry["converged_leg"] = {"reference": f"profiles/converged/{stem.name}.npy: oracle, accumulations [{spp}, {17 * spp}), disjoint from the compared ones",
+                                          "device_vs_converged": both(gpu, converged), "oracle_vs_converged": both(cpu, converged)}
+        out[f"spp{spp}"] = entry
     return out
 
 
@@ -343,20 +483,21 @@ def rooflines_of(counters, times, per_ray, small, fused, samples_per_step, traff
         if not t or t["ms"] <= 0 or t["launches"] == 0:
             continue
         nbytes = kernel_bytes.get(name)
+        seconds_per_launch = t["ms"] / t["launches"] * 1e-3
         entry = {"bound": "hbm", "kernel": kernel_names.get(name, name), "peak": HBM_PEAK_GBS, "unit": "GB/s", "avg_launch_ms": t["ms"] / t["launches"],
                  "launches": t["launches"], "total_ms": t["ms"]}
-        if nbytes is not None:
-            gbs = nbytes / (t["ms"] * 1e-3) / 1e9
-            entry.update({"achieved": gbs, "achieved_model": "algorithmic bytes (SURVEY.md 8d: every node visit 64 B, every triangle test 48 B, ...), not HBM traffic",
-                          "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nbytes / t["launches"]})
-            if gbs > HBM_PEAK_GBS:
-                entry["frac_note"] = ("the algorithmic byte model exceeds the HBM peak: most node and triangle reads are served by L1 / L2 (hit rates in profiles/sq_limiters.json), "
-                                      "so this fraction says the model over-counts, not that HBM is saturated; frac_counter is the HBM-side figure")
         measured = traffic.get(name)
         entry["traffic"] = measured
-        if measured:
-            counter_gbs = measured / (t["ms"] / t["launches"] * 1e-3) / 1e9
-            entry.update({"achieved_counter": counter_gbs, "frac_counter": counter_gbs / HBM_PEAK_GBS})
+        if nbytes is not None:      # SURVEY.md 8d's byte model: an upper bound on what the algorithm touches, most of it served by L1 / L2
+            model_gbs = nbytes / (t["ms"] * 1e-3) / 1e9
+            entry.update({"achieved_model": model_gbs, "frac_model": model_gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nbytes / t["launches"],
+                          "model": "SURVEY.md 8d: every node visit 64 B, every triangle test 48 B, queue records once; counts cache hits, so it can exceed the HBM peak"})
+        if measured:                # the headline fraction: bytes that actually crossed the L2's memory side (rocprofv3 counters) / duration / peak
+            counter_gbs = measured / seconds_per_launch / 1e9
+            entry.update({"achieved": counter_gbs, "frac": counter_gbs / HBM_PEAK_GBS, "frac_basis": "counters: (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per launch / HIP-event launch duration / peak"})
+        elif nbytes is not None:    # no counters for this kernel: the model, capped by what the roof allows, and marked as such
+            entry.update({"achieved": min(entry["achieved_model"], HBM_PEAK_GBS), "frac": min(entry["frac_model"], 1.0),
+                          "frac_basis": "byte model (no counter pass available for this kernel), capped at the peak"})
         rooflines[name] = entry
     return rooflines, kernel_times
 
@@ -367,7 +508,7 @@ def measure(ctx, scene, scene_name, bounces, args, rank, world, device, steps, w
     import torch.distributed as dist
     from bifrost3d_amd import capi, distributed
     W, H = args.width, args.height
-    S = args.spp_per_pass * world
+    S = args.spp_per_pass * (1 if args.fixed_frame else world)
     on_host = world > 1 and args.dist_backend == "gloo"
     ctx.upload_scene(scene)
     ctx.set_wavefront_count(args.wavefronts)
@@ -420,7 +561,9 @@ def measure(ctx, scene, scene_name, bounces, args, rank, world, device, steps, w
     for _ in range(steps):
         run_pass(a)
         a += S
+    t_gather = time.perf_counter()
     finish_frame()
+    gather_ms = (time.perf_counter() - t_gather) * 1e3
     sync()
     elapsed = time.perf_counter() - t0
 
@@ -432,10 +575,13 @@ def measure(ctx, scene, scene_name, bounces, args, rank, world, device, steps, w
             stats = stats.cpu()
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        per_rank = [torch.zeros_like(stats) for _ in range(world)]
+        dist.all_gather(per_rank, stats)
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
         elapsed = float(mx[0])
     total = {"closest_rays": float(stats[1]), "shadow_rays": float(stats[2]), "camera_rays": float(stats[3])}
-    result = {"elapsed": elapsed, "total": total, "counters": counters, "times": times, "per_ray": per_ray, "S": S}
+    result = {"elapsed": elapsed, "total": total, "counters": counters, "times": times, "per_ray": per_ray, "S": S, "gather_ms": gather_ms,
+              "rank_elapsed": [float(t[0]) for t in per_rank] if world > 1 else [elapsed]}
     if rank == 0:
         result["frame_ok"] = bool(torch.isfinite(frame.float()).all().item()) and float(frame[..., :3].float().mean()) > 0
         result["small"] = ctx.trace_variant() == capi.TRACE_EXHAUSTIVE
@@ -444,14 +590,21 @@ def measure(ctx, scene, scene_name, bounces, args, rank, world, device, steps, w
     return result
 
 
-def summarise(result, scene_name, scene_text, bounces, args, world, steps):
+def summarise(result, scene_name, scene_text, bounces, args, world, steps, live_traffic=None):
     """The figures of one measured workload as the bench line reports them (rank 0)."""
     W, H, S = args.width, args.height, result["S"]
     key = f"{scene_name}:{W}x{H}:spp{args.spp_per_pass}:bounces{bounces}"
     if scene_name == "atrium":
         key += f":tris{args.atrium_triangles}"
     key += f":wf{result['wavefronts']}"
-    traffic, traffic_source = load_measured_traffic(key) if world == 1 else ({}, None)
+    traffic, traffic_source = ({}, None)
+    if world == 1:
+        if live_traffic and live_traffic[0]:
+            traffic, traffic_source = live_traffic
+        elif args.pmc_traffic != "off":
+            traffic, traffic_source = load_measured_traffic(key)
+            if live_traffic and traffic_source is not None:
+                traffic_source["live_measurement_failed"] = live_traffic[1]
     rooflines, kernel_times = rooflines_of(result["counters"], result["times"], result["per_ray"], result["small"], result["fused"], S, traffic)
     dominant = max(rooflines, key=lambda n: rooflines[n]["total_ms"])
     roofline = dict(rooflines[dominant])
@@ -477,6 +630,22 @@ def main():
     args = parse_args()
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
+
+    # test hooks of tests/test_bench_spawn_cpu.py: a rank that dies at start-up, a rank that never gets anywhere
+    if os.environ.get("RANK") is not None and os.environ.get("HIPR_BENCH_TEST_FAIL_RANK") == os.environ.get("RANK"):
+        sys.exit(3)
+    if os.environ.get("RANK") is not None and os.environ.get("HIPR_BENCH_TEST_HANG_RANK") in (os.environ.get("RANK"), "all"):
+        time.sleep(3600)
+    if args.pmc_child:      # a counter pass of measure_traffic_live: the timed region only
+        args.no_cpu_baseline = args.no_other_workloads = args.no_rmse = args.no_plugin = True
+        args.pmc_traffic = "off"
+    # roofline.traffic, measured by child processes under rocprofv3 BEFORE this process initialises the GPU (importing torch does not)
+    live_traffic = None
+    under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
+    if args.gpus == 1 and args.pmc_traffic == "auto" and not args.scene_file and not under_profiler:     # no profiler inside a profiler
+        live_traffic = measure_traffic_live(sys.argv[1:])
+        if not live_traffic[0]:
+            sys.stderr.write(f"bench.py: live counter passes unavailable ({live_traffic[1]}); falling back to profiles/pmc_traffic.json\n")
 
     # stdout carries ONE line, the result: libraries that chat on stdout (gloo's rendezvous message, the renderer's device announcement) go to stderr
     sys.stdout.flush()
@@ -517,10 +686,10 @@ def main():
     result = measure(ctx, scene, scene_name, bounces, args, rank, world, device, args.steps, args.warmup, sync)
 
     if rank == 0:
-        main_figures = summarise(result, scene_name, scene_text, bounces, args, world, args.steps)
+        main_figures = summarise(result, scene_name, scene_text, bounces, args, world, args.steps, live_traffic)
         out = {
             "metric": METRIC, "value": main_figures["value"], "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": main_figures["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "ms_per_step": main_figures["ms_per_step"], "higher_is_better": True, "scaling": "strong" if args.fixed_frame and world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": main_figures["workload"], "frame": [args.width, args.height], "spp_per_step": main_figures["spp_per_step"], "spp_total": main_figures["spp_total"],
                        "parallelism": f"tiles8x8-round-robin-x{world}" if world > 1 else "single-gpu", "wavefronts": result["wavefronts"],
                        "ms_per_256spp_frame": main_figures["ms_per_256spp_frame"], "rays_per_step": main_figures["rays_per_step"],
@@ -529,13 +698,17 @@ def main():
                        "rmse_note": "no OptiX image exists or can be produced here (DESIGN.md); rmse_vs_oracle compares with the pinned CPU oracle at equal spp and seed"},
             "roofline": main_figures["roofline"], "roofline_by_kernel": main_figures["roofline_by_kernel"], "kernel_ms_per_step": main_figures["kernel_ms_per_step"],
         }
+        if world > 1:
+            out["ranks"] = {"ms_per_step": [e / args.steps * 1e3 for e in result["rank_elapsed"]], "gather_ms": result["gather_ms"],
+                            "paths_per_gpu_per_step": int(main_figures["pixel_samples"] / args.steps / world),
+                            "note": "ms_per_step per rank = that rank's own clock over the timed region (the line's ms_per_step is the maximum); gather_ms = rank 0's time in the "
+                                    "final gather of the half4 tiles + the scatter kernel, inside the timed region"}
         if world == 1:
             copy_gbs = measured_copy_bandwidth(device)
             out["roofline"]["measured_copy_bandwidth"] = {"GB/s": copy_gbs, "what": "1 GiB device-to-device copy, bytes read + written, best of five (torch)",
-                                                          "frac_counter_of_copy": out["roofline"]["achieved_counter"] / copy_gbs if out["roofline"].get("achieved_counter") else None,
-                                                          "frac_of_copy": out["roofline"]["achieved"] / copy_gbs}
-            if not args.no_rmse and scene.desc.triangle_count <= 300000:
-                out["config"]["rmse_vs_oracle"] = rmse_against_oracle(ctx, scene, bounces)
+                                                          "frac_of_copy": out["roofline"]["achieved"] / copy_gbs if out["roofline"].get("achieved") else None}
+            if not args.no_rmse:
+                out["config"]["rmse_vs_oracle"] = rmse_against_oracle(ctx, scene, bounces, converged_name=scene_name if not args.scene_file else None)
             if not args.no_other_workloads and not args.scene_file:
                 others = {}
                 for other in ("cornell_diffuse", "material"):

@@ -612,6 +612,9 @@ constexpr uint32_t TRACE_CHUNK_MAX = 512; // rays a wave claims per global atomi
 // that start on the same shard work on neighbouring rays. A wave that drains its shard steals from the next.
 constexpr uint32_t TRACE_SHARDS = 64;   // == wave size: a drained wave probes all of them with one load per lane
 constexpr uint32_t TRACE_SHARD_STRIDE = 16;   // uint32 words between shard counters
+#ifndef HIPR_NODE_QUAD_GATHER
+#define HIPR_NODE_QUAD_GATHER 0
+#endif
 constexpr int TRACE_SPILL_ENTRIES = 96;       // stack entries beyond the LDS stack, in scratch memory (OVERFLOW kernels only)
 
 // MODE: which rays one launch serves.
@@ -635,6 +638,13 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(tra
                                                                   int refill_below, DeviceCounters* counters) {
     __shared__ int s_stack[STACK * TRACE_BLOCK];
     int* stack = s_stack + threadIdx.x;
+#if HIPR_NODE_QUAD_GATHER
+    // Node fetch by quads (see the node block): four planes of 64 x 16 B per wave, each padded by 16 B so that a lane's four b128 reads of its own node
+    // fall on different banks than those of the lanes served in the same LDS cycle.
+    constexpr int TILE_PLANE = 65;
+    __shared__ uint4 s_tile[(TRACE_BLOCK / 64) * 4 * TILE_PLANE];
+    uint4* tile = s_tile + (threadIdx.x >> 6) * 4 * TILE_PLANE;
+#endif
     // Entries beyond the LDS stack (only trees whose worst case needs more than STACK entries are compiled with OVERFLOW) go
     // to a per-lane array in scratch memory; traversals rarely get that deep.
     int spill[OVERFLOW ? TRACE_SPILL_ENTRIES : 1];
@@ -822,10 +832,45 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(tra
                     }
                     testing = !need_pop && !take_next;   // more triangles in this leaf, and the ray still wants them
                 }
-            } else if (node_mode) {
+            }
+#if HIPR_NODE_QUAD_GATHER
+            else {
+                // The 64 B nodes are fetched by QUADS of lanes: in instruction i the four lanes of a quad load the four 16 B quarters of the node of quad-mate i
+                // (one contiguous 64 B read of the L1 instead of four 16 B reads in four instructions), straight into LDS (global_load_lds_dwordx4: lane l's
+                // 16 B land at plane i + 16 l). Afterwards every lane reads its own node, which its quad assembled in plane (lane % 4). A divergent 16 B load
+                // costs the CU's address / tag pipeline one cycle per lane whatever it returns; this way a node costs it one lane-load, not four.
+                const uint32_t packed = (uint32_t(cur) << 1) | (node_mode ? 1u : 0u);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t mate = i == 0 ? __builtin_amdgcn_mov_dpp(packed, 0x00, 0xF, 0xF, false) : i == 1 ? __builtin_amdgcn_mov_dpp(packed, 0x55, 0xF, 0xF, false)
+                                        : i == 2 ? __builtin_amdgcn_mov_dpp(packed, 0xAA, 0xF, 0xF, false) : __builtin_amdgcn_mov_dpp(packed, 0xFF, 0xF, 0xF, false);
+                    if (mate & 1u)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sc.wide_nodes + 4 * size_t(mate >> 1) + (lane & 3u)),
+                                                         (__attribute__((address_space(3))) void*)(tile + i * TILE_PLANE), 16, 0, 0);
+                }
+                __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the wave's loads have landed in its planes
+            }
+            if (!(__popcll(tmask) > __popcll(nmask)) && node_mode) {
+                const uint4* np = tile + (lane & 3u) * TILE_PLANE + (lane & ~3u);
+                const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
+#else
+            else if (node_mode) {
                 // One compressed 4-wide node (HiprWideNode): 4 gathers of 16 B serve what ~2.1 BVH2 nodes (8.4 gathers) did.
                 const uint4* np = sc.wide_nodes + 4 * size_t(cur);
                 const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
+#endif
+#ifdef HIPR_EXTRA_NODE_LOADS
+                // Sensitivity experiment (tools/gpu_round3_b.sh): N more 16 B loads per lane from the node's own line -- no new cache line, no new miss, only more
+                // work for the address / tag pipeline. The pointer is laundered so that the loads are not merged with the four above.
+                uint32_t extra_bits = 0u;
+#pragma unroll
+                for (int e = 0; e < HIPR_EXTRA_NODE_LOADS; ++e) {
+                    unsigned long long laundered = (unsigned long long)(np + (e & 3));
+                    asm volatile("" : "+v"(laundered));
+                    const uint4 x = *reinterpret_cast<const uint4*>(laundered);
+                    extra_bits |= (x.x == 0x7FC12345u) & (x.w == 0x7FC54321u);
+                }
+#endif
                 if (INSTRUMENT) { nodes += is_shadow ? 0u : 1u; shadow_nodes += is_shadow ? 1u : 0u; }
                 // slab distances of a quantised bound q: fma(float(q), A, B) with A = 2^(e - 127) * inv_d, B = fma(origin, inv_d, -ood)
                 const float ax = __uint_as_float((w0.w & 0xFFu) << 23) * inv.x, ay = __uint_as_float(((w0.w >> 8) & 0xFFu) << 23) * inv.y,
@@ -865,6 +910,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(tra
                     }
                 }
                 take_next = key[0] != 0xFFFFFFFFu;
+#ifdef HIPR_EXTRA_NODE_LOADS
+                take_next = take_next | (extra_bits != 0u);
+#endif
                 next_item = child[0];
                 need_pop = !take_next;
             }

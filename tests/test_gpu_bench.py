@@ -31,7 +31,11 @@ def test_bench_line_contract_single_gpu():
     assert line["config"]["frame_finite_and_lit"] and "workload" in line["config"]
     roofline = line["roofline"]
     assert roofline["bound"] in ("hbm", "mfma") and roofline["unit"] == "GB/s" and roofline["peak"] == 8000.0
-    assert roofline["frac"] == pytest.approx(roofline["achieved"] / roofline["peak"])
+    assert roofline["frac"] == pytest.approx(roofline["achieved"] / roofline["peak"]) and 0.0 < roofline["frac"] <= 1.0
+    # the headline fraction is counter based and measured by this very run (two rocprofv3 --pmc child runs before the timed one); the byte model sits next to it
+    assert roofline["traffic"] and roofline["traffic_source"]["measured"].startswith("live"), roofline.get("traffic_source")
+    assert roofline["achieved"] == pytest.approx(roofline["traffic"] / (roofline["avg_launch_ms"] * 1e-3) / 1e9)
+    assert "frac_model" in roofline and "observed_limiter" in roofline
 
 
 def test_bench_two_ranks_on_one_device():
@@ -42,3 +46,8 @@ def test_bench_two_ranks_on_one_device():
     # weak scaling: each rank traces the per-GPU share of one rank alone, on its half of the tiles -> twice the paths, and (same scene, same camera,
     # deterministic sampling) about twice the rays of the single-rank step
     assert two["config"]["rays_per_step"] == pytest.approx(2.0 * one["config"]["rays_per_step"], rel=0.02)
+    assert two["scaling"] == "weak" and len(two["ranks"]["ms_per_step"]) == 2 and two["ranks"]["gather_ms"] >= 0.0
+    # the same job split over the ranks: the rays of one rank alone, half of the paths per GPU
+    fixed = run_bench(["--gpus", "2", "--share-device", "--dist-backend", "gloo", "--fixed-frame"])
+    assert fixed["scaling"] == "strong" and fixed["config"]["rays_per_step"] == pytest.approx(one["config"]["rays_per_step"], rel=0.02)
+    assert fixed["ranks"]["paths_per_gpu_per_step"] * 2 == pytest.approx(one["config"]["pixel_samples"] / one["steps"], rel=0.01)

@@ -301,6 +301,68 @@ def test_device_group_renders_the_single_context_image(ctx, oracle_q):
     assert counters.camera_rays == w * h * spp
 
 
+def test_device_group_over_distinct_devices_gathers_through_rccl(ctx):
+    """The same contract over as many DISTINCT devices as the box has (2 ... 8): the members' tiles then travel by RCCL point-to-point inside the process
+    (ncclCommInitAll; member 0 posts one ncclRecv per peer, every peer one ncclSend). Skipped on a one-GPU box, where the copy path above is all there is."""
+    import ctypes as C
+    import torch
+    lib = ctx.lib
+    n = min(int(lib.hipr_device_count()), 8)
+    if n < 2:
+        pytest.skip("one device: the RCCL transport needs distinct devices")
+    scene = Scene("atrium", param0=20000, param1=3)
+    w, h, spp, batch = 200, 120, 4, 2
+    single, _ = render_gpu(ctx, scene, w, h, spp, 4, samples_per_pass=batch)
+    reference = torch.zeros((h, w, 4), dtype=torch.float16, device="cuda:0")
+    ctx.set_frame(w, h, 0, 1, batch)
+    for a in range(0, spp, batch):
+        ctx.render_pass(scene.camera(w, h, accumulations=a, max_bounce_count=4), reference.data_ptr(), w, synchronize=True)
+    devices = (C.c_int * n)(*range(n))
+    group = C.c_void_p()
+    assert lib.hipr_group_create(devices, n, C.byref(group)) == 0
+    try:
+        assert b"rccl" in lib.hipr_group_gather_description(group).lower(), lib.hipr_group_gather_description(group)
+        tables = capi.load_tables()
+        t = capi.HiprTables(*[a.ctypes.data_as(C.POINTER(C.c_float)) for a in tables])
+        assert lib.hipr_group_upload_tables(group, C.byref(t)) == 0
+        assert lib.hipr_group_upload_scene(group, C.byref(scene.desc)) == 0
+        state = scene.state
+        assert lib.hipr_group_set_scene_state(group, C.byref(state)) == 0
+        assert lib.hipr_group_set_frame(group, w, h, batch) == 0
+        frame = torch.zeros((h, w, 4), dtype=torch.float16, device="cuda:0")
+        torch.cuda.synchronize()
+        for a in range(0, spp, batch):
+            cam = scene.camera(w, h, accumulations=a, max_bounce_count=4)
+            assert lib.hipr_group_trace_pass(group, C.byref(cam)) == 0
+            assert lib.hipr_group_accumulate_samples(group, 0, batch, a, C.c_void_p(frame.data_ptr()), w, 1) == 0
+        accumulation = np.zeros((h, w, 4), np.float64)
+        assert lib.hipr_group_read_accumulation(group, accumulation.ctypes.data_as(C.POINTER(C.c_double)), w * h) == 0
+    finally:
+        lib.hipr_group_destroy(group)
+    assert np.array_equal(accumulation, single)
+    assert torch.equal(frame.cpu(), reference.cpu())
+
+
+def test_device_group_reports_the_failing_member(ctx):
+    """A member that fails on a worker thread: the status comes back, nothing hangs, and hipr_last_error() on the CALLING thread names the member and carries
+    its message (a pass before any scene is uploaded fails on every member; so does a fold of samples that were never traced)."""
+    import ctypes as C
+    lib = ctx.lib
+    devices = (C.c_int * 3)(0, 0, 0)
+    group = C.c_void_p()
+    assert lib.hipr_group_create(devices, 3, C.byref(group)) == 0
+    try:
+        assert lib.hipr_group_set_frame(group, 64, 64, 1) == 0
+        cam = Scene("cornell").camera(64, 64, accumulations=0, max_bounce_count=1)
+        assert lib.hipr_group_trace_pass(group, C.byref(cam)) != 0
+        message = lib.hipr_last_error().decode()
+        assert "device group member" in message and "must be set before rendering" in message, message
+        assert lib.hipr_group_accumulate_samples(group, 0, 1, 0, None, 0, 1) != 0
+        assert "device group member" in lib.hipr_last_error().decode()
+    finally:
+        lib.hipr_group_destroy(group)
+
+
 @pytest.mark.parametrize("quads", [1, 3, 12])
 def test_refitted_scene_on_the_device_bit_exact(ctx, oracle_q, quads):
     """hipr_update_scene_geometry after SceneBuilder::update_model_transforms moved a model (BVH refit, topology kept): closest hits, shadow

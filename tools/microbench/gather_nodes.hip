@@ -4,6 +4,8 @@
 //                    quad's 4 nodes); 64 B contiguous per quad and instruction
 //   C  quad gather + LDS transpose so that every lane ends up with its own node (the usable form of B)
 //   D  quad gather + a 4 x 4 transpose inside the quad through DPP (two butterfly stages of v_cndmask_b32 with a quad_perm source: 32 VALU, no LDS)
+//   F  quad gather straight into LDS (global_load_lds_dwordx4: no staging registers, no ds_write), planes padded by 16 B so that the b128 reads of a lane's
+//      own node are conflict free; 38 of 64 lanes
 //   E  like D, but only `ACTIVE` of the 64 lanes want a node (the trace kernel averages 38 working lanes per node iteration): lane gather with
 //      the idle lanes masked against quad gather with the loads of idle quad-mates masked
 // Build: hipcc -O3 --offload-arch=gfx950 -o gather_nodes gather_nodes.hip ; run: ./gather_nodes
@@ -19,6 +21,8 @@ __device__ inline uint32_t hash(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x 
 template <int MODE>
 __global__ __launch_bounds__(128) void k_gather(const float4* nodes, uint32_t node_mask, int iterations, float* out) {
     __shared__ float4 s_tile[MODE == 2 ? 128 * 4 : 1];
+    constexpr int PLANE = 65;   // uint4 per plane: 64 lanes + 16 B of padding
+    __shared__ uint4 s_dma[MODE == 6 ? 2 * 4 * PLANE : 1];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t seed = hash(blockIdx.x * 128u + threadIdx.x + 1u);
     float acc = 0.0f;
@@ -38,6 +42,28 @@ __global__ __launch_bounds__(128) void k_gather(const float4* nodes, uint32_t no
                 v[i] = nodes[4 * size_t(leader_node) + j];
             }
             acc += v[0].x + v[1].y + v[2].z + v[3].w;
+        } else if (MODE == 6) {
+            const bool want = (hash(seed ^ 0x9E3779B9u) & 63u) < 38u;
+            const uint32_t j = lane & 3u;
+            uint4* tile = s_dma + wave * 4 * PLANE;
+            const uint32_t packed = (node << 1) | (want ? 1u : 0u);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t mate = i == 0 ? __builtin_amdgcn_mov_dpp(packed, 0x00, 0xF, 0xF, false) : i == 1 ? __builtin_amdgcn_mov_dpp(packed, 0x55, 0xF, 0xF, false)
+                                    : i == 2 ? __builtin_amdgcn_mov_dpp(packed, 0xAA, 0xF, 0xF, false) : __builtin_amdgcn_mov_dpp(packed, 0xFF, 0xF, 0xF, false);
+                if (mate & 1u)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const uint4*>(nodes) + 4 * size_t(mate >> 1) + j),
+                                                     (__attribute__((address_space(3))) void*)(tile + i * PLANE), 16, 0, 0);
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the wave's DMA writes have landed
+            if (want) {
+                const uint4* mine = tile + (lane & 3u) * PLANE + (lane & ~3u);
+                uint32_t x = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const uint4 v = mine[k]; x += v.x ^ (v.y + (v.z ^ v.w)); }
+                acc += __uint_as_float(x);
+            }
+            __builtin_amdgcn_wave_barrier();
         } else if (MODE == 3 || MODE == 4 || MODE == 5) {
             const bool want = MODE == 3 || ((hash(seed ^ 0x9E3779B9u) & 63u) < 38u);   // E: 38 of 64 lanes on average, scattered
             const uint32_t j = lane & 3u;
@@ -112,7 +138,7 @@ int main() {
     const int blocks = 256 * 12, iterations = 256;   // 12 blocks of 2 waves per CU = 6 waves per SIMD, like the trace kernel
     float* out;
     CHECK(hipMalloc(&out, size_t(blocks) * 128 * 4));
-    for (uint32_t log_nodes : {12u, 14u, 17u, 20u, 23u}) {   // 256 KB, 1 MB, 8 MB, 64 MB, 512 MB of nodes
+    for (uint32_t log_nodes : {7u, 8u, 9u, 12u, 14u, 16u, 17u, 20u, 23u}) {   // 8 / 16 / 32 KB (inside the 32 KB L1), 256 KB, 1 MB, 4 MB, 8 MB, 64 MB, 512 MB of nodes
         const size_t count = size_t(1) << log_nodes;
         float4* nodes;
         CHECK(hipMalloc(&nodes, count * 64));
@@ -124,10 +150,12 @@ int main() {
         const double d = run<3>(nodes, uint32_t(count - 1), out, blocks, iterations);
         const double e_lane = run<4>(nodes, uint32_t(count - 1), out, blocks, iterations);
         const double e_quad = run<5>(nodes, uint32_t(count - 1), out, blocks, iterations);
+        const double f_dma = run<6>(nodes, uint32_t(count - 1), out, blocks, iterations);
         printf("nodes %8zu (%7.1f MB): lane gather %7.3f ms = %6.1f Gnodes/s (%5.0f GB/s) | quad gather %7.3f ms = %6.1f Gnodes/s | quad + LDS transpose %7.3f ms = %6.1f Gnodes/s\n",
                count, count * 64 / 1e6, a, fetches / a / 1e6, fetches * 64 / a / 1e6, b, fetches / b / 1e6, c, fetches / c / 1e6);
         printf("                             quad + DPP transpose %7.3f ms = %6.1f Gnodes/s | 38 of 64 lanes: lane gather %7.3f ms = %6.1f Gnodes/s, quad + DPP %7.3f ms = %6.1f Gnodes/s\n",
                d, fetches / d / 1e6, e_lane, fetches * (38.0 / 64.0) / e_lane / 1e6, e_quad, fetches * (38.0 / 64.0) / e_quad / 1e6);
+        printf("                             38 of 64 lanes, quad gather through LDS-DMA %7.3f ms = %6.1f Gnodes/s\n", f_dma, fetches * (38.0 / 64.0) / f_dma / 1e6);
         CHECK(hipFree(nodes));
     }
     return 0;
