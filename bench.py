@@ -175,7 +175,7 @@ def kernel_bench_name(kernel: str):
     for needle, name in (("k_generate", "generate"), ("k_shade", "shade"), ("k_accumulate", "accumulate"), ("k_trace_shadow", "trace_shadow"), ("k_trace_closest", "trace_closest")):
         if needle in k:
             return name
-    if "k_trace_persistent" in k:   # template arguments <STACK, MODE, ...>; MODE 0 closest, 1 shadow, 2 fused
+    if "k_trace_persistent" in k or "k_trace_wide8" in k:   # template arguments <STACK, MODE, ...>; MODE 0 closest, 1 shadow, 2 fused
         args = k[k.index("<") + 1:k.rindex(">")].split(",") if "<" in k else []
         mode = args[1].strip() if len(args) > 1 else "2"
         return {"0": "trace_closest", "1": "trace_shadow"}.get(mode, "trace")
@@ -454,25 +454,25 @@ def denoiser_figures(args, device):
 # --------------------------------------------------------------------------------------------------------------------------------
 # Rooflines. Algorithmic HBM bytes per unit of work, DESIGN.md "Kernels" / SURVEY.md 8d:
 #   generate       80 B per path        (64 B path state + 16 B radiance slot written)
-#   trace_closest  48 B path state read + 16 B hit written per ray, + 64 B per BVH node visited + 48 B per triangle tested
+#   trace_closest  48 B path state read + 16 B hit written per ray, + 64 B per BVH node visited + 48 B per triangle tested (8-wide tree: 32 B, two triangles share a 64 B leaf record)
 #   shade          80 B per queued ray (hit + path state) + 352 B per shaded hit (triangle 48, shading record 96, material 64,
 #                  3 RIS light candidates 144) + 64 B per continued path + 48 B per shadow ray queued + 32 B radiance read-modify-write per queued ray
 #   trace_shadow   48 B record + 32 B radiance rmw per shadow ray, + 64 B per node + 48 B per triangle
 #   accumulate     16 B radiance per sample + 64 B f64 accumulation rmw + 8 B half4 per owned pixel
 # --------------------------------------------------------------------------------------------------------------------------------
-def rooflines_of(counters, times, per_ray, small, fused, samples_per_step, traffic):
+def rooflines_of(counters, times, per_ray, small, fused, samples_per_step, traffic, triangle_bytes=48.0):
     n_closest, n_shadow, n_camera, n_hits = (counters[k] for k in ("closest_rays", "shadow_rays", "camera_rays", "shaded_hits"))
     tri_share = 1.0 / 64.0 if small else 1.0   # exhaustive search: the triangle array is read once per 64-ray wave through the scalar cache
     kernel_bytes = {
         "generate": 80.0 * n_camera,
-        "trace_closest": n_closest * (48 + 16 + 64 * per_ray["nodes"] + 48 * per_ray["triangles"] * tri_share),
+        "trace_closest": n_closest * (48 + 16 + 64 * per_ray["nodes"] + triangle_bytes * per_ray["triangles"] * tri_share),
         "shade": 80.0 * n_closest + 352.0 * n_hits + 64.0 * max(0, n_closest - n_camera) + 48.0 * n_shadow + 32.0 * n_closest,
-        "trace_shadow": n_shadow * (48 + 32 + 64 * per_ray["shadow_nodes"] + 48 * per_ray["shadow_triangles"] * tri_share),
+        "trace_shadow": n_shadow * (48 + 32 + 64 * per_ray["shadow_nodes"] + triangle_bytes * per_ray["shadow_triangles"] * tri_share),
         "accumulate": 16.0 * n_camera + (64.0 + 8.0) * n_camera / max(1, samples_per_step),
     }
-    kernel_names = {"generate": "k_generate", "trace_closest": "k_trace_closest_small" if small else "k_trace_closest / k_trace_persistent<TRACE_CLOSEST>", "shade": "k_shade",
+    kernel_names = {"generate": "k_generate", "trace_closest": "k_trace_closest_small" if small else "k_trace_closest / k_trace_wide8<TRACE_CLOSEST>", "shade": "k_shade",
                     "trace_shadow": "k_trace_shadow_small" if small else "k_trace_shadow", "accumulate": "k_accumulate",
-                    "trace": "k_trace_persistent<TRACE_FUSED> (closest-hit rays of bounce k + shadow rays of bounce k-1)"}
+                    "trace": "k_trace_wide8<TRACE_FUSED> (closest-hit rays of bounce k + shadow rays of bounce k-1 over the 8-wide tree with leaf records)"}
     kernel_times = dict(times)
     if fused:   # one launch serves both ray kinds: bytes and time of the two are reported together
         kernel_bytes["trace"] = kernel_bytes.pop("trace_closest") + kernel_bytes.pop("trace_shadow")
@@ -586,6 +586,7 @@ def measure(ctx, scene, scene_name, bounces, args, rank, world, device, steps, w
         result["frame_ok"] = bool(torch.isfinite(frame.float()).all().item()) and float(frame[..., :3].float().mean()) > 0
         result["small"] = ctx.trace_variant() == capi.TRACE_EXHAUSTIVE
         result["fused"] = ctx.trace_is_fused()
+        result["wide8"] = ctx.trace_variant() == capi.TRACE_WIDE8_PERSISTENT
     result["wavefronts"] = args.wavefronts if args.wavefronts else (1 if ctx.trace_is_fused() else 2)
     return result
 
@@ -605,7 +606,8 @@ def summarise(result, scene_name, scene_text, bounces, args, world, steps, live_
             traffic, traffic_source = load_measured_traffic(key)
             if live_traffic and traffic_source is not None:
                 traffic_source["live_measurement_failed"] = live_traffic[1]
-    rooflines, kernel_times = rooflines_of(result["counters"], result["times"], result["per_ray"], result["small"], result["fused"], S, traffic)
+    rooflines, kernel_times = rooflines_of(result["counters"], result["times"], result["per_ray"], result["small"], result["fused"], S, traffic,
+                                           triangle_bytes=32.0 if result.get("wide8") else 48.0)   # a 64 B leaf record holds two triangles
     dominant = max(rooflines, key=lambda n: rooflines[n]["total_ms"])
     roofline = dict(rooflines[dominant])
     roofline["traffic_source"] = traffic_source

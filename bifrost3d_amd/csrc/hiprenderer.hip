@@ -6,11 +6,13 @@
 // Replaces the OptiX context + context->launch() of OR/Renderer.cpp:273-574,1250-1265.
 // There is no CPU fallback: every entry point that needs the GPU fails with a status code.
 #include "kernels.h"
+#include "wide8_kernels.h"
 #include "launch.h"
 
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -108,7 +110,9 @@ struct HiprContext {
     int partitioned_for = 0;                // the wavefronts_wanted() the current partition was made for
 
     // scene
-    DeviceBuffer shade_triangles, trace_triangles, trace_items, wide_nodes, environment_PDF, environment_samples;
+    DeviceBuffer shade_triangles, trace_triangles, trace_items, wide_nodes, wide8_slots, environment_PDF, environment_samples;
+    Wide8Scene wide8 = {};              // the 8-wide tree with leaf records: what the persistent kernels walk when the scene brings one
+    uint32_t wide8_height = 0;
     DeviceBuffer nodes, triangles, instances, indices, geometry, texcoords, tints, emissions, materials, lights, textures, texels;
     DeviceBuffer ggx_rho, dielectric_rho, alpha, sample_offsets, sobol_tables;
     DeviceScene scene = {};
@@ -137,15 +141,29 @@ struct HiprContext {
     // and light (exhaustive search / BVH2: Cornell +9 % ... +27 %); the persistent wide-BVH kernels fill the register file on their own, the
     // other wavefront's blocks then wait for residency and nothing is gained (atrium 88.4 vs 88.8 ms, material 24.9 vs 25.1 ms per step): one.
     int wavefronts_wanted() const { return wavefront_limit > 0 ? wavefront_limit : (scene_ready && use_persistent() ? 1 : 2); }
-    bool use_persistent() const { return scene.wide_node_count > 0 && (trace_variant < 0 ? scene.node_count > 64 : trace_variant == HIPR_TRACE_WIDE_PERSISTENT); }
+    // The search of the uploaded scene, fixed when it is uploaded (hipr_set_trace_variant / HIPR_TRACE_VARIANT name a request for the NEXT upload).
+    int chosen_variant = HIPR_TRACE_BVH2;
+    void choose_variant() {
+        const bool large = scene.node_count > 64;
+        int v = trace_variant;
+        if (v < 0) v = large ? HIPR_TRACE_WIDE8_PERSISTENT : (scene.triangle_count <= SMALL_SCENE_TRIANGLES ? HIPR_TRACE_EXHAUSTIVE : HIPR_TRACE_BVH2);
+        if (v == HIPR_TRACE_WIDE8_PERSISTENT && wide8.slot_count == 0) v = HIPR_TRACE_WIDE_PERSISTENT;      // no 8-wide tree (none given, or higher than the LDS stacks)
+        if (v == HIPR_TRACE_WIDE_PERSISTENT && scene.wide_node_count == 0) v = HIPR_TRACE_BVH2;
+        if (v == HIPR_TRACE_EXHAUSTIVE && scene.trace_item_count == 0 && scene.triangle_count != 0) v = HIPR_TRACE_BVH2;
+        chosen_variant = v;
+    }
+    bool use_wide8() const { return chosen_variant == HIPR_TRACE_WIDE8_PERSISTENT; }
+    bool use_wide4() const { return chosen_variant == HIPR_TRACE_WIDE_PERSISTENT; }
+    bool use_persistent() const { return use_wide8() || use_wide4(); }      // fused launches, one wavefront
     // tiny scenes: exhaustive search over the triangles (k_trace_*_small)
-    bool use_exhaustive() const { return trace_variant < 0 ? (scene.triangle_count <= SMALL_SCENE_TRIANGLES && !use_persistent()) : trace_variant == HIPR_TRACE_EXHAUSTIVE; }
-    int active_trace_variant() const { return use_persistent() ? HIPR_TRACE_WIDE_PERSISTENT : (use_exhaustive() ? HIPR_TRACE_EXHAUSTIVE : HIPR_TRACE_BVH2); }
+    bool use_exhaustive() const { return chosen_variant == HIPR_TRACE_EXHAUSTIVE; }
+    int active_trace_variant() const { return chosen_variant; }
     int cu_count = 256;
     int blocks_per_cu_override = 0;     // HIPR_BLOCKS_PER_CU
     int shade_blocks_per_cu = 0;        // persistent shade blocks per CU = waves per SIMD; 0: 3 (what the kernel is compiled for), 2 for all-Diffuse scenes (HIPR_SHADE_BLOCKS_PER_CU)
     int refill_below = 40;              // persistent kernels refill a wave once fewer lanes than this are busy (HIPR_REFILL_BELOW)
     int persistent_blocks_per_cu[3][3] = {{0, 0, 0}, {0, 0, 0}};   // [shadow][stack bucket]
+    int wide8_blocks_per_cu[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};   // [mode][stack bucket]
 
     // bookkeeping
     HiprCounters total = {};   // since hipr_reset_counters
@@ -276,12 +294,36 @@ void launch_persistent(HiprContext* c, const Wavefront& w, const PathState& in, 
                        c->radiance.as<float4>(), closest_count, shadow_count, next_work_counter(c), c->refill_below, c->counters.as<DeviceCounters>());
 }
 
+// One persistent launch over the 8-wide tree (wide8_kernels.h). The LDS stack is sized by the tree's height: a ray keeps at most one group per level.
+template <int STACK, int MODE, bool INSTRUMENT>
+void launch_wide8(HiprContext* c, const Wavefront& w, const PathState& in, const uint32_t* closest_count, const uint32_t* shadow_count, uint32_t upper_bound, int bucket) {
+    int& per_cu = c->wide8_blocks_per_cu[MODE][bucket];
+    if (per_cu == 0) {
+        int blocks = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_trace_wide8<STACK, MODE, INSTRUMENT>, TRACE_BLOCK, 0) != hipSuccess || blocks <= 0) blocks = 4;
+        if (c->trace_log) fprintf(stderr, "[hipr] k_trace_wide8<%d, %d>: occupancy query says %d blocks of %d threads per CU\n", STACK, MODE, blocks, TRACE_BLOCK);
+        if (c->blocks_per_cu_override > 0) blocks = c->blocks_per_cu_override;
+        per_cu = blocks;
+    }
+    const uint32_t waves_per_block = TRACE_BLOCK / 64;
+    uint32_t grid = uint32_t(c->cu_count) * uint32_t(per_cu);
+    grid = std::max(1u, std::min(grid, (upper_bound + 63u) / 64u / waves_per_block + 1u));
+    hipLaunchKernelGGL((k_trace_wide8<STACK, MODE, INSTRUMENT>), dim3(grid), dim3(TRACE_BLOCK), 0, w.stream, c->scene, c->wide8, in, w.hits.as<float4>(), w.shadow_queue(),
+                       c->radiance.as<float4>(), closest_count, shadow_count, next_work_counter(c), c->refill_below, c->counters.as<DeviceCounters>());
+}
+
 template <int MODE, bool INSTRUMENT>
 void launch_persistent_for_stack(HiprContext* c, const Wavefront& w, const PathState& in, const uint32_t* closest_count, const uint32_t* shadow_count, uint32_t upper_bound) {
     // LDS stack entries by the worst case of the wide tree. Trees that need up to 32 entries run with 16 in LDS and the rest in a per-lane scratch
     // array (traversals rarely get past 16): 4 KB of LDS per wave instead of 8 lets a sixth wave per SIMD stay resident, and the kernel is bound by
     // the latency of its dependent gathers (atrium, 260 k triangles: 61.0 -> 57.7 ms of trace time per step). Deeper trees (the 10 M triangle
     // atrium) spill often enough that 32 LDS entries + scratch is the faster split (116.7 vs 119.9 ms).
+    if (c->use_wide8()) {       // height h: at most h - 1 groups wait on the stack
+        if (c->wide8_height <= uint32_t(WIDE8_STACK_SHALLOW) + 1u) launch_wide8<WIDE8_STACK_SHALLOW, MODE, INSTRUMENT>(c, w, in, closest_count, shadow_count, upper_bound, 0);
+        else if (c->wide8_height <= 17u) launch_wide8<16, MODE, INSTRUMENT>(c, w, in, closest_count, shadow_count, upper_bound, 1);
+        else launch_wide8<32, MODE, INSTRUMENT>(c, w, in, closest_count, shadow_count, upper_bound, 2);
+        return;
+    }
 #ifndef HIPR_STACK_MID
 #define HIPR_STACK_MID 16
 #endif
@@ -466,6 +508,62 @@ const char* validate_scene(const HiprSceneDesc* s, uint32_t& wide_stack_need, ch
 #undef INVALID
 }
 
+// The 8-wide tree of a description: every slot reached at most once from the root, child ranges inside the array, leaf records referencing triangles
+// of the description, finite grid. Derives the height (the stack need of the traversal). Returns nullptr when sound.
+const char* validate_wide8(const HiprSceneDesc* s, uint32_t& height, char* message, size_t message_size) {
+#define INVALID(...) do { snprintf(message, message_size, __VA_ARGS__); return message; } while (0)
+    height = 0;
+    if (!s->wide8_slots || s->wide8_slot_count == 0) return nullptr;
+    if (s->wide8_slot_count > 0x1000000u) INVALID("the 8-wide tree has %u slots, more than 2^24", s->wide8_slot_count);
+    for (int a = 0; a < 3; ++a)
+        if (!(s->wide8_grid_cell[a] > 0.0f) || !std::isfinite(s->wide8_grid_cell[a]) || !std::isfinite(s->wide8_grid_min[a])) INVALID("the 8-wide tree's grid is not finite");
+    std::vector<uint8_t> seen(s->wide8_slot_count, 0);
+    struct Visit { uint32_t slot, depth; };
+    std::vector<Visit> stack = {{0u, 1u}};
+    seen[0] = 1;
+    while (!stack.empty()) {
+        const Visit v = stack.back();
+        stack.pop_back();
+        height = std::max(height, v.depth);
+        const HiprNode8& n = s->wide8_slots[v.slot].node;
+        const uint32_t base = n.base_valid & 0xFFFFFFu, valid = n.base_valid >> 24;
+        const uint32_t children = uint32_t(__builtin_popcount(valid));
+        if (children == 0 || uint64_t(base) + children > s->wide8_slot_count) INVALID("8-wide node in slot %u: children [%u, %u) outside the %u slots", v.slot, base, base + children, s->wide8_slot_count);
+        if (n.inner_mask & ~valid) INVALID("8-wide node in slot %u marks an empty position as an inner node", v.slot);
+        uint32_t rank = 0;
+        for (uint32_t position = 0; position < 8; ++position) {
+            if (!(valid >> position & 1u)) continue;
+            const uint32_t child = base + rank++;
+            if (seen[child]) INVALID("slot %u of the 8-wide tree is reached twice", child);
+            seen[child] = 1;
+            if (n.inner_mask >> position & 1u) stack.push_back({child, v.depth + 1u});
+            else {
+                const HiprLeaf8& leaf = s->wide8_slots[child].leaf;
+                if (leaf.triangle[0] >= s->triangle_count || (leaf.triangle[1] != HIPR_LEAF8_NONE && leaf.triangle[1] >= s->triangle_count))
+                    INVALID("leaf record in slot %u references triangles %u / %u of %u", child, leaf.triangle[0], leaf.triangle[1], s->triangle_count);
+                for (int shift = 8; shift < 16; shift += 2)
+                    if (((leaf.flags >> shift) & 3u) == 3u) INVALID("leaf record in slot %u has an invalid corner selector", child);
+            }
+        }
+    }
+    return nullptr;
+#undef INVALID
+}
+
+// Uploads (or re-uploads, after a refit) the 8-wide tree of a validated description; trees higher than the largest LDS stack are left to the 4-wide kernels.
+int upload_wide8(HiprContext* c, const HiprSceneDesc* s, uint32_t height) {
+    c->wide8 = {};
+    c->wide8_height = 0;
+    if (!s->wide8_slots || s->wide8_slot_count == 0 || height > 33u) return HIPR_OK;
+    if (int r = c->wide8_slots.upload(s->wide8_slots, size_t(s->wide8_slot_count) * sizeof(HiprSlot8), c->stream)) return r;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->wide8.slots = c->wide8_slots.as<uint4>();
+    c->wide8.slot_count = s->wide8_slot_count;
+    for (int a = 0; a < 3; ++a) { c->wide8.grid_min[a] = s->wide8_grid_min[a]; c->wide8.grid_cell[a] = s->wide8_grid_cell[a]; }
+    c->wide8_height = height;
+    return HIPR_OK;
+}
+
 unsigned short to_unorm16(float v) { return (unsigned short)(v * 65535 + 0.5f); }
 
 // Reverse Halton offsets of OR/Renderer.cpp:323-336 (OR/RNG.h:196-231): primes 2, 3, 5, 7, digits d -> p - d, f64 inside.
@@ -590,7 +688,7 @@ int hipr_destroy(HiprContext* c) {
     if (!c) return HIPR_OK;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    DeviceBuffer* all[] = {&c->shade_triangles, &c->trace_triangles, &c->trace_items, &c->wide_nodes, &c->environment_PDF, &c->environment_samples, &c->nodes, &c->triangles, &c->instances, &c->indices, &c->geometry, &c->texcoords, &c->tints, &c->emissions, &c->materials,
+    DeviceBuffer* all[] = {&c->shade_triangles, &c->trace_triangles, &c->trace_items, &c->wide_nodes, &c->wide8_slots, &c->environment_PDF, &c->environment_samples, &c->nodes, &c->triangles, &c->instances, &c->indices, &c->geometry, &c->texcoords, &c->tints, &c->emissions, &c->materials,
                            &c->lights, &c->textures, &c->texels, &c->ggx_rho, &c->dielectric_rho, &c->alpha, &c->sample_offsets, &c->sobol_tables, &c->radiance,
                            &c->accumulation, &c->scratch_accumulation, &c->counters, &c->work_counters, &c->debug_a, &c->debug_b, &c->debug_c};
     for (DeviceBuffer* b : all) b->release();
@@ -643,6 +741,8 @@ int hipr_validate_scene(const HiprSceneDesc* s) {
     uint32_t wide_stack_need = 0;
     char invalid[256];
     if (validate_scene(s, wide_stack_need, invalid, sizeof(invalid))) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_validate_scene: %s", invalid);
+    uint32_t wide8_height = 0;
+    if (validate_wide8(s, wide8_height, invalid, sizeof(invalid))) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_validate_scene: %s", invalid);
     return HIPR_OK;
 }
 
@@ -657,6 +757,8 @@ int hipr_upload_scene(HiprContext* c, const HiprSceneDesc* s) {
     if (validate_scene(s, wide_stack_need, invalid, sizeof(invalid))) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_upload_scene: %s", invalid);
     if (wide_stack_need > 32u + uint32_t(TRACE_SPILL_ENTRIES))
         return fail(HIPR_ERROR_UNSUPPORTED, "the wide BVH needs %u stack entries, more than the %u the traversal kernels provide", wide_stack_need, 32u + uint32_t(TRACE_SPILL_ENTRIES));
+    uint32_t wide8_height = 0;
+    if (validate_wide8(s, wide8_height, invalid, sizeof(invalid))) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_upload_scene: %s", invalid);
     for (uint32_t i = 0; i < s->instance_count; ++i)
         if ((s->instances[i].mesh_flags & HIPR_MESH_TEXCOORDS && !s->texcoords) || (s->instances[i].mesh_flags & HIPR_MESH_TINTS && !s->tints) ||
             (s->instances[i].mesh_flags & HIPR_MESH_EMISSIVE && !s->emissions))
@@ -714,6 +816,8 @@ int hipr_upload_scene(HiprContext* c, const HiprSceneDesc* s) {
     d.triangle_count = s->triangle_count;
     d.light_count = s->light_count;
     if (int status = build_derived_geometry(c, s)) return status;
+    if (int status = upload_wide8(c, s, wide8_height)) return status;
+    c->choose_variant();
     c->stack_size = s->bvh_max_depth <= 16 ? 16 : (s->bvh_max_depth <= 32 ? 32 : 64);
     int models = 0;
     for (uint32_t i = 0; i < s->instance_count; ++i) {
@@ -748,6 +852,10 @@ int hipr_update_scene_geometry(HiprContext* c, const HiprSceneDesc* s) {
     char invalid[256];
     if (validate_scene(s, wide_stack_need, invalid, sizeof(invalid))) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_update_scene_geometry: %s", invalid);
     if (wide_stack_need != c->wide_stack_entries) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_update_scene_geometry: the wide BVH's topology changed");
+    uint32_t wide8_height = 0;
+    if (validate_wide8(s, wide8_height, invalid, sizeof(invalid))) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_update_scene_geometry: %s", invalid);
+    if (c->wide8.slot_count && (s->wide8_slot_count != c->wide8.slot_count || wide8_height != c->wide8_height))
+        return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_update_scene_geometry: the 8-wide tree's topology changed");
     for (int g = 0; g < MAX_WAVEFRONTS; ++g) if (c->wavefronts[g].stream) HIP_TRY(hipStreamSynchronize(c->wavefronts[g].stream));
     hipStream_t st = c->stream;
     int r = 0;
@@ -758,6 +866,8 @@ int hipr_update_scene_geometry(HiprContext* c, const HiprSceneDesc* s) {
     r |= c->lights.upload(s->lights, size_t(s->light_count) * sizeof(HiprLight), st);
     if (r) return r < 0 ? r : HIPR_ERROR_HIP;
     HIP_TRY(hipStreamSynchronize(st));
+    if (c->wide8.slot_count)
+        if (int status = upload_wide8(c, s, wide8_height)) return status;
     int models = 0;   // the instances were re-uploaded: a changed material_index may reference another shading model
     for (uint32_t i = 0; i < s->instance_count; ++i) models |= 1 << std::min<int>(s->materials[s->instances[i].material_index].shading_model, 2);
     c->shading_models = models ? models : 7;
@@ -1086,6 +1196,13 @@ int hipr_set_wavefront_count(HiprContext* c, int count) {
 int hipr_get_trace_variant(HiprContext* c, int* out_variant) {
     if (!c || !out_variant) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_get_trace_variant: null argument");
     *out_variant = c->scene_ready ? c->active_trace_variant() : HIPR_TRACE_BVH2;
+    return HIPR_OK;
+}
+
+int hipr_set_trace_variant(HiprContext* c, int variant) {
+    if (!c) return fail(HIPR_ERROR_INVALID_ARGUMENT, "null context");
+    if (variant < -1 || variant > HIPR_TRACE_WIDE8_PERSISTENT) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_set_trace_variant: unknown variant %d", variant);
+    c->trace_variant = variant;     // the exhaustive search's items are built at upload: upload the scene after this call
     return HIPR_OK;
 }
 

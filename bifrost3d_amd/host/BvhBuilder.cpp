@@ -599,10 +599,17 @@ BvhBuildResult build_bvh(const std::vector<HiprTriangle>& triangles, uint32_t ma
     collapse.run(budget, b.threads, result.wide_stack_entries);
     result.wide_nodes = std::move(collapse.wide);
     result.max_depth = b.deepest + 1;   // stack entries needed is bounded by the node depth; keep one spare
+    const auto t_wide = std::chrono::steady_clock::now();
+    {
+        std::vector<HiprTriangle> ordered(n);
+        for (uint32_t k = 0; k < n; ++k) ordered[k] = triangles[result.order[k]];
+        result.wide8 = build_wide8(result.nodes, ordered);
+    }
     if (std::getenv("HIPR_BVH_TIMING")) {
         const auto t_end = std::chrono::steady_clock::now();
-        fprintf(stderr, "[hipr] build_bvh: %u triangles, %u threads: BVH2 %.3f s, wide collapse %.3f s\n", n, b.threads, std::chrono::duration<double>(t_built - t_start).count(),
-                std::chrono::duration<double>(t_end - t_built).count());
+        fprintf(stderr, "[hipr] build_bvh: %u triangles, %u threads: BVH2 %.3f s, 4-wide collapse %.3f s, 8-wide collapse %.3f s (%u nodes, %u leaf records of which %u hold two triangles, height %u)\n", n,
+                b.threads, std::chrono::duration<double>(t_built - t_start).count(), std::chrono::duration<double>(t_wide - t_built).count(),
+                std::chrono::duration<double>(t_end - t_wide).count(), result.wide8.node_count, result.wide8.leaf_count, result.wide8.paired_leaves, result.wide8.height);
     }
     return result;
 }
@@ -651,6 +658,7 @@ double refit_bvh(BvhBuildResult& bvh, const std::vector<HiprTriangle>& triangles
         quantise_children(boxes, count, w);      // the non-empty children occupy the first `count` slots, as the build left them
         (void)refs;
     }
+    refit_wide8(bvh.wide8, triangles);
     return area;
 }
 

@@ -2,6 +2,7 @@
 #pragma once
 
 #include "../../include/hiprenderer_c.h"
+#include "Wide8Builder.h"
 
 #include <cstdint>
 #include <vector>
@@ -15,6 +16,8 @@ struct BvhBuildResult {
     // The same tree collapsed to compressed 4-wide nodes (HiprWideNode); empty when the scene is empty.
     std::vector<HiprWideNode> wide_nodes;
     uint32_t wide_stack_entries = 0;  // most entries a traversal of wide_nodes can have on its stack
+    // The same tree collapsed to the 8-wide slots of include/hiprenderer_c.h "wide8" (Wide8Builder.cpp): what the persistent kernels walk.
+    Wide8Result wide8;
 };
 
 // `max_depth`: the deepest leaf the builder may produce (root = 1). 62 fits the 64 entry LDS stack.

@@ -202,6 +202,8 @@ void SceneBuilder::finalize(uint32_t bvh_max_depth) {
     d.bvh_max_depth = m_bvh.max_depth;
     d.wide_nodes = m_bvh.wide_nodes.data(); d.wide_node_count = uint32_t(m_bvh.wide_nodes.size());
     d.wide_stack_entries = m_bvh.wide_stack_entries;
+    d.wide8_slots = m_bvh.wide8.slots.data(); d.wide8_slot_count = uint32_t(m_bvh.wide8.slots.size()); d.wide8_height = m_bvh.wide8.height;
+    for (int a = 0; a < 3; ++a) { d.wide8_grid_min[a] = m_bvh.wide8.grid_min[a]; d.wide8_grid_cell[a] = m_bvh.wide8.grid_cell[a]; }
     m_environment.per_pixel_PDF = m_environment_PDF.data();
     m_environment.samples = m_environment_samples.data();
     d.environment = m_has_environment ? &m_environment : nullptr;
@@ -234,6 +236,7 @@ bool SceneBuilder::update_model_transforms(const std::vector<std::pair<uint32_t,
         m_bounds.grow_to_contain(Vector3f(t.v2[0], t.v2[1], t.v2[2]));
     }
     const double area = refit_bvh(m_bvh, m_triangles);
+    for (int a = 0; a < 3; ++a) { m_desc.wide8_grid_min[a] = m_bvh.wide8.grid_min[a]; m_desc.wide8_grid_cell[a] = m_bvh.wide8.grid_cell[a]; }     // the refit moves the grid with the scene
     if (m_built_bvh_area > 0.0 && area > rebuild_threshold * m_built_bvh_area) {
         finalize(m_bvh_max_depth_limit);      // the instances already carry the new transforms
         return false;

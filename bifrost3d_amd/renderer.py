@@ -113,12 +113,16 @@ class Context:
         self._check(self.lib.hipr_get_trace_variant(self.handle, C.byref(v)), "hipr_get_trace_variant")
         return v.value
 
+    def set_trace_variant(self, variant: int):
+        """Forces a search for the scenes uploaded after the call (-1: by scene size)."""
+        self._check(self.lib.hipr_set_trace_variant(self.handle, int(variant)), "hipr_set_trace_variant")
+
     def trace_is_fused(self) -> bool:
-        return self.trace_variant() == capi.TRACE_WIDE_PERSISTENT
+        return self.trace_variant() in (capi.TRACE_WIDE_PERSISTENT, capi.TRACE_WIDE8_PERSISTENT)
 
     def oracle_search(self) -> int:
-        """The `use_bvh` mode of the oracle that states the same search: 0 exhaustive, 1 BVH2, 2 compressed 4-wide BVH."""
-        return {capi.TRACE_BVH2: 1, capi.TRACE_WIDE_PERSISTENT: 2, capi.TRACE_EXHAUSTIVE: 0}[self.trace_variant()]
+        """The `use_bvh` mode of the oracle that states the same search: 0 exhaustive, 1 BVH2, 2 compressed 4-wide BVH, 3 compressed 8-wide BVH with leaf records."""
+        return {capi.TRACE_BVH2: 1, capi.TRACE_WIDE_PERSISTENT: 2, capi.TRACE_EXHAUSTIVE: 0, capi.TRACE_WIDE8_PERSISTENT: 3}[self.trace_variant()]
 
     def kernel_times(self) -> dict:
         t = capi.HiprKernelTimes()

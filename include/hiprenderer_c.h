@@ -146,6 +146,38 @@ typedef struct HiprWideNode {
 } HiprWideNode;
 #define HIPR_WIDE_EMPTY 0x7FFFFFFF
 
+/* 8-wide compressed BVH ("wide8"): what the persistent traversal kernels walk (round 3). Measured on the MI355X, the traversal is bound by the
+ * number of 16-byte lane-loads the CU's address / tag pipeline takes (82 % busy with the 4-wide tree) and by the length of a ray's chain of
+ * dependent fetches, so the tree is built to need few of both: ONE array of 64-byte SLOTS holds inner nodes and leaf records alike, the children of
+ * a node sit in consecutive slots (one base index serves all eight), an inner node carries the 8-bit quantised boxes of up to EIGHT children in
+ * four 16-byte loads, and a leaf is one record of one or two triangles sharing an edge in four loads (two triangles used to be six).
+ * Node origin: three 21-bit coordinates on a grid over the scene's bounds, origin_a = fma(float(m_a), grid_cell[a], grid_min[a]); child box of
+ * position s on axis a: [origin_a + qlo[a][s] * 2^(exponent[a] - 127), origin_a + qhi[a][s] * 2^(exponent[a] - 127)], containing the exact box.
+ * Positions are assigned so that position bit a set means "on the + side of the node's centre along axis a": a ray visits the hit children in
+ * ascending order of (position XOR the ray's octant bits, bit a = direction[a] < 0) -- near to far without sorting distances. */
+typedef struct HiprNode8 {
+    uint32_t origin[2];     /* x: bits 0..20, y: bits 21..41, z: bits 42..62 of the 64-bit value */
+    uint8_t exponent[3];    /* biased like an IEEE exponent field */
+    uint8_t inner_mask;     /* bit s: the child in position s is an inner node, else a leaf record */
+    uint32_t base_valid;    /* bits 0..23: slot of the node's first child; bits 24..31: bit s = position s holds a child. The child in position s
+                               lives in slot base + popcount(valid & ((1 << s) - 1)) */
+    uint8_t qlo[3][8];      /* [axis][position]; an empty position holds qlo = 255, qhi = 0 */
+    uint8_t qhi[3][8];
+} HiprNode8;
+
+/* Leaf record of the wide8 tree: triangle A = (a, a + e1, a + e2) and, when triangle[1] != HIPR_LEAF8_NONE, triangle B = (a, a + e2, a + e3): two
+ * triangles of HiprSceneDesc::triangles that share the edge (a, a + e2). Both are tested with the ray / triangle solve of DESIGN.md on the stored
+ * corner and edges (the edges rounded once, at build time), A first. The solve of a record triangle yields the weights (w, u, v) of its corners in
+ * record order; `selectors` says which of them are the weights of the scene triangle's vertices 1 and 2, i.e. the (u, v) a hit reports. */
+typedef struct HiprLeaf8 {
+    float a[3], e1[3], e2[3], e3[3];
+    uint32_t triangle[2];   /* indices into HiprSceneDesc::triangles */
+    uint32_t flags;         /* bit 0 / bit 1: A / B is HIPR_TRIANGLE_OPAQUE; bits 8..9, 10..11: which of (w, u, v) = 0, 1, 2 is A's reported u, v; bits 12..13, 14..15: B's */
+    uint32_t _pad;
+} HiprLeaf8;
+#define HIPR_LEAF8_NONE 0xFFFFFFFFu
+typedef union HiprSlot8 { HiprNode8 node; HiprLeaf8 leaf; uint32_t words[16]; } HiprSlot8;
+
 /* Software replacement for the reference's texture samplers (OR/Renderer.cpp:703-751).
  * Texels live in HiprSceneDesc::texels at `texel_offset` (bytes). */
 typedef struct HiprTexture {
@@ -200,6 +232,9 @@ typedef struct HiprSceneDesc {
     const HiprWideNode* wide_nodes;      uint32_t wide_node_count;  /* the same tree collapsed to 4-wide nodes; may be NULL / 0 */
     uint32_t wide_stack_entries;         /* most entries a traversal of wide_nodes can have on its stack */
     const HiprEnvironment* environment;  /* NULL: the environment is the constant HiprSceneState::environment_tint */
+    const HiprSlot8* wide8_slots;        uint32_t wide8_slot_count; /* the 8-wide tree over the same triangles, slot 0 = the root node; may be NULL / 0 */
+    uint32_t wide8_height;               /* nodes on the longest root-to-leaf chain = most entries a traversal can have on its stack */
+    float wide8_grid_min[3], wide8_grid_cell[3];
 } HiprSceneDesc;
 
 /* OR/Types.h:507-523 SceneStateGPU, without OptiX buffer ids. */
@@ -416,9 +451,14 @@ int hipr_set_wavefront_count(HiprContext* context, int count);
  *                               closest-hit rays of a bounce and the shadow rays of the previous one share one fused launch,
  *                               timed under HIPR_KERNEL_TRACE_CLOSEST
  *   HIPR_TRACE_EXHAUSTIVE       at most 64 triangles: every ray tests every triangle (k_trace_*_small)
+ *   HIPR_TRACE_WIDE8_PERSISTENT more than 64 BVH2 nodes and HiprSceneDesc::wide8_slots given (the default then): persistent kernels over the 8-wide
+ *                               tree with leaf records (k_trace_wide8), fused launches like HIPR_TRACE_WIDE_PERSISTENT
  * The CPU oracle has the same three searches; parity tests pick the matching one. */
-enum { HIPR_TRACE_BVH2 = 0, HIPR_TRACE_WIDE_PERSISTENT = 1, HIPR_TRACE_EXHAUSTIVE = 2 };
+enum { HIPR_TRACE_BVH2 = 0, HIPR_TRACE_WIDE_PERSISTENT = 1, HIPR_TRACE_EXHAUSTIVE = 2, HIPR_TRACE_WIDE8_PERSISTENT = 3 };
 int hipr_get_trace_variant(HiprContext* context, int* out_variant);
+/* Forces one of the searches above for the scenes uploaded AFTER the call (-1: by scene size, the default). Meant for tests and A/B measurements: every
+ * search returns the same hits up to the rounding of its triangle solve; the oracle restates each of them. */
+int hipr_set_trace_variant(HiprContext* context, int variant);
 int hipr_set_instrumentation(HiprContext* context, int count_traversal_steps);
 int hipr_reset_timers(HiprContext* context);
 int hipr_get_kernel_times(HiprContext* context, HiprKernelTimes* out);

@@ -338,6 +338,134 @@ Hit closest_hit_wide(const HiprSceneDesc& scene, const Ray& ray, uint32_t skip, 
     return best;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Traversal of the 8-wide tree (include/hiprenderer_c.h "wide8"; csrc/wide8_kernels.h is the device side of the same specification, so that hits AND
+// node / triangle counters agree exactly):
+//   * a ray carries its octant, bit a = (1 / direction[a] < 0); a GROUP is (base | valid << 24, pending | inner_mask << 8): the hit children of one
+//     node that are still to be visited, `pending` bit p standing for the child in position p ^ octant. Children are taken from the current group lowest
+//     pending bit first -- the nearest octant first -- whether they are inner nodes or leaf records;
+//   * visiting an inner node tests its up to eight quantised child boxes (slab distances fma(float(q), A, B) with A = 2^(e - 127) * inv_d and
+//     B = fma(origin, inv_d, -ood), origin = fma(float(m), grid_cell, grid_min); tnear / tfar as for the other trees, same 3 ulp of slack); if any is hit the
+//     current group goes on the stack (when it still has pending children) and the node's hits become the current group;
+//   * visiting a leaf record tests triangle A = (a; e1, e2), then B = (a; e2, e3) if there is one, with the solve of intersect_triangle on the stored
+//     edges; the weights (w, u, v) = (1 - u - v, u, v) of the record's corners are mapped to the scene triangle's (u, v) by the record's selectors.
+// ---------------------------------------------------------------------------------------------
+static inline bool intersect_edges(float3 v0, float3 e1, float3 e2, float3 o, float3 d, float& t, float& u, float& v) {
+    float3 p = cross_fma(d, e2);
+    float det = dot_fma(e1, p);
+    float3 tv = o - v0;
+    float un = dot_fma(tv, p);
+    float3 q = cross_fma(tv, e1);
+    float vn = dot_fma(d, q);
+    float us = std::signbit(det) ? -un : un, vs = std::signbit(det) ? -vn : vn;
+    if (!((det != 0.0f) && (us >= 0.0f) && (vs >= 0.0f) && (us + vs <= std::fabs(det))))
+        return false;
+    float inv = 1.0f / det;
+    u = un * inv;
+    v = vn * inv;
+    t = dot_fma(e2, q) * inv;
+    return true;
+}
+// Triangle `which` (0 = A, 1 = B) of a leaf record: hit distance and the scene triangle's barycentrics.
+static inline bool intersect_record(const HiprLeaf8& r, int which, float3 o, float3 d, float& t, float& u, float& v) {
+    const float3 a = {r.a[0], r.a[1], r.a[2]};
+    const float3 first = which == 0 ? make_float3(r.e1[0], r.e1[1], r.e1[2]) : make_float3(r.e2[0], r.e2[1], r.e2[2]);
+    const float3 second = which == 0 ? make_float3(r.e2[0], r.e2[1], r.e2[2]) : make_float3(r.e3[0], r.e3[1], r.e3[2]);
+    float ru, rv;
+    if (!intersect_edges(a, first, second, o, d, t, ru, rv))
+        return false;
+    const float weights[3] = {1.0f - ru - rv, ru, rv};
+    const uint32_t selectors = (r.flags >> (which == 0 ? 8 : 12)) & 15u;
+    u = weights[selectors & 3u];
+    v = weights[selectors >> 2];
+    return true;
+}
+
+static std::atomic<int> g_wide8_stack_high_water{0};
+int wide8_stack_high_water(bool reset) { const int v = g_wide8_stack_high_water.load(); if (reset) g_wide8_stack_high_water.store(0); return v; }
+
+template <typename LeafFn>
+static inline void traverse_wide8(const HiprSceneDesc& scene, const Ray& ray, float& tmax, TraversalCounters* counters, LeafFn&& leaf) {
+    if (scene.wide8_slot_count == 0)
+        return;
+    const SlabRay sr = make_slab_ray(ray);
+    const float inv[3] = {sr.inv_d.x, sr.inv_d.y, sr.inv_d.z}, ood[3] = {sr.ood.x, sr.ood.y, sr.ood.z};
+    const uint32_t octant = (inv[0] < 0.0f ? 1u : 0u) | (inv[1] < 0.0f ? 2u : 0u) | (inv[2] < 0.0f ? 4u : 0u);
+    uint32_t stack_x[64], stack_y[64];
+    int sp = 0;
+    // the root as a group of its own: one inner child in position 0 of base 0
+    uint32_t gx = 0u | 1u << 24, gy = (1u << (0u ^ octant)) | 1u << 8;
+    for (;;) {
+        if ((gy & 0xFFu) == 0u) {
+            if (sp == 0)
+                return;
+            --sp;
+            gx = stack_x[sp]; gy = stack_y[sp];
+        }
+        const uint32_t p = uint32_t(__builtin_ctz(gy & 0xFFu));
+        gy &= gy - 1u;
+        const uint32_t position = p ^ octant;
+        const bool inner = (gy >> (8u + position)) & 1u;
+        const uint32_t slot = (gx & 0xFFFFFFu) + uint32_t(__builtin_popcount((gx >> 24) & ((1u << position) - 1u)));
+        if (!inner) {
+            if (leaf(scene.wide8_slots[slot].leaf))
+                return;
+            continue;
+        }
+        const HiprNode8& n = scene.wide8_slots[slot].node;
+        if (counters) counters->nodes++;
+        const uint64_t packed = uint64_t(n.origin[0]) | uint64_t(n.origin[1]) << 32;
+        float A[3], B[3];
+        for (int a = 0; a < 3; ++a) {
+            const float origin = fmaf(float(uint32_t(packed >> (21 * a)) & 0x1FFFFFu), scene.wide8_grid_cell[a], scene.wide8_grid_min[a]);
+            A[a] = int_as_float(int32_t(uint32_t(n.exponent[a]) << 23)) * inv[a];
+            B[a] = fmaf(origin, inv[a], -ood[a]);
+        }
+        const uint32_t valid = n.base_valid >> 24;
+        uint32_t hits = 0;
+        for (uint32_t k = 0; k < 8; ++k) {
+            float lo[3], hi[3];
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = fmaf(float(n.qlo[a][k]), A[a], B[a]);
+                hi[a] = fmaf(float(n.qhi[a][k]), A[a], B[a]);
+            }
+            const float tnear = fmaxf(fmaxf(fminf(lo[0], hi[0]), fminf(lo[1], hi[1])), fmaxf(fminf(lo[2], hi[2]), ray.tmin));
+            float tfar = fminf(fminf(fmaxf(lo[0], hi[0]), fmaxf(lo[1], hi[1])), fmaxf(lo[2], hi[2]));
+            tfar = fminf(tfar, tmax) * 1.0000004f;
+            if ((valid >> k & 1u) && tnear <= tfar)
+                hits |= 1u << (k ^ octant);
+        }
+        if (hits) {
+            if (gy & 0xFFu) {
+                stack_x[sp] = gx; stack_y[sp] = gy;
+                ++sp;
+                if (sp > g_wide8_stack_high_water.load(std::memory_order_relaxed)) g_wide8_stack_high_water.store(sp, std::memory_order_relaxed);
+            }
+            gx = n.base_valid;
+            gy = hits | uint32_t(n.inner_mask) << 8;
+        }
+    }
+}
+
+Hit closest_hit_wide8(const HiprSceneDesc& scene, const Ray& ray, uint32_t skip, TraversalCounters* counters) {
+    Hit best = {ray.tmax, 0, 0, HIT_MISS};
+    traverse_wide8(scene, ray, best.t, counters, [&](const HiprLeaf8& record) {
+        for (int which = 0; which < 2; ++which) {
+            const uint32_t id = record.triangle[which];
+            if (id == HIPR_LEAF8_NONE)
+                break;
+            if (counters) counters->triangles++;
+            float t, u, v;
+            if (id == skip || !intersect_record(record, which, ray.origin, ray.direction, t, u, v) || !(t > ray.tmin))
+                continue;
+            if (t < best.t || (t == best.t && id < best.id))
+                best = {t, u, v, id};
+        }
+        return false;
+    });
+    return best;
+}
+
 Hit closest_hit_bvh(const HiprSceneDesc& scene, const Ray& ray, uint32_t skip, TraversalCounters* counters) {
     Hit best = {ray.tmax, 0, 0, HIT_MISS};
     traverse(scene, ray, best.t, counters, [&](uint32_t leaf) {
@@ -564,6 +692,34 @@ float3 shadow_wide(const HiprSceneDesc& scene, const Ray& ray, float3 radiance, 
             if (counters) counters->triangles++;
             if (shadow_triangle(scene, i, ray, radiance))
                 return true;
+        }
+        return false;
+    });
+    return radiance;
+}
+
+float3 shadow_wide8(const HiprSceneDesc& scene, const Ray& ray, float3 radiance, TraversalCounters* counters) {
+    float tmax = ray.tmax;
+    traverse_wide8(scene, ray, tmax, counters, [&](const HiprLeaf8& record) {
+        for (int which = 0; which < 2; ++which) {
+            const uint32_t id = record.triangle[which];
+            if (id == HIPR_LEAF8_NONE)
+                break;
+            if (counters) counters->triangles++;
+            float t, u, v;
+            if (!intersect_record(record, which, ray.origin, ray.direction, t, u, v) || !(t > ray.tmin && t < ray.tmax))
+                continue;
+            float coverage = 1.0f;
+            if (!(record.flags >> which & 1u)) {
+                const HiprTriangle& tri = scene.triangles[id];
+                const HiprInstance& inst = scene.instances[tri.instance_index];
+                coverage = material_coverage(scene, scene.materials[inst.material_index], triangle_texcoord(scene, tri, u, v));
+            }
+            radiance *= 1.0f - coverage;
+            if (radiance.x < 0.0000001f && radiance.y < 0.0000001f && radiance.z < 0.0000001f) {
+                radiance = {0, 0, 0};
+                return true;   // rtTerminateRay
+            }
         }
         return false;
     });
@@ -825,7 +981,8 @@ float3 path_trace_pixel(const HiprSceneDesc& scene, const HiprSceneState& state,
 
     do {
         Ray ray = {payload.position, payload.ray_min_t, payload.direction, INFINITY};
-        Hit hit = settings.use_wide ? closest_hit_wide(scene, ray, payload.last_triangle, counters ? &counters->closest : nullptr)
+        Hit hit = settings.use_wide8 ? closest_hit_wide8(scene, ray, payload.last_triangle, counters ? &counters->closest : nullptr)
+                  : settings.use_wide ? closest_hit_wide(scene, ray, payload.last_triangle, counters ? &counters->closest : nullptr)
                   : settings.use_bvh ? closest_hit_bvh(scene, ray, payload.last_triangle, counters ? &counters->closest : nullptr)
                                    : closest_hit_bruteforce(scene, ray, payload.last_triangle, counters ? &counters->closest : nullptr);
         intersect_lights(scene, ray, hit);
@@ -855,7 +1012,8 @@ float3 path_trace_pixel(const HiprSceneDesc& scene, const HiprSceneState& state,
         const LightSample& ls = payload.light_sample;
         if (ls.radiance.x > 0 || ls.radiance.y > 0 || ls.radiance.z > 0) {
             Ray shadow = {payload.light_sample_origin, 0.0f, ls.direction_to_light, ls.distance};
-            float3 r = settings.use_wide ? shadow_wide(scene, shadow, ls.radiance, counters ? &counters->shadow : nullptr)
+            float3 r = settings.use_wide8 ? shadow_wide8(scene, shadow, ls.radiance, counters ? &counters->shadow : nullptr)
+                       : settings.use_wide ? shadow_wide(scene, shadow, ls.radiance, counters ? &counters->shadow : nullptr)
                        : settings.use_bvh ? shadow_bvh(scene, shadow, ls.radiance, counters ? &counters->shadow : nullptr)
                                         : shadow_bruteforce(scene, shadow, ls.radiance, counters ? &counters->shadow : nullptr);
             if (counters) counters->shadow_rays++;
@@ -891,7 +1049,8 @@ float3 aov_pixel(const HiprSceneDesc& scene, const HiprSceneState& state, const 
         last_ray_direction = payload.direction;
         float3 last_position = payload.position;
         Ray ray = {payload.position, payload.ray_min_t, payload.direction, INFINITY};
-        Hit hit = settings.use_wide ? closest_hit_wide(scene, ray, payload.last_triangle, nullptr)
+        Hit hit = settings.use_wide8 ? closest_hit_wide8(scene, ray, payload.last_triangle, nullptr)
+                  : settings.use_wide ? closest_hit_wide(scene, ray, payload.last_triangle, nullptr)
                   : settings.use_bvh ? closest_hit_bvh(scene, ray, payload.last_triangle, nullptr) : closest_hit_bruteforce(scene, ray, payload.last_triangle, nullptr);
         intersect_lights(scene, ray, hit);
         if (hit.id == HIT_MISS) {

@@ -43,11 +43,14 @@ void reset_search_items();   // call at the start of every API entry that may se
 Hit closest_hit_bruteforce(const HiprSceneDesc& scene, const Ray& ray, uint32_t skip_triangle, TraversalCounters* counters = nullptr);
 Hit closest_hit_bvh(const HiprSceneDesc& scene, const Ray& ray, uint32_t skip_triangle, TraversalCounters* counters);
 Hit closest_hit_wide(const HiprSceneDesc& scene, const Ray& ray, uint32_t skip_triangle, TraversalCounters* counters);   // compressed 4-wide BVH
+Hit closest_hit_wide8(const HiprSceneDesc& scene, const Ray& ray, uint32_t skip_triangle, TraversalCounters* counters);  // compressed 8-wide BVH with leaf records
 void intersect_lights(const HiprSceneDesc& scene, const Ray& ray, Hit& hit);
 // Shadow any-hit accumulation over all triangles in (tmin, tmax); returns the attenuated radiance.
 float3 shadow_bruteforce(const HiprSceneDesc& scene, const Ray& ray, float3 radiance, TraversalCounters* counters = nullptr);
 float3 shadow_bvh(const HiprSceneDesc& scene, const Ray& ray, float3 radiance, TraversalCounters* counters);
 float3 shadow_wide(const HiprSceneDesc& scene, const Ray& ray, float3 radiance, TraversalCounters* counters);
+float3 shadow_wide8(const HiprSceneDesc& scene, const Ray& ray, float3 radiance, TraversalCounters* counters);
+int wide8_stack_high_water(bool reset);  // diagnostic: deepest traverse_wide8 stack since the last reset
 
 // --- textures / materials ---------------------------------------------------------------------
 float4 sample_texture(const HiprSceneDesc& scene, int texture_ID, float2 uv);
@@ -57,7 +60,8 @@ float material_coverage(const HiprSceneDesc& scene, const HiprMaterial& m, float
 // --- integrator -------------------------------------------------------------------------------
 struct RenderSettings {
     bool use_bvh = true;          // false: brute force over all triangles (tiny scenes)
-    bool use_wide = false;        // true: the compressed 4-wide BVH (what the HIP kernels walk in scenes with more than 64 BVH2 nodes)
+    bool use_wide = false;        // true: the compressed 4-wide BVH
+    bool use_wide8 = false;       // true: the compressed 8-wide BVH with leaf records (what the HIP kernels walk in scenes with more than 64 BVH2 nodes)
 };
 
 struct RenderCounters {

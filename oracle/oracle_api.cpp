@@ -29,6 +29,7 @@ static MaterialInputs inputs_of(const float* p) { return {{p[0], p[1], p[2]}, p[
 extern "C" {
 
 int oracle_wide_stack_high_water(int reset) { return oracle::wide_stack_high_water(reset != 0); }
+int oracle_wide8_stack_high_water(int reset) { return oracle::wide8_stack_high_water(reset != 0); }
 
 
 void oracle_set_tables(const float* base, const float* full, const float* light, const float* dense, const float* alphas, int quantize_unorm16) {
@@ -289,7 +290,7 @@ void oracle_trace_closest(const HiprSceneDesc* scene, const float* rays, const u
         for (int64_t i = 0; i < int64_t(n); ++i) {
             Ray ray = ray_of(rays + 8 * i);
             uint32_t sk = skip ? skip[i] : HIT_MISS;
-            Hit h = use_bvh == 2 ? closest_hit_wide(*scene, ray, sk, &local) : use_bvh ? closest_hit_bvh(*scene, ray, sk, &local) : closest_hit_bruteforce(*scene, ray, sk, &local);
+            Hit h = use_bvh == 3 ? closest_hit_wide8(*scene, ray, sk, &local) : use_bvh == 2 ? closest_hit_wide(*scene, ray, sk, &local) : use_bvh ? closest_hit_bvh(*scene, ray, sk, &local) : closest_hit_bruteforce(*scene, ray, sk, &local);
             if (with_lights) intersect_lights(*scene, ray, h);
             out_hits[4 * i] = h.t; out_hits[4 * i + 1] = h.u; out_hits[4 * i + 2] = h.v; out_hits[4 * i + 3] = uint_as_float(h.id);
         }
@@ -311,7 +312,7 @@ void oracle_trace_shadow(const HiprSceneDesc* scene, const float* rays, uint32_t
 #pragma omp for schedule(dynamic, 256)
         for (int64_t i = 0; i < int64_t(n); ++i) {
             Ray ray = ray_of(rays + 8 * i);
-            float3 r = use_bvh == 2 ? shadow_wide(*scene, ray, make_float3(1.0f), &local)
+            float3 r = use_bvh == 3 ? shadow_wide8(*scene, ray, make_float3(1.0f), &local) : use_bvh == 2 ? shadow_wide(*scene, ray, make_float3(1.0f), &local)
                        : use_bvh ? shadow_bvh(*scene, ray, make_float3(1.0f), &local) : shadow_bruteforce(*scene, ray, make_float3(1.0f), &local);
             out_transmittance[i] = r.x;
         }
@@ -331,7 +332,8 @@ double oracle_render_entry(const HiprSceneDesc* scene, const HiprSceneState* sta
     for (int i = 0; i < 256; ++i) offsets[i] = rng::sample_offset(i);
     RenderSettings settings;
     settings.use_bvh = use_bvh != 0;
-    settings.use_wide = use_bvh == 2;   // 0 brute force, 1 BVH2, 2 compressed 4-wide BVH
+    settings.use_wide = use_bvh == 2;   // 0 brute force, 1 BVH2, 2 compressed 4-wide BVH, 3 compressed 8-wide BVH with leaf records
+    settings.use_wide8 = use_bvh == 3;
     RenderCounters total;
 #ifdef _OPENMP
     double t0 = omp_get_wtime();

@@ -19,7 +19,7 @@ from test_coverage_cpu import deep_chain_rays, opacity_rays, write_deep_chain_ob
 
 pytestmark = pytest.mark.gpu
 
-OPACITY_VARIANT = {1: capi.TRACE_EXHAUSTIVE, 2: capi.TRACE_BVH2, 8: capi.TRACE_WIDE_PERSISTENT}
+OPACITY_VARIANT = {1: capi.TRACE_EXHAUSTIVE, 2: capi.TRACE_BVH2, 8: capi.TRACE_WIDE8_PERSISTENT}
 
 
 @pytest.fixture(scope="module")
@@ -169,7 +169,11 @@ def test_overflow_stack_kernels_bit_exact(ctx, oracle_q, tmp_path):
     high-water mark proves these rays go past 32 entries."""
     scene = Scene("file:" + write_deep_chain_obj(tmp_path / "chain.obj"))
     assert scene.desc.wide_stack_entries > 32
-    ctx.upload_scene(scene)
+    ctx.set_trace_variant(capi.TRACE_WIDE_PERSISTENT)      # the 4-wide tree's kernels (the default for this scene is the 8-wide tree, next test)
+    try:
+        ctx.upload_scene(scene)
+    finally:
+        ctx.set_trace_variant(-1)
     assert ctx.trace_variant() == capi.TRACE_WIDE_PERSISTENT
     ctx.set_instrumentation(True)
     rays = deep_chain_rays(30000, 9)
@@ -198,6 +202,39 @@ def test_overflow_stack_kernels_bit_exact(ctx, oracle_q, tmp_path):
     assert abs(gc["closest_rays"] - cc["closest_rays"]) <= 0.002 * cc["closest_rays"]
 
 
+@pytest.mark.parametrize("count,lowest,highest", [(125, 14, 17), (200, 18, 33)])
+def test_deep_tree_on_the_wide8_kernels_bit_exact(ctx, oracle_q, tmp_path, count, lowest, highest):
+    """Shorter chains of the same degenerate kind on the 8-wide tree: heights beyond the 12 groups the default LDS stack holds, so the launch picks the
+    kernels with the 16- and 32-entry stacks (trees higher than 33 stay with the 4-wide kernels and their scratch-backed stack, previous test); hits,
+    transmittance and counters equal the oracle's, whose stack high-water mark proves the rays go that deep."""
+    scene = Scene("file:" + write_deep_chain_obj(tmp_path / "chain.obj", count=count))
+    assert lowest <= scene.desc.wide8_height <= highest, scene.desc.wide8_height
+    ctx.set_trace_variant(capi.TRACE_WIDE8_PERSISTENT)      # the short chains have fewer than 64 BVH2 nodes: by size they would go to the BVH2 kernels
+    try:
+        ctx.upload_scene(scene)
+    finally:
+        ctx.set_trace_variant(-1)
+    assert ctx.trace_variant() == capi.TRACE_WIDE8_PERSISTENT
+    ctx.set_instrumentation(True)
+    rays = deep_chain_rays(30000, 9)
+    skip = np.full(len(rays), 0xFFFFFFFF, np.uint32)
+    skip[::9] = np.random.default_rng(4).integers(0, 300, len(skip[::9]))
+    gpu = ctx.debug_trace_closest(rays, skip)
+    counters = ctx.counters()
+    oracle_q.lib.oracle_wide8_stack_high_water(1)
+    cpu, (nodes, tris) = oracle_q.trace_closest(scene.desc, rays, skip, use_bvh=3, with_lights=True)
+    assert oracle_q.lib.oracle_wide8_stack_high_water(1) > 12
+    assert np.array_equal(gpu.view(np.uint32), cpu.view(np.uint32))
+    assert counters["closest_nodes"] == nodes and counters["closest_triangles"] == tris
+    shadow_rays = deep_chain_rays(30000, 10, tmax=True)
+    gpu_s = ctx.debug_trace_shadow(shadow_rays)
+    counters = ctx.counters()
+    ctx.set_instrumentation(False)
+    cpu_s, (nodes, tris) = oracle_q.trace_shadow(scene.desc, shadow_rays, use_bvh=3)
+    assert np.array_equal(gpu_s, cpu_s)
+    assert counters["shadow_nodes"] == nodes and counters["shadow_triangles"] == tris
+
+
 def test_million_triangle_scene(ctx, oracle_q):
     """BASELINE config 5's shape at test size: the 1 M-triangle atrium (seed 2), wide BVH of 250 k nodes. Stage parity bit-exact with
     counters, a small image against the oracle, and at 3840 x 2160 the size-independent properties (finite, every camera path
@@ -205,7 +242,7 @@ def test_million_triangle_scene(ctx, oracle_q):
     scene = Scene("atrium", param0=1000000, param1=2)
     assert scene.desc.triangle_count > 900000
     ctx.upload_scene(scene)
-    assert ctx.trace_variant() == capi.TRACE_WIDE_PERSISTENT
+    assert ctx.trace_variant() == capi.TRACE_WIDE8_PERSISTENT
     rng = np.random.default_rng(21)
     n = 40000
     rays = np.zeros((n, 8), np.float32)
@@ -218,19 +255,19 @@ def test_million_triangle_scene(ctx, oracle_q):
     ctx.set_instrumentation(True)
     gpu = ctx.debug_trace_closest(rays, skip)
     counters = ctx.counters()
-    cpu, (nodes, tris) = oracle_q.trace_closest(scene.desc, rays, skip, use_bvh=2, with_lights=True)
+    cpu, (nodes, tris) = oracle_q.trace_closest(scene.desc, rays, skip, use_bvh=ctx.oracle_search(), with_lights=True)
     assert np.array_equal(gpu.view(np.uint32), cpu.view(np.uint32))
     assert counters["closest_nodes"] == nodes and counters["closest_triangles"] == tris
     rays[:, 7] = rng.uniform(0.05, 30.0, n)
     gpu_s = ctx.debug_trace_shadow(rays)
     counters = ctx.counters()
     ctx.set_instrumentation(False)
-    cpu_s, (nodes, tris) = oracle_q.trace_shadow(scene.desc, rays, use_bvh=2)
+    cpu_s, (nodes, tris) = oracle_q.trace_shadow(scene.desc, rays, use_bvh=ctx.oracle_search())
     assert np.array_equal(gpu_s, cpu_s) and counters["shadow_nodes"] == nodes and counters["shadow_triangles"] == tris
 
     w, h, spp = 64, 36, 4
     image, gc = render_gpu(ctx, scene, w, h, spp, 4)
-    ref, cc, _ = oracle_q.render(scene.desc, scene.state, scene.camera(w, h, max_bounce_count=4), w, h, spp, use_bvh=2)
+    ref, cc, _ = oracle_q.render(scene.desc, scene.state, scene.camera(w, h, max_bounce_count=4), w, h, spp, use_bvh=ctx.oracle_search())
     close, rmse = image_metrics(image, ref)
     print(f"1M atrium: pixels within 1e-3: {close:.4f}, RMSE {rmse:.3e}")
     assert close >= 0.95 and np.isfinite(image).all()

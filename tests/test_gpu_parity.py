@@ -45,7 +45,16 @@ def cornell_tessellated():
     return Scene("cornell", param0=3)
 
 
-EXPECTED_VARIANT = {"cornell": capi.TRACE_EXHAUSTIVE, "cornell_tessellated": capi.TRACE_BVH2, "atrium": capi.TRACE_WIDE_PERSISTENT}
+EXPECTED_VARIANT = {"cornell": capi.TRACE_EXHAUSTIVE, "cornell_tessellated": capi.TRACE_BVH2, "atrium": capi.TRACE_WIDE8_PERSISTENT, "atrium_4wide": capi.TRACE_WIDE_PERSISTENT}
+
+
+@pytest.fixture
+def search(ctx):
+    """Scene names ending in _4wide run on the 4-wide tree's kernels (the 8-wide tree with leaf records is the default for scenes of that size)."""
+    def choose(scene_name):
+        ctx.set_trace_variant(capi.TRACE_WIDE_PERSISTENT if scene_name.endswith("_4wide") else -1)
+    yield choose
+    ctx.set_trace_variant(-1)
 
 
 def random_rays(rng, n, lo, hi, tmax=np.inf):
@@ -83,15 +92,16 @@ def test_camera_rays_bit_exact(ctx, oracle_q, cornell, size):
         assert np.array_equal(d[valid, :3].view(np.uint32), ed[:, :3].view(np.uint32))
 
 
-@pytest.mark.parametrize("scene_name", ["cornell", "cornell_tessellated", "atrium"])
-def test_closest_hit_bit_exact(ctx, oracle_q, cornell, cornell_tessellated, atrium, scene_name):
-    scene = {"cornell": cornell, "cornell_tessellated": cornell_tessellated, "atrium": atrium}[scene_name]
+@pytest.mark.parametrize("scene_name", ["cornell", "cornell_tessellated", "atrium", "atrium_4wide"])
+def test_closest_hit_bit_exact(ctx, oracle_q, cornell, cornell_tessellated, atrium, scene_name, search):
+    scene = {"cornell": cornell, "cornell_tessellated": cornell_tessellated, "atrium": atrium, "atrium_4wide": atrium}[scene_name]
+    search(scene_name)
     ctx.upload_scene(scene)
     ctx.set_instrumentation(True)
     rng = np.random.default_rng(11)
-    lo, hi = (-14.0, 14.0) if scene_name == "atrium" else (-0.6, 0.6)
+    lo, hi = (-14.0, 14.0) if scene_name.startswith("atrium") else (-0.6, 0.6)
     rays = random_rays(rng, 50000, lo, hi)
-    if scene_name == "atrium":
+    if scene_name.startswith("atrium"):
         rays[:, 1] = np.abs(rays[:, 1]) * 0.7
     w, h = 96, 54
     cam = scene.camera(w, h)
@@ -108,8 +118,8 @@ def test_closest_hit_bit_exact(ctx, oracle_q, cornell, cornell_tessellated, atri
     gpu = ctx.debug_trace_closest(rays, skip)
     counters = ctx.counters()
     ctx.set_instrumentation(False)
-    # more than 64 BVH2 nodes: persistent kernels over the compressed 4-wide BVH (oracle mode 2); at most 64 triangles: exhaustive
-    # search (oracle mode 0). The oracle states the same search, so counters agree too.
+    # more than 64 BVH2 nodes: persistent kernels over the compressed 8-wide BVH with leaf records (oracle mode 3; mode 2 = the 4-wide tree); at most
+    # 64 triangles: exhaustive search (oracle mode 0). The oracle states the same search, so counters agree too.
     cpu, (nodes, tris) = oracle_q.trace_closest(scene.desc, rays, skip, use_bvh=ctx.oracle_search(), with_lights=True)
     assert ctx.trace_variant() == EXPECTED_VARIANT[scene_name]
     assert np.array_equal(gpu.view(np.uint32), cpu.view(np.uint32)), "t, u, v and primitive id must match bit for bit"
@@ -118,21 +128,29 @@ def test_closest_hit_bit_exact(ctx, oracle_q, cornell, cornell_tessellated, atri
     # difference: two coincident surfaces (the Cornell boxes stand on the floor) whose hit distances differ in the
     # last ulp may be resolved to the other surface, because box culling compares against the best distance so far.
     brute, _ = oracle_q.trace_closest(scene.desc, rays[:8000], skip[:8000], use_bvh=False, with_lights=True)
-    differs = (brute.view(np.uint32) != cpu[:8000].view(np.uint32)).any(axis=1)
+    if ctx.trace_variant() == capi.TRACE_WIDE8_PERSISTENT:
+        # a leaf record solves its triangles from the corner they share, not from their first vertex: the same hit, with t / u / v rounded differently
+        differs = brute[:, 3].view(np.uint32) != cpu[:8000, 3].view(np.uint32)
+        same = ~differs & np.isfinite(brute[:, 0])
+        assert np.all(np.abs(brute[same, 0] - cpu[:8000][same, 0]) <= 2e-5 * (1.0 + np.abs(brute[same, 0])))
+        assert np.all(np.abs(brute[same, 1:3] - cpu[:8000][same, 1:3]) <= 2e-3)
+    else:
+        differs = (brute.view(np.uint32) != cpu[:8000].view(np.uint32)).any(axis=1)
     assert differs.mean() <= 2e-3
-    assert np.all(np.abs(brute[differs, 0] - cpu[:8000][differs, 0]) <= 1e-5 * (1.0 + np.abs(brute[differs, 0])))
+    assert np.all(np.abs(brute[differs, 0] - cpu[:8000][differs, 0]) <= 2e-5 * (1.0 + np.abs(brute[differs, 0])))
     assert (gpu[:, 3].view(np.uint32) != 0xFFFFFFFF).mean() > 0.5
 
 
-@pytest.mark.parametrize("scene_name", ["cornell", "cornell_tessellated", "atrium"])
-def test_shadow_rays_bit_exact(ctx, oracle_q, cornell, cornell_tessellated, atrium, scene_name):
-    scene = {"cornell": cornell, "cornell_tessellated": cornell_tessellated, "atrium": atrium}[scene_name]
+@pytest.mark.parametrize("scene_name", ["cornell", "cornell_tessellated", "atrium", "atrium_4wide"])
+def test_shadow_rays_bit_exact(ctx, oracle_q, cornell, cornell_tessellated, atrium, scene_name, search):
+    scene = {"cornell": cornell, "cornell_tessellated": cornell_tessellated, "atrium": atrium, "atrium_4wide": atrium}[scene_name]
+    search(scene_name)
     ctx.upload_scene(scene)
     ctx.set_instrumentation(True)
     rng = np.random.default_rng(13)
-    lo, hi = (-12.0, 12.0) if scene_name == "atrium" else (-0.45, 0.45)
+    lo, hi = (-12.0, 12.0) if scene_name.startswith("atrium") else (-0.45, 0.45)
     rays = random_rays(rng, 40000, lo, hi)
-    rays[:, 7] = rng.uniform(0.05, 30.0 if scene_name == "atrium" else 3.0, len(rays)).astype(np.float32)
+    rays[:, 7] = rng.uniform(0.05, 30.0 if scene_name.startswith("atrium") else 3.0, len(rays)).astype(np.float32)
     gpu = ctx.debug_trace_shadow(rays)
     counters = ctx.counters()
     ctx.set_instrumentation(False)
@@ -156,12 +174,20 @@ def rmse(a, b):
     return float(np.sqrt(np.mean((a[..., :3] - b[..., :3]) ** 2)))
 
 
-def image_bar(name, gpu, cpu, close_at_least, rmse_at_most, band=1e-3):
+def image_bar(name, gpu, cpu, close_at_least, rmse_at_most, band=1e-3, outliers=0):
     """The statistical image bar: the share of pixels within `band` relative of the oracle's and the RMSE, both stated per test from what
-    was measured on the MI355X (gpurun_out/r02_image_metrics.txt: the bars sit a factor of a few above the measured figures)."""
+    was measured on the MI355X (profiles/r02_image_metrics.txt, r03_image_metrics.txt: the bars sit a factor of a few above the measured figures).
+    `outliers`: that many pixels with the largest error are left out of the RMSE -- scenes with polished metals under a delta light hold the odd sample
+    whose path takes another discrete decision under the shade kernel's approximate arithmetic (one such firefly in a 48 x 27 x 4 spp frame is the whole
+    RMSE); profiles/r03_rmse_protocol_*.json shows those differences to be zero-mean. The share of close pixels bounds how many there may be."""
     rel = np.abs(gpu[..., :3] - cpu[..., :3]) / (np.abs(cpu[..., :3]) + 1e-3)
     close = float((rel.max(axis=-1) <= band).mean())
     value = rmse(gpu, cpu)
+    if outliers:
+        squared = ((gpu[..., :3] - cpu[..., :3]) ** 2).sum(axis=-1).ravel()
+        kept = np.sort(squared)[:len(squared) - outliers]
+        print(f"IMAGE-METRIC {name}: rmse of all pixels {value:.3e}, without the {outliers} worst {float(np.sqrt(kept.sum() / (3 * len(kept)))):.3e}")
+        value = float(np.sqrt(kept.sum() / (3 * len(kept))))
     print(f"IMAGE-METRIC {name}: close({band:g}) {close:.4f} rmse {value:.3e} mean {float(cpu[..., :3].mean()):.3f}")
     assert np.isfinite(gpu).all()
     assert close >= close_at_least, (name, close)
@@ -209,7 +235,7 @@ def test_atrium_image_matches_oracle(ctx, oracle_q, atrium):
     w, h, spp = 48, 27, 4
     gpu, _ = render_gpu(ctx, atrium, w, h, spp, 4)
     cpu, _, _ = oracle_q.render(atrium.desc, atrium.state, atrium.camera(w, h, max_bounce_count=4), w, h, spp, use_bvh=ctx.oracle_search())
-    image_bar("atrium_20k", gpu, cpu, 0.99, 1e-3, band=2e-3)
+    image_bar("atrium_20k", gpu, cpu, 0.995, 2e-4, band=2e-3, outliers=2)      # measured: 0.9992, 5e-5 without the outliers (at most one so far)
 
 
 def test_tiling_and_batching_are_bit_invariant(ctx, cornell):
@@ -381,7 +407,7 @@ def test_material_scene_image_matches_oracle(ctx, oracle_q, coat):
     assert scene.camera(64, 36).max_bounce_count == 32
     w, h, spp = 96, 54, 4
     gpu, gc = render_gpu(ctx, scene, w, h, spp, 32)
-    assert ctx.trace_variant() == capi.TRACE_WIDE_PERSISTENT
+    assert ctx.trace_variant() == capi.TRACE_WIDE8_PERSISTENT
     cpu, cc, _ = oracle_q.render(scene.desc, scene.state, scene.camera(w, h, max_bounce_count=32), w, h, spp, use_bvh=ctx.oracle_search())
     image_bar("material_coat" if coat else "material", gpu, cpu, 0.995, 1e-3, band=2e-3)
     for key in ("closest_rays", "shadow_rays"):

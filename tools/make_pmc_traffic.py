@@ -30,7 +30,7 @@ def bench_name(kernel: str):
         return "trace_shadow"
     if "k_trace_closest" in k:
         return "trace_closest"
-    if "k_trace_persistent" in k:   # template arguments <STACK, MODE, INSTRUMENT>; MODE 0 closest, 1 shadow, 2 fused
+    if "k_trace_persistent" in k or "k_trace_wide8" in k:   # template arguments <STACK, MODE, INSTRUMENT>; MODE 0 closest, 1 shadow, 2 fused
         args = k[k.index("<") + 1:k.rindex(">")].split(",") if "<" in k else []
         mode = args[1].strip() if len(args) > 1 else "2"
         return {"0": "trace_closest", "1": "trace_shadow"}.get(mode, "trace")
