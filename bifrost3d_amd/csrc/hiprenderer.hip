@@ -6,6 +6,9 @@
 // Replaces the OptiX context + context->launch() of OR/Renderer.cpp:273-574,1250-1265.
 // There is no CPU fallback: every entry point that needs the GPU fails with a status code.
 #include "kernels.h"
+#ifndef HIPR_WIDE8_LOW_BUCKET
+#define HIPR_WIDE8_LOW_BUCKET 0
+#endif
 #include "wide8_kernels.h"
 #include "launch.h"
 
@@ -163,7 +166,7 @@ struct HiprContext {
     int shade_blocks_per_cu = 0;        // persistent shade blocks per CU = waves per SIMD; 0: 3 (what the kernel is compiled for), 2 for all-Diffuse scenes (HIPR_SHADE_BLOCKS_PER_CU)
     int refill_below = 40;              // persistent kernels refill a wave once fewer lanes than this are busy (HIPR_REFILL_BELOW)
     int persistent_blocks_per_cu[3][3] = {{0, 0, 0}, {0, 0, 0}};   // [shadow][stack bucket]
-    int wide8_blocks_per_cu[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};   // [mode][stack bucket]
+    int wide8_blocks_per_cu[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};   // [mode][stack bucket]
 
     // bookkeeping
     HiprCounters total = {};   // since hipr_reset_counters
@@ -319,6 +322,10 @@ void launch_persistent_for_stack(HiprContext* c, const Wavefront& w, const PathS
     // the latency of its dependent gathers (atrium, 260 k triangles: 61.0 -> 57.7 ms of trace time per step). Deeper trees (the 10 M triangle
     // atrium) spill often enough that 32 LDS entries + scratch is the faster split (116.7 vs 119.9 ms).
     if (c->use_wide8()) {       // height h: at most h - 1 groups wait on the stack
+#if HIPR_WIDE8_LOW_BUCKET
+        if (c->wide8_height <= 9u) launch_wide8<8, MODE, INSTRUMENT>(c, w, in, closest_count, shadow_count, upper_bound, 3);
+        else
+#endif
         if (c->wide8_height <= uint32_t(WIDE8_STACK_SHALLOW) + 1u) launch_wide8<WIDE8_STACK_SHALLOW, MODE, INSTRUMENT>(c, w, in, closest_count, shadow_count, upper_bound, 0);
         else if (c->wide8_height <= 17u) launch_wide8<16, MODE, INSTRUMENT>(c, w, in, closest_count, shadow_count, upper_bound, 1);
         else launch_wide8<32, MODE, INSTRUMENT>(c, w, in, closest_count, shadow_count, upper_bound, 2);

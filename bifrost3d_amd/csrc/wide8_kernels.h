@@ -20,6 +20,10 @@
 //     child is hit, the current group is pushed when it still has pending children, and the node's hits become the current group.
 //   * visiting a record: triangle A = (a; e1, e2), then B = (a; e2, e3), each with the Moeller-Trumbore solve of kernels.h on the stored edges; the
 //     weights (1 - u - v, u, v) of the record's corners become the scene triangle's (u, v) through the record's selectors.
+// Tried and not adopted (round 3): TWO rays per lane, the lane bringing forward whichever of its rays has an item of the kind the wave is working on
+// (tools/experiments/wide8_kernels_two_rays_per_lane.h.txt; per-ray order unchanged, the parity tests pass with it). The wave's instructions would find
+// ~56 instead of 38 lanes with work, but the second set of ray registers (26 per lane) does not fit next to the node block's ~50 temporaries: at four
+// waves per SIMD the compiler still spills 114 VGPRs and the atrium's trace time goes from 50.2 to 83.0 ms per step (profiles/r03_ab_two_rays_per_lane.txt).
 // The wave-level machinery (persistent waves claiming 64-ray chunks from sharded counters, refilling idle lanes, one KIND of item per iteration chosen by
 // a wave vote, fused closest-hit + shadow launches) is that of k_trace_persistent (kernels.h), which remains for the 4-wide tree.
 #pragma once
@@ -39,7 +43,10 @@ constexpr int WIDE8_STACK_SHALLOW = 12;      // 12 KB per block of two waves: tw
 #ifndef HIPR_WIDE8_WAVES
 #define HIPR_WIDE8_WAVES 6
 #endif
-HD constexpr int wide8_waves_per_simd(int stack_entries) { return stack_entries <= 12 ? HIPR_WIDE8_WAVES : (stack_entries <= 16 ? 5 : 4); }
+#ifndef HIPR_WIDE8_WAVES_LOW
+#define HIPR_WIDE8_WAVES_LOW 6
+#endif
+HD constexpr int wide8_waves_per_simd(int stack_entries) { return stack_entries <= 8 ? HIPR_WIDE8_WAVES_LOW : (stack_entries <= 12 ? HIPR_WIDE8_WAVES : (stack_entries <= 16 ? 5 : 4)); }
 
 template <int STACK, int MODE, bool INSTRUMENT>
 __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(wide8_waves_per_simd(STACK)))) void k_trace_wide8(DeviceScene sc, Wide8Scene tree, PathState in, float4* hits, ShadowQueue q,

@@ -263,7 +263,9 @@ struct Collapse {
     }
 
     // Writes the wide node of tree node n into `slot` and its subtree behind the current end of the array; returns the height below (and including) it.
-    uint32_t emit_node(uint32_t slot, int32_t n, uint32_t depth) {
+    // `queue` (breadth-first layout): the inner children are not descended into here but appended for the caller's loop.
+    struct Queued { uint32_t slot; int32_t node; uint32_t depth; };
+    uint32_t emit_node(uint32_t slot, int32_t n, uint32_t depth, std::vector<Queued>* queue = nullptr) {
         std::vector<int32_t> children;
         const TreeNode& t = tree[size_t(n)];
         if (t.left < 0) children.push_back(n);      // a scene of a single record: the root node holds it
@@ -305,8 +307,10 @@ struct Collapse {
             if (child_at[s] < 0) continue;
             const int32_t child = children[size_t(child_at[s])];
             const uint32_t child_slot = next++;
-            if (tree[size_t(child)].left >= 0) height = std::max(height, emit_node(child_slot, child, depth + 1));
-            else {
+            if (tree[size_t(child)].left >= 0) {
+                if (queue) { queue->push_back({child_slot, child, depth + 1}); height = std::max(height, depth + 1); }
+                else height = std::max(height, emit_node(child_slot, child, depth + 1));
+            } else {
                 out.slots[child_slot].leaf = tree[size_t(child)].record;
                 out.leaf_count += 1;
                 out.paired_leaves += tree[size_t(child)].record.triangle[1] != HIPR_LEAF8_NONE;
@@ -377,7 +381,16 @@ Wide8Result build_wide8(const std::vector<HiprBvhNode>& nodes, const std::vector
     Collapse collapse(nodes, triangles, result);
     collapse.build_tree();
     collapse.optimise();
-    result.height = collapse.emit_node(0, 0, 1);
+    // Layout: depth first (a subtree's slots stay together) or, HIPR_WIDE8_LAYOUT=bfs, level by level (the upper levels, mostly inner nodes, stay dense).
+    const char* layout = std::getenv("HIPR_WIDE8_LAYOUT");
+    if (layout && !std::strcmp(layout, "bfs")) {
+        std::vector<Collapse::Queued> queue = {{0u, 0, 1u}};
+        for (size_t next = 0; next < queue.size() && !collapse.overflow; ++next) {
+            const Collapse::Queued item = queue[next];
+            result.height = std::max(result.height, collapse.emit_node(item.slot, item.node, item.depth, &queue));
+        }
+    } else
+        result.height = collapse.emit_node(0, 0, 1);
     if (collapse.overflow) return Wide8Result();      // more than 2^24 slots: the caller keeps the 4-wide tree
     return result;
 }
