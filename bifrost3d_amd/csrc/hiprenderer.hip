@@ -78,7 +78,7 @@ struct Wavefront {
     hipStream_t stream = nullptr;       // wavefront 0 runs on the context stream, the others on their own
     hipStream_t own_stream = nullptr;
     hipEvent_t shade_done[2] = {nullptr, nullptr}, counts_copied[2] = {nullptr, nullptr}, finished = nullptr;   // by bounce parity: two bounces are in flight
-    DeviceBuffer path[2][4], hits, shadow[3], queue_counts;
+    DeviceBuffer path[2][4], hits, shadow[3], queue_counts, order, order_taken;   // order: k_classify_hits' listing of a bounce's rays; order_taken: its two counters, one 8-byte word per bounce parity
     uint32_t* host_counts = nullptr;    // pinned: {continuing paths, shadow rays} per bounce parity, [4] staging word
     uint32_t first_slot = 0, n_slots = 0;
 
@@ -88,7 +88,7 @@ struct Wavefront {
     ShadowQueue shadow_queue() const { return {shadow[0].as<float4>(), shadow[1].as<float4>(), shadow[2].as<float4>()}; }
     void release() {
         for (auto& buffers : path) for (DeviceBuffer& b : buffers) b.release();
-        hits.release(); queue_counts.release();
+        hits.release(); queue_counts.release(); order.release(); order_taken.release();
         for (DeviceBuffer& b : shadow) b.release();
         for (hipEvent_t e : shade_done) if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : counts_copied) if (e) (void)hipEventDestroy(e);
@@ -165,6 +165,7 @@ struct HiprContext {
     int blocks_per_cu_override = 0;     // HIPR_BLOCKS_PER_CU
     int shade_blocks_per_cu = 0;        // persistent shade blocks per CU = waves per SIMD; 0: 3 (what the kernel is compiled for), 2 for all-Diffuse scenes (HIPR_SHADE_BLOCKS_PER_CU)
     int refill_below = 40;              // persistent kernels refill a wave once fewer lanes than this are busy (HIPR_REFILL_BELOW)
+    bool shade_ordered = true;          // k_classify_hits before k_shade (HIPR_SHADE_ORDERED=0: shade in queue order)
     int persistent_blocks_per_cu[3][3] = {{0, 0, 0}, {0, 0, 0}};   // [shadow][stack bucket]
     int wide8_blocks_per_cu[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};   // [mode][stack bucket]
 
@@ -383,11 +384,21 @@ void launch_trace_fused(HiprContext* c, const Wavefront& w, const PathState& in,
 }
 
 void launch_shade(HiprContext* c, const Wavefront& w, const HiprCameraState& camera, int cur, uint32_t alive, const uint32_t* in_count, uint32_t* out_counts) {
+    // The rays of the bounce listed by kind (kernels.h k_classify_hits): the shade kernel's batches then hold surface hits only, or none.
+    const uint32_t* order = nullptr;
+    // Pays where a good share of a bounce's rays did not hit a surface (the atrium's open roof: shade 23.3 -> 21.4 ms per step) and costs a pass over the hits
+    // where nearly all did (the closed Cornell box: +7 %): on for the scenes of the persistent kernels, which are the large ones.
+    if (c->shade_ordered && c->use_persistent() && c->entry == HIPR_ENTRY_PATH_TRACING) {
+        unsigned long long* taken = reinterpret_cast<unsigned long long*>(w.order_taken.as<uint32_t>() + COUNT_PAIR_STRIDE * cur);
+        (void)hipMemsetAsync(taken, 0, 8, w.stream);
+        hipLaunchKernelGGL(k_classify_hits, dim3(grid_for(alive, 256u * CLASSIFY_ROUNDS, uint32_t(c->cu_count) * 8u)), dim3(256), 0, w.stream, w.hits.as<float4>(), in_count, w.order.as<uint32_t>(), taken);
+        order = w.order.as<uint32_t>();
+    }
     // persistent blocks: three per CU stay resident (3 waves per SIMD), each walks the queue with a grid stride, one batch ahead on its inputs
     // measured: the Default / Transmissive kernels gain from a third wave per SIMD (atrium 29.4 -> 25.9 ms of shading per step), the lighter all-Diffuse
     // kernel loses (Cornell 18 390 -> 17 194 Mrays/s)
     const uint32_t blocks_per_cu = c->shade_blocks_per_cu > 0 ? uint32_t(c->shade_blocks_per_cu) : (c->shading_models == 2 ? 2u : 3u);
-    ShadeLaunch a = {grid_for(alive, SHADE_BLOCK, uint32_t(c->cu_count) * blocks_per_cu), w.stream, c->scene, camera, c->entry, w.path_state(cur), w.hits.as<float4>(), w.path_state(1 - cur),
+    ShadeLaunch a = {grid_for(alive, SHADE_BLOCK, uint32_t(c->cu_count) * blocks_per_cu), w.stream, c->scene, camera, c->entry, w.path_state(cur), w.hits.as<float4>(), order, w.path_state(1 - cur),
                      w.shadow_queue(), c->radiance.as<float4>(), in_count, reinterpret_cast<unsigned long long*>(out_counts), c->counters.as<DeviceCounters>()};
     hipr::launch_shade(c->shading_models, a);
 }
@@ -411,12 +422,13 @@ int partition_path_slots(HiprContext* c) {
         const size_t bytes = size_t(std::max(w.n_slots, 64u)) * 16;
         if (g >= c->wavefront_count) {   // queues of wavefronts this pass size does not use go back to the allocator
             for (auto& buffers : w.path) for (DeviceBuffer& b : buffers) b.release();
-            w.hits.release();
+            w.hits.release(); w.order.release();
             for (DeviceBuffer& b : w.shadow) b.release();
             continue;
         }
         for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) r |= w.path[i][j].resize(bytes);
         r |= w.hits.resize(bytes);
+        r |= w.order.resize(bytes / 4);
         for (int j = 0; j < 3; ++j) r |= w.shadow[j].resize(bytes);
     }
     r |= c->radiance.resize(slots * 16);
@@ -646,7 +658,7 @@ int hipr_create(int device_id, HiprContext** out_context) {
         for (int i = 0; i < 2; ++i)
             ok = ok && hipEventCreateWithFlags(&w.shade_done[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&w.counts_copied[i], hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&w.finished, hipEventDisableTiming) == hipSuccess && hipHostMalloc((void**)&w.host_counts, 8 * sizeof(uint32_t)) == hipSuccess &&
-             w.queue_counts.resize(2 * COUNT_PAIR_STRIDE * sizeof(uint32_t)) == 0;
+             w.queue_counts.resize(2 * COUNT_PAIR_STRIDE * sizeof(uint32_t)) == 0 && w.order_taken.resize(2 * COUNT_PAIR_STRIDE * sizeof(uint32_t)) == 0;
     }
     if (!ok) {
         hipr_destroy(c);
@@ -665,6 +677,7 @@ int hipr_create(int device_id, HiprContext** out_context) {
     if (const char* v = getenv("HIPR_BLOCKS_PER_CU")) c->blocks_per_cu_override = atoi(v);
     if (const char* v = getenv("HIPR_WAVEFRONTS")) c->wavefront_limit = std::max(0, std::min(MAX_WAVEFRONTS, atoi(v)));
     if (const char* v = getenv("HIPR_TRACE_LOG")) c->trace_log = atoi(v) != 0;
+    if (const char* v = getenv("HIPR_SHADE_ORDERED")) c->shade_ordered = atoi(v) != 0;
     HIP_TRY(hipMemsetAsync(c->counters.ptr, 0, sizeof(DeviceCounters), c->stream));
 
     float offsets[256 * 4];

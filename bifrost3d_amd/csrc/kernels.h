@@ -30,7 +30,7 @@ constexpr int TRACE_BLOCK = 128;   // 2 waves; LDS stack = STACK * 128 * 4 B
 #define HIPR_SHADE_BLOCK_THREADS 256
 #endif
 constexpr int SHADE_BLOCK = HIPR_SHADE_BLOCK_THREADS;
-constexpr int SHADE_TRIANGLE_QUADS = 6;   // float4 per shading record (96 B), see k_build_shade_triangles
+constexpr int SHADE_TRIANGLE_QUADS = 8;   // float4 per shading record (128 B = one cache line), see k_build_shade_triangles
 
 struct DeviceScene {
     const float4* nodes;
@@ -951,10 +951,12 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(tra
 // ---------------------------------------------------------------------------------------------
 // Shading records. The reference resolves a hit through instance -> mesh buffers -> index -> vertex (TriangleAttributes.cu:35-84,
 // four dependent fetches); here everything the shade kernel interpolates is flattened per world-space triangle when the scene
-// is uploaded, so a hit costs ONE dependent fetch of 96 B next to the 48 B of positions:
-//   quad 0..2: object-to-world transformed vertex normal i (not normalised: sum(w_i * M n_i) = M sum(w_i * n_i), so the
+// is uploaded, so a hit costs ONE dependent fetch of ONE 128 B cache line (round 3: the world-space positions sit in the record too -- the shade kernel's
+// gathers miss the L2, and a 48 B triangle plus a 96 B record used to touch three to four lines per hit):
+//   quad 0..2: the triangle as in `triangles` (v0, v1, v2, instance index, primitive index), .w of quad 2 = bits(tint2)
+//   quad 3..5: object-to-world transformed vertex normal i (not normalised: sum(w_i * M n_i) = M sum(w_i * n_i), so the
 //              interpolated normal is the one the per-hit transform gives), .w = bits(material index | instance id | mesh flags)
-//   quad 3   : uv0.xy, uv1.xy       quad 4: uv2.xy, bits(tint0), bits(tint1)       quad 5: bits(tint2), 0, 0, 0
+//   quad 6   : uv0.xy, uv1.xy       quad 7: uv2.xy, bits(tint0), bits(tint1)
 // Per-vertex emission (rare) still goes through the instance.
 // ---------------------------------------------------------------------------------------------
 // What the trace kernels read per triangle: the vertex and the two edges the test works on (the edges rounded once, here, as
@@ -979,7 +981,7 @@ __global__ __launch_bounds__(256) void k_build_shade_triangles(DeviceScene sc, f
     const uint32_t i[3] = {idx[0], idx[1], idx[2]};
     const float* M = inst.object_to_world;
     const uint32_t words[3] = {uint32_t(inst.material_index), uint32_t(inst.instance_id), inst.mesh_flags};
-    float4* q = out + SHADE_TRIANGLE_QUADS * size_t(t);
+    float4* q = out + SHADE_TRIANGLE_QUADS * size_t(t) + 3;
     for (int k = 0; k < 3; ++k) {
         f3 n = {0, 0, 0};
         if (inst.mesh_flags & HIPR_MESH_NORMALS) {
@@ -994,7 +996,63 @@ __global__ __launch_bounds__(256) void k_build_shade_triangles(DeviceScene sc, f
     if (inst.mesh_flags & HIPR_MESH_TINTS) for (int k = 0; k < 3; ++k) tint[k] = sc.tints[inst.vertex_offset + i[k]];
     q[3] = make_float4(uv[0].x, uv[0].y, uv[1].x, uv[1].y);
     q[4] = make_float4(uv[2].x, uv[2].y, __uint_as_float(tint[0]), __uint_as_float(tint[1]));
-    q[5] = make_float4(__uint_as_float(tint[2]), 0.0f, 0.0f, 0.0f);
+    q[-3] = sc.triangles[3 * size_t(t)];
+    q[-2] = sc.triangles[3 * size_t(t) + 1];
+    q[-1] = make_float4(tc.x, tc.y, tc.z, __uint_as_float(tint[2]));
+}
+
+// ---------------------------------------------------------------------------------------------
+// K5c: the order in which the shade kernel takes the rays of a bounce. A wave of k_shade runs the surface code -- attributes, material, three RIS light
+// candidates, BSDF sample: thousands of instructions -- as long as ONE of its 64 rays hit a triangle, and 42 % of the atrium's traced rays did not
+// (they escaped, hit a light, or sit in a dead slot): measured 28 of 64 lanes live per instruction. This pass lists the indices of the rays that hit a
+// triangle from the front of `order` and all others from its back (one 64-bit atomic per block of 256 rays reserves both ranges; inside a block the rays
+// keep their order), so that all but one or two of the shade kernel's batches are of one kind. Which rays are shaded, and what each yields, is unchanged.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t CLASSIFY_ROUNDS = 16;      // rounds of 256 rays a block lists per reservation: 4096 rays per atomic (one 64-bit atomic on one address costs ~8 ns device-wide)
+__global__ __launch_bounds__(256) void k_classify_hits(const float4* __restrict__ hits, const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ order,
+                                                       unsigned long long* taken /* low word: surface hits listed, high word: others listed */) {
+    __shared__ uint32_t s_surface[4], s_other[4];
+    __shared__ unsigned long long s_base;
+    const uint32_t n = *count_ptr;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (uint32_t chunk = blockIdx.x * (256u * CLASSIFY_ROUNDS); chunk < n; chunk += gridDim.x * (256u * CLASSIFY_ROUNDS)) {
+        // pass 1: what the chunk holds, one bit per round and thread
+        uint32_t surface_bits = 0u, valid_bits = 0u;
+#pragma unroll
+        for (uint32_t r = 0; r < CLASSIFY_ROUNDS; ++r) {
+            const uint32_t i = chunk + r * 256u + threadIdx.x;
+            const uint32_t id = i < n ? __float_as_uint(hits[i].w) : HIPR_HIT_MISS;
+            surface_bits |= (i < n && id != HIPR_HIT_MISS && !(id & HIPR_HIT_LIGHT)) ? (1u << r) : 0u;
+            valid_bits |= i < n ? (1u << r) : 0u;
+        }
+        uint32_t surfaces = uint32_t(__popc(surface_bits)), others = uint32_t(__popc(valid_bits & ~surface_bits));
+        for (int off = 32; off > 0; off >>= 1) { surfaces += __shfl_xor(surfaces, off); others += __shfl_xor(others, off); }
+        if (lane == 0) { s_surface[wave] = surfaces; s_other[wave] = others; }
+        __syncthreads();
+        if (threadIdx.x == 0) s_base = atomicAdd(taken, (unsigned long long)(s_surface[0] + s_surface[1] + s_surface[2] + s_surface[3]) |
+                                                         (unsigned long long)(s_other[0] + s_other[1] + s_other[2] + s_other[3]) << 32);
+        __syncthreads();
+        // pass 2: places inside the block's two ranges, rays in (round, thread) order
+        uint32_t front = uint32_t(s_base), back = uint32_t(s_base >> 32);
+#pragma unroll
+        for (uint32_t r = 0; r < CLASSIFY_ROUNDS; ++r) {
+            const bool surface = (surface_bits >> r) & 1u, other = ((valid_bits & ~surface_bits) >> r) & 1u;
+            const unsigned long long surface_mask = wave_ballot(surface), other_mask = wave_ballot(other);
+            if (lane == 0) { s_surface[wave] = uint32_t(__popcll(surface_mask)); s_other[wave] = uint32_t(__popcll(other_mask)); }
+            __syncthreads();
+            uint32_t before_surface = 0, before_other = 0, round_surface = 0, round_other = 0;
+            for (uint32_t w = 0; w < 4; ++w) {
+                before_surface += w < wave ? s_surface[w] : 0u; before_other += w < wave ? s_other[w] : 0u;
+                round_surface += s_surface[w]; round_other += s_other[w];
+            }
+            const uint32_t i = chunk + r * 256u + threadIdx.x;
+            if (surface) order[front + before_surface + uint32_t(__popcll(surface_mask & lt))] = i;
+            if (other) order[n - 1u - (back + before_other + uint32_t(__popcll(other_mask & lt)))] = i;
+            front += round_surface; back += round_other;
+            __syncthreads();
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

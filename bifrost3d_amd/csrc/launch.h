@@ -13,6 +13,7 @@ struct ShadeLaunch {
     int entry;                 // HIPR_ENTRY_*
     PathState in;
     const float4* hits;
+    const uint32_t* order;     // k_classify_hits: the queue entries in the order the kernel takes them (surface hits first); nullptr = queue order
     PathState out;
     ShadowQueue shadows;
     float4* radiance;

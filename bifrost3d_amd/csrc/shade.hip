@@ -10,7 +10,7 @@ namespace hipr {
 
 template <int MODELS, bool AOV>
 static void launch_models(const ShadeLaunch& a) {
-    hipLaunchKernelGGL((k_shade<MODELS, AOV>), dim3(a.grid), dim3(SHADE_BLOCK), 0, a.stream, a.scene, a.camera, a.entry, a.in, a.hits, a.out, a.shadows, a.radiance,
+    hipLaunchKernelGGL((k_shade<MODELS, AOV>), dim3(a.grid), dim3(SHADE_BLOCK), 0, a.stream, a.scene, a.camera, a.entry, a.in, a.hits, a.order, a.out, a.shadows, a.radiance,
                        a.in_count, a.out_counts, a.counters);
 }
 

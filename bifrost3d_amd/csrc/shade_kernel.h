@@ -275,14 +275,17 @@ struct ShadeInputs {
     float4 o, d, t, hit;   // origin + tmin, direction + pdf, throughput + bounces, (t, u, v, id)
 };
 
-HD ShadeInputs shade_fetch_inputs(const PathState& in, const float4* hits, uint32_t i, uint32_t n) {
+// `i`: the queue entry, or HIPR_DEAD_SLOT for none (past the end of the queue).
+HD ShadeInputs shade_fetch_inputs(const PathState& in, const float4* hits, uint32_t i) {
     ShadeInputs r;
     r.meta = make_uint4(HIPR_DEAD_SLOT, 0u, 0u, 0u);
     r.o = r.d = r.t = make_float4(0, 0, 0, 0);
     r.hit = make_float4(0, 0, 0, __uint_as_float(HIPR_HIT_MISS));
-    if (i < n) { r.meta = in.meta[i]; r.o = in.o_tmin[i]; r.d = in.d_pdf[i]; r.t = in.thr_bounces[i]; r.hit = hits[i]; }
+    if (i != HIPR_DEAD_SLOT) { r.meta = in.meta[i]; r.o = in.o_tmin[i]; r.d = in.d_pdf[i]; r.t = in.thr_bounces[i]; r.hit = hits[i]; }
     return r;
 }
+// The queue entry that place j of the shading order holds (k_classify_hits; the queue's own order without it).
+HD uint32_t shade_entry(const uint32_t* order, uint32_t j, uint32_t n) { return j < n ? (order ? order[j] : j) : HIPR_DEAD_SLOT; }
 HD bool shade_hits_triangle(const ShadeInputs& in) {
     const uint32_t id = __float_as_uint(in.hit.w);
     return in.meta.x != HIPR_DEAD_SLOT && id != HIPR_HIT_MISS && !(id & HIPR_HIT_LIGHT);
@@ -292,10 +295,10 @@ HD ShadeGeometry shade_fetch_geometry(const DeviceScene& sc, const ShadeInputs& 
     g.ta = g.tb = g.tc = g.s0 = g.s1 = g.s2 = g.s3 = g.s4 = g.s5 = make_float4(0, 0, 0, 0);
     if (shade_hits_triangle(in)) {
         const uint32_t id = __float_as_uint(in.hit.w);
-        const float4* tp = sc.triangles + 3 * size_t(id);
-        const float4* sp = sc.shade_triangles + SHADE_TRIANGLE_QUADS * size_t(id);
-        g.ta = tp[0]; g.tb = tp[1]; g.tc = tp[2];
-        g.s0 = sp[0]; g.s1 = sp[1]; g.s2 = sp[2]; g.s3 = sp[3]; g.s4 = sp[4]; g.s5 = sp[5];
+        const float4* sp = sc.shade_triangles + SHADE_TRIANGLE_QUADS * size_t(id);      // one 128 B line: positions, normals, uvs, tints, ids
+        g.ta = sp[0]; g.tb = sp[1]; g.tc = sp[2];
+        g.s0 = sp[3]; g.s1 = sp[4]; g.s2 = sp[5]; g.s3 = sp[6]; g.s4 = sp[7];
+        g.s5 = make_float4(g.tc.w, 0.0f, 0.0f, 0.0f);
     }
     return g;
 }
@@ -319,7 +322,7 @@ HD HiprMaterial shade_fetch_material(const DeviceScene& sc, const ShadeInputs& i
 #endif
 constexpr uint32_t SHADE_LDS_LIGHTS = 32;   // light arrays up to this size are copied to LDS (1.5 KB); larger ones are read from global memory
 template <int MODELS, bool AOV>
-__global__ __launch_bounds__(SHADE_BLOCK, HIPR_SHADE_WAVES) void k_shade(DeviceScene sc, HiprCameraState cam, int entry, PathState in, const float4* hits, PathState out,
+__global__ __launch_bounds__(SHADE_BLOCK, HIPR_SHADE_WAVES) void k_shade(DeviceScene sc, HiprCameraState cam, int entry, PathState in, const float4* hits, const uint32_t* order, PathState out,
                                                         ShadowQueue shadows, float4* radiance, const uint32_t* count_ptr, unsigned long long* out_counts,
                                                         DeviceCounters* counters) {
 #if HIPR_SHADE_ONE_BARRIER
@@ -341,7 +344,8 @@ __global__ __launch_bounds__(SHADE_BLOCK, HIPR_SHADE_WAVES) void k_shade(DeviceS
     if (blockIdx.x * SHADE_BLOCK >= n) return;
     const uint32_t stride = gridDim.x * SHADE_BLOCK;
     uint32_t base = blockIdx.x * SHADE_BLOCK;
-    ShadeInputs cur = shade_fetch_inputs(in, hits, base + threadIdx.x, n);
+    ShadeInputs cur = shade_fetch_inputs(in, hits, shade_entry(order, base + threadIdx.x, n));
+    uint32_t next_entry = shade_entry(order, base + stride + threadIdx.x, n);      // the entries are looked up two batches ahead, the inputs one
     for (uint32_t w = threadIdx.x; w < SOBOL_TABLE_WORDS; w += SHADE_BLOCK) s_sobol[w] = sc.sobol_tables[w];
 #if HIPR_SHADE_LDS_TABLES
     for (uint32_t w = threadIdx.x; w < 32 * 32; w += SHADE_BLOCK) { s_ggx_rho[w] = sc.tables.ggx_rho[w]; s_alpha[w] = sc.tables.alpha[w]; }
@@ -367,7 +371,8 @@ __global__ __launch_bounds__(SHADE_BLOCK, HIPR_SHADE_WAVES) void k_shade(DeviceS
 #endif
     for (; base < n; base += stride) {
         // inputs of the next batch: issued now, first used after this batch has been shaded
-        const ShadeInputs next = shade_fetch_inputs(in, hits, base + stride + threadIdx.x, n);
+        const ShadeInputs next = shade_fetch_inputs(in, hits, next_entry);
+        next_entry = shade_entry(order, base + 2u * stride + threadIdx.x, n);
 
         ShadeOutput so;
         so.continues = so.shadow = so.shaded = false;

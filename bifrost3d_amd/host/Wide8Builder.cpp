@@ -16,6 +16,8 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
+#include <cstdio>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -78,7 +80,7 @@ bool make_record(const std::vector<HiprTriangle>& triangles, uint32_t index_a, u
 struct TreeNode {
     Box box;
     int32_t left = -1, right = -1;      // both -1: a leaf
-    HiprLeaf8 record = {};
+    int32_t record = -1;                // leaf: index into Collapse::records
 };
 
 struct Collapse {
@@ -87,6 +89,7 @@ struct Collapse {
     Wide8Result& out;
     bool overflow = false;
     std::vector<TreeNode> tree;
+    std::vector<HiprLeaf8> records;
     Collapse(const std::vector<HiprBvhNode>& n, const std::vector<HiprTriangle>& t, Wide8Result& o) : nodes(n), triangles(t), out(o) {}
     // Ylitie et al. 2017, section 3.1: cost[n][i - 1] = the lowest SAH cost of the subtree of n when it appears in its parent wide node as a forest of at
     // most i roots (i = 1 .. 7); a node that becomes a wide node itself hands its two subtrees up to 8 roots in total. split[n][j - 2] = how many of j roots
@@ -104,15 +107,19 @@ struct Collapse {
         return b;
     }
 
-    // The records of a BVH2 leaf: every triangle pairs with the first later one of the same instance that shares exactly two corners with it.
-    void records_of_leaf(int32_t ref, std::vector<TreeNode>& into) const {
+    // The records of a BVH2 leaf (at most 8): every triangle pairs with the first later one of the same instance that shares exactly two corners with it.
+    // The records go to `records`; `leaves` receives one tree leaf per record. Returns their number.
+    size_t records_of_leaf(int32_t ref, TreeNode* leaves) {
         const uint32_t code = uint32_t(~ref), first = code >> 3, count = (code & 7u) + 1u;
         bool used[8] = {false, false, false, false, false, false, false, false};
+        size_t made = 0;
         for (uint32_t i = 0; i < count; ++i) {
             if (used[i]) continue;
             used[i] = true;
             const HiprTriangle& A = triangles[first + i];
-            TreeNode leaf;
+            TreeNode& leaf = leaves[made++];
+            leaf = TreeNode();
+            HiprLeaf8 record;
             bool paired = false;
             for (uint32_t j = i + 1; j < count && !paired; ++j) {
                 if (used[j] || triangles[first + j].instance_index != A.instance_index) continue;
@@ -125,11 +132,13 @@ struct Collapse {
                 }
                 if (shared != 2) continue;
                 // A as (a, b, c) with b its own corner: a = the vertex before b, c = the one after
-                if (make_record(triangles, first + i, first + j, (own_a + 2) % 3, leaf.record)) { used[j] = true; paired = true; leaf.box = triangle_box(A); leaf.box.grow(triangle_box(B)); }
+                if (make_record(triangles, first + i, first + j, (own_a + 2) % 3, record)) { used[j] = true; paired = true; leaf.box = triangle_box(A); leaf.box.grow(triangle_box(B)); }
             }
-            if (!paired) { make_record(triangles, first + i, HIPR_LEAF8_NONE, 0, leaf.record); leaf.box = triangle_box(A); }
-            into.push_back(leaf);
+            if (!paired) { make_record(triangles, first + i, HIPR_LEAF8_NONE, 0, record); leaf.box = triangle_box(A); }
+            leaf.record = int32_t(records.size());
+            records.push_back(record);
         }
+        return made;
     }
 
     // Appends the subtree of a BVH2 child reference (inner node or leaf) and returns its index.
@@ -151,17 +160,16 @@ struct Collapse {
                 pending.push_back({n.child[1], child_box(n, 1), index, 1});
                 pending.push_back({n.child[0], child_box(n, 0), index, 0});
             } else {
-                std::vector<TreeNode> records;
-                records_of_leaf(p.ref, records);
+                TreeNode leaves[8];
+                const size_t r = records_of_leaf(p.ref, leaves);
                 // r records -> a chain: ((r0, r1), r2) ... numbered parent first
                 index = int32_t(tree.size());
-                if (records.size() == 1) tree.push_back(records[0]);
+                if (r == 1) tree.push_back(leaves[0]);
                 else {
                     // inner nodes of the chain, outermost first
-                    const size_t r = records.size();
-                    std::vector<Box> prefix(r);
-                    prefix[0] = records[0].box;
-                    for (size_t k = 1; k < r; ++k) { prefix[k] = prefix[k - 1]; prefix[k].grow(records[k].box); }
+                    Box prefix[8];
+                    prefix[0] = leaves[0].box;
+                    for (size_t k = 1; k < r; ++k) { prefix[k] = prefix[k - 1]; prefix[k].grow(leaves[k].box); }
                     int32_t parent = -1;
                     for (size_t k = r - 1; k >= 1; --k) {     // node covering records 0..k: left = node covering 0..k-1 (or record 0), right = record k
                         const int32_t inner = int32_t(tree.size());
@@ -169,12 +177,12 @@ struct Collapse {
                         tree[size_t(inner)].box = prefix[k];
                         if (parent >= 0) tree[size_t(parent)].left = inner;
                         const int32_t right_leaf = int32_t(tree.size());
-                        tree.push_back(records[k]);
+                        tree.push_back(leaves[k]);
                         tree[size_t(inner)].right = right_leaf;
                         parent = inner;
                     }
                     const int32_t first_leaf = int32_t(tree.size());
-                    tree.push_back(records[0]);
+                    tree.push_back(leaves[0]);
                     tree[size_t(parent)].left = first_leaf;
                 }
             }
@@ -185,6 +193,8 @@ struct Collapse {
     }
 
     void build_tree() {
+        tree.reserve(triangles.size() + triangles.size() / 8 + 16);
+        records.reserve(triangles.size() / 2 + triangles.size() / 8 + 16);
         const HiprBvhNode& root = nodes[0];
         if (root.child[0] == root.child[1] && root.child[0] < 0) {      // the single-leaf root references its leaf twice
             Box b = child_box(root, 0);
@@ -311,9 +321,9 @@ struct Collapse {
                 if (queue) { queue->push_back({child_slot, child, depth + 1}); height = std::max(height, depth + 1); }
                 else height = std::max(height, emit_node(child_slot, child, depth + 1));
             } else {
-                out.slots[child_slot].leaf = tree[size_t(child)].record;
+                out.slots[child_slot].leaf = records[size_t(tree[size_t(child)].record)];
                 out.leaf_count += 1;
-                out.paired_leaves += tree[size_t(child)].record.triangle[1] != HIPR_LEAF8_NONE;
+                out.paired_leaves += out.slots[child_slot].leaf.triangle[1] != HIPR_LEAF8_NONE;
             }
         }
         return height;
@@ -379,8 +389,11 @@ Wide8Result build_wide8(const std::vector<HiprBvhNode>& nodes, const std::vector
     result.slots.reserve(triangles.size() / 2 + triangles.size() / 6 + 16);
     result.slots.resize(1);
     Collapse collapse(nodes, triangles, result);
+    const auto t0 = std::chrono::steady_clock::now();
     collapse.build_tree();
+    const auto t1 = std::chrono::steady_clock::now();
     collapse.optimise();
+    const auto t2 = std::chrono::steady_clock::now();
     // Layout: depth first (a subtree's slots stay together) or, HIPR_WIDE8_LAYOUT=bfs, level by level (the upper levels, mostly inner nodes, stay dense).
     const char* layout = std::getenv("HIPR_WIDE8_LAYOUT");
     if (layout && !std::strcmp(layout, "bfs")) {
@@ -391,6 +404,9 @@ Wide8Result build_wide8(const std::vector<HiprBvhNode>& nodes, const std::vector
         }
     } else
         result.height = collapse.emit_node(0, 0, 1);
+    if (std::getenv("HIPR_BVH_TIMING"))
+        fprintf(stderr, "[hipr]   8-wide: records + binary tree %.3f s, collapse optimisation %.3f s, layout + quantisation %.3f s\n", std::chrono::duration<double>(t1 - t0).count(),
+                std::chrono::duration<double>(t2 - t1).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t2).count());
     if (collapse.overflow) return Wide8Result();      // more than 2^24 slots: the caller keeps the 4-wide tree
     return result;
 }

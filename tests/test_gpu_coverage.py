@@ -47,6 +47,14 @@ def render_gpu(ctx, scene, w, h, spp, max_bounce, samples_per_pass=1, state=None
     return ctx.read_accumulation(), ctx.counters()
 
 
+def rmse_without_worst(gpu, cpu, outliers):
+    """RMSE over all but the `outliers` pixels of largest error: a path that takes another discrete decision under the shade kernel's approximate
+    arithmetic is one firefly in a small low-spp frame and the whole RMSE (profiles/r03_rmse_protocol_*.json: zero-mean)."""
+    squared = ((gpu[..., :3] - cpu[..., :3]) ** 2).sum(axis=-1).ravel()
+    kept = np.sort(squared)[:len(squared) - outliers]
+    return float(np.sqrt(kept.sum() / (3 * len(kept))))
+
+
 def image_metrics(gpu, cpu):
     diff = gpu[..., :3] - cpu[..., :3]
     rel = np.abs(diff) / (np.abs(cpu[..., :3]) + 1e-3)
@@ -198,7 +206,7 @@ def test_overflow_stack_kernels_bit_exact(ctx, oracle_q, tmp_path):
     image, gc = render_gpu(ctx, scene, w, h, spp, 4)
     ref, cc, _ = oracle_q.render(scene.desc, scene.state, scene.camera(w, h, max_bounce_count=4), w, h, spp, use_bvh=2)
     close, rmse = image_metrics(image, ref)
-    assert close >= 0.97 and rmse <= 0.01 * max(1.0, float(ref[..., :3].mean())), (close, rmse)
+    assert close >= 0.995 and rmse_without_worst(image, ref, 2) <= 1e-4 * max(1.0, float(ref[..., :3].mean())), (close, rmse)     # measured: every pixel within 1e-3, RMSE 1e-6
     assert abs(gc["closest_rays"] - cc["closest_rays"]) <= 0.002 * cc["closest_rays"]
 
 
@@ -269,8 +277,9 @@ def test_million_triangle_scene(ctx, oracle_q):
     image, gc = render_gpu(ctx, scene, w, h, spp, 4)
     ref, cc, _ = oracle_q.render(scene.desc, scene.state, scene.camera(w, h, max_bounce_count=4), w, h, spp, use_bvh=ctx.oracle_search())
     close, rmse = image_metrics(image, ref)
-    print(f"1M atrium: pixels within 1e-3: {close:.4f}, RMSE {rmse:.3e}")
-    assert close >= 0.95 and np.isfinite(image).all()
+    print(f"1M atrium: pixels within 1e-3: {close:.4f}, RMSE {rmse:.3e}, without the 2 worst pixels {rmse_without_worst(image, ref, 2):.3e}")
+    # measured on the MI355X (profiles/r03_image_metrics.txt): 0.98 of the pixels within 1e-3 relative, RMSE of all but the two worst pixels 1e-4
+    assert close >= 0.97 and rmse_without_worst(image, ref, 2) <= 1e-3 and rmse <= 0.05 * float(ref[..., :3].mean()) and np.isfinite(image).all()
     for key in ("closest_rays", "shadow_rays"):
         assert abs(gc[key] - cc[key]) <= 0.003 * cc[key], (key, gc[key], cc[key])
 
@@ -291,6 +300,66 @@ def test_million_triangle_scene(ctx, oracle_q):
         valid = (x < w) & (y < h) & (tile < tiles_x * tiles_y)
         assembled[y[valid], x[valid]] = part[valid]
     assert np.array_equal(assembled, full)
+
+
+def test_ten_million_triangle_scene_at_4k(ctx, oracle_q):
+    """BASELINE config 5 at its size on one GPU: the 10 M-triangle atrium (seed 2), 3840 x 2160. Stage parity on 20 k rays bit for bit with counters
+    against the oracle's search over the same 8-wide tree, a small image against the oracle, and at full size the size-independent properties: finite,
+    every camera path traced, batching bit-invariant, tiling over two phases assembling the full frame."""
+    scene = Scene("atrium", param0=10000000, param1=2)
+    assert scene.desc.triangle_count > 9000000 and scene.desc.wide8_slot_count > 0
+    ctx.upload_scene(scene)
+    assert ctx.trace_variant() == capi.TRACE_WIDE8_PERSISTENT
+    rng = np.random.default_rng(22)
+    n = 20000
+    rays = np.zeros((n, 8), np.float32)
+    rays[:, 0:3] = rng.uniform(-14, 14, (n, 3))
+    rays[:, 1] = np.abs(rays[:, 1]) * 0.7
+    d = rng.normal(size=(n, 3))
+    rays[:, 4:7] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    rays[:, 7] = np.inf
+    skip = np.full(n, 0xFFFFFFFF, np.uint32)
+    ctx.set_instrumentation(True)
+    gpu = ctx.debug_trace_closest(rays, skip)
+    counters = ctx.counters()
+    cpu, (nodes, tris) = oracle_q.trace_closest(scene.desc, rays, skip, use_bvh=ctx.oracle_search(), with_lights=True)
+    assert np.array_equal(gpu.view(np.uint32), cpu.view(np.uint32))
+    assert counters["closest_nodes"] == nodes and counters["closest_triangles"] == tris
+    rays[:, 7] = rng.uniform(0.05, 30.0, n)
+    gpu_s = ctx.debug_trace_shadow(rays)
+    counters = ctx.counters()
+    ctx.set_instrumentation(False)
+    cpu_s, (nodes, tris) = oracle_q.trace_shadow(scene.desc, rays, use_bvh=ctx.oracle_search())
+    assert np.array_equal(gpu_s, cpu_s) and counters["shadow_nodes"] == nodes and counters["shadow_triangles"] == tris
+    assert (gpu[:, 3].view(np.uint32) != 0xFFFFFFFF).mean() > 0.5 and 0.02 < (gpu_s == 0).mean() < 0.99
+
+    w, h, spp = 96, 54, 4
+    image, gc = render_gpu(ctx, scene, w, h, spp, 4)
+    ref, cc, _ = oracle_q.render(scene.desc, scene.state, scene.camera(w, h, max_bounce_count=4), w, h, spp, use_bvh=ctx.oracle_search())
+    close, rmse = image_metrics(image, ref)
+    print(f"10M atrium: pixels within 1e-3: {close:.4f}, RMSE {rmse:.3e}, without the 4 worst pixels {rmse_without_worst(image, ref, 4):.3e}")
+    assert close >= 0.95 and rmse_without_worst(image, ref, 4) <= 2e-3 and np.isfinite(image).all()
+    for key in ("closest_rays", "shadow_rays"):
+        assert abs(gc[key] - cc[key]) <= 0.003 * cc[key], (key, gc[key], cc[key])
+
+    w, h = 3840, 2160
+    full, counters = render_gpu(ctx, scene, w, h, 2, 4, samples_per_pass=2)
+    assert np.isfinite(full).all() and counters["camera_rays"] == 2 * w * h and counters["shadow_rays"] > 0
+    one_by_one, _ = render_gpu(ctx, scene, w, h, 2, 4, samples_per_pass=1)
+    assert np.array_equal(one_by_one, full)
+    tiles_x, tiles_y = (w + 7) // 8, (h + 7) // 8
+    assembled = np.zeros_like(full)
+    for phase in range(2):
+        ctx.set_frame(w, h, phase, 2, 2)
+        ctx.render_pass(scene.camera(w, h, accumulations=0, max_bounce_count=4), synchronize=True)
+        part = ctx.read_accumulation()
+        k = np.arange(part.shape[0])
+        tile = (k // 64) * 2 + phase
+        x, y = (tile % tiles_x) * 8 + (k % 64) % 8, (tile // tiles_x) * 8 + (k % 64) // 8
+        valid = (x < w) & (y < h) & (tile < tiles_x * tiles_y)
+        assembled[y[valid], x[valid]] = part[valid]
+    assert np.array_equal(assembled, full)
+    ctx.set_frame(8, 8)       # give the 4K queues back
 
 
 def test_device_group_renders_the_single_context_image(ctx, oracle_q):
