@@ -316,7 +316,7 @@ def rmse_against_oracle(ctx, scene, bounces, spps=(8, 256), width=160, height=90
         stem = ROOT / "profiles" / "converged" / f"{converged_name}_{width}x{height}_acc{spp}_{17 * spp}" if converged_name else None
         if stem is not None and Path(str(stem) + ".npy").exists() and Path(str(stem) + ".json").exists():
             meta = json.loads(Path(str(stem) + ".json").read_text())
-            if meta.get("triangles") == int(scene.desc.triangle_count) and meta.get("bounces") == bounces and meta.get("search") == ctx.oracle_search():
+            if meta.get("triangles") == int(scene.desc.triangle_count) and meta.get("bounces") == bounces:      # any of the oracle's searches converges to the same image
                 converged = np.load(str(stem) + ".npy").astype(np.float64)
                 entry["converged_leg"] = {"reference": f"profiles/converged/{stem.name}.npy: oracle, accumulations [{spp}, {17 * spp}), disjoint from the compared ones",
                                           "device_vs_converged": both(gpu, converged), "oracle_vs_converged": both(cpu, converged)}

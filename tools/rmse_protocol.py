@@ -82,7 +82,7 @@ def main():
     meta_ok = False
     if Path(str(stem) + ".npy").exists() and Path(str(stem) + ".json").exists():
         meta = json.loads(Path(str(stem) + ".json").read_text())
-        meta_ok = meta.get("triangles") == int(scene.desc.triangle_count) and meta.get("bounces") == bounces and meta.get("search") == search
+        meta_ok = meta.get("triangles") == int(scene.desc.triangle_count) and meta.get("bounces") == bounces      # any of the oracle's searches converges to the same image
     if meta_ok:
         converged = np.load(str(stem) + ".npy").astype(np.float64)
         out["converged_source"] = f"profiles/converged/{stem.name}.npy (tools/converged_reference.py, {meta['seconds']:.0f} s on {meta['threads']} host threads)"
