@@ -78,7 +78,7 @@ struct Wavefront {
     hipStream_t stream = nullptr;       // wavefront 0 runs on the context stream, the others on their own
     hipStream_t own_stream = nullptr;
     hipEvent_t shade_done[2] = {nullptr, nullptr}, counts_copied[2] = {nullptr, nullptr}, finished = nullptr;   // by bounce parity: two bounces are in flight
-    DeviceBuffer path[2][4], hits, shadow[3], queue_counts, order, order_taken;   // order: k_classify_hits' listing of a bounce's rays; order_taken: its two counters, one 8-byte word per bounce parity
+    DeviceBuffer path[2][4], hits, shadow[3], queue_counts, order, nee_flags;   // queue_counts: COUNT_LINES 64 B lines (see there); order: k_classify_hits' listing of a bounce's rays
     uint32_t* host_counts = nullptr;    // pinned: {continuing paths, shadow rays} per bounce parity, [4] staging word
     uint32_t first_slot = 0, n_slots = 0;
 
@@ -88,7 +88,7 @@ struct Wavefront {
     ShadowQueue shadow_queue() const { return {shadow[0].as<float4>(), shadow[1].as<float4>(), shadow[2].as<float4>()}; }
     void release() {
         for (auto& buffers : path) for (DeviceBuffer& b : buffers) b.release();
-        hits.release(); queue_counts.release(); order.release(); order_taken.release();
+        hits.release(); queue_counts.release(); order.release(); nee_flags.release();
         for (DeviceBuffer& b : shadow) b.release();
         for (hipEvent_t e : shade_done) if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : counts_copied) if (e) (void)hipEventDestroy(e);
@@ -99,7 +99,12 @@ struct Wavefront {
     }
 };
 constexpr int MAX_WAVEFRONTS = 4;
-constexpr int COUNT_PAIR_STRIDE = 16;   // uint32 words between the two queue-size pairs of a wavefront (one 64 B line each)
+constexpr int COUNT_PAIR_STRIDE = 16;   // uint32 words between the counters of a wavefront (one 64 B line each)
+// A wavefront's counters: lines 0-2 the queue-size pairs {paths, shadow rays}, bounce k reads pair k % 3 and fills pair (k + 1) % 3; lines 3-4
+// k_classify_hits' 8-byte counter of bounce parity 0 and 1. Nothing in the stream zeroes them between bounces: the shade kernel of bounce k zeroes
+// pair (k + 2) % 3 -- read last by bounce k - 1, whose sizes the host has read back before it queues bounce k -- and the listing counter of parity (k + 1) & 1.
+constexpr int COUNT_PAIRS = 3, COUNT_LINES = 5;
+constexpr int HOST_COUNT_WORDS = 8 + COUNT_LINES * COUNT_PAIR_STRIDE;   // pinned: 2 x {paths, shadow rays} read back, [4..8) spare, then the image of the counters at the start of a pass
 
 } // namespace
 
@@ -130,13 +135,35 @@ struct HiprContext {
     FrameInfo frame = {};
     bool frame_ready = false;
     uint32_t n_slots = 0;   // owned_tiles * 64 * samples_per_pass
+    // Pass pipelining (scenes of the persistent kernels, one wavefront per pass): consecutive passes alternate between two SLOTS -- wavefronts[0] / [1] with
+    // their queues and streams, `radiance` / `radiance_other`, two halves of the work-counter ring -- and a pass whose live paths have dwindled to a
+    // sliver hands its remaining bounces to the GPU blindly (the kernels read their sizes on the device) and returns: the tail, a chain of launches that
+    // each run as long as ONE traversal takes, drains on its stream while the next pass's full-size launches run on the other one.
+    struct PassSlot {
+        bool pending = false;           // a detached tail is (or may be) still running on the slot's stream
+        uint32_t alive_at_detach = 0;   // paths that entered the first bounce of the tail
+        uint32_t first_parity = 0;      // the first tail bounce's sizes come back through the wavefront's regular read-back pair of this parity
+        uint32_t blind_bounces = 0;     // bounces after it, read back into `tail_counts`
+        uint32_t next_bounce = 0;       // the bounce that would follow the tail
+        uint32_t* tail_counts = nullptr;   // pinned: {paths that continue, shadow rays queued} per blind bounce
+        uint32_t work_index = 0;        // next unused claim-counter set of the slot's half of the ring
+        HiprCameraState camera = {};    // of the pass that left the tail (finish_slot may have to queue more bounces)
+    } pass_slots[2];
+    int active_slot = 0;                // the slot whose pass is being queued (next_work_counter)
+    int traced_slot = 0;                // the slot of the last hipr_trace_pass: what hipr_accumulate_samples folds
+    int next_slot = 0;
+    bool pipeline_passes = false;       // hipr_set_pass_pipelining / HIPR_PIPELINE_PASSES=1; off by default: measured slower
+    bool pipelining_now = false;        // the pass being queued is a pipelined one
+    int pipeline_spare_blocks = 1;      // HIPR_PIPELINE_SPARE_BLOCKS
+    hipEvent_t accumulated = nullptr;   // the last hipr_accumulate_samples: the next one (on the other slot's stream) folds after it
+    bool accumulated_valid = false;
+    DeviceBuffer radiance_other;        // the other slot's radiance (the two swap when the slots do)
     uint32_t traced_samples = 0;        // samples the radiance buffer holds since the last hipr_trace_pass
     float pass_depth_normalizer = 0.0f; // depth entry: far - near of the traced pass's camera
     DeviceBuffer radiance, accumulation, scratch_accumulation, counters, work_counters;
     bool use_scratch = false;
     int entry = HIPR_ENTRY_PATH_TRACING;
     DeviceBuffer& active_accumulation() { return use_scratch ? scratch_accumulation : accumulation; }
-    uint32_t work_index = 0;            // next unused persistent-kernel work counter (zeroed 256 at a time)
     int trace_variant = -1;             // 1: persistent kernels, 0: one ray per lane, -1: pick by BVH size (HIPR_TRACE_VARIANT)
     uint32_t wide_stack_entries = 0;
     // persistent kernels walk the compressed 4-wide BVH; without one (HiprSceneDesc::wide_nodes == NULL) the plain BVH2 kernels serve every scene
@@ -164,7 +191,9 @@ struct HiprContext {
     int cu_count = 256;
     int blocks_per_cu_override = 0;     // HIPR_BLOCKS_PER_CU
     int shade_blocks_per_cu = 0;        // persistent shade blocks per CU = waves per SIMD; 0: 3 (what the kernel is compiled for), 2 for all-Diffuse scenes (HIPR_SHADE_BLOCKS_PER_CU)
+    uint32_t shade_ordered_from = 1u << 18;   // bounces with fewer paths than this are shaded in queue order (HIPR_SHADE_ORDERED_FROM)
     int refill_below = 40;              // persistent kernels refill a wave once fewer lanes than this are busy (HIPR_REFILL_BELOW)
+    bool shade_split = false;           // HIPR_SHADE_SPLIT=1: the shade kernel as two, next event estimation and the rest (shade_kernel.h; measured)
     bool shade_ordered = true;          // k_classify_hits before k_shade (HIPR_SHADE_ORDERED=0: shade in queue order)
     int persistent_blocks_per_cu[3][3] = {{0, 0, 0}, {0, 0, 0}};   // [shadow][stack bucket]
     int wide8_blocks_per_cu[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};   // [mode][stack bucket]
@@ -190,16 +219,31 @@ struct HiprContext {
         }
         return event_pool[events_used++];
     }
+    // An event in a stream costs the command processor about 6 us between two kernels -- a tenth of a bounce of a few thousand paths -- so launches that
+    // follow each other on a stream share the event between them: the stop of the one is the start of the next (until break_chain()).
+    struct Chain { hipStream_t stream; hipEvent_t event; } chains[MAX_WAVEFRONTS + 1] = {};
+    Chain& chain_of(hipStream_t on) {
+        for (Chain& ch : chains) if (ch.stream == on) return ch;
+        for (Chain& ch : chains) if (!ch.event) { ch.stream = on; return ch; }
+        chains[0] = {on, nullptr};
+        return chains[0];
+    }
+    void break_chain(hipStream_t on) { chain_of(on).event = nullptr; }     // something other than a timed launch was queued on the stream
     void begin_timed(int kernel, hipStream_t on) {
         if (!timing) return;
-        TimedLaunch t = {kernel, next_event(), next_event()};
+        Chain& ch = chain_of(on);
+        TimedLaunch t = {kernel, ch.event ? ch.event : next_event(), next_event()};
         if (!t.start || !t.stop) return;
-        (void)hipEventRecord(t.start, on);
+        if (!ch.event) (void)hipEventRecord(t.start, on);
+        ch.event = nullptr;
         timed.push_back(t);
     }
-    void end_timed(hipStream_t on) {
-        if (!timing || timed.empty()) return;
+    // Returns the event recorded behind the launch (nullptr with timing off).
+    hipEvent_t end_timed(hipStream_t on) {
+        if (!timing || timed.empty()) return nullptr;
         (void)hipEventRecord(timed.back().stop, on);
+        chain_of(on).event = timed.back().stop;
+        return timed.back().stop;
     }
     // Requires the stream to be idle (called after a synchronize).
     void collect_times() {
@@ -212,6 +256,7 @@ struct HiprContext {
         }
         timed.clear();
         events_used = 0;
+        for (Chain& ch : chains) ch.event = nullptr;
     }
 };
 
@@ -270,14 +315,17 @@ constexpr uint32_t WORK_SET_WORDS = TRACE_SHARDS * TRACE_SHARD_STRIDE;   // one 
 constexpr uint32_t WORK_COUNTERS = WORK_SETS * WORK_SET_WORDS;
 
 // Hands out a zeroed work counter for one persistent launch; re-zeroes the ring when it wraps (stream ordered).
+// Each pass slot has its own half of the buffer (two passes may be in flight, each re-zeroing its own sets at its start on its own stream).
 uint32_t* next_work_counter(HiprContext* c) {
-    if (c->work_index >= WORK_SETS) {   // out of sets inside a pass (the used prefix is re-zeroed at every pass start): drain and re-zero
+    uint32_t& index = c->pass_slots[c->active_slot].work_index;
+    uint32_t* ring = c->work_counters.as<uint32_t>() + size_t(c->active_slot) * WORK_COUNTERS;
+    if (index >= WORK_SETS) {   // out of sets inside a pass (the used prefix is re-zeroed at every pass start): drain and re-zero
         for (int g = 0; g < MAX_WAVEFRONTS; ++g) if (c->wavefronts[g].stream) (void)hipStreamSynchronize(c->wavefronts[g].stream);
-        (void)hipMemsetAsync(c->work_counters.ptr, 0, WORK_COUNTERS * sizeof(uint32_t), c->stream);
+        (void)hipMemsetAsync(ring, 0, WORK_COUNTERS * sizeof(uint32_t), c->stream);
         (void)hipStreamSynchronize(c->stream);
-        c->work_index = 0;
+        index = 0;
     }
-    return c->work_counters.as<uint32_t>() + size_t(c->work_index++) * WORK_SET_WORDS;
+    return ring + size_t(index++) * WORK_SET_WORDS;
 }
 
 // One persistent launch over the path queue (closest_count != nullptr), the shadow queue (shadow_count != nullptr) or both.
@@ -310,7 +358,8 @@ void launch_wide8(HiprContext* c, const Wavefront& w, const PathState& in, const
         per_cu = blocks;
     }
     const uint32_t waves_per_block = TRACE_BLOCK / 64;
-    uint32_t grid = uint32_t(c->cu_count) * uint32_t(per_cu);
+    // pipelined passes: one block slot per CU stays free, so that the other slot's tail launches find room next to this pass's persistent blocks
+    uint32_t grid = uint32_t(c->cu_count) * uint32_t(c->pipelining_now && per_cu > 2 ? per_cu - c->pipeline_spare_blocks : per_cu);
     grid = std::max(1u, std::min(grid, (upper_bound + 63u) / 64u / waves_per_block + 1u));
     hipLaunchKernelGGL((k_trace_wide8<STACK, MODE, INSTRUMENT>), dim3(grid), dim3(TRACE_BLOCK), 0, w.stream, c->scene, c->wide8, in, w.hits.as<float4>(), w.shadow_queue(),
                        c->radiance.as<float4>(), closest_count, shadow_count, next_work_counter(c), c->refill_below, c->counters.as<DeviceCounters>());
@@ -383,23 +432,27 @@ void launch_trace_fused(HiprContext* c, const Wavefront& w, const PathState& in,
     launch_persistent_for_stack<TRACE_FUSED, INSTRUMENT>(c, w, in, closest_count, shadow_count, upper_bound);
 }
 
-void launch_shade(HiprContext* c, const Wavefront& w, const HiprCameraState& camera, int cur, uint32_t alive, const uint32_t* in_count, uint32_t* out_counts) {
+void launch_shade(HiprContext* c, const Wavefront& w, const HiprCameraState& camera, int cur, uint32_t alive, const uint32_t* in_count, uint32_t* out_counts, uint32_t* zero_pair) {
     // The rays of the bounce listed by kind (kernels.h k_classify_hits): the shade kernel's batches then hold surface hits only, or none.
     const uint32_t* order = nullptr;
     // Pays where a good share of a bounce's rays did not hit a surface (the atrium's open roof: shade 23.3 -> 21.4 ms per step) and costs a pass over the hits
     // where nearly all did (the closed Cornell box: +7 %): on for the scenes of the persistent kernels, which are the large ones.
-    if (c->shade_ordered && c->use_persistent() && c->entry == HIPR_ENTRY_PATH_TRACING) {
-        unsigned long long* taken = reinterpret_cast<unsigned long long*>(w.order_taken.as<uint32_t>() + COUNT_PAIR_STRIDE * cur);
-        (void)hipMemsetAsync(taken, 0, 8, w.stream);
+    // A bounce of a few thousand paths runs one wave per SIMD at most: the order they are taken in changes nothing, the listing pass would cost a launch.
+    uint32_t* taken_words = w.queue_counts.as<uint32_t>() + COUNT_PAIR_STRIDE * COUNT_PAIRS;
+    if (c->shade_ordered && c->use_persistent() && c->entry == HIPR_ENTRY_PATH_TRACING && alive >= c->shade_ordered_from) {
+        unsigned long long* taken = reinterpret_cast<unsigned long long*>(taken_words + COUNT_PAIR_STRIDE * cur);
         hipLaunchKernelGGL(k_classify_hits, dim3(grid_for(alive, 256u * CLASSIFY_ROUNDS, uint32_t(c->cu_count) * 8u)), dim3(256), 0, w.stream, w.hits.as<float4>(), in_count, w.order.as<uint32_t>(), taken);
         order = w.order.as<uint32_t>();
     }
     // persistent blocks: three per CU stay resident (3 waves per SIMD), each walks the queue with a grid stride, one batch ahead on its inputs
     // measured: the Default / Transmissive kernels gain from a third wave per SIMD (atrium 29.4 -> 25.9 ms of shading per step), the lighter all-Diffuse
     // kernel loses (Cornell 18 390 -> 17 194 Mrays/s)
-    const uint32_t blocks_per_cu = c->shade_blocks_per_cu > 0 ? uint32_t(c->shade_blocks_per_cu) : (c->shading_models == 2 ? 2u : 3u);
+    const bool split = c->shade_split && c->entry == HIPR_ENTRY_PATH_TRACING && c->scene.light_count != 0 && w.nee_flags.ptr;
+    const uint32_t blocks_per_cu = c->shade_blocks_per_cu > 0 ? uint32_t(c->shade_blocks_per_cu) : (split ? uint32_t(HIPR_SHADE_SPLIT_WAVES) : (c->shading_models == 2 ? 2u : 3u));
     ShadeLaunch a = {grid_for(alive, SHADE_BLOCK, uint32_t(c->cu_count) * blocks_per_cu), w.stream, c->scene, camera, c->entry, w.path_state(cur), w.hits.as<float4>(), order, w.path_state(1 - cur),
-                     w.shadow_queue(), c->radiance.as<float4>(), in_count, reinterpret_cast<unsigned long long*>(out_counts), c->counters.as<DeviceCounters>()};
+                     w.shadow_queue(), c->radiance.as<float4>(), in_count, reinterpret_cast<unsigned long long*>(out_counts), reinterpret_cast<unsigned long long*>(zero_pair),
+                     reinterpret_cast<unsigned long long*>(taken_words + COUNT_PAIR_STRIDE * (1 - cur)), split ? w.nee_flags.as<unsigned char>() : nullptr,
+                     c->counters.as<DeviceCounters>()};
     hipr::launch_shade(c->shading_models, a);
 }
 
@@ -419,25 +472,168 @@ int partition_path_slots(HiprContext* c) {
         const uint64_t first = std::min<uint64_t>(slots, share * g);
         w.first_slot = uint32_t(first);
         w.n_slots = g >= c->wavefront_count ? 0u : uint32_t(std::min<uint64_t>(share, slots - first));
+        const bool second_slot = g == 1 && c->wavefront_count == 1 && c->pipeline_passes && c->partitioned_for == 1;    // the other pass slot: a copy of wavefront 0's share
+        if (second_slot) { w.first_slot = c->wavefronts[0].first_slot; w.n_slots = c->wavefronts[0].n_slots; }
         const size_t bytes = size_t(std::max(w.n_slots, 64u)) * 16;
-        if (g >= c->wavefront_count) {   // queues of wavefronts this pass size does not use go back to the allocator
+        if (g >= c->wavefront_count && !second_slot) {   // queues of wavefronts this pass size does not use go back to the allocator
             for (auto& buffers : w.path) for (DeviceBuffer& b : buffers) b.release();
-            w.hits.release(); w.order.release();
+            w.hits.release(); w.order.release(); w.nee_flags.release();
             for (DeviceBuffer& b : w.shadow) b.release();
             continue;
         }
         for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) r |= w.path[i][j].resize(bytes);
         r |= w.hits.resize(bytes);
         r |= w.order.resize(bytes / 4);
+        if (c->shade_split) r |= w.nee_flags.resize(bytes / 16);
         for (int j = 0; j < 3; ++j) r |= w.shadow[j].resize(bytes);
     }
+    const bool two_slots = c->wavefront_count == 1 && c->pipeline_passes && c->partitioned_for == 1;
+    if (!two_slots) {
+        if (c->traced_slot == 1 && c->radiance_other.ptr) std::swap(c->radiance, c->radiance_other);      // the slots are gone: `radiance` is wavefront 0's again
+        c->radiance_other.release();
+        c->traced_slot = c->next_slot = c->active_slot = 0;
+    }
     r |= c->radiance.resize(slots * 16);
+    if (two_slots) r |= c->radiance_other.resize(slots * 16);
     return r;
 }
 
 int check_context(HiprContext* c) {
     if (!c) return fail(HIPR_ERROR_INVALID_ARGUMENT, "null context");
     HIP_TRY(hipSetDevice(c->device));
+    return HIPR_OK;
+}
+
+// Bounce k of a wavefront = trace stage + shade(k). The trace stage serves the closest-hit rays of bounce k AND the shadow rays
+// shade(k - 1) queued (they are independent; radiance slots are still updated in the order shade(0), shadow(0), shade(1), ...):
+// one fused persistent launch for big scenes, two plain launches otherwise. All queue sizes stay on the device; the host only
+// needs them to stop. `bound`: an upper bound of the bounce's rays (sizes the launches); `host_sizes`: where the sizes the bounce
+// produced -- {paths that continue, shadow rays queued} -- are read back to (nullptr: the wavefront's regular pair of the bounce's parity).
+int enqueue_bounce(HiprContext* c, Wavefront& w, const HiprCameraState& camera, uint32_t k, uint32_t bound, uint32_t* host_sizes = nullptr) {
+    const bool fused = c->use_persistent();
+    if (!host_sizes) host_sizes = w.host_counts + 2 * (k & 1u);
+
+    // Queue sizes live in three 8-byte pairs, 64 B apart (COUNT_PAIRS): pair[k % 3] = {paths of bounce k, shadow rays shade(k - 1) queued}.
+    // shade(k) fills pair[(k + 1) % 3] with one 64-bit atomic per block and zeroes pair[(k + 2) % 3] for shade(k + 1).
+    uint32_t* counts = w.queue_counts.as<uint32_t>();
+    const int parity = int(k & 1u);
+    uint32_t* in_count = counts + COUNT_PAIR_STRIDE * (k % COUNT_PAIRS);
+    uint32_t* shadow_in = in_count + 1;
+    uint32_t* out_count = counts + COUNT_PAIR_STRIDE * ((k + 1u) % COUNT_PAIRS);
+    uint32_t* zero_pair = counts + COUNT_PAIR_STRIDE * ((k + 2u) % COUNT_PAIRS);
+    const size_t first_timed = c->timed.size();
+    // a bounce queued blindly (pipelined passes) is not behind the host's read of the sizes of bounce k - 2, which sit in the pair its shade kernel zeroes
+    if (host_sizes != w.host_counts + 2 * (k & 1u) && k >= 2) {
+        HIP_TRY(hipStreamWaitEvent(w.stream, w.counts_copied[parity], 0));
+        c->break_chain(w.stream);
+    }
+
+    c->begin_timed(HIPR_KERNEL_TRACE_CLOSEST, w.stream);
+    if (k > 0 && fused) {
+        if (c->instrument) launch_trace_fused<true>(c, w, w.path_state(parity), in_count, shadow_in, 2u * bound);
+        else launch_trace_fused<false>(c, w, w.path_state(parity), in_count, shadow_in, 2u * bound);
+    } else {
+        if (c->instrument) launch_trace_closest<true>(c, w, w.path_state(parity), in_count, bound);
+        else launch_trace_closest<false>(c, w, w.path_state(parity), in_count, bound);
+    }
+    c->end_timed(w.stream);
+    if (k > 0 && !fused) {
+        c->begin_timed(HIPR_KERNEL_TRACE_SHADOW, w.stream);
+        if (c->instrument) launch_trace_shadow<true>(c, w, shadow_in, bound);
+        else launch_trace_shadow<false>(c, w, shadow_in, bound);
+        c->end_timed(w.stream);
+    }
+
+    c->begin_timed(HIPR_KERNEL_SHADE, w.stream);
+    launch_shade(c, w, camera, parity, bound, in_count, out_count, zero_pair);
+    hipEvent_t shaded = c->end_timed(w.stream);
+    if (!shaded) {
+        shaded = w.shade_done[parity];
+        HIP_TRY(hipEventRecord(shaded, w.stream));
+    }
+    HIP_TRY(hipStreamWaitEvent(c->copy_stream, shaded, 0));
+    HIP_TRY(hipMemcpyAsync(host_sizes, out_count, 8, hipMemcpyDeviceToHost, c->copy_stream));     // {paths that continue, shadow rays}
+    HIP_TRY(hipEventRecord(w.counts_copied[parity], c->copy_stream));
+
+    if (c->instrument && c->trace_log) {   // diagnostic (HIPR_TRACE_LOG=1): per-bounce counters and kernel times; serialises the pass
+        HIP_TRY(hipStreamSynchronize(w.stream));
+        HIP_TRY(hipStreamSynchronize(c->copy_stream));
+        DeviceCounters dc;
+        HIP_TRY(hipMemcpy(&dc, c->counters.ptr, sizeof(dc), hipMemcpyDeviceToHost));
+        const DeviceCounters& p = c->trace_log_previous;
+        fprintf(stderr, "[hipr] wavefront %d bounce %u: <= %u closest rays: nodes %llu tris %llu | shadow rays of the previous bounce: nodes %llu tris %llu | kernels",
+                int(&w - c->wavefronts), k, bound, dc.closest_nodes - p.closest_nodes, dc.closest_triangles - p.closest_triangles, dc.shadow_nodes - p.shadow_nodes,
+                dc.shadow_triangles - p.shadow_triangles);
+        for (size_t i = first_timed; i < c->timed.size(); ++i) {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, c->timed[i].start, c->timed[i].stop);
+            fprintf(stderr, " %s %.1f us", c->timed[i].kernel == HIPR_KERNEL_SHADE ? "shade" : (c->timed[i].kernel == HIPR_KERNEL_TRACE_SHADOW ? "shadow" : "trace"), ms * 1e3f);
+        }
+        fprintf(stderr, " -> %u paths continue, %u shadow rays\n", w.host_counts[2 * parity], w.host_counts[2 * parity + 1]);
+        if (dc.node_iterations != p.node_iterations) {
+            const double ni = double(dc.node_iterations - p.node_iterations), ti = double(dc.triangle_iterations - p.triangle_iterations);
+            fprintf(stderr, "[hipr]     wave iterations: %.0f node (%.1f lanes working) + %.0f triangle (%.1f lanes working); %.1f lanes busy on average; %llu refills\n", ni,
+                    double(dc.node_lanes - p.node_lanes) / ni, ti, ti > 0 ? double(dc.triangle_lanes - p.triangle_lanes) / ti : 0.0,
+                    double(dc.busy_lanes - p.busy_lanes) / (ni + ti), dc.refills - p.refills);
+            const double pushes = double(dc.pushes - p.pushes);
+            if (pushes > 0)
+                fprintf(stderr, "[hipr]     stack pushes: %.0f, of which %.3f %% onto entry 16 or deeper and %.3f %% onto entry 24 or deeper\n", pushes,
+                        100.0 * double(dc.pushes_past_16 - p.pushes_past_16) / pushes, 100.0 * double(dc.pushes_past_24 - p.pushes_past_24) / pushes);
+        }
+        c->trace_log_previous = dc;
+    }
+    return HIPR_OK;
+}
+
+// Brings the books of a pass slot up to date: waits for the tail its last pass left on the slot's stream and adds the rays of the tail's bounces to the
+// totals (their queue sizes were read back bounce by bounce into pinned memory). Should paths have outlived the blind bounces (hits that keep being
+// rejected and retraced do not count as bounces), the pass is finished here bounce by bounce.
+int finish_slot(HiprContext* c, int slot_index) {
+    HiprContext::PassSlot& slot = c->pass_slots[slot_index];
+    if (!slot.pending) return HIPR_OK;
+    Wavefront& w = c->wavefronts[slot_index];
+    HIP_TRY(hipStreamSynchronize(w.stream));
+    HIP_TRY(hipStreamSynchronize(c->copy_stream));
+    slot.pending = false;
+    uint32_t in = slot.alive_at_detach, shadows = 0;
+    for (uint32_t t = 0; t <= slot.blind_bounces && in > 0; ++t) {
+        const uint32_t* sizes = t == 0 ? w.host_counts + 2 * slot.first_parity : slot.tail_counts + 2 * (t - 1);
+        c->total.closest_rays += in;
+        c->total.shadow_rays += sizes[1];
+        c->total.iterations += 1;
+        in = sizes[0];
+        shadows = sizes[1];
+    }
+    if (in == 0 && shadows == 0) return HIPR_OK;
+    // the last blind bounce left paths (or only shadow rays): carry on the ordinary way
+    const int saved_slot = c->active_slot;
+    c->active_slot = slot_index;
+    const bool swap = slot_index != c->traced_slot;     // launches write the radiance of the pass being finished
+    if (swap) std::swap(c->radiance, c->radiance_other);
+    int status = HIPR_OK;
+    for (uint32_t k = slot.next_bounce; status == HIPR_OK; ++k) {
+        status = enqueue_bounce(c, w, slot.camera, k, std::max(in, 1u));
+        if (status == HIPR_OK && hipEventSynchronize(w.counts_copied[k & 1u]) != hipSuccess) status = fail(HIPR_ERROR_HIP, "hipEventSynchronize failed while a pass was being finished");
+        if (status != HIPR_OK || in == 0) break;     // in == 0: that bounce only traced the last shadow rays
+        c->total.closest_rays += in;
+        c->total.shadow_rays += w.host_counts[2 * (k & 1u) + 1];
+        c->total.iterations += 1;
+        in = w.host_counts[2 * (k & 1u)];
+        if (k > 8192) status = fail(HIPR_ERROR_HIP, "wavefront loop did not terminate");
+    }
+    if (swap) std::swap(c->radiance, c->radiance_other);
+    c->active_slot = saved_slot;
+    if (status == HIPR_OK) HIP_TRY(hipStreamSynchronize(w.stream));
+    return status;
+}
+
+// Every pass queued so far is complete on the device and in the books (the entry points that read results, change the frame or the scene, or collect
+// timings start here).
+int finish_all(HiprContext* c) {
+    for (int slot = 0; slot < 2; ++slot)
+        if (int s = finish_slot(c, slot)) return s;
+    for (int g = 0; g < MAX_WAVEFRONTS; ++g) if (c->wavefronts[g].stream) HIP_TRY(hipStreamSynchronize(c->wavefronts[g].stream));
+    HIP_TRY(hipStreamSynchronize(c->copy_stream));
     return HIPR_OK;
 }
 
@@ -649,7 +845,8 @@ int hipr_create(int device_id, HiprContext** out_context) {
     HiprContext* c = new HiprContext();
     c->device = device_id;
     bool ok = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess &&
-              hipEventCreateWithFlags(&c->pass_start, hipEventDisableTiming) == hipSuccess;
+              hipEventCreateWithFlags(&c->pass_start, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->accumulated, hipEventDisableTiming) == hipSuccess &&
+              hipHostMalloc((void**)&c->pass_slots[0].tail_counts, 2 * 128 * sizeof(uint32_t)) == hipSuccess && hipHostMalloc((void**)&c->pass_slots[1].tail_counts, 2 * 128 * sizeof(uint32_t)) == hipSuccess;
     c->stream = c->own_stream;
     for (int g = 0; ok && g < MAX_WAVEFRONTS; ++g) {
         Wavefront& w = c->wavefronts[g];
@@ -657,27 +854,31 @@ int hipr_create(int device_id, HiprContext** out_context) {
         w.stream = g == 0 ? c->stream : w.own_stream;
         for (int i = 0; i < 2; ++i)
             ok = ok && hipEventCreateWithFlags(&w.shade_done[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&w.counts_copied[i], hipEventDisableTiming) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&w.finished, hipEventDisableTiming) == hipSuccess && hipHostMalloc((void**)&w.host_counts, 8 * sizeof(uint32_t)) == hipSuccess &&
-             w.queue_counts.resize(2 * COUNT_PAIR_STRIDE * sizeof(uint32_t)) == 0 && w.order_taken.resize(2 * COUNT_PAIR_STRIDE * sizeof(uint32_t)) == 0;
+        ok = ok && hipEventCreateWithFlags(&w.finished, hipEventDisableTiming) == hipSuccess && hipHostMalloc((void**)&w.host_counts, HOST_COUNT_WORDS * sizeof(uint32_t)) == hipSuccess &&
+             w.queue_counts.resize(COUNT_LINES * COUNT_PAIR_STRIDE * sizeof(uint32_t)) == 0;
     }
     if (!ok) {
         hipr_destroy(c);
         return fail(HIPR_ERROR_HIP, "stream / event / pinned allocation failed");
     }
-    if (c->counters.resize(sizeof(DeviceCounters)) || c->work_counters.resize(WORK_COUNTERS * sizeof(uint32_t))) {
+    if (c->counters.resize(sizeof(DeviceCounters)) || c->work_counters.resize(2 * WORK_COUNTERS * sizeof(uint32_t))) {
         hipr_destroy(c);
         return HIPR_ERROR_OUT_OF_MEMORY;
     }
-    c->work_index = WORK_SETS;   // forces the first launch to zero the ring
+    c->pass_slots[0].work_index = c->pass_slots[1].work_index = WORK_SETS;   // forces the first launch of either slot to zero its ring
     hipDeviceProp_t props;
     if (hipGetDeviceProperties(&props, device_id) == hipSuccess && props.multiProcessorCount > 0) c->cu_count = props.multiProcessorCount;
     if (const char* v = getenv("HIPR_TRACE_VARIANT")) c->trace_variant = atoi(v);
     if (const char* v = getenv("HIPR_REFILL_BELOW")) c->refill_below = atoi(v);
+    if (const char* v = getenv("HIPR_SHADE_ORDERED_FROM")) c->shade_ordered_from = uint32_t(atoll(v));
     if (const char* v = getenv("HIPR_SHADE_BLOCKS_PER_CU")) c->shade_blocks_per_cu = std::max(1, atoi(v));
     if (const char* v = getenv("HIPR_BLOCKS_PER_CU")) c->blocks_per_cu_override = atoi(v);
     if (const char* v = getenv("HIPR_WAVEFRONTS")) c->wavefront_limit = std::max(0, std::min(MAX_WAVEFRONTS, atoi(v)));
     if (const char* v = getenv("HIPR_TRACE_LOG")) c->trace_log = atoi(v) != 0;
     if (const char* v = getenv("HIPR_SHADE_ORDERED")) c->shade_ordered = atoi(v) != 0;
+    if (const char* v = getenv("HIPR_SHADE_SPLIT")) c->shade_split = atoi(v) != 0;
+    if (const char* v = getenv("HIPR_PIPELINE_PASSES")) c->pipeline_passes = atoi(v) != 0;
+    if (const char* v = getenv("HIPR_PIPELINE_SPARE_BLOCKS")) c->pipeline_spare_blocks = std::max(0, atoi(v));
     HIP_TRY(hipMemsetAsync(c->counters.ptr, 0, sizeof(DeviceCounters), c->stream));
 
     float offsets[256 * 4];
@@ -696,7 +897,7 @@ int hipr_create(int device_id, HiprContext** out_context) {
                 sobol[(d * 4 + k) * 256 + b] = v;
             }
     if (int s = c->sobol_tables.upload(sobol.data(), sobol.size() * 4, c->stream)) { delete c; return s; }
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int finish_status = finish_all(c)) return finish_status;
     c->scene.sobol_tables = c->sobol_tables.as<uint32_t>();
     c->scene.sample_offsets = c->sample_offsets.as<float4>();
     c->scene.next_event_sample_count = 3;   // OR/Renderer.cpp:479
@@ -709,12 +910,14 @@ int hipr_destroy(HiprContext* c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     DeviceBuffer* all[] = {&c->shade_triangles, &c->trace_triangles, &c->trace_items, &c->wide_nodes, &c->wide8_slots, &c->environment_PDF, &c->environment_samples, &c->nodes, &c->triangles, &c->instances, &c->indices, &c->geometry, &c->texcoords, &c->tints, &c->emissions, &c->materials,
-                           &c->lights, &c->textures, &c->texels, &c->ggx_rho, &c->dielectric_rho, &c->alpha, &c->sample_offsets, &c->sobol_tables, &c->radiance,
+                           &c->lights, &c->textures, &c->texels, &c->ggx_rho, &c->dielectric_rho, &c->alpha, &c->sample_offsets, &c->sobol_tables, &c->radiance, &c->radiance_other,
                            &c->accumulation, &c->scratch_accumulation, &c->counters, &c->work_counters, &c->debug_a, &c->debug_b, &c->debug_c};
     for (DeviceBuffer* b : all) b->release();
     for (Wavefront& w : c->wavefronts) w.release();
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     if (c->pass_start) (void)hipEventDestroy(c->pass_start);
+    if (c->accumulated) (void)hipEventDestroy(c->accumulated);
+    for (auto& slot : c->pass_slots) if (slot.tail_counts) (void)hipHostFree(slot.tail_counts);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     delete c;
@@ -723,7 +926,7 @@ int hipr_destroy(HiprContext* c) {
 
 int hipr_set_stream(HiprContext* c, void* hip_stream) {
     if (int s = check_context(c)) return s;
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int finish_status = finish_all(c)) return finish_status;
     c->collect_times();
     c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
     c->wavefronts[0].stream = c->stream;
@@ -748,7 +951,7 @@ int hipr_upload_tables(HiprContext* c, const HiprTables* t) {
     if (int s = c->ggx_rho.upload(rho.data(), rho.size() * 2, c->stream)) return s;
     if (int s = c->dielectric_rho.upload(diel.data(), diel.size() * 2, c->stream)) return s;
     if (int s = c->alpha.upload(alpha.data(), alpha.size() * 2, c->stream)) return s;
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int finish_status = finish_all(c)) return finish_status;
     c->scene.tables = {c->ggx_rho.as<ushort2>(), c->dielectric_rho.as<ushort2>(), c->alpha.as<unsigned short>()};
     c->tables_ready = true;
     return HIPR_OK;
@@ -783,7 +986,7 @@ int hipr_upload_scene(HiprContext* c, const HiprSceneDesc* s) {
         if ((s->instances[i].mesh_flags & HIPR_MESH_TEXCOORDS && !s->texcoords) || (s->instances[i].mesh_flags & HIPR_MESH_TINTS && !s->tints) ||
             (s->instances[i].mesh_flags & HIPR_MESH_EMISSIVE && !s->emissions))
             return fail(HIPR_ERROR_INVALID_ARGUMENT, "instance %u flags an attribute whose pool is null", i);
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int finish_status = finish_all(c)) return finish_status;
     hipStream_t st = c->stream;
     int r = 0;
     r |= c->nodes.upload(s->nodes, size_t(s->node_count) * sizeof(HiprBvhNode), st);
@@ -906,7 +1109,7 @@ int hipr_set_frame(HiprContext* c, const HiprFrameDesc* f) {
     if (int s = check_context(c)) return s;
     if (!f || f->width == 0 || f->height == 0 || f->tile_stride == 0 || f->tile_phase >= f->tile_stride || f->samples_per_pass == 0)
         return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_set_frame: bad frame description");
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int finish_status = finish_all(c)) return finish_status;
     FrameInfo fi;
     fi.width = f->width; fi.height = f->height;
     fi.tiles_x = (f->width + 7) / 8;
@@ -925,7 +1128,7 @@ int hipr_set_frame(HiprContext* c, const HiprFrameDesc* f) {
     r |= c->accumulation.resize(acc_bytes);
     if (r) return HIPR_ERROR_OUT_OF_MEMORY;
     HIP_TRY(hipMemsetAsync(c->accumulation.ptr, 0, acc_bytes, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int finish_status = finish_all(c)) return finish_status;
     c->frame_ready = true;
     c->traced_samples = 0;
     return HIPR_OK;
@@ -948,7 +1151,7 @@ int hipr_set_entry_point(HiprContext* c, int entry) {
 int hipr_use_scratch_accumulation(HiprContext* c, int enable) {
     if (int s = check_context(c)) return s;
     if (!c->frame_ready) return fail(HIPR_ERROR_NOT_READY, "no frame set");
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int finish_status = finish_all(c)) return finish_status;
     c->collect_times();
     if (enable) {
         const size_t bytes = size_t(c->frame.owned_tiles) * 64 * sizeof(double4);
@@ -973,7 +1176,7 @@ int hipr_set_samples_per_pass(HiprContext* c, uint32_t samples_per_pass) {
     const uint64_t slots = uint64_t(c->frame.owned_tiles) * 64u * samples_per_pass;
     if (samples_per_pass == 0 || slots > 0x7FFFFFFFull) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_set_samples_per_pass: %llu path slots per pass", (unsigned long long)slots);
     if (samples_per_pass == c->frame.samples_per_pass) return HIPR_OK;
-    HIP_TRY(hipStreamSynchronize(c->stream));      // the queues may move
+    if (int finish_status = finish_all(c)) return finish_status;      // the queues may move
     c->collect_times();
     c->frame.samples_per_pass = samples_per_pass;
     if (partition_path_slots(c)) return HIPR_ERROR_OUT_OF_MEMORY;
@@ -990,6 +1193,7 @@ int hipr_trace_pass(HiprContext* c, const HiprCameraState* camera) {
     if (!camera) return fail(HIPR_ERROR_INVALID_ARGUMENT, "null camera");
     if (!c->tables_ready || !c->scene_ready || !c->frame_ready) return fail(HIPR_ERROR_NOT_READY, "tables, scene and frame must be set before rendering");
     if (c->partitioned_for != c->wavefronts_wanted()) {      // the scene uploaded since hipr_set_frame wants another split of the path slots
+        if (int s = finish_all(c)) return s;
         for (int g = 0; g < MAX_WAVEFRONTS; ++g) if (c->wavefronts[g].stream) HIP_TRY(hipStreamSynchronize(c->wavefronts[g].stream));
         c->collect_times();
         if (partition_path_slots(c)) return HIPR_ERROR_OUT_OF_MEMORY;
@@ -1011,110 +1215,56 @@ int hipr_trace_pass(HiprContext* c, const HiprCameraState* camera) {
     }
     pass.camera_rays = valid_pixels * f.samples_per_pass;
 
-    if (c->work_index > 0) {   // claim counters used by the previous pass (every wavefront stream is ordered behind pass_start)
-        HIP_TRY(hipMemsetAsync(c->work_counters.ptr, 0, size_t(std::min(c->work_index, WORK_SETS)) * WORK_SET_WORDS * sizeof(uint32_t), c->stream));
-        c->work_index = 0;
+    // Pipelined passes (HiprContext::PassSlot): this pass takes the slot the pass before the last one used, whose tail has long drained.
+    const bool pipelined = c->pipeline_passes && c->use_persistent() && c->wavefront_count == 1 && c->radiance_other.ptr && !c->instrument;
+    const int slot = pipelined ? c->next_slot : 0;
+    c->pipelining_now = pipelined;
+    if (pipelined) {
+        if (int s = finish_slot(c, slot)) return s;
+        c->next_slot = 1 - slot;
+    } else if (int s = finish_all(c)) return s;
+    if (slot != c->traced_slot) std::swap(c->radiance, c->radiance_other);      // `radiance` is the buffer of the pass being traced / last traced
+    c->traced_slot = slot;
+    c->active_slot = slot;
+    const int first_wavefront = pipelined ? slot : 0, end_wavefront = pipelined ? slot + 1 : c->wavefront_count;
+    hipStream_t lead = c->wavefronts[first_wavefront].stream;
+
+    HiprContext::PassSlot& ps = c->pass_slots[slot];
+    if (ps.work_index > 0) {   // claim counters used by the slot's previous pass (the slot's stream is ordered behind it)
+        HIP_TRY(hipMemsetAsync(c->work_counters.as<uint32_t>() + size_t(slot) * WORK_COUNTERS, 0, size_t(std::min(ps.work_index, WORK_SETS)) * WORK_SET_WORDS * sizeof(uint32_t), lead));
+        ps.work_index = 0;
     }
-    HIP_TRY(hipEventRecord(c->pass_start, c->stream));
-
-    // Bounce k of a wavefront = trace stage + shade(k). The trace stage serves the closest-hit rays of bounce k AND the shadow rays
-    // shade(k - 1) queued (they are independent; radiance slots are still updated in the order shade(0), shadow(0), shade(1), ...):
-    // one fused persistent launch for big scenes, two plain launches otherwise. All queue sizes stay on the device; the host only
-    // needs them to stop, so it enqueues bounce k + 1 (sized by the known upper bound: the rays of bounce k) BEFORE it waits for
-    // the sizes bounce k produced -- the GPU never idles on the read-back.
-    const bool fused = c->use_persistent();
-    auto enqueue_bounce = [&](Wavefront& w, uint32_t k, uint32_t bound) -> int {
-        // Queue sizes live in two 8-byte pairs, 64 B apart: pair[k & 1] = {paths of bounce k, shadow rays shade(k - 1) queued}.
-        // shade(k) fills pair[(k + 1) & 1] with one 64-bit atomic per block.
-        uint32_t* counts = w.queue_counts.as<uint32_t>();
-        const int parity = int(k & 1u);
-        uint32_t* in_count = counts + COUNT_PAIR_STRIDE * parity;
-        uint32_t* shadow_in = in_count + 1;
-        uint32_t* out_count = counts + COUNT_PAIR_STRIDE * (1 - parity);
-        uint32_t* shadow_out = out_count + 1;
-        const size_t first_timed = c->timed.size();
-        HIP_TRY(hipMemsetAsync(out_count, 0, 8, w.stream));
-
-        c->begin_timed(HIPR_KERNEL_TRACE_CLOSEST, w.stream);
-        if (k > 0 && fused) {
-            if (c->instrument) launch_trace_fused<true>(c, w, w.path_state(parity), in_count, shadow_in, 2u * bound);
-            else launch_trace_fused<false>(c, w, w.path_state(parity), in_count, shadow_in, 2u * bound);
-        } else {
-            if (c->instrument) launch_trace_closest<true>(c, w, w.path_state(parity), in_count, bound);
-            else launch_trace_closest<false>(c, w, w.path_state(parity), in_count, bound);
-        }
-        c->end_timed(w.stream);
-        if (k > 0 && !fused) {
-            c->begin_timed(HIPR_KERNEL_TRACE_SHADOW, w.stream);
-            if (c->instrument) launch_trace_shadow<true>(c, w, shadow_in, bound);
-            else launch_trace_shadow<false>(c, w, shadow_in, bound);
-            c->end_timed(w.stream);
-        }
-
-        c->begin_timed(HIPR_KERNEL_SHADE, w.stream);
-        launch_shade(c, w, *camera, parity, bound, in_count, out_count);
-        c->end_timed(w.stream);
-        HIP_TRY(hipEventRecord(w.shade_done[parity], w.stream));
-        HIP_TRY(hipStreamWaitEvent(c->copy_stream, w.shade_done[parity], 0));
-        HIP_TRY(hipMemcpyAsync(w.host_counts + 2 * parity, out_count, 4, hipMemcpyDeviceToHost, c->copy_stream));
-        HIP_TRY(hipMemcpyAsync(w.host_counts + 2 * parity + 1, shadow_out, 4, hipMemcpyDeviceToHost, c->copy_stream));
-        HIP_TRY(hipEventRecord(w.counts_copied[parity], c->copy_stream));
-
-        if (c->instrument && c->trace_log) {   // diagnostic (HIPR_TRACE_LOG=1): per-bounce counters and kernel times; serialises the pass
-            HIP_TRY(hipStreamSynchronize(w.stream));
-            HIP_TRY(hipStreamSynchronize(c->copy_stream));
-            DeviceCounters dc;
-            HIP_TRY(hipMemcpy(&dc, c->counters.ptr, sizeof(dc), hipMemcpyDeviceToHost));
-            const DeviceCounters& p = c->trace_log_previous;
-            fprintf(stderr, "[hipr] wavefront %d bounce %u: <= %u closest rays: nodes %llu tris %llu | shadow rays of the previous bounce: nodes %llu tris %llu | kernels",
-                    int(&w - c->wavefronts), k, bound, dc.closest_nodes - p.closest_nodes, dc.closest_triangles - p.closest_triangles, dc.shadow_nodes - p.shadow_nodes,
-                    dc.shadow_triangles - p.shadow_triangles);
-            for (size_t i = first_timed; i < c->timed.size(); ++i) {
-                float ms = 0;
-                (void)hipEventElapsedTime(&ms, c->timed[i].start, c->timed[i].stop);
-                fprintf(stderr, " %s %.1f us", c->timed[i].kernel == HIPR_KERNEL_SHADE ? "shade" : (c->timed[i].kernel == HIPR_KERNEL_TRACE_SHADOW ? "shadow" : "trace"), ms * 1e3f);
-            }
-            fprintf(stderr, " -> %u paths continue, %u shadow rays\n", w.host_counts[2 * parity], w.host_counts[2 * parity + 1]);
-            if (dc.node_iterations != p.node_iterations) {
-                const double ni = double(dc.node_iterations - p.node_iterations), ti = double(dc.triangle_iterations - p.triangle_iterations);
-                fprintf(stderr, "[hipr]     wave iterations: %.0f node (%.1f lanes working) + %.0f triangle (%.1f lanes working); %.1f lanes busy on average; %llu refills\n", ni,
-                        double(dc.node_lanes - p.node_lanes) / ni, ti, ti > 0 ? double(dc.triangle_lanes - p.triangle_lanes) / ti : 0.0,
-                        double(dc.busy_lanes - p.busy_lanes) / (ni + ti), dc.refills - p.refills);
-                const double pushes = double(dc.pushes - p.pushes);
-                if (pushes > 0)
-                    fprintf(stderr, "[hipr]     stack pushes: %.0f, of which %.3f %% onto entry 16 or deeper and %.3f %% onto entry 24 or deeper\n", pushes,
-                            100.0 * double(dc.pushes_past_16 - p.pushes_past_16) / pushes, 100.0 * double(dc.pushes_past_24 - p.pushes_past_24) / pushes);
-            }
-            c->trace_log_previous = dc;
-        }
-        return HIPR_OK;
-    };
+    if (!pipelined) HIP_TRY(hipEventRecord(c->pass_start, c->stream));
 
     // Start every wavefront: camera rays + bounce 0.
     uint32_t alive[MAX_WAVEFRONTS] = {}, bounce[MAX_WAVEFRONTS] = {};
     bool running[MAX_WAVEFRONTS] = {};
-    for (int g = 0; g < c->wavefront_count; ++g) {
+    for (int g = first_wavefront; g < end_wavefront; ++g) {
         Wavefront& w = c->wavefronts[g];
-        if (g > 0) HIP_TRY(hipStreamWaitEvent(w.stream, c->pass_start, 0));
-        w.host_counts[4] = w.n_slots;   // pinned staging pair {paths, 0 shadow rays}, rewritten only after the syncs of the next pass
-        w.host_counts[5] = 0;
-        HIP_TRY(hipMemcpyAsync(w.queue_counts.as<uint32_t>(), w.host_counts + 4, 8, hipMemcpyHostToDevice, w.stream));
+        if (!pipelined && g > 0) HIP_TRY(hipStreamWaitEvent(w.stream, c->pass_start, 0));
+        // the counters at the start of a pass: pair 0 = {paths, 0 shadow rays}, all others zero (pinned image, rewritten only after the syncs of the next pass)
+        memset(w.host_counts + 8, 0, COUNT_LINES * COUNT_PAIR_STRIDE * sizeof(uint32_t));
+        w.host_counts[8] = w.n_slots;
+        HIP_TRY(hipMemcpyAsync(w.queue_counts.as<uint32_t>(), w.host_counts + 8, COUNT_LINES * COUNT_PAIR_STRIDE * sizeof(uint32_t), hipMemcpyHostToDevice, w.stream));
+        c->break_chain(w.stream);
         c->begin_timed(HIPR_KERNEL_GENERATE, w.stream);
         hipLaunchKernelGGL(k_generate, dim3((w.n_slots + 255) / 256), dim3(256), 0, w.stream, f, *camera, w.path_state(0), c->radiance.as<float4>(), w.first_slot, w.n_slots);
         c->end_timed(w.stream);
         alive[g] = w.n_slots;
         running[g] = true;
-        if (int s = enqueue_bounce(w, 0, alive[g])) return s;
+        if (int s = enqueue_bounce(c, w, *camera, 0, alive[g])) return s;
     }
     // Round robin over the wavefronts: queue the next bounce speculatively (at most `alive` paths continue), then read the sizes
-    // the current one produced. A wavefront whose paths all ended has, with that last speculative bounce, also traced its last shadow rays.
+    // the current one produced -- the GPU never idles on the read-back. A wavefront whose paths all ended has, with that last speculative
+    // bounce, also traced its last shadow rays.
     pass.closest_rays -= n - uint32_t(std::min<uint64_t>(n, pass.camera_rays));   // dead lanes of partial tiles are queued but never traced
-    for (int remaining = c->wavefront_count; remaining > 0;) {
-        for (int g = 0; g < c->wavefront_count; ++g) {
+    bool detached = false;
+    for (int remaining = end_wavefront - first_wavefront; remaining > 0 && !detached;) {
+        for (int g = first_wavefront; g < end_wavefront; ++g) {
             if (!running[g]) continue;
             Wavefront& w = c->wavefronts[g];
             const uint32_t k = bounce[g];
-            if (int s = enqueue_bounce(w, k + 1, alive[g])) return s;
+            if (int s = enqueue_bounce(c, w, *camera, k + 1, alive[g])) return s;
             HIP_TRY(hipEventSynchronize(w.counts_copied[k & 1u]));
             pass.closest_rays += alive[g];
             pass.shadow_rays += w.host_counts[2 * (k & 1u) + 1];
@@ -1124,10 +1274,26 @@ int hipr_trace_pass(HiprContext* c, const HiprCameraState* camera) {
             if (alive[g] == 0) {
                 running[g] = false;
                 --remaining;
-                if (g > 0) {
+                if (!pipelined && g > 0) {
                     HIP_TRY(hipEventRecord(w.finished, w.stream));
                     HIP_TRY(hipStreamWaitEvent(c->stream, w.finished, 0));
                 }
+            } else if (pipelined && k >= 1 && uint64_t(alive[g]) * 64u < w.n_slots) {
+                // A sliver of the paths is left (bounce k + 1 is queued for them already). Every bounce that can follow is queued now, sized by this
+                // count and reading its own on the device: those the camera's bounce limit allows, one more for the last shadow rays, and a reserve
+                // for hits that get rejected and retraced without counting as a bounce (finish_slot() takes over if that reserve runs out).
+                const uint32_t reserve = 8u;
+                const uint32_t blind = std::min(120u, (camera->max_bounce_count + 2u > k ? camera->max_bounce_count + 2u - k : 1u) + reserve);
+                for (uint32_t t = 0; t < blind; ++t)
+                    if (int s = enqueue_bounce(c, w, *camera, k + 2 + t, alive[g], ps.tail_counts + 2 * t)) return s;
+                ps.pending = true;
+                ps.alive_at_detach = alive[g];
+                ps.first_parity = (k + 1) & 1u;
+                ps.blind_bounces = blind;
+                ps.next_bounce = k + 2 + blind;
+                ps.camera = *camera;
+                detached = true;
+                break;
             }
             if (k > 4096) return fail(HIPR_ERROR_HIP, "wavefront loop did not terminate");
         }
@@ -1147,7 +1313,7 @@ int hipr_trace_pass(HiprContext* c, const HiprCameraState* camera) {
     c->total.shadow_rays += pass.shadow_rays;
     c->total.iterations += pass.iterations;
     if (c->instrument || c->timed.size() > 2048) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (int s = finish_all(c)) return s;
         c->collect_times();
     }
     return HIPR_OK;
@@ -1161,13 +1327,20 @@ int hipr_accumulate_samples(HiprContext* c, uint32_t first_sample, uint32_t samp
         return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_accumulate_samples: samples [%u, %u) of a traced pass of %u", first_sample, first_sample + sample_count, c->traced_samples);
     if (out_half4_device && c->frame.tile_stride == 1 && out_pitch_pixels < c->frame.width) return fail(HIPR_ERROR_INVALID_ARGUMENT, "output pitch smaller than the frame width");
     const FrameInfo& f = c->frame;
-    c->begin_timed(HIPR_KERNEL_ACCUMULATE, c->stream);
-    hipLaunchKernelGGL(k_accumulate, dim3((f.owned_tiles * 64 + 255) / 256), dim3(256), 0, c->stream, f, first_sample, sample_count, first_accumulation, c->radiance.as<float4>(),
+    // The fold runs on the stream of the slot that traced the samples, behind that pass's tail; two consecutive folds may be on different streams and
+    // both update the running mean and the frame: the later one waits for the earlier one.
+    hipStream_t stream = c->wavefronts[c->traced_slot].stream;
+    if (c->accumulated_valid) HIP_TRY(hipStreamWaitEvent(stream, c->accumulated, 0));
+    c->break_chain(stream);
+    c->begin_timed(HIPR_KERNEL_ACCUMULATE, stream);
+    hipLaunchKernelGGL(k_accumulate, dim3((f.owned_tiles * 64 + 255) / 256), dim3(256), 0, stream, f, first_sample, sample_count, first_accumulation, c->radiance.as<float4>(),
                        c->active_accumulation().as<double4>(), static_cast<ushort4*>(out_half4_device), out_pitch_pixels, c->pass_depth_normalizer);
-    c->end_timed(c->stream);
+    c->end_timed(stream);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->accumulated, stream));
+    c->accumulated_valid = true;
     if (synchronize || c->instrument || c->timed.size() > 2048) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (int s = finish_all(c)) return s;
         c->collect_times();
     }
     return HIPR_OK;
@@ -1175,7 +1348,7 @@ int hipr_accumulate_samples(HiprContext* c, uint32_t first_sample, uint32_t samp
 
 int hipr_synchronize(HiprContext* c) {
     if (int s = check_context(c)) return s;
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int finish_status = finish_all(c)) return finish_status;
     c->collect_times();
     return HIPR_OK;
 }
@@ -1183,7 +1356,7 @@ int hipr_synchronize(HiprContext* c) {
 int hipr_get_counters(HiprContext* c, HiprCounters* out) {
     if (int s = check_context(c)) return s;
     if (!out) return fail(HIPR_ERROR_INVALID_ARGUMENT, "null counters");
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int finish_status = finish_all(c)) return finish_status;
     c->collect_times();
     DeviceCounters dc;
     HIP_TRY(hipMemcpy(&dc, c->counters.ptr, sizeof(dc), hipMemcpyDeviceToHost));
@@ -1198,7 +1371,7 @@ int hipr_get_counters(HiprContext* c, HiprCounters* out) {
 
 int hipr_reset_counters(HiprContext* c) {
     if (int s = check_context(c)) return s;
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int finish_status = finish_all(c)) return finish_status;
     c->collect_times();
     HIP_TRY(hipMemset(c->counters.ptr, 0, sizeof(DeviceCounters)));
     c->total = {};
@@ -1226,6 +1399,14 @@ int hipr_set_trace_variant(HiprContext* c, int variant) {
     return HIPR_OK;
 }
 
+int hipr_set_pass_pipelining(HiprContext* c, int enable) {
+    if (int s = check_context(c)) return s;
+    if (int s = finish_all(c)) return s;
+    c->pipeline_passes = enable != 0;
+    if (c->frame_ready && partition_path_slots(c)) return HIPR_ERROR_OUT_OF_MEMORY;      // the second slot's queues come and go with the setting
+    return HIPR_OK;
+}
+
 int hipr_set_instrumentation(HiprContext* c, int count_traversal_steps) {
     if (!c) return fail(HIPR_ERROR_INVALID_ARGUMENT, "null context");
     c->instrument = count_traversal_steps != 0;
@@ -1234,7 +1415,7 @@ int hipr_set_instrumentation(HiprContext* c, int count_traversal_steps) {
 
 int hipr_reset_timers(HiprContext* c) {
     if (int s = check_context(c)) return s;
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int finish_status = finish_all(c)) return finish_status;
     c->collect_times();
     c->times = {};
     return HIPR_OK;
@@ -1243,7 +1424,7 @@ int hipr_reset_timers(HiprContext* c) {
 int hipr_get_kernel_times(HiprContext* c, HiprKernelTimes* out) {
     if (int s = check_context(c)) return s;
     if (!out) return fail(HIPR_ERROR_INVALID_ARGUMENT, "null output");
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int finish_status = finish_all(c)) return finish_status;
     c->collect_times();
     *out = c->times;
     return HIPR_OK;
@@ -1256,7 +1437,7 @@ int hipr_read_accumulation(HiprContext* c, double* out_rgba, uint64_t capacity_p
     const uint64_t owned = uint64_t(f.owned_tiles) * 64;
     const uint64_t needed = f.tile_stride == 1 ? uint64_t(f.width) * f.height : owned;
     if (!out_rgba || capacity_pixels < needed) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_read_accumulation: need room for %llu pixels", (unsigned long long)needed);
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int finish_status = finish_all(c)) return finish_status;
     c->collect_times();
     if (f.tile_stride != 1) {
         HIP_TRY(hipMemcpy(out_rgba, c->active_accumulation().ptr, owned * 32, hipMemcpyDeviceToHost));
@@ -1294,7 +1475,7 @@ int hipr_device_malloc(HiprContext* c, uint64_t bytes, void** out_device_pointer
 int hipr_device_free(HiprContext* c, void* device_pointer) {
     if (int s = check_context(c)) return s;
     if (!device_pointer) return HIPR_OK;
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int finish_status = finish_all(c)) return finish_status;
     HIP_TRY(hipFree(device_pointer));
     return HIPR_OK;
 }
@@ -1310,7 +1491,7 @@ int hipr_copy_to_host(HiprContext* c, void* host, const void* device_pointer, ui
     if (int s = check_context(c)) return s;
     if (!host || !device_pointer) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_copy_to_host: bad argument");
     HIP_TRY(hipMemcpyAsync(host, device_pointer, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int finish_status = finish_all(c)) return finish_status;
     return HIPR_OK;
 }
 
@@ -1337,7 +1518,7 @@ int hipr_debug_generate(HiprContext* c, const HiprCameraState* camera, uint32_t 
     if (bo.resize(size_t(n) * 16) | bd.resize(size_t(n) * 16) | bt.resize(size_t(n) * 16) | bm.resize(size_t(n) * 16) | br.resize(size_t(n) * 16)) return HIPR_ERROR_OUT_OF_MEMORY;
     const PathState out = {bo.as<float4>(), bd.as<float4>(), bt.as<float4>(), bm.as<uint4>()};
     hipLaunchKernelGGL(k_generate, dim3((n + 255) / 256), dim3(256), 0, c->stream, f, cam, out, br.as<float4>(), 0u, n);
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int finish_status = finish_all(c)) return finish_status;
     if (out_origin_tmin) HIP_TRY(hipMemcpy(out_origin_tmin, bo.ptr, size_t(n) * 16, hipMemcpyDeviceToHost));
     if (out_direction) HIP_TRY(hipMemcpy(out_direction, bd.ptr, size_t(n) * 16, hipMemcpyDeviceToHost));
     bo.release(); bd.release(); bt.release(); bm.release(); br.release();
@@ -1361,7 +1542,7 @@ int hipr_debug_shading(HiprContext* c, int shading_model, const float* params10,
     if (r) return HIPR_ERROR_OUT_OF_MEMORY;
     hipr::launch_debug_shading(c->stream, c->scene.tables, shading_model, bp.as<float>(), bw.as<float>(), bi.as<float>(), int(n), mode, bo.as<float>());
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int finish_status = finish_all(c)) return finish_status;
     HIP_TRY(hipMemcpy(out_n7, bo.ptr, size_t(n) * 28, hipMemcpyDeviceToHost));
     bp.release(); bw.release(); bi.release(); bo.release();
     return HIPR_OK;
@@ -1376,7 +1557,7 @@ int hipr_debug_light(HiprContext* c, const HiprLight* light, const float* positi
     if (bp.upload(position3, 3 * 4, c->stream) | bi.upload(in_n3, size_t(n) * 12, c->stream) | bo.resize(size_t(n) * 32)) return HIPR_ERROR_OUT_OF_MEMORY;
     hipr::launch_debug_light(c->stream, *light, bp.as<float>(), bi.as<float>(), int(n), mode, bo.as<float>());
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int finish_status = finish_all(c)) return finish_status;
     HIP_TRY(hipMemcpy(out_n8, bo.ptr, size_t(n) * 32, hipMemcpyDeviceToHost));
     bp.release(); bi.release(); bo.release();
     return HIPR_OK;
@@ -1389,7 +1570,7 @@ int hipr_debug_sobol(HiprContext* c, const uint32_t* triples, uint32_t n, uint32
     if (int s = c->debug_a.upload(triples, size_t(n) * 12, c->stream)) return s;
     if (int s = c->debug_b.resize(size_t(n) * 16)) return s;
     hipLaunchKernelGGL(k_debug_sobol, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->debug_a.as<uint32_t>(), n, c->debug_b.as<uint32_t>(), c->sobol_tables.as<uint32_t>());
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int finish_status = finish_all(c)) return finish_status;
     HIP_TRY(hipMemcpy(out_uint4, c->debug_b.ptr, size_t(n) * 16, hipMemcpyDeviceToHost));
     return HIPR_OK;
 }
@@ -1397,7 +1578,7 @@ int hipr_debug_sobol(HiprContext* c, const uint32_t* triples, uint32_t n, uint32
 int hipr_debug_sample_offsets(HiprContext* c, float* out_256x4) {
     if (int s = check_context(c)) return s;
     if (!out_256x4) return fail(HIPR_ERROR_INVALID_ARGUMENT, "null argument");
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int finish_status = finish_all(c)) return finish_status;
     HIP_TRY(hipMemcpy(out_256x4, c->sample_offsets.ptr, 256 * 4 * sizeof(float), hipMemcpyDeviceToHost));
     return HIPR_OK;
 }
@@ -1432,7 +1613,7 @@ int hipr_debug_trace_closest(HiprContext* c, const float* rays, const uint32_t* 
     w.hits = bh;
     if (c->instrument) launch_trace_closest<true>(c, w, in, bc.as<uint32_t>(), n);
     else launch_trace_closest<false>(c, w, in, bc.as<uint32_t>(), n);
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int finish_status = finish_all(c)) return finish_status;
     HIP_TRY(hipMemcpy(out_hits, bh.ptr, size_t(n) * 16, hipMemcpyDeviceToHost));
     c->total = {};
     c->total.closest_rays = n;
@@ -1465,7 +1646,7 @@ int hipr_debug_trace_shadow(HiprContext* c, const float* rays, uint32_t n, float
     if (c->instrument) launch_trace_shadow<true>(c, w, bc.as<uint32_t>(), n);
     else launch_trace_shadow<false>(c, w, bc.as<uint32_t>(), n);
     c->radiance = saved_radiance;
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int finish_status = finish_all(c)) return finish_status;
     std::vector<float> result(size_t(n) * 4);
     HIP_TRY(hipMemcpy(result.data(), bacc.ptr, result.size() * 4, hipMemcpyDeviceToHost));
     for (uint32_t i = 0; i < n; ++i) out_transmittance[i] = result[4 * i];

@@ -30,6 +30,9 @@ constexpr int TRACE_BLOCK = 128;   // 2 waves; LDS stack = STACK * 128 * 4 B
 #define HIPR_SHADE_BLOCK_THREADS 256
 #endif
 constexpr int SHADE_BLOCK = HIPR_SHADE_BLOCK_THREADS;
+#ifndef HIPR_SHADE_SPLIT_WAVES
+#define HIPR_SHADE_SPLIT_WAVES 4    // waves per SIMD the two halves of the split shade kernel are compiled for (shade_kernel.h SHADE_PART_*)
+#endif
 constexpr int SHADE_TRIANGLE_QUADS = 8;   // float4 per shading record (128 B = one cache line), see k_build_shade_triangles
 
 struct DeviceScene {

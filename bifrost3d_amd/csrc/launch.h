@@ -19,6 +19,9 @@ struct ShadeLaunch {
     float4* radiance;
     const uint32_t* in_count;
     unsigned long long* out_counts;   // {paths that continue, shadow rays queued}: one 8-byte word so that a block reserves both with one atomic
+    unsigned long long* zero_a;       // two 8-byte counters the kernel zeroes for the kernels of the next bounce (nullptr: none)
+    unsigned long long* zero_b;
+    unsigned char* nee_flags;         // one byte per queue entry: non-null runs the kernel as its two halves (shade_kernel.h SHADE_PART_*)
     DeviceCounters* counters;
 };
 

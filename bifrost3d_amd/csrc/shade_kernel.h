@@ -35,7 +35,15 @@ struct ShadeOutput {
     f3 o, d; float tmin, bsdf_pdf; f3 throughput; uint32_t bounces, last_triangle;
     f3 so, sd; float stmax; f3 sradiance;
     f3 add_radiance;
+    bool nee_reached;    // SHADE_PART_NEE: the hit was accepted and next event estimation ran ...
+    bool nee_valid;      // ... and kept a light sample with a valid PDF
 };
+
+// The shade kernel whole, or as two kernels run one after the other over the same queue (HIPR_SHADE_SPLIT=1): next event estimation (queues the shadow
+// rays and leaves one flag per accepted hit: was a light sample kept -- the one thing the BSDF sample needs to know of it, MonteCarlo.cu:224) and the
+// rest (emission, miss and light hits, rejected hits, BSDF sampling; queues the paths that continue). Both halves redo the hit's attributes, textures
+// and shading setup; each needs fewer registers than the whole.
+constexpr int SHADE_PART_ALL = 0, SHADE_PART_NEE = 1, SHADE_PART_BSDF = 2;
 
 // What shade_path reads of the hit triangle, fetched one loop iteration ahead by k_shade.
 struct ShadeGeometry {
@@ -43,12 +51,14 @@ struct ShadeGeometry {
     float4 s0, s1, s2, s3, s4, s5;     // shading record (k_build_shade_triangles)
 };
 
-template <int MODELS, bool AOV>
+template <int MODELS, bool AOV, int PART = SHADE_PART_ALL>
 HD void shade_path(const DeviceScene& sc, const HiprCameraState& cam, int entry, const uint32_t* sobol_lds, f3 ro, f3 rd, float bsdf_pdf, f3 throughput, uint32_t bounces,
-                   uint32_t last_triangle, uint32_t pixel_hash, uint32_t accumulation, float4 hit, const ShadeGeometry& geo, const HiprMaterial& mp, ShadeOutput& out) {
-    out.continues = out.shadow = out.shaded = false;
+                   uint32_t last_triangle, uint32_t pixel_hash, uint32_t accumulation, float4 hit, const ShadeGeometry& geo, const HiprMaterial& mp, bool nee_kept_a_sample,
+                   ShadeOutput& out) {
+    out.continues = out.shadow = out.shaded = out.nee_reached = out.nee_valid = false;
     out.add_radiance = mk3(0.0f);
     const uint32_t id = __float_as_uint(hit.w);
+    if (PART == SHADE_PART_NEE && (id == HIPR_HIT_MISS || (id & HIPR_HIT_LIGHT))) return;
     if (id == HIPR_HIT_MISS) {
         if (AOV) {   // material_index stays 0 -> black; the depth entry adds |origin - 1e30 * direction| (SimpleRGPs.cu:227-239, 349-362)
             if (entry == HIPR_ENTRY_DEPTH) out.add_radiance = mk3(length(ro - 1e30f * rd));
@@ -98,12 +108,14 @@ HD void shade_path(const DeviceScene& sc, const HiprCameraState& cam, int entry,
     const float coverage = material_coverage(sc, mp, texcoord);
     if (backside_cull || coverage < bsdf_u.w) {
         // rejected hit: same ray, tmin bumped past it, counters untouched (MonteCarlo.cu:159-164)
+        if (PART == SHADE_PART_NEE) return;
         out.continues = true;
         out.o = ro; out.d = rd; out.tmin = nextafterf(hit.x, __builtin_inff()); out.bsdf_pdf = bsdf_pdf;
         out.throughput = throughput; out.bounces = bounces; out.last_triangle = last_triangle;
         return;
     }
-    out.shaded = true;
+    out.shaded = PART != SHADE_PART_NEE;
+    out.nee_reached = true;
 
     const f3 position = p1 * u + p2 * v + p0 * w;
     f3 shading_normal = geometric_normal;
@@ -202,11 +214,11 @@ HD void shade_path(const DeviceScene& sc, const HiprCameraState& cam, int entry,
         return;
     }
 
-    out.add_radiance = throughput * emission * mk3(mp.emission[0], mp.emission[1], mp.emission[2]);
+    if (PART != SHADE_PART_NEE) out.add_radiance = throughput * emission * mk3(mp.emission[0], mp.emission[1], mp.emission[2]);
 
     // --- next event estimation: streaming RIS over the light candidates (MonteCarlo.cu:91-123) ------
     LightSample kept = light_sample_none();
-    if (sc.light_count != 0) {
+    if (PART != SHADE_PART_BSDF && sc.light_count != 0) {
         const f4 base = sobol4f_tables(accumulation, pixel_hash, 8u * bounces + 1u, sobol_lds);
         const int n = sc.next_event_sample_count;
         for (int s = 0; s < n; ++s) {
@@ -237,12 +249,17 @@ HD void shade_path(const DeviceScene& sc, const HiprCameraState& cam, int entry,
         }
         kept.radiance /= float(n);
     }
-    const f3 light_origin = offset_ray_origin(position, kept.dir, geometric_normal);
-    kept.radiance *= throughput;
-    if (kept.radiance.x > 0 || kept.radiance.y > 0 || kept.radiance.z > 0) {
-        out.shadow = true;
-        out.so = light_origin; out.sd = kept.dir; out.stmax = kept.distance; out.sradiance = kept.radiance;
+    if (PART != SHADE_PART_BSDF) {
+        const f3 light_origin = offset_ray_origin(position, kept.dir, geometric_normal);
+        kept.radiance *= throughput;
+        if (kept.radiance.x > 0 || kept.radiance.y > 0 || kept.radiance.z > 0) {
+            out.shadow = true;
+            out.so = light_origin; out.sd = kept.dir; out.stmax = kept.distance; out.sradiance = kept.radiance;
+        }
+        out.nee_valid = pdf_is_valid(kept.pdf);
+        if (PART == SHADE_PART_NEE) return;
     }
+    const bool light_sample_kept = PART == SHADE_PART_BSDF ? nee_kept_a_sample : pdf_is_valid(kept.pdf);
 
     // --- BSDF sampling (MonteCarlo.cu:204-232) ---------------------------------------------------
     const Sample bs = shading_sample<MODELS>(shading, wo, mk3(bsdf_u.x, bsdf_u.y, bsdf_u.z));
@@ -254,7 +271,7 @@ HD void shade_path(const DeviceScene& sc, const HiprCameraState& cam, int entry,
     const float cos_geometric = dot(direction, geometric_normal);
     if (is_reflection ? cos_geometric < 0.0f : cos_geometric >= 0.0f)
         direction = reflect(direction, geometric_normal);
-    if (!pdf_is_valid(kept.pdf)) new_pdf = pdf_disable_MIS(new_pdf);
+    if (!light_sample_kept) new_pdf = pdf_disable_MIS(new_pdf);
     bounces += 1u;
 
     out.o = offset_ray_origin(position, direction, geometric_normal);
@@ -271,6 +288,7 @@ HD void shade_path(const DeviceScene& sc, const HiprCameraState& cam, int entry,
 // triangle, shading record and material are requested once the hit id has arrived, behind the compaction barriers. The four
 // dependent gathers of a hit (path state -> hit -> triangle / record -> material) are thereby off the critical path.
 struct ShadeInputs {
+    uint32_t entry;        // the queue entry (HIPR_DEAD_SLOT: none)
     uint4 meta;            // slot, last accepted triangle, pixel hash, accumulation
     float4 o, d, t, hit;   // origin + tmin, direction + pdf, throughput + bounces, (t, u, v, id)
 };
@@ -278,6 +296,7 @@ struct ShadeInputs {
 // `i`: the queue entry, or HIPR_DEAD_SLOT for none (past the end of the queue).
 HD ShadeInputs shade_fetch_inputs(const PathState& in, const float4* hits, uint32_t i) {
     ShadeInputs r;
+    r.entry = i;
     r.meta = make_uint4(HIPR_DEAD_SLOT, 0u, 0u, 0u);
     r.o = r.d = r.t = make_float4(0, 0, 0, 0);
     r.hit = make_float4(0, 0, 0, __uint_as_float(HIPR_HIT_MISS));
@@ -321,10 +340,11 @@ HD HiprMaterial shade_fetch_material(const DeviceScene& sc, const ShadeInputs& i
 #define HIPR_SHADE_ONE_BARRIER 1
 #endif
 constexpr uint32_t SHADE_LDS_LIGHTS = 32;   // light arrays up to this size are copied to LDS (1.5 KB); larger ones are read from global memory
-template <int MODELS, bool AOV>
-__global__ __launch_bounds__(SHADE_BLOCK, HIPR_SHADE_WAVES) void k_shade(DeviceScene sc, HiprCameraState cam, int entry, PathState in, const float4* hits, const uint32_t* order, PathState out,
+constexpr int shade_waves_per_simd(int part) { return part == SHADE_PART_ALL ? HIPR_SHADE_WAVES : HIPR_SHADE_SPLIT_WAVES; }
+template <int MODELS, bool AOV, int PART>
+__global__ __launch_bounds__(SHADE_BLOCK, shade_waves_per_simd(PART)) void k_shade(DeviceScene sc, HiprCameraState cam, int entry, PathState in, const float4* hits, const uint32_t* order, PathState out,
                                                         ShadowQueue shadows, float4* radiance, const uint32_t* count_ptr, unsigned long long* out_counts,
-                                                        DeviceCounters* counters) {
+                                                        unsigned long long* zero_a, unsigned long long* zero_b, unsigned char* nee_flags, DeviceCounters* counters) {
 #if HIPR_SHADE_ONE_BARRIER
     __shared__ unsigned long long s_arrivals[2];
     __shared__ uint32_t s_base[4];
@@ -341,6 +361,12 @@ __global__ __launch_bounds__(SHADE_BLOCK, HIPR_SHADE_WAVES) void k_shade(DeviceS
     __shared__ HiprLight s_lights[SHADE_LDS_LIGHTS];
 #endif
     const uint32_t n = *count_ptr;
+    // The counters the NEXT bounce's kernels fill start from zero; nothing on the device reads or writes them while this kernel runs (hiprenderer.hip
+    // enqueue_bounce). A fill command in the stream for each costs more than this whole kernel does on a bounce of a few thousand paths.
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (zero_a) *zero_a = 0ull;
+        if (zero_b) *zero_b = 0ull;
+    }
     if (blockIdx.x * SHADE_BLOCK >= n) return;
     const uint32_t stride = gridDim.x * SHADE_BLOCK;
     uint32_t base = blockIdx.x * SHADE_BLOCK;
@@ -378,8 +404,11 @@ __global__ __launch_bounds__(SHADE_BLOCK, HIPR_SHADE_WAVES) void k_shade(DeviceS
         so.continues = so.shadow = so.shaded = false;
         const uint32_t slot = cur.meta.x, pixel_hash = cur.meta.z, accumulation = cur.meta.w;
         if (slot != HIPR_DEAD_SLOT) {
-            shade_path<MODELS, AOV>(sc, cam, entry, s_sobol, mk3(cur.o.x, cur.o.y, cur.o.z), mk3(cur.d.x, cur.d.y, cur.d.z), cur.d.w, mk3(cur.t.x, cur.t.y, cur.t.z),
-                                    __float_as_uint(cur.t.w), cur.meta.y, pixel_hash, accumulation, cur.hit, geo, mat, so);
+            bool nee_kept_a_sample = false;
+            if (PART == SHADE_PART_BSDF && shade_hits_triangle(cur)) nee_kept_a_sample = nee_flags[cur.entry] != 0;   // written for every accepted hit; read by those only
+            shade_path<MODELS, AOV, PART>(sc, cam, entry, s_sobol, mk3(cur.o.x, cur.o.y, cur.o.z), mk3(cur.d.x, cur.d.y, cur.d.z), cur.d.w, mk3(cur.t.x, cur.t.y, cur.t.z),
+                                          __float_as_uint(cur.t.w), cur.meta.y, pixel_hash, accumulation, cur.hit, geo, mat, nee_kept_a_sample, so);
+            if (PART == SHADE_PART_NEE && so.nee_reached) nee_flags[cur.entry] = so.nee_valid ? 1 : 0;
             if (so.add_radiance.x != 0.0f || so.add_radiance.y != 0.0f || so.add_radiance.z != 0.0f) {
                 float4 acc = radiance[slot];
                 acc.x += so.add_radiance.x; acc.y += so.add_radiance.y; acc.z += so.add_radiance.z;

@@ -243,6 +243,64 @@ def test_deep_tree_on_the_wide8_kernels_bit_exact(ctx, oracle_q, tmp_path, count
     assert counters["shadow_nodes"] == nodes and counters["shadow_triangles"] == tris
 
 
+@pytest.mark.parametrize("name,kwargs,bounces", [("material", dict(), 32), ("atrium", dict(param0=20000, param1=3), 4), ("opacity", dict(param0=8), 32)])
+def test_pipelined_passes_render_the_unpipelined_frames(ctx, name, kwargs, bounces):
+    """hipr_set_pass_pipelining: consecutive passes on alternating queue sets and streams, a pass's last bounces queued blindly while the next pass starts --
+    the running mean, the half4 frame and the ray counters are those of passes that run to their end one after the other, bit for bit; also when the reserve
+    of blind bounces runs out (the opacity scene's coverage 0.75 planes reject hits without counting a bounce) and the pass is finished when its slot comes up."""
+    import torch
+    scene = Scene(name, **kwargs)
+    w, h, batch, passes = 160, 96, 4, 5
+    results = []
+    for pipelined in (False, True):
+        ctx.set_pass_pipelining(pipelined)
+        try:
+            ctx.upload_scene(scene)
+            assert ctx.trace_is_fused()
+            ctx.set_frame(w, h, 0, 1, batch)
+            ctx.reset_counters()
+            frame = torch.zeros((h, w, 4), dtype=torch.float16, device="cuda")
+            for p in range(passes):
+                ctx.render_pass(scene.camera(w, h, accumulations=p * batch, max_bounce_count=bounces), frame.data_ptr(), w)
+            ctx.synchronize()
+            results.append((ctx.read_accumulation(), frame.cpu(), ctx.counters()))
+        finally:
+            ctx.set_pass_pipelining(False)
+    (mean_a, frame_a, counters_a), (mean_b, frame_b, counters_b) = results
+    assert np.array_equal(mean_a, mean_b) and torch.equal(frame_a, frame_b)
+    for key in ("camera_rays", "closest_rays", "shadow_rays", "shaded_hits"):
+        assert counters_a[key] == counters_b[key], (key, counters_a[key], counters_b[key])
+    assert counters_a["closest_rays"] > counters_a["camera_rays"]
+
+
+@pytest.mark.parametrize("name,kwargs,bounces", [("material", dict(), 32), ("atrium", dict(param0=20000, param1=3), 4), ("cornell", dict(), 8), ("opacity", dict(param0=8), 32)])
+def test_split_shade_kernel_renders_the_same_frames(ctx, monkeypatch, name, kwargs, bounces):
+    """HIPR_SHADE_SPLIT=1 (an experiment kept in the tree): next event estimation and the rest of the shade kernel as two launches over the
+    same queue, one flag byte per accepted hit between them. Running mean and ray counters are those of the whole kernel, bit for bit."""
+    from bifrost3d_amd.renderer import Context
+    scene = Scene(name, **kwargs)
+    w, h, batch, passes = 160, 96, 4, 3
+    results = []
+    for split in (False, True):
+        monkeypatch.setenv("HIPR_SHADE_SPLIT", "1" if split else "0")
+        c = Context(0)
+        try:
+            c.upload_scene(scene)
+            c.set_frame(w, h, 0, 1, batch)
+            c.reset_counters()
+            for p in range(passes):
+                c.render_pass(scene.camera(w, h, accumulations=p * batch, max_bounce_count=bounces))
+            c.synchronize()
+            results.append((c.read_accumulation(), c.counters()))
+        finally:
+            c.close()
+    (mean_a, counters_a), (mean_b, counters_b) = results
+    assert np.array_equal(mean_a, mean_b)
+    for key in ("camera_rays", "closest_rays", "shadow_rays", "shaded_hits"):
+        assert counters_a[key] == counters_b[key], (key, counters_a[key], counters_b[key])
+    assert counters_a["shadow_rays"] > 0
+
+
 def test_million_triangle_scene(ctx, oracle_q):
     """BASELINE config 5's shape at test size: the 1 M-triangle atrium (seed 2), wide BVH of 250 k nodes. Stage parity bit-exact with
     counters, a small image against the oracle, and at 3840 x 2160 the size-independent properties (finite, every camera path
