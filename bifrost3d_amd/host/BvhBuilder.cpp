@@ -600,11 +600,7 @@ BvhBuildResult build_bvh(const std::vector<HiprTriangle>& triangles, uint32_t ma
     result.wide_nodes = std::move(collapse.wide);
     result.max_depth = b.deepest + 1;   // stack entries needed is bounded by the node depth; keep one spare
     const auto t_wide = std::chrono::steady_clock::now();
-    {
-        std::vector<HiprTriangle> ordered(n);
-        for (uint32_t k = 0; k < n; ++k) ordered[k] = triangles[result.order[k]];
-        result.wide8 = build_wide8(result.nodes, ordered);
-    }
+    result.wide8 = build_wide8(result.nodes, OrderedTriangles{triangles.data(), result.order.data(), n});
     if (std::getenv("HIPR_BVH_TIMING")) {
         const auto t_end = std::chrono::steady_clock::now();
         fprintf(stderr, "[hipr] build_bvh: %u triangles, %u threads: BVH2 %.3f s, 4-wide collapse %.3f s, 8-wide collapse %.3f s (%u nodes, %u leaf records of which %u hold two triangles, height %u)\n", n,
@@ -658,7 +654,7 @@ double refit_bvh(BvhBuildResult& bvh, const std::vector<HiprTriangle>& triangles
         quantise_children(boxes, count, w);      // the non-empty children occupy the first `count` slots, as the build left them
         (void)refs;
     }
-    refit_wide8(bvh.wide8, triangles);
+    refit_wide8(bvh.wide8, OrderedTriangles{triangles.data(), nullptr, triangles.size()});
     return area;
 }
 

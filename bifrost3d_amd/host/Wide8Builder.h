@@ -3,6 +3,7 @@
 
 #include "../../include/hiprenderer_c.h"
 
+#include <cstddef>
 #include <cstdint>
 #include <vector>
 
@@ -15,10 +16,20 @@ struct Wide8Result {
     uint32_t node_count = 0, leaf_count = 0, paired_leaves = 0;
 };
 
+// The scene's triangles in the order the BVH2's leaves reference them, without a copy: element k is triangles[order[k]] (order == nullptr: triangles[k]).
+struct OrderedTriangles {
+    const HiprTriangle* triangles = nullptr;
+    const uint32_t* order = nullptr;
+    size_t count = 0;
+    const HiprTriangle& operator[](size_t k) const { return triangles[order ? order[k] : k]; }
+    size_t size() const { return count; }
+    bool empty() const { return count == 0; }
+};
+
 // Collapses a BVH2 (HiprBvhNode[], leaves referencing ranges of `triangles_in_leaf_order`) into the 8-wide tree of include/hiprenderer_c.h "wide8".
-Wide8Result build_wide8(const std::vector<HiprBvhNode>& nodes, const std::vector<HiprTriangle>& triangles_in_leaf_order);
+Wide8Result build_wide8(const std::vector<HiprBvhNode>& nodes, const OrderedTriangles& triangles_in_leaf_order);
 
 // Transform-only update: same topology, new triangle positions. Rewrites every leaf record from `triangles_in_leaf_order` and requantises every node.
-void refit_wide8(Wide8Result& tree, const std::vector<HiprTriangle>& triangles_in_leaf_order);
+void refit_wide8(Wide8Result& tree, const OrderedTriangles& triangles_in_leaf_order);
 
 } // namespace HIPRenderer

@@ -350,8 +350,9 @@ def test_a_far_move_makes_the_builder_rebuild(oracle):
 
 
 def test_parallel_bvh_build_is_the_sequential_build():
-    """The host BVH build runs its top levels and its subtrees on several threads for large scenes (host/BvhBuilder.cpp); the tree, the wide tree
-    and the triangle order must be the single-threaded ones byte for byte (the oracle and the kernels' counters are pinned on that tree)."""
+    """The host BVH build runs its top levels and its subtrees on several threads for large scenes (host/BvhBuilder.cpp), and so do the three phases of the
+    8-wide collapse (host/Wide8Builder.cpp); the tree, the wide trees and the triangle order must be the single-threaded ones byte for byte (the oracle and
+    the kernels' counters are pinned on that tree)."""
     import os
     import subprocess
     import sys
@@ -361,9 +362,9 @@ def test_parallel_bvh_build_is_the_sequential_build():
         env = dict(os.environ, HIPR_BVH_THREADS=threads, HIPR_BVH_TIMING="1")
         done = subprocess.run([sys.executable, probe, "400000"], capture_output=True, text=True, env=env, timeout=600)
         assert done.returncode == 0, done.stderr[-1000:]
-        assert f"{threads} threads" in done.stderr, done.stderr[-500:]          # the thread count took effect
+        assert f"{threads} threads" in done.stderr and f"8-wide on {threads} threads" in done.stderr, done.stderr[-500:]          # the thread count took effect
         lines[threads] = done.stdout.strip().split()
-    triangles, nodes, wide_nodes, _, digest = lines["1"]
-    assert int(triangles) > 262144 and int(nodes) > 0 and int(wide_nodes) > 0
+    triangles, nodes, wide_nodes, wide8_slots, wide8_height, _, digest = lines["1"]
+    assert int(triangles) > 262144 and int(nodes) > 0 and int(wide_nodes) > 0 and int(wide8_slots) > 0 and int(wide8_height) > 4
     for threads in ("3", "8"):
-        assert lines[threads][:3] == [triangles, nodes, wide_nodes] and lines[threads][4] == digest, (threads, lines[threads], lines["1"])
+        assert lines[threads][:5] == [triangles, nodes, wide_nodes, wide8_slots, wide8_height] and lines[threads][6] == digest, (threads, lines[threads], lines["1"])

@@ -12,4 +12,5 @@ h = hashlib.sha256()
 h.update(C.string_at(d.nodes, d.node_count * 64))
 h.update(C.string_at(d.wide_nodes, d.wide_node_count * 64))
 h.update(C.string_at(d.triangles, d.triangle_count * 48))
-print(d.triangle_count, d.node_count, d.wide_node_count, f"{dt:.2f}s", h.hexdigest()[:16])
+h.update(C.string_at(d.wide8_slots, d.wide8_slot_count * 64))
+print(d.triangle_count, d.node_count, d.wide_node_count, d.wide8_slot_count, d.wide8_height, f"{dt:.2f}s", h.hexdigest()[:16])
