@@ -75,7 +75,7 @@ def derived(c):
 
 if sums:
     lines = [f"# SQ / TCC / TCP counters of the atrium bench (bench.py --scene atrium --steps 2 --warmup 1, one wavefront), rocprofv3 --pmc, four separate passes",
-             "# (tools/profile_sq.sh, tools/gpu_round2_profiles.sh, tools/collect_profiles.py). Sums over all dispatches of a kernel in the run; SQ_*_CYCLES are quad-cycles summed over waves.",
+             "# (tools/profile_sq.sh, tools/gpu_round3_profiles.sh, tools/collect_profiles.py). Sums over all dispatches of a kernel in the run; SQ_*_CYCLES are quad-cycles summed over waves.",
              "# derived: share of wave time = counter / SQ_WAVE_CYCLES; lanes per VALU instruction = SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU; L2 hit = TCC_HIT / TCC_REQ; L1 hit = 1 - TCP_TCC_READ_REQ / TCP_TOTAL_CACHE_ACCESSES",
              ""]
     limiters = {}
@@ -101,8 +101,13 @@ if sums:
 
     table = {"atrium": {"source": f"profiles/{tag}_atrium_sq_counters.txt (rocprofv3 --pmc SQ_*, TCC_*, TCP_* passes of this workload)",
                         "summary": "per-wave latency of dependent gathers and arithmetic at partial lane occupancy, not HBM bytes (DESIGN.md section 5: sensitivity experiments)"}}
-    fused, shade = pick("k_trace_persistent<16, 2, false") or pick("k_trace_persistent<32, 2, false"), pick("k_shade<1, false>")
-    if fused:
+    wide8 = pick("k_trace_wide8<12, 2, false")
+    fused, shade = wide8 or pick("k_trace_persistent<16, 2, false") or pick("k_trace_persistent<32, 2, false"), pick("k_shade<1, false")
+    if fused and wide8:
+        table["atrium"]["k_trace_wide8<12, TRACE_FUSED>"] = entry(fused, 6)
+        table["atrium"]["summary"] = ("VALU issue (wave time the pipe issues x 6 waves per SIMD) at 37 of 64 lanes per instruction and the address pipeline, not HBM bytes "
+                                      "(DESIGN.md section 5: issue-rate table, TA_TA_BUSY, sensitivity experiments)")
+    elif fused:
         table["atrium"]["k_trace_persistent<16, TRACE_FUSED, overflow to scratch>" if "<16" in fused else "k_trace_persistent<32, TRACE_FUSED>"] = entry(fused, 6 if "<16" in fused else 5)
     if shade:
         table["atrium"]["k_shade<1, false>"] = entry(shade, 3)
