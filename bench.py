@@ -588,6 +588,27 @@ def measure(ctx, scene, scene_name, bounces, args, rank, world, device, steps, w
         result["fused"] = ctx.trace_is_fused()
         result["wide8"] = ctx.trace_variant() == capi.TRACE_WIDE8_PERSISTENT
     result["wavefronts"] = args.wavefronts if args.wavefronts else (1 if ctx.trace_is_fused() else 2)
+    if world == 1 and result.get("wide8") and not args.pmc_child:
+        # The same frames with every refused closest hit retraced, as the reference does it (hipr_set_backface_culling 0): a short run beside the line's own,
+        # for the ray count and the time the stepping saves. Outside the timed region.
+        ctx.set_backface_culling(False)
+        try:
+            run_pass(a)
+            ctx.synchronize()
+            ctx.reset_counters()
+            t1 = time.perf_counter()
+            for k in range(2):
+                run_pass(a + (k + 1) * S)
+            ctx.synchronize()
+            seconds = time.perf_counter() - t1
+            rc = ctx.counters()
+        finally:
+            ctx.set_backface_culling(True)
+        rays = rc["closest_rays"] + rc["shadow_rays"]
+        result["retrace_mode"] = {"Mrays_per_s": rays / seconds * 1e-6, "ms_per_step": seconds / 2 * 1e3, "rays_per_step": rays / 2, "closest_rays_per_step": rc["closest_rays"] / 2,
+                                  "steps": 2, "note": "hipr_set_backface_culling(0): closest hits on the back of one-sided surfaces go to the hit program, which refuses them and has the ray "
+                                                      "traced again (ORS/MonteCarlo.cu:147-164), one more BVH query each; the line's own figures step over them in the traversal -- "
+                                                      "same frames, fewer rays"}
     return result
 
 
@@ -700,6 +721,11 @@ def main():
                        "rmse_note": "no OptiX image exists or can be produced here (DESIGN.md); rmse_vs_oracle compares with the pinned CPU oracle at equal spp and seed"},
             "roofline": main_figures["roofline"], "roofline_by_kernel": main_figures["roofline_by_kernel"], "kernel_ms_per_step": main_figures["kernel_ms_per_step"],
         }
+        if result.get("wide8"):
+            out["config"]["backface_culling"] = ("hipr_set_backface_culling 1 (the default): the 8-wide traversal steps over closest hits on the back of one-sided surfaces instead of "
+                                                  "handing them to the hit program to be refused and retraced; rays counted are the BVH queries actually made")
+        if "retrace_mode" in result:
+            out["retrace_mode"] = result["retrace_mode"]
         if world > 1:
             out["ranks"] = {"ms_per_step": [e / args.steps * 1e3 for e in result["rank_elapsed"]], "gather_ms": result["gather_ms"],
                             "paths_per_gpu_per_step": int(main_figures["pixel_samples"] / args.steps / world),

@@ -193,6 +193,7 @@ struct HiprContext {
     int shade_blocks_per_cu = 0;        // persistent shade blocks per CU = waves per SIMD; 0: 3 (what the kernel is compiled for), 2 for all-Diffuse scenes (HIPR_SHADE_BLOCKS_PER_CU)
     uint32_t shade_ordered_from = 1u << 18;   // bounces with fewer paths than this are shaded in queue order (HIPR_SHADE_ORDERED_FROM)
     int refill_below = 40;              // persistent kernels refill a wave once fewer lanes than this are busy (HIPR_REFILL_BELOW)
+    bool cull_backfaces = true;         // hipr_set_backface_culling / HIPR_BACKFACE_CULLING=0
     bool shade_split = false;           // HIPR_SHADE_SPLIT=1: the shade kernel as two, next event estimation and the rest (shade_kernel.h; measured)
     bool shade_ordered = true;          // k_classify_hits before k_shade (HIPR_SHADE_ORDERED=0: shade in queue order)
     int persistent_blocks_per_cu[3][3] = {{0, 0, 0}, {0, 0, 0}};   // [shadow][stack bucket]
@@ -676,6 +677,11 @@ const char* validate_scene(const HiprSceneDesc* s, uint32_t& wide_stack_need, ch
         if (tri.instance_index >= s->instance_count) INVALID("triangle %u references instance %u of %u", t, tri.instance_index, s->instance_count);
         const HiprInstance& inst = s->instances[tri.instance_index];
         if (tri.primitive_index >= primitive_total - inst.index_offset) INVALID("triangle %u references primitive %u beyond the index pool", t, tri.primitive_index);
+        if (tri.flags & HIPR_TRIANGLE_ONE_SIDED) {      // the traversal may step over hits on its back: only where the hit program would refuse them
+            const HiprMaterial& m = s->materials[inst.material_index];
+            if ((m.flags & (HIPR_MATERIAL_CUTOUT | HIPR_MATERIAL_THIN_WALLED)) || m.shading_model == HIPR_SHADING_TRANSMISSIVE)
+                INVALID("triangle %u is flagged HIPR_TRIANGLE_ONE_SIDED but material %d is thin-walled, a cut-out or transmissive", t, inst.material_index);
+        }
         const uint32_t* idx = s->indices + 3 * size_t(inst.index_offset + tri.primitive_index);
         for (int k = 0; k < 3; ++k)
             if (idx[k] >= s->vertex_count - inst.vertex_offset) INVALID("triangle %u: vertex index %u is beyond the vertex pool", t, idx[k]);
@@ -758,6 +764,12 @@ const char* validate_wide8(const HiprSceneDesc* s, uint32_t& height, char* messa
                     INVALID("leaf record in slot %u references triangles %u / %u of %u", child, leaf.triangle[0], leaf.triangle[1], s->triangle_count);
                 for (int shift = 8; shift < 16; shift += 2)
                     if (((leaf.flags >> shift) & 3u) == 3u) INVALID("leaf record in slot %u has an invalid corner selector", child);
+                for (int which = 0; which < 2; ++which) {
+                    if (leaf.triangle[which] == HIPR_LEAF8_NONE) continue;
+                    const bool one_sided = (s->triangles[leaf.triangle[which]].flags & HIPR_TRIANGLE_ONE_SIDED) != 0;
+                    if ((leaf.flags >> (2 + which) & 1u) && !one_sided) INVALID("leaf record in slot %u marks triangle %u one-sided, the triangle is not", child, leaf.triangle[which]);
+                }
+                if ((leaf.flags & 12u) && !(leaf.facing_margin >= 0.0f && std::isfinite(leaf.facing_margin))) INVALID("leaf record in slot %u has no valid facing margin", child);
             }
         }
     }
@@ -775,6 +787,7 @@ int upload_wide8(HiprContext* c, const HiprSceneDesc* s, uint32_t height) {
     c->wide8.slots = c->wide8_slots.as<uint4>();
     c->wide8.slot_count = s->wide8_slot_count;
     for (int a = 0; a < 3; ++a) { c->wide8.grid_min[a] = s->wide8_grid_min[a]; c->wide8.grid_cell[a] = s->wide8_grid_cell[a]; }
+    c->wide8.cull_backfaces = c->cull_backfaces ? 1u : 0u;
     c->wide8_height = height;
     return HIPR_OK;
 }
@@ -877,6 +890,7 @@ int hipr_create(int device_id, HiprContext** out_context) {
     if (const char* v = getenv("HIPR_TRACE_LOG")) c->trace_log = atoi(v) != 0;
     if (const char* v = getenv("HIPR_SHADE_ORDERED")) c->shade_ordered = atoi(v) != 0;
     if (const char* v = getenv("HIPR_SHADE_SPLIT")) c->shade_split = atoi(v) != 0;
+    if (const char* v = getenv("HIPR_BACKFACE_CULLING")) c->cull_backfaces = atoi(v) != 0;
     if (const char* v = getenv("HIPR_PIPELINE_PASSES")) c->pipeline_passes = atoi(v) != 0;
     if (const char* v = getenv("HIPR_PIPELINE_SPARE_BLOCKS")) c->pipeline_spare_blocks = std::max(0, atoi(v));
     HIP_TRY(hipMemsetAsync(c->counters.ptr, 0, sizeof(DeviceCounters), c->stream));
@@ -1396,6 +1410,14 @@ int hipr_set_trace_variant(HiprContext* c, int variant) {
     if (!c) return fail(HIPR_ERROR_INVALID_ARGUMENT, "null context");
     if (variant < -1 || variant > HIPR_TRACE_WIDE8_PERSISTENT) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_set_trace_variant: unknown variant %d", variant);
     c->trace_variant = variant;     // the exhaustive search's items are built at upload: upload the scene after this call
+    return HIPR_OK;
+}
+
+int hipr_set_backface_culling(HiprContext* c, int enable) {
+    if (int s = check_context(c)) return s;
+    if (int s = finish_all(c)) return s;
+    c->cull_backfaces = enable != 0;
+    c->wide8.cull_backfaces = c->cull_backfaces ? 1u : 0u;
     return HIPR_OK;
 }
 

@@ -36,6 +36,7 @@ struct Wide8Scene {
     const uint4* slots;          // HiprSlot8, 4 x uint4 each
     uint32_t slot_count;
     float grid_min[3], grid_cell[3];
+    uint32_t cull_backfaces;     // hipr_set_backface_culling: closest hits clearly on the back of a one-sided record triangle are stepped over
 };
 
 // LDS stack entries (8 bytes each) by tree height: the stack holds at most one group per level above the current one.
@@ -197,6 +198,15 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(wid
                     const f3 e2 = mk3(__uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x));
                     const f3 e3 = mk3(__uint_as_float(r2.y), __uint_as_float(r2.z), __uint_as_float(r2.w));
                     const uint32_t flags = r3.z;
+                    // Closest hits the hit program would refuse -- a one-sided surface reached from behind, MonteCarlo.cu:147-164 -- and have the ray traced again from
+                    // just past: stepped over here. The solve's determinant carries the facing, positive from the front of the record's winding (B's may be the
+                    // other way round: flags bit 4); refused below -facing_margin, never (limit -inf) for a two-sided triangle or with the culling off.
+#ifndef HIPR_WIDE8_CULL_CODE
+#define HIPR_WIDE8_CULL_CODE 1      // 0: compiled out (A/B of what the test itself costs)
+#endif
+                    const uint32_t cull = HIPR_WIDE8_CULL_CODE && tree.cull_backfaces != 0u ? flags : 0u;
+                    const float refuse_a_below = (cull & 4u) ? -__uint_as_float(r3.w) : -__builtin_inff();
+                    const float refuse_b_below = (cull & 8u) ? -__uint_as_float(r3.w) : -__builtin_inff();
                     bool testing = true;
                     advance = true;
 #pragma unroll
@@ -230,7 +240,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(wid
                                 }
                             }
                             if constexpr (MODE != TRACE_SHADOW) {
-                                const bool closer = !is_shadow & hit & (id != pay_k) & (t > tmin) & ((t < tmax) | ((t == tmax) & (id < __float_as_uint(pay_z))));
+                                const float facing = which == 0 ? test.det : __uint_as_float(__float_as_uint(test.det) ^ ((flags & 16u) << 27));
+                                const bool refused = facing < (which == 0 ? refuse_a_below : refuse_b_below);
+                                const bool closer = !is_shadow & hit & !refused & (id != pay_k) & (t > tmin) & ((t < tmax) | ((t == tmax) & (id < __float_as_uint(pay_z))));
                                 tmax = closer ? t : tmax; pay_x = closer ? u : pay_x; pay_y = closer ? v : pay_y; pay_z = closer ? __uint_as_float(id) : pay_z;
                             }
                         }

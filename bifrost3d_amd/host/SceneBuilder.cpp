@@ -155,6 +155,11 @@ static bool statically_opaque(const HiprMaterial& m) {
     return m.coverage >= 1.0f;
 }
 
+// backside_cull of the hit program (OptiXRenderer/Shading/MonteCarlo.cu:147-164): !hit_from_front && !thin_walled && !transmissive, thin_walled = cut-out or thin-walled.
+static bool refuses_hits_from_behind(const HiprMaterial& m) {
+    return !(m.flags & (HIPR_MATERIAL_CUTOUT | HIPR_MATERIAL_THIN_WALLED)) && m.shading_model != HIPR_SHADING_TRANSMISSIVE;
+}
+
 void SceneBuilder::finalize(uint32_t bvh_max_depth) {
     std::vector<HiprTriangle> world;
     m_bounds = AABB::invalid();
@@ -163,6 +168,7 @@ void SceneBuilder::finalize(uint32_t bvh_max_depth) {
         const MeshRecord& mesh = m_meshes[m_instance_mesh[i]];
         const float* M = inst.object_to_world;
         const bool opaque = statically_opaque(m_materials[inst.material_index]);
+        const bool one_sided = refuses_hits_from_behind(m_materials[inst.material_index]);
         auto to_world = [&](uint32_t v, float* out) {
             const float* p = m_geometry[mesh.vertex_offset + v].position;
             for (int r = 0; r < 3; ++r) out[r] = M[4 * r] * p[0] + M[4 * r + 1] * p[1] + M[4 * r + 2] * p[2] + M[4 * r + 3];
@@ -174,7 +180,7 @@ void SceneBuilder::finalize(uint32_t bvh_max_depth) {
             to_world(idx[0], t.v0); to_world(idx[1], t.v1); to_world(idx[2], t.v2);
             t.instance_index = i;
             t.primitive_index = p;
-            t.flags = opaque ? HIPR_TRIANGLE_OPAQUE : 0;
+            t.flags = (opaque ? HIPR_TRIANGLE_OPAQUE : 0) | (one_sided ? HIPR_TRIANGLE_ONE_SIDED : 0);
             world.push_back(t);
         }
     }

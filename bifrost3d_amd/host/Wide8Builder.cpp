@@ -59,7 +59,7 @@ bool make_record(const OrderedTriangles& triangles, uint32_t index_a, uint32_t i
     out.triangle[0] = index_a;
     out.triangle[1] = HIPR_LEAF8_NONE;
     // record corner k of A is A's vertex (rotation + k) % 3, so A's vertex j is record corner (j - rotation) mod 3: its weight is (w, u, v)[that]
-    uint32_t flags = (A.flags & HIPR_TRIANGLE_OPAQUE ? 1u : 0u) | uint32_t((1 - rotation_a + 3) % 3) << 8 | uint32_t((2 - rotation_a + 3) % 3) << 10;
+    uint32_t flags = (A.flags & HIPR_TRIANGLE_OPAQUE ? 1u : 0u) | (A.flags & HIPR_TRIANGLE_ONE_SIDED ? 4u : 0u) | uint32_t((1 - rotation_a + 3) % 3) << 8 | uint32_t((2 - rotation_a + 3) % 3) << 10;
     if (index_b != HIPR_LEAF8_NONE) {
         const HiprTriangle& B = triangles[index_b];
         int where[3] = {-1, -1, -1};      // record corner (0 = a, 1 = c, 2 = d) of B's vertex j
@@ -72,9 +72,15 @@ bool make_record(const OrderedTriangles& triangles, uint32_t index_a, uint32_t i
         if (!d || where[0] == where[1] || where[0] == where[2] || where[1] == where[2]) return false;   // not two shared corners + one own
         for (int k = 0; k < 3; ++k) out.e3[k] = d[k] - a[k];
         out.triangle[1] = index_b;
-        flags |= (B.flags & HIPR_TRIANGLE_OPAQUE ? 2u : 0u) | uint32_t(where[1]) << 12 | uint32_t(where[2]) << 14;
+        flags |= (B.flags & HIPR_TRIANGLE_OPAQUE ? 2u : 0u) | (B.flags & HIPR_TRIANGLE_ONE_SIDED ? 8u : 0u) | uint32_t(where[1]) << 12 | uint32_t(where[2]) << 14;
+        // B's vertices 0, 1, 2 sit on the record's corners where[0], where[1], where[2] of (a, c, d): an odd permutation means B is wound the other way round
+        const bool even = (where[0] == 0 && where[1] == 1) || (where[0] == 1 && where[1] == 2) || (where[0] == 2 && where[1] == 0);
+        if (!even) flags |= 16u;
     }
     out.flags = flags;
+    float squares = 0.0f;
+    for (int k = 0; k < 3; ++k) squares += out.e1[k] * out.e1[k] + out.e2[k] * out.e2[k] + out.e3[k] * out.e3[k];
+    out.facing_margin = squares * (1.0f / 8192.0f);
     return true;
 }
 

@@ -117,6 +117,9 @@ class Context:
         """Forces a search for the scenes uploaded after the call (-1: by scene size)."""
         self._check(self.lib.hipr_set_trace_variant(self.handle, int(variant)), "hipr_set_trace_variant")
 
+    def set_backface_culling(self, enable: bool):
+        self._check(self.lib.hipr_set_backface_culling(self.handle, int(enable)), "hipr_set_backface_culling")
+
     def set_pass_pipelining(self, enable: bool):
         self._check(self.lib.hipr_set_pass_pipelining(self.handle, int(enable)), "hipr_set_pass_pipelining")
 

@@ -350,9 +350,10 @@ Hit closest_hit_wide(const HiprSceneDesc& scene, const Ray& ray, uint32_t skip, 
 //   * visiting a leaf record tests triangle A = (a; e1, e2), then B = (a; e2, e3) if there is one, with the solve of intersect_triangle on the stored
 //     edges; the weights (w, u, v) = (1 - u - v, u, v) of the record's corners are mapped to the scene triangle's (u, v) by the record's selectors.
 // ---------------------------------------------------------------------------------------------
-static inline bool intersect_edges(float3 v0, float3 e1, float3 e2, float3 o, float3 d, float& t, float& u, float& v) {
+static inline bool intersect_edges(float3 v0, float3 e1, float3 e2, float3 o, float3 d, float& t, float& u, float& v, float* determinant = nullptr) {
     float3 p = cross_fma(d, e2);
     float det = dot_fma(e1, p);
+    if (determinant) *determinant = det;
     float3 tv = o - v0;
     float un = dot_fma(tv, p);
     float3 q = cross_fma(tv, e1);
@@ -367,13 +368,15 @@ static inline bool intersect_edges(float3 v0, float3 e1, float3 e2, float3 o, fl
     return true;
 }
 // Triangle `which` (0 = A, 1 = B) of a leaf record: hit distance and the scene triangle's barycentrics.
-static inline bool intersect_record(const HiprLeaf8& r, int which, float3 o, float3 d, float& t, float& u, float& v) {
+// `facing`: the solve's determinant signed by the SCENE triangle's winding (positive: the ray arrives at its front), HiprLeaf8::flags bit 4.
+static inline bool intersect_record(const HiprLeaf8& r, int which, float3 o, float3 d, float& t, float& u, float& v, float* facing = nullptr) {
     const float3 a = {r.a[0], r.a[1], r.a[2]};
     const float3 first = which == 0 ? make_float3(r.e1[0], r.e1[1], r.e1[2]) : make_float3(r.e2[0], r.e2[1], r.e2[2]);
     const float3 second = which == 0 ? make_float3(r.e2[0], r.e2[1], r.e2[2]) : make_float3(r.e3[0], r.e3[1], r.e3[2]);
-    float ru, rv;
-    if (!intersect_edges(a, first, second, o, d, t, ru, rv))
+    float ru, rv, det;
+    if (!intersect_edges(a, first, second, o, d, t, ru, rv, &det))
         return false;
+    if (facing) *facing = (which == 1 && (r.flags & 16u)) ? -det : det;
     const float weights[3] = {1.0f - ru - rv, ru, rv};
     const uint32_t selectors = (r.flags >> (which == 0 ? 8 : 12)) & 15u;
     u = weights[selectors & 3u];
@@ -447,16 +450,24 @@ static inline void traverse_wide8(const HiprSceneDesc& scene, const Ray& ray, fl
     }
 }
 
+// hipr_set_backface_culling (include/hiprenderer_c.h), the oracle's side: on by default like the device's. A closest hit on a record triangle flagged
+// one-sided whose facing is below -facing_margin is stepped over -- what the hit program would refuse (MonteCarlo.cu:147-164) and retrace past.
+static std::atomic<bool> g_cull_backfaces{true};
+void set_backface_culling(bool enable) { g_cull_backfaces.store(enable); }
+bool backface_culling() { return g_cull_backfaces.load(); }
 Hit closest_hit_wide8(const HiprSceneDesc& scene, const Ray& ray, uint32_t skip, TraversalCounters* counters) {
     Hit best = {ray.tmax, 0, 0, HIT_MISS};
+    const bool cull = backface_culling();
     traverse_wide8(scene, ray, best.t, counters, [&](const HiprLeaf8& record) {
         for (int which = 0; which < 2; ++which) {
             const uint32_t id = record.triangle[which];
             if (id == HIPR_LEAF8_NONE)
                 break;
             if (counters) counters->triangles++;
-            float t, u, v;
-            if (id == skip || !intersect_record(record, which, ray.origin, ray.direction, t, u, v) || !(t > ray.tmin))
+            float t, u, v, facing;
+            if (id == skip || !intersect_record(record, which, ray.origin, ray.direction, t, u, v, &facing) || !(t > ray.tmin))
+                continue;
+            if (cull && (record.flags >> (2 + which) & 1u) && facing < -record.facing_margin)
                 continue;
             if (t < best.t || (t == best.t && id < best.id))
                 best = {t, u, v, id};
@@ -1007,6 +1018,7 @@ float3 path_trace_pixel(const HiprSceneDesc& scene, const HiprSceneState& state,
         } else {
             bool accepted = closest_hit_program(scene, state, cam, offsets, payload, hit, ray.direction);
             if (accepted && counters) counters->shaded_hits++;
+            if (!accepted && counters) counters->rejected_hits++;
         }
 
         const LightSample& ls = payload.light_sample;

@@ -50,7 +50,9 @@ float3 shadow_bruteforce(const HiprSceneDesc& scene, const Ray& ray, float3 radi
 float3 shadow_bvh(const HiprSceneDesc& scene, const Ray& ray, float3 radiance, TraversalCounters* counters);
 float3 shadow_wide(const HiprSceneDesc& scene, const Ray& ray, float3 radiance, TraversalCounters* counters);
 float3 shadow_wide8(const HiprSceneDesc& scene, const Ray& ray, float3 radiance, TraversalCounters* counters);
-int wide8_stack_high_water(bool reset);  // diagnostic: deepest traverse_wide8 stack since the last reset
+int wide8_stack_high_water(bool reset);
+void set_backface_culling(bool enable);      // the 8-wide search steps over closest hits on the back of one-sided triangles (default on, like the device)
+bool backface_culling();  // diagnostic: deepest traverse_wide8 stack since the last reset
 
 // --- textures / materials ---------------------------------------------------------------------
 float4 sample_texture(const HiprSceneDesc& scene, int texture_ID, float2 uv);
@@ -66,6 +68,7 @@ struct RenderSettings {
 
 struct RenderCounters {
     uint64_t camera_rays = 0, closest_rays = 0, shadow_rays = 0, shaded_hits = 0;
+    uint64_t rejected_hits = 0;      // closest hits the hit program refused (back side of a one-sided surface, coverage below the drawn number): retraced, MonteCarlo.cu:159-164
     TraversalCounters closest, shadow;
 };
 

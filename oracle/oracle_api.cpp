@@ -30,6 +30,8 @@ extern "C" {
 
 int oracle_wide_stack_high_water(int reset) { return oracle::wide_stack_high_water(reset != 0); }
 int oracle_wide8_stack_high_water(int reset) { return oracle::wide8_stack_high_water(reset != 0); }
+void oracle_set_backface_culling(int enable) { oracle::set_backface_culling(enable != 0); }
+int oracle_backface_culling() { return oracle::backface_culling() ? 1 : 0; }
 
 
 void oracle_set_tables(const float* base, const float* full, const float* light, const float* dense, const float* alphas, int quantize_unorm16) {
@@ -371,13 +373,14 @@ double oracle_render_entry(const HiprSceneDesc* scene, const HiprSceneState* sta
                 total.camera_rays += local.camera_rays; total.closest_rays += local.closest_rays; total.shadow_rays += local.shadow_rays;
                 total.shaded_hits += local.shaded_hits; total.closest.nodes += local.closest.nodes; total.closest.triangles += local.closest.triangles;
                 total.shadow.nodes += local.shadow.nodes; total.shadow.triangles += local.shadow.triangles;
+                total.rejected_hits += local.rejected_hits;
             }
         }
     }
     if (counters9) {
         counters9[0] = total.camera_rays; counters9[1] = total.closest_rays; counters9[2] = total.shadow_rays; counters9[3] = total.shaded_hits;
         counters9[4] = total.closest.nodes; counters9[5] = total.closest.triangles; counters9[6] = total.shadow.nodes; counters9[7] = total.shadow.triangles;
-        counters9[8] = 0;
+        counters9[8] = total.rejected_hits;
     }
 #ifdef _OPENMP
     return omp_get_wtime() - t0;

@@ -12,6 +12,7 @@ for p in (str(ROOT), str(ROOT / "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "culling: the oracle's 8-wide search steps over the back of one-sided triangles, as by default (tests/test_wide8_cpu.py turns it off otherwise)")
 
 
 @pytest.fixture(scope="session")

@@ -198,7 +198,14 @@ class Oracle:
         seconds = self.lib.oracle_render_entry(C.byref(scene), C.byref(state), C.byref(cam), width, height, accumulation_count, int(use_bvh), entry,
                                                accum.ctypes.data_as(C.POINTER(C.c_double)), counters)
         names = [f[0] for f in capi.HiprCounters._fields_]
-        return accum, dict(zip(names, list(counters))), seconds
+        result = dict(zip(names, list(counters)))
+        result["rejected_hits"] = result.pop("iterations")      # the oracle has no launch iterations; its ninth counter is the hits its hit program refused
+        result["iterations"] = 0
+        return accum, result, seconds
+
+    def set_backface_culling(self, enable: bool):
+        """The oracle's side of hipr_set_backface_culling: its 8-wide search (use_bvh=3) steps over closest hits on the back of one-sided triangles."""
+        self.lib.oracle_set_backface_culling(int(enable))
 
     def pmjbn(self, count=16384, candidates=8):
         out = np.zeros((count, 2), np.float32)

@@ -14,6 +14,14 @@ def oracle():
     return get_oracle(True)
 
 
+@pytest.fixture(autouse=True)
+def geometric_search(oracle):
+    """These are comparisons of geometric searches: the 8-wide search's stepping over the back of one-sided triangles is off (tests/test_wide8_cpu.py has its tests)."""
+    oracle.set_backface_culling(False)
+    yield
+    oracle.set_backface_culling(True)
+
+
 def awkward_rays(lo, hi, seed):
     from test_gpu_edges import awkward_rays as rays      # one definition for both sides
     return rays(lo, hi, seed)

@@ -121,7 +121,7 @@ def test_awkward_rays_bit_exact(ctx, oracle_q, name, kwargs, variant):
         assert np.array_equal(gpu.view(np.uint32), cpu.view(np.uint32))
         assert counters["closest_nodes"] == nodes and counters["closest_triangles"] == tris
         hit = gpu[:, 3].view(np.uint32) != 0xFFFFFFFF
-        assert 0.3 < hit.mean() <= 1.0 and np.isfinite(gpu[hit, 0]).all()
+        assert 0.1 < hit.mean() <= 1.0 and np.isfinite(gpu[hit, 0]).all()      # the 8-wide search steps over hits on the back of one-sided surfaces
         # the same rays as shadow rays of finite and of zero extent
         shadow = rays.copy()
         shadow[:, 3] = 0.0

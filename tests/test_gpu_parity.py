@@ -129,6 +129,24 @@ def test_closest_hit_bit_exact(ctx, oracle_q, cornell, cornell_tessellated, atri
     # last ulp may be resolved to the other surface, because box culling compares against the best distance so far.
     brute, _ = oracle_q.trace_closest(scene.desc, rays[:8000], skip[:8000], use_bvh=False, with_lights=True)
     if ctx.trace_variant() == capi.TRACE_WIDE8_PERSISTENT:
+        # The 8-wide search as a GEOMETRIC search, on both sides: without the stepping over hits on the back of one-sided surfaces that it does by default
+        # (hipr_set_backface_culling; above, device and oracle agreed bit for bit WITH it).
+        ctx.set_backface_culling(False)
+        oracle_q.set_backface_culling(False)
+        try:
+            ctx.set_instrumentation(True)
+            ctx.reset_counters()
+            gpu_geometric = ctx.debug_trace_closest(rays, skip)
+            counters = ctx.counters()
+            ctx.set_instrumentation(False)
+            cpu, (nodes, tris) = oracle_q.trace_closest(scene.desc, rays, skip, use_bvh=ctx.oracle_search(), with_lights=True)
+        finally:
+            ctx.set_backface_culling(True)
+            oracle_q.set_backface_culling(True)
+        assert np.array_equal(gpu_geometric.view(np.uint32), cpu.view(np.uint32)) and counters["closest_nodes"] == nodes and counters["closest_triangles"] == tris
+        stepped_over = (gpu[:, 3].view(np.uint32) != gpu_geometric[:, 3].view(np.uint32)).mean()
+        assert (0.05 < stepped_over < 0.5) if scene_name == "atrium" else stepped_over < 0.05
+        gpu = gpu_geometric
         # a leaf record solves its triangles from the corner they share, not from their first vertex: the same hit, with t / u / v rounded differently
         differs = brute[:, 3].view(np.uint32) != cpu[:8000, 3].view(np.uint32)
         same = ~differs & np.isfinite(brute[:, 0])

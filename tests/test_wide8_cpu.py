@@ -21,6 +21,15 @@ def oracle():
     return get_oracle(True)
 
 
+@pytest.fixture(autouse=True)
+def geometric_search(request, oracle):
+    """The tests of this file compare the 8-wide search with the other searches as GEOMETRIC searches: its stepping over hits on the back of one-sided
+    triangles (hipr_set_backface_culling, on by default) is off for them, and tested by the cases marked `culling` at the end."""
+    oracle.set_backface_culling("culling" in request.keywords)
+    yield
+    oracle.set_backface_culling(True)
+
+
 def slots_of(desc):
     return np.ctypeslib.as_array(C.cast(desc.wide8_slots, C.POINTER(C.c_uint32)), shape=(desc.wide8_slot_count, 16)).copy()
 
@@ -283,3 +292,157 @@ def test_validate_scene_rejects_a_broken_tree():
     C.memmove(C.byref(d), C.byref(desc), C.sizeof(capi.HiprSceneDesc))
     d.wide8_grid_cell[1] = 0.0
     rejected(d, "grid")
+
+
+# ---- stepping over the back of one-sided surfaces (hipr_set_backface_culling) -------------------------------------------------------------------------------
+
+def refused(scene, rays, hits):
+    """Which of the hits the hit program refuses for being on the back of a one-sided surface (MonteCarlo.cu:147-164), decided the way IT decides:
+    normalised geometric normal . direction >= 0 on a material that is neither thin-walled, a cut-out nor transmissive."""
+    tris = scene.triangles()
+    ids = hits[:, 3].view(np.uint32)
+    on_triangle = (ids != NONE) & ((ids & 0x80000000) == 0)
+    safe = np.where(on_triangle, ids, 0)
+    corners = tris[safe][:, :9].view(np.float32).reshape(-1, 3, 3)
+    normal = np.cross(corners[:, 1] - corners[:, 0], corners[:, 2] - corners[:, 0])
+    normal /= np.maximum(np.linalg.norm(normal, axis=1, keepdims=True), 1e-30)
+    behind = (normal * rays[:, 4:7]).sum(axis=1) >= 0.0
+    one_sided = (tris[safe][:, 11] & capi.TRIANGLE_ONE_SIDED) != 0
+    return on_triangle & behind & one_sided
+
+
+def write_mixed_winding_obj(path):
+    """Sheets of quads in three orientations whose second triangle is wound against the first in every other quad (bit 4 of a record's flags), plus a few
+    quads standing exactly on a sheet (coincident surfaces). The OBJ default material is one-sided."""
+    rng = np.random.default_rng(5)
+    vertices, faces = [], []
+    for sheet in range(6):
+        axis, level = sheet % 3, 0.3 * (sheet // 3) - 0.15 + 0.07 * sheet
+        for i in range(6):
+            for j in range(6):
+                corners = []
+                for du, dv in ((0, 0), (1, 0), (1, 1), (0, 1)):
+                    p = [0.0, 0.0, 0.0]
+                    p[axis] = level
+                    p[(axis + 1) % 3] = (i + du) / 6.0 - 0.5
+                    p[(axis + 2) % 3] = (j + dv) / 6.0 - 0.5
+                    corners.append(tuple(p))
+                base = len(vertices)
+                vertices += corners
+                first = (base + 1, base + 2, base + 3)
+                second = (base + 1, base + 3, base + 4) if (i + j + sheet) % 2 == 0 else (base + 1, base + 4, base + 3)      # same edge, other way round
+                rotate = int(rng.integers(0, 3))
+                faces += [first, second[rotate:] + second[:rotate]]
+    with open(path, "w") as f:
+        for v in vertices:
+            f.write("v %.9g %.9g %.9g\n" % v)
+        for face in faces:
+            f.write("f %d %d %d\n" % face)
+    return str(path)
+
+
+@pytest.mark.culling
+@pytest.mark.parametrize("name,kwargs,lo,hi", [("atrium", dict(param0=20000, param1=3), -12.0, 12.0), ("cornell", dict(param0=3), -0.5, 0.5), ("mixed_winding", {}, -0.7, 0.7)])
+def test_stepping_over_refused_hits_finds_what_the_retrace_finds(oracle, tmp_path, name, kwargs, lo, hi):
+    """With the culling on, the 8-wide search returns for every ray what tracing again from just past every refused hit ends on -- except where a refused
+    triangle COINCIDES with another surface (the Cornell boxes stand on the floor: a ray inside a box leaves through its bottom AND the floor at one distance):
+    the retrace starts past both, the stepping search finds the floor (include/hiprenderer_c.h, hipr_set_backface_culling)."""
+    scene = Scene("file:" + write_mixed_winding_obj(tmp_path / "mixed.obj")) if name == "mixed_winding" else Scene(name, **kwargs)
+    if name == "mixed_winding":
+        flags = slots_of(scene.desc)[[slot for slot, _, is_node, _ in walk(scene.desc) if not is_node], 14]
+        assert ((flags >> 4) & 1).any() and not ((flags >> 4) & 1).all()
+    rng = np.random.default_rng(17)
+    rays = np.zeros((40000, 8), np.float32)
+    rays[:, 0:3] = rng.uniform(lo, hi, (len(rays), 3))
+    if name == "atrium":
+        rays[:, 1] = np.abs(rays[:, 1]) * 0.7
+    d = rng.normal(size=(len(rays), 3))
+    rays[:, 4:7] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    rays[:, 7] = np.inf
+    skip = np.full(len(rays), NONE, np.uint32)
+    stepped, (nodes_on, _) = oracle.trace_closest(scene.desc, rays, skip, use_bvh=3, with_lights=False)
+    oracle.set_backface_culling(False)
+    expected, (nodes_off, _) = oracle.trace_closest(scene.desc, rays, skip, use_bvh=3, with_lights=False)
+    retraces, chain = 0, []
+    pending = refused(scene, rays, expected)
+    assert pending.mean() > (0.05 if name != "cornell" else 0.0)
+    current = rays.copy()
+    for _ in range(64):
+        if not pending.any():
+            break
+        retraces += int(pending.sum())
+        chain.append(np.where(pending, expected[:, 0], np.float32(np.nan)))
+        current[pending, 3] = np.nextafter(expected[pending, 0], np.float32(np.inf))      # tmin just past the refused hit, as the hit program sets it
+        again, (nodes_again, _) = oracle.trace_closest(scene.desc, current[pending], skip[pending], use_bvh=3, with_lights=False)
+        nodes_off += nodes_again
+        expected[pending] = again
+        pending_rays = np.flatnonzero(pending)
+        still = refused(scene, current[pending], again)
+        pending = np.zeros(len(rays), bool)
+        pending[pending_rays[still]] = True
+    assert not pending.any()
+    different = ~(stepped.view(np.uint32) == expected.view(np.uint32)).all(axis=1)
+    # (a) hits inside the facing margin (grazing by 1e-4) are left to the hit program: the stepping search returns the refused hit itself
+    left_to_the_hit_program = refused(scene, rays, stepped)
+    # (b) a surface at the distance of a refused hit: found by the stepping search, skipped by the retrace
+    refused_distances = np.stack(chain, axis=1) if chain else np.zeros((len(rays), 0), np.float32)
+    coincident = (np.abs(refused_distances - stepped[:, :1]) <= 4e-7 * np.abs(stepped[:, :1])).any(axis=1)
+    assert (different & ~left_to_the_hit_program & ~coincident).sum() == 0
+    assert (different & left_to_the_hit_program).mean() <= 2e-4
+    assert (different & coincident).mean() <= (1e-2 if name == "cornell" else 1e-4)
+    if name != "cornell":
+        assert retraces > 0.1 * len(rays) and nodes_on < nodes_off      # one traversal with fewer node visits than the retraces together
+
+
+@pytest.mark.culling
+@pytest.mark.parametrize("name,kwargs,bounces", [("atrium", dict(param0=20000, param1=3), 4), ("opacity", dict(param0=8), 16), ("material", {}, 8), ("cornell", dict(param0=3), 6)])
+def test_frames_do_not_depend_on_the_culling(oracle, name, kwargs, bounces):
+    """Same paths, same frames, bit for bit; only the refused hits and their retraces are gone (atrium: a sixth of the closest-hit queries)."""
+    scene = Scene(name, **kwargs)
+    w, h, spp = 64, 36, 4
+    camera = scene.camera(w, h, max_bounce_count=bounces)
+    stepping, c_on, _ = oracle.render(scene.desc, scene.state, camera, w, h, spp, use_bvh=3)
+    oracle.set_backface_culling(False)
+    retracing, c_off, _ = oracle.render(scene.desc, scene.state, camera, w, h, spp, use_bvh=3)
+    four_wide, c_four, _ = oracle.render(scene.desc, scene.state, camera, w, h, spp, use_bvh=2)
+    assert np.array_equal(stepping, retracing)
+    assert c_on["shaded_hits"] == c_off["shaded_hits"] and c_on["shadow_rays"] == c_off["shadow_rays"]
+    assert c_on["closest_rays"] + c_off["rejected_hits"] - c_on["rejected_hits"] == c_off["closest_rays"]      # one query less per refused hit stepped over
+    assert c_off["rejected_hits"] == c_four["rejected_hits"]
+    if name == "atrium":
+        assert c_off["rejected_hits"] > 0.1 * c_off["closest_rays"] and c_on["rejected_hits"] <= 0.001 * c_off["rejected_hits"]
+    if name == "opacity":
+        assert c_on["rejected_hits"] == c_off["rejected_hits"] > 0      # coverage below the drawn number: nothing the traversal could decide
+
+
+@pytest.mark.culling
+def test_one_sided_flags_follow_the_materials(oracle):
+    scene = Scene("atrium", param0=20000, param1=3)
+    d = scene.desc
+    tris = scene.triangles()
+    one_sided = (tris[:, 11] & capi.TRIANGLE_ONE_SIDED) != 0
+    assert 0.3 < one_sided.mean() <= 1.0
+    for t in np.random.default_rng(2).integers(0, len(tris), 500):
+        m = d.materials[d.instances[int(tris[t, 9])].material_index]
+        expected = not (m.flags & (capi.MATERIAL_CUTOUT | capi.MATERIAL_THIN_WALLED)) and m.shading_model != capi.SHADING_TRANSMISSIVE
+        assert bool(one_sided[t]) == expected
+    # the records carry the flags of their triangles, the winding bit only where there is a second triangle, and a margin
+    slots = slots_of(d)
+    leaves = np.array([slot for slot, _, is_node, _ in walk(d) if not is_node])
+    flags, margin = slots[leaves, 14], slots[leaves, 15].view(np.float32)
+    assert np.array_equal((flags >> 2) & 1, one_sided[slots[leaves, 12]].astype(np.uint32))
+    paired = slots[leaves, 13] != NONE
+    assert np.array_equal(((flags >> 3) & 1)[paired], one_sided[slots[leaves, 13][paired]].astype(np.uint32))
+    assert not ((flags >> 4) & 1).any()      # a consistently wound mesh: the second triangle of a pair follows the shared edge the other way (test above: mixed windings)
+    assert (margin > 0).all() and np.isfinite(margin).all()
+    # a flag on a triangle whose material is two-sided is refused by the validation
+    thin = [i for i in range(d.material_count) if d.materials[i].flags & capi.MATERIAL_THIN_WALLED]
+    assert thin
+    victim = next(t for t in range(len(tris)) if d.instances[int(tris[t, 9])].material_index in thin)
+    assert not (tris[victim, 11] & capi.TRIANGLE_ONE_SIDED)
+    d.triangles[victim].flags |= capi.TRIANGLE_ONE_SIDED
+    try:
+        assert capi.load_library().hipr_validate_scene(C.byref(d)) != 0
+    finally:
+        d.triangles[victim].flags &= ~capi.TRIANGLE_ONE_SIDED
+    assert capi.load_library().hipr_validate_scene(C.byref(d)) == 0
