@@ -588,7 +588,7 @@ def measure(ctx, scene, scene_name, bounces, args, rank, world, device, steps, w
         result["fused"] = ctx.trace_is_fused()
         result["wide8"] = ctx.trace_variant() == capi.TRACE_WIDE8_PERSISTENT
     result["wavefronts"] = args.wavefronts if args.wavefronts else (1 if ctx.trace_is_fused() else 2)
-    if world == 1 and result.get("wide8") and not args.pmc_child:
+    if world == 1 and result.get("wide8") and not args.pmc_child and not getattr(args, "under_profiler", False):      # kept out of profiled runs: their per-kernel averages are the line's own launches
         # The same frames with every refused closest hit retraced, as the reference does it (hipr_set_backface_culling 0): a short run beside the line's own,
         # for the ray count and the time the stepping saves. Outside the timed region.
         ctx.set_backface_culling(False)
@@ -665,6 +665,7 @@ def main():
     # roofline.traffic, measured by child processes under rocprofv3 BEFORE this process initialises the GPU (importing torch does not)
     live_traffic = None
     under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
+    args.under_profiler = under_profiler
     if args.gpus == 1 and args.pmc_traffic == "auto" and not args.scene_file and not under_profiler:     # no profiler inside a profiler
         live_traffic = measure_traffic_live(sys.argv[1:])
         if not live_traffic[0]:

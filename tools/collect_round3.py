@@ -26,7 +26,7 @@ for source, target in (("bench_default.json", "r03_bench_final.json"), ("bench_u
                        ("bench_atrium_1spp.json", "r03_bench_atrium_1spp.json"), ("bench_2rank_gloo_shared_device.json", "r03_bench_2rank_gloo_shared_device.json")):
     if (src / source).exists() and (src / source).stat().st_size:
         lines[target] = one_line(source, target)
-stats = sorted(src.glob("trace/**/*kernel_stats.csv"))
+stats = sorted(src.glob("trace/**/*kernel_stats.csv"), key=lambda f: f.stat().st_mtime, reverse=True)      # the newest run
 if stats:
     shutil.copy(stats[0], profiles / "r03_atrium_kernel_stats.csv")
 for name in ("rmse_protocol_480x270.json", "rmse_protocol_160x90.json"):
