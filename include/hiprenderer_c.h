@@ -481,7 +481,8 @@ int hipr_set_pass_pipelining(HiprContext* context, int enable);
  * a hit itself -- when the triangle carries HIPR_TRIANGLE_ONE_SIDED and the hit is behind by more than HiprLeaf8::facing_margin -- and goes on to the hit the
  * retrace would have found. Same paths, same frames (tested against the retracing search); one BVH query less per refused hit: 18 % of the closest-hit
  * queries of the atrium. Hits inside the margin still go to the hit program. The one difference: a refused triangle that COINCIDES with another surface at the
- * same distance no longer hides it (the retrace starts past both). 0 restores the retrace for every refused hit. */
+ * same distance no longer hides it (the retrace starts past both). 0 restores the retrace for every refused hit. Applies to every closest-hit query of
+ * the 8-wide search, the stage-level hipr_debug_trace_closest included. */
 int hipr_set_backface_culling(HiprContext* context, int enable);
 int hipr_set_instrumentation(HiprContext* context, int count_traversal_steps);
 int hipr_reset_timers(HiprContext* context);
