@@ -36,6 +36,11 @@ def test_bench_line_contract_single_gpu():
     assert roofline["traffic"] and roofline["traffic_source"]["measured"].startswith("live"), roofline.get("traffic_source")
     assert roofline["achieved"] == pytest.approx(roofline["traffic"] / (roofline["avg_launch_ms"] * 1e-3) / 1e9)
     assert "frac_model" in roofline and "observed_limiter" in roofline
+    # the same frames with every refused hit retraced, timed beside the line: more rays (the atrium's one-sided colonnade and drapes seen from behind), more time
+    retrace = line["retrace_mode"]
+    assert "backface_culling" in line["config"]
+    assert 1.05 * line["config"]["rays_per_step"] < retrace["rays_per_step"] < 1.3 * line["config"]["rays_per_step"]
+    assert retrace["ms_per_step"] > 1.03 * line["ms_per_step"] and retrace["Mrays_per_s"] > 0
 
 
 def test_bench_two_ranks_on_one_device():
