@@ -29,6 +29,9 @@ The ONE JSON line rank 0 prints carries the contract keys plus
                     all Diffuse) at reduced size next to the device's, equal ray counters, like-for-like Mrays/s (N = 1 only);
   other_workloads   BASELINE configs[1] (Cornell, all Diffuse) and configs[2] (material scene, 32 bounces) measured the same way after
                     the main timed region, each with value / ms per 256 spp / roofline / rmse (N = 1 only; --no-other-workloads skips);
+  retrace_mode      rays are BVH queries actually made. The 8-wide traversal steps over closest hits the hit program would refuse (back of a one-sided surface)
+                    instead of having them refused and retraced as the reference does (hipr_set_backface_culling, default on; same frames): this block is two
+                    steps of the same workload with that off -- the ray count and time of the reference's way, beside the line's own (N = 1, outside the timed region);
   config.rmse_vs_oracle   RMSE against the CPU oracle at equal spp and seed, 8 and 256 spp on a 160 x 90 frame, both definitions of SURVEY.md 8d, the bias
                     statistics of the difference, and each image's distance to a converged (16 x spp, disjoint accumulations) oracle image.
 """
