@@ -220,7 +220,7 @@ def measure_traffic_live(argv):
         cmd = [rocprof, "--pmc", counter, "--output-format", "csv", "-d", tmp, "--", sys.executable, str(Path(__file__).resolve())] + passthrough + \
               ["--pmc-child", "--steps", "2", "--warmup", "1", "--gpus", "1"]
         try:
-            r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=600, cwd=tmp, env=dict(os.environ, TMPDIR=tmp))
+            r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=240, cwd=tmp, env=dict(os.environ, TMPDIR=tmp))      # a pass takes seconds; the first import of torch on a fresh box up to two minutes
         except (subprocess.TimeoutExpired, OSError) as e:
             shutil.rmtree(tmp, ignore_errors=True)
             return {}, {"error": f"rocprofv3 --pmc {counter}: {e}"}
