@@ -220,8 +220,18 @@ def measure_traffic_live(argv):
         cmd = [rocprof, "--pmc", counter, "--output-format", "csv", "-d", tmp, "--", sys.executable, str(Path(__file__).resolve())] + passthrough + \
               ["--pmc-child", "--steps", "2", "--warmup", "1", "--gpus", "1"]
         try:
-            r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=240, cwd=tmp, env=dict(os.environ, TMPDIR=tmp))      # a pass takes seconds; the first import of torch on a fresh box up to two minutes
-        except (subprocess.TimeoutExpired, OSError) as e:
+            # a pass takes seconds (the first import of torch on a fresh box up to two minutes); its own process group, so that a pass that hangs is ended whole
+            child = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, cwd=tmp, env=dict(os.environ, TMPDIR=tmp), start_new_session=True)
+            try:
+                _, err = child.communicate(timeout=240)
+            except subprocess.TimeoutExpired:
+                import signal
+                os.killpg(child.pid, signal.SIGKILL)      # exactly the group this call started
+                child.communicate()
+                shutil.rmtree(tmp, ignore_errors=True)
+                return {}, {"error": f"rocprofv3 --pmc {counter}: no result after 240 s"}
+            r = subprocess.CompletedProcess(cmd, child.returncode, None, err)
+        except OSError as e:
             shutil.rmtree(tmp, ignore_errors=True)
             return {}, {"error": f"rocprofv3 --pmc {counter}: {e}"}
         sums, launches = {}, {}
