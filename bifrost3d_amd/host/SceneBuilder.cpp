@@ -113,18 +113,39 @@ uint32_t SceneBuilder::add_texture(const ImageData& image, bool repeat_u, bool r
     return uint32_t(m_textures.size() - 1);
 }
 
+static bool mirrors(const float* M) {
+    const double det = double(M[0]) * (double(M[5]) * M[10] - double(M[6]) * M[9]) - double(M[1]) * (double(M[4]) * M[10] - double(M[6]) * M[8]) +
+                       double(M[2]) * (double(M[4]) * M[9] - double(M[5]) * M[8]);
+    return det < 0.0;
+}
+
+uint32_t SceneBuilder::index_offset_for(uint32_t mesh, const float* object_to_world) {
+    MeshRecord& r = m_meshes[mesh];
+    if (!mirrors(object_to_world)) return r.index_offset;
+    if (r.mirrored_index_offset == 0xFFFFFFFFu) {
+        r.mirrored_index_offset = uint32_t(m_indices.size() / 3);
+        for (uint32_t p = 0; p < r.primitive_count; ++p) {
+            const size_t at = 3 * size_t(r.index_offset + p);
+            const uint32_t a = m_indices[at], b = m_indices[at + 1], c = m_indices[at + 2];
+            m_indices.push_back(a); m_indices.push_back(c); m_indices.push_back(b);
+        }
+    }
+    return r.mirrored_index_offset;
+}
+
 uint32_t SceneBuilder::add_model(uint32_t mesh, uint32_t material, const Transform& transform, uint32_t explicit_model_index) {
     // create_model + transformable_model, OptiXRenderer/Renderer.cpp:138-182
     const MeshRecord& r = m_meshes[mesh];
     HiprInstance inst = {};
     Matrix3x4f m = to_matrix3x4(transform);
     std::memcpy(inst.object_to_world, m.begin(), sizeof(inst.object_to_world));
-    inst.index_offset = r.index_offset;
-    inst.vertex_offset = r.vertex_offset;
+    const uint32_t vertex_offset = r.vertex_offset, mesh_flags = r.flags;      // `r` may move: the mirrored copy grows m_indices only, but keep to values
+    inst.index_offset = index_offset_for(mesh, inst.object_to_world);
+    inst.vertex_offset = vertex_offset;
     const uint32_t model_index = explicit_model_index ? explicit_model_index : uint32_t(m_instances.size()) + 1;   // UID index, 0 is invalid
     inst.instance_id = int32_t((1u << 30) | model_index);                 // InstanceID::make(MeshModel, index)
     inst.material_index = int32_t(material);
-    inst.mesh_flags = r.flags;
+    inst.mesh_flags = mesh_flags;
     m_instances.push_back(inst);
     m_instance_mesh.push_back(mesh);
     return model_index;
@@ -175,7 +196,7 @@ void SceneBuilder::finalize(uint32_t bvh_max_depth) {
             m_bounds.grow_to_contain(Vector3f(out[0], out[1], out[2]));
         };
         for (uint32_t p = 0; p < mesh.primitive_count; ++p) {
-            const uint32_t* idx = &m_indices[3 * size_t(mesh.index_offset + p)];
+            const uint32_t* idx = &m_indices[3 * size_t(inst.index_offset + p)];      // the instance's triples: mirrored instances have their own
             HiprTriangle t = {};
             to_world(idx[0], t.v0); to_world(idx[1], t.v1); to_world(idx[2], t.v2);
             t.instance_index = i;
@@ -221,6 +242,7 @@ bool SceneBuilder::update_model_transforms(const std::vector<std::pair<uint32_t,
         for (size_t i = 0; i < m_instances.size(); ++i)
             if (uint32_t(m_instances[i].instance_id) == ((1u << 30) | update.first)) {
                 Matrix3x4f m = to_matrix3x4(update.second);
+                if (mirrors(m.begin()) != mirrors(m_instances[i].object_to_world)) return false;      // the instance turns inside out: its index triples change, a rebuild
                 std::memcpy(m_instances[i].object_to_world, m.begin(), sizeof(m_instances[i].object_to_world));
                 moved[i] = true;
             }
@@ -230,7 +252,7 @@ bool SceneBuilder::update_model_transforms(const std::vector<std::pair<uint32_t,
             const HiprInstance& inst = m_instances[t.instance_index];
             const MeshRecord& mesh = m_meshes[m_instance_mesh[t.instance_index]];
             const float* M = inst.object_to_world;
-            const uint32_t* idx = &m_indices[3 * size_t(mesh.index_offset + t.primitive_index)];
+            const uint32_t* idx = &m_indices[3 * size_t(inst.index_offset + t.primitive_index)];
             float* corners[3] = {t.v0, t.v1, t.v2};
             for (int k = 0; k < 3; ++k) {
                 const float* p = m_geometry[mesh.vertex_offset + idx[k]].position;

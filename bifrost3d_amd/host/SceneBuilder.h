@@ -86,7 +86,11 @@ public:
     size_t model_count() const { return m_instances.size(); }
 
 private:
-    struct MeshRecord { uint32_t index_offset, vertex_offset, primitive_count, vertex_count, flags; };
+    struct MeshRecord { uint32_t index_offset, vertex_offset, primitive_count, vertex_count, flags; uint32_t mirrored_index_offset = 0xFFFFFFFFu; };
+    // The index triples an instance of `mesh` under `object_to_world` uses: the mesh's own, or -- a transform that mirrors (negative determinant) -- a copy of
+    // them with the second and third corner exchanged, so that the world-space corners wind the way the reference's transformed geometric normal points
+    // (rtTransformNormal through the inverse transpose, ORS/MonteCarlo.cu:147) and every consumer of the triple order sees the same triangle.
+    uint32_t index_offset_for(uint32_t mesh, const float* object_to_world);
     std::vector<MeshRecord> m_meshes;
     std::vector<uint32_t> m_indices;
     std::vector<HiprVertexGeometry> m_geometry;

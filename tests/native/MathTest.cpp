@@ -146,3 +146,55 @@ CPU_TEST_F(MathFixture, blue_noise_points_fill_exactly_the_requested_range) {   
     for (int i = 0; i < 7; ++i) EXPECT_TRUE(odd[i].x >= 0.0f && odd[i].x < 1.0f && odd[i].y >= 0.0f && odd[i].y < 1.0f);
     for (int i = 7; i < 11; ++i) EXPECT_TRUE(odd[i].x == sentinel.x);
 }
+
+// A transform that MIRRORS (negative uniform scale): the reference carries the object-space geometric normal through the inverse transpose
+// (rtTransformNormal, OptiXRenderer/Shading/MonteCarlo.cu:147), so the front of the triangle stays its object-space front. The flattened world-space
+// corners must wind accordingly: SceneBuilder gives such an instance its own index triples with two corners exchanged, and every consumer of the
+// triple order (positions, normals, texture coordinates) follows.
+#include "../../bifrost3d_amd/host/SceneBuilder.h"
+
+CPU_TEST_F(MathFixture, a_mirroring_instance_keeps_its_front_side) {
+    using namespace HIPRenderer;
+    SceneBuilder scene;
+    MeshData mesh;
+    mesh.name = "triangle";
+    mesh.positions = {Vector3f(0, 0, 0), Vector3f(1, 0, 0), Vector3f(0, 1, 0)};      // counter-clockwise seen from +z: geometric normal +z
+    mesh.normals = {Vector3f(0, 0, 1), Vector3f(0, 0, 1), Vector3f(0, 0, 1)};
+    mesh.texcoords = {Vector2f{0, 0}, Vector2f{1, 0}, Vector2f{0, 1}};
+    mesh.primitives = {Vector3ui{0, 1, 2}};
+    const uint32_t mesh_index = scene.add_mesh(mesh);
+    HiprMaterial material = {};
+    material.tint[0] = material.tint[1] = material.tint[2] = 0.5f;
+    material.roughness = 0.5f; material.coverage = 1.0f;
+    const uint32_t material_index = scene.add_material(material);
+    const Quaternionf turned = Quaternionf::from_angle_axis(degrees_to_radians(40.0f), normalize(Vector3f(0.3f, 1.0f, -0.2f)));
+    scene.add_model(mesh_index, material_index, Transform(Vector3f(0, 0, 0), turned, 2.0f));
+    scene.add_model(mesh_index, material_index, Transform(Vector3f(5, 0, 0), turned, -2.0f));
+    scene.add_model(mesh_index, material_index, Transform(Vector3f(-5, 0, 0), turned, -0.5f));      // a second mirrored instance shares the copy
+    scene.finalize();
+    const HiprSceneDesc& d = scene.desc();
+    EXPECT_EQ(3u, d.triangle_count);
+    EXPECT_EQ(6u, d.index_count);       // the mesh's triple and ONE mirrored copy
+    EXPECT_EQ(d.instances[1].index_offset, d.instances[2].index_offset);
+    EXPECT_TRUE(d.instances[0].index_offset != d.instances[1].index_offset);
+    for (uint32_t t = 0; t < d.triangle_count; ++t) {
+        const HiprTriangle& tri = d.triangles[t];
+        const HiprInstance& inst = d.instances[tri.instance_index];
+        const float* M = inst.object_to_world;
+        const Vector3f p0(tri.v0[0], tri.v0[1], tri.v0[2]), p1(tri.v1[0], tri.v1[1], tri.v1[2]), p2(tri.v2[0], tri.v2[1], tri.v2[2]);
+        const Vector3f world_normal = normalize(cross(p1 - p0, p2 - p0));
+        // rtTransformNormal: the object-space normal (0, 0, 1) through the inverse transpose of M = s R, i.e. (1 / s) R n
+        const float s = tri.instance_index == 0 ? 2.0f : (tri.instance_index == 1 ? -2.0f : -0.5f);
+        const Vector3f expected = normalize(Vector3f(M[2], M[6], M[10]) / (s * s));      // M n / s^2 = R n / s
+        EXPECT_TRUE(almost_equal(world_normal, expected, 64));
+        // the corners are the instance's triple through the instance's matrix, in that order
+        const uint32_t* idx = d.indices + 3 * size_t(inst.index_offset + tri.primitive_index);
+        const HiprVertexGeometry& g1 = d.geometry[inst.vertex_offset + idx[1]];
+        const Vector3f from_triple(M[0] * g1.position[0] + M[1] * g1.position[1] + M[2] * g1.position[2] + M[3], M[4] * g1.position[0] + M[5] * g1.position[1] + M[6] * g1.position[2] + M[7],
+                                   M[8] * g1.position[0] + M[9] * g1.position[1] + M[10] * g1.position[2] + M[11]);
+        EXPECT_TRUE(almost_equal(p1, from_triple, 4));
+    }
+    // a transform-only update that turns an instance inside out cannot be a refit: the triples change
+    EXPECT_TRUE(!scene.update_model_transforms({{1u, Transform(Vector3f(0, 1, 0), turned, -2.0f)}}));
+    EXPECT_TRUE(scene.update_model_transforms({{2u, Transform(Vector3f(5, 1, 0), turned, -3.0f)}}));
+}
