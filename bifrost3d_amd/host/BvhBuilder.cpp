@@ -20,6 +20,8 @@
 #include <cfloat>
 #include <cstdlib>
 #include <cmath>
+#include <exception>
+#include <mutex>
 #include <thread>
 
 namespace HIPRenderer {
@@ -58,16 +60,28 @@ static unsigned build_threads() {
     return value;
 }
 
+// An exception (out of memory) must not leave a worker thread: the first one is kept and thrown again on the caller once the threads are joined.
+struct Failure {
+    std::exception_ptr first;
+    std::mutex lock;
+    template <typename F> void guard(F f) {
+        try { f(); } catch (...) { std::lock_guard<std::mutex> g(lock); if (!first) first = std::current_exception(); }
+    }
+    void rethrow() { if (first) std::rethrow_exception(first); }
+};
+
 // f(chunk, begin, end) over `chunks` equal slices of [begin, end), on as many threads; chunk 0 runs on the caller.
 template <typename F>
 static void for_chunks(uint32_t begin, uint32_t end, unsigned chunks, F f) {
     const uint64_t count = end - begin;
     auto slice = [&](unsigned c) { return uint32_t(begin + count * c / chunks); };
+    Failure failure;
     std::vector<std::thread> workers;
     workers.reserve(chunks > 0 ? chunks - 1 : 0);
-    for (unsigned c = 1; c < chunks; ++c) workers.emplace_back([&, c] { f(c, slice(c), slice(c + 1)); });
-    f(0u, slice(0), slice(1));
+    for (unsigned c = 1; c < chunks; ++c) workers.emplace_back([&, c] { failure.guard([&] { f(c, slice(c), slice(c + 1)); }); });
+    failure.guard([&] { f(0u, slice(0), slice(1)); });
     for (std::thread& w : workers) w.join();
+    failure.rethrow();
 }
 
 constexpr uint32_t PARALLEL_RANGE = 1u << 17;      // ranges at least this long are binned and partitioned on several threads
@@ -312,10 +326,12 @@ struct Builder {
                 task.deepest = sub.deepest;
             }
         };
+        Failure failure;
         std::vector<std::thread> workers;
-        for (unsigned t = 1; t < threads; ++t) workers.emplace_back(worker);
-        worker();
+        for (unsigned t = 1; t < threads; ++t) workers.emplace_back([&] { failure.guard(worker); });
+        failure.guard(worker);
         for (std::thread& w : workers) w.join();
+        failure.rethrow();
         const auto x2 = std::chrono::steady_clock::now();
         for (const Task& task : tasks) deepest = std::max(deepest, task.deepest);
         std::vector<HiprBvhNode> top = std::move(nodes);
@@ -341,10 +357,12 @@ struct Builder {
                 std::vector<HiprBvhNode>().swap(tasks[k].nodes);
             }
         };
+        Failure copy_failure;
         std::vector<std::thread> copiers;
-        for (unsigned t = 1; t < threads; ++t) copiers.emplace_back(copier);
-        copier();
+        for (unsigned t = 1; t < threads; ++t) copiers.emplace_back([&] { copy_failure.guard(copier); });
+        copy_failure.guard(copier);
         for (std::thread& w : copiers) w.join();
+        copy_failure.rethrow();
         nodes = std::move(out);
         if (std::getenv("HIPR_BVH_TIMING"))
             fprintf(stderr, "[hipr]   top tree %.3f s (%zu subtree tasks of <= %u triangles), subtrees %.3f s, stitch %.3f s\n", std::chrono::duration<double>(x1 - x0).count(), tasks.size(), subtree_cutoff,
@@ -517,10 +535,12 @@ struct WideCollapse {
                 task.wide = std::move(sub.wide);
             }
         };
+        Failure failure;
         std::vector<std::thread> workers;
-        for (unsigned t = 1; t < threads; ++t) workers.emplace_back(worker);
-        worker();
+        for (unsigned t = 1; t < threads; ++t) workers.emplace_back([&] { failure.guard(worker); });
+        failure.guard(worker);
         for (std::thread& w : workers) w.join();
+        failure.rethrow();
 
         std::vector<HiprWideNode> top = std::move(wide);
         std::vector<uint32_t> top_at(top.size()), task_at(tasks.size());
@@ -548,10 +568,12 @@ struct WideCollapse {
                 std::vector<HiprWideNode>().swap(tasks[k].wide);
             }
         };
+        Failure copy_failure;
         std::vector<std::thread> copiers;
-        for (unsigned t = 1; t < threads; ++t) copiers.emplace_back(copier);
-        copier();
+        for (unsigned t = 1; t < threads; ++t) copiers.emplace_back([&] { copy_failure.guard(copier); });
+        copy_failure.guard(copier);
         for (std::thread& w : copiers) w.join();
+        copy_failure.rethrow();
         wide = std::move(out);
     }
 };

@@ -22,6 +22,8 @@
 #include <cstdlib>
 #include <atomic>
 #include <cstring>
+#include <exception>
+#include <mutex>
 #include <thread>
 #include <utility>
 
@@ -120,11 +122,22 @@ template <typename F>
 void run_tasks(size_t count, unsigned threads, F f) {
     if (threads <= 1 || count <= 1) { for (size_t i = 0; i < count; ++i) f(i); return; }
     std::atomic<size_t> next{0};
-    auto worker = [&] { for (size_t i = next.fetch_add(1); i < count; i = next.fetch_add(1)) f(i); };
+    std::exception_ptr failure;      // an exception (out of memory) must not leave a worker thread: the first one is handed to the caller
+    std::mutex failure_lock;
+    auto worker = [&] {
+        try {
+            for (size_t i = next.fetch_add(1); i < count; i = next.fetch_add(1)) f(i);
+        } catch (...) {
+            next.store(count);
+            std::lock_guard<std::mutex> guard(failure_lock);
+            if (!failure) failure = std::current_exception();
+        }
+    };
     std::vector<std::thread> workers;
     for (unsigned t = 1; t < threads; ++t) workers.emplace_back(worker);
     worker();
     for (std::thread& w : workers) w.join();
+    if (failure) std::rethrow_exception(failure);
 }
 
 // The three phases -- records + binary tree, dynamic program, layout -- each run the same way: the top of the tree on the caller, the subtrees below it as
