@@ -301,6 +301,41 @@ def test_split_shade_kernel_renders_the_same_frames(ctx, monkeypatch, name, kwar
     assert counters_a["shadow_rays"] > 0
 
 
+@pytest.mark.parametrize("name,kwargs,bounces", [("atrium", dict(param0=20000, param1=3), 4), ("material", dict(), 8), ("opacity", dict(param0=8), 16)])
+def test_frames_do_not_depend_on_the_backface_culling(ctx, oracle_q, name, kwargs, bounces):
+    """hipr_set_backface_culling: the 8-wide traversal steps over closest hits on the back of one-sided surfaces (default) or hands them to the hit program to be
+    refused and retraced (0, the reference's way). Same running mean bit for bit; one closest-hit query less per hit stepped over -- and the oracle's counters."""
+    scene = Scene(name, **kwargs)
+    w, h, batch, passes = 160, 96, 4, 3
+    results = []
+    ctx.set_trace_variant(capi.TRACE_WIDE8_PERSISTENT)
+    try:
+        ctx.upload_scene(scene)
+        assert ctx.trace_variant() == capi.TRACE_WIDE8_PERSISTENT
+        for culling in (True, False):
+            ctx.set_backface_culling(culling)
+            ctx.set_frame(w, h, 0, 1, batch)
+            ctx.reset_counters()
+            for p in range(passes):
+                ctx.render_pass(scene.camera(w, h, accumulations=p * batch, max_bounce_count=bounces))
+            ctx.synchronize()
+            results.append((ctx.read_accumulation(), ctx.counters()))
+    finally:
+        ctx.set_backface_culling(True)
+        ctx.set_trace_variant(-1)
+    (stepping, c_on), (retracing, c_off) = results
+    assert np.array_equal(stepping, retracing)
+    assert c_on["shaded_hits"] == c_off["shaded_hits"] and c_on["shadow_rays"] == c_off["shadow_rays"] and c_on["camera_rays"] == c_off["camera_rays"]
+    assert c_on["closest_rays"] <= c_off["closest_rays"]
+    if name == "atrium":
+        assert c_on["closest_rays"] < 0.92 * c_off["closest_rays"]
+    if name == "material":
+        assert c_off["closest_rays"] - c_on["closest_rays"] <= 1e-4 * c_off["closest_rays"]      # closed meshes: next to nothing is ever reached from behind
+    _, oracle_counters, _ = oracle_q.render(scene.desc, scene.state, scene.camera(w, h, accumulations=0, max_bounce_count=bounces), w, h, batch * passes, use_bvh=3)
+    for key in ("closest_rays", "shadow_rays", "shaded_hits"):
+        assert abs(c_on[key] - oracle_counters[key]) <= max(2, oracle_counters[key] // 2000), (key, c_on[key], oracle_counters[key])
+
+
 def test_million_triangle_scene(ctx, oracle_q):
     """BASELINE config 5's shape at test size: the 1 M-triangle atrium (seed 2), wide BVH of 250 k nodes. Stage parity bit-exact with
     counters, a small image against the oracle, and at 3840 x 2160 the size-independent properties (finite, every camera path
