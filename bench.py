@@ -77,6 +77,7 @@ def parse_args(argv=None):
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-other-workloads", action="store_true", help="skip BASELINE configs[1] and configs[2] after the main timed region")
     p.add_argument("--no-rmse", action="store_true")
+    p.add_argument("--no-scaling-proxy", action="store_true", help="skip the one-GPU proxy of the N-GPU tile split (scaling_proxy key)")
     p.add_argument("--no-plugin", action="store_true", help="skip the run through the C++ HIPRenderer::Renderer class (plugin_renderer key)")
     p.add_argument("--cpu-baseline-seconds", type=float, default=10.0)
     p.add_argument("--master-port", type=int, default=0, help="rendezvous port when this process spawns the ranks itself (0: pick a free one)")
@@ -172,15 +173,25 @@ def library_sha16() -> str:
     return hashlib.sha256(Path(capi.LIB_PATH).read_bytes()).hexdigest()[:16]
 
 
+# the SQ pass of the live counter runs (roofline_valu): wave64 VALU instructions issued, lane-cycles spent in them, quad-cycles the VALU was executing
+VALU_COUNTERS = ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES")
+RATE_KERNEL_ITERATIONS = 4096      # hipr_debug_valu_issue_rates: 8 blocks of 4 waves per CU, iterations x 8 instructions per wave
+
+
 def kernel_bench_name(kernel: str):
     """Bench key of a kernel name as rocprofv3 prints it (the keys of kernel_ms_per_step / roofline_by_kernel)."""
     k = kernel.split("(")[0]
     for needle, name in (("k_generate", "generate"), ("k_shade", "shade"), ("k_accumulate", "accumulate"), ("k_trace_shadow", "trace_shadow"), ("k_trace_closest", "trace_closest")):
         if needle in k:
             return name
-    if "k_trace_persistent" in k or "k_trace_wide8" in k:   # template arguments <STACK, MODE, ...>; MODE 0 closest, 1 shadow, 2 fused
+    if "k_trace_persistent" in k or "k_trace_wide8" in k:   # template arguments <STACK, MODE, INSTRUMENT, ...>; MODE 0 closest, 1 shadow, 2 fused
         args = k[k.index("<") + 1:k.rindex(">")].split(",") if "<" in k else []
         mode = args[1].strip() if len(args) > 1 else "2"
+        if len(args) > 2 and args[2].strip() == "true":
+            # the INSTRUMENTED build of the kernel (the two counting passes before the warm-up; it keeps ten counters per lane and spills): not the kernel the
+            # timed region runs. Round 3 averaged its launches into the traffic per launch -- 11 GB written per launch against 1.8 GB -- which is where the
+            # "7x write amplification" of that round's line came from.
+            return None
         return {"0": "trace_closest", "1": "trace_shadow"}.get(mode, "trace")
     return None
 
@@ -213,12 +224,16 @@ def measure_traffic_live(argv):
         if a.split("=")[0] in ("--steps", "--warmup", "--gpus", "--pmc-traffic", "--cpu-baseline-seconds", "--master-port", "--spawn-deadline"):
             continue
         passthrough.append(a)
-    totals = {"FETCH_SIZE": {}, "WRITE_SIZE": {}}
+    totals = {}
+    rate_kernels = {}
     t0 = time.perf_counter()
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    # three passes: the TCC has four counter slots (FETCH_SIZE and WRITE_SIZE cannot share one), the SQ counters of the VALU roof go together
+    passes = (("FETCH_SIZE",), ("WRITE_SIZE",), VALU_COUNTERS)
+    for counters in passes:
         tmp = tempfile.mkdtemp(prefix="hipr_pmc_")
-        cmd = [rocprof, "--pmc", counter, "--output-format", "csv", "-d", tmp, "--", sys.executable, str(Path(__file__).resolve())] + passthrough + \
+        cmd = [rocprof, "--pmc", *counters, "--output-format", "csv", "-d", tmp, "--", sys.executable, str(Path(__file__).resolve())] + passthrough + \
               ["--pmc-child", "--steps", "2", "--warmup", "1", "--gpus", "1"]
+        label = " ".join(counters)
         try:
             # a pass takes seconds (the first import of torch on a fresh box up to two minutes); its own process group, so that a pass that hangs is ended whole
             child = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, cwd=tmp, env=dict(os.environ, TMPDIR=tmp), start_new_session=True)
@@ -229,35 +244,50 @@ def measure_traffic_live(argv):
                 os.killpg(child.pid, signal.SIGKILL)      # exactly the group this call started
                 child.communicate()
                 shutil.rmtree(tmp, ignore_errors=True)
-                return {}, {"error": f"rocprofv3 --pmc {counter}: no result after 240 s"}
+                return {}, {"error": f"rocprofv3 --pmc {label}: no result after 240 s"}
             r = subprocess.CompletedProcess(cmd, child.returncode, None, err)
         except OSError as e:
             shutil.rmtree(tmp, ignore_errors=True)
-            return {}, {"error": f"rocprofv3 --pmc {counter}: {e}"}
-        sums, launches = {}, {}
+            return {}, {"error": f"rocprofv3 --pmc {label}: {e}"}
+        sums, launches, durations = {c: {} for c in counters}, {c: {} for c in counters}, {}
         for f in Path(tmp).rglob("*counter_collection.csv"):
             with open(f, newline="") as fh:
                 for row in csv.DictReader(fh):
-                    if row["Counter_Name"] != counter:
+                    counter = row["Counter_Name"]
+                    if counter not in sums:
                         continue
+                    raw = row["Kernel_Name"].split("(")[0]
                     name = kernel_bench_name(row["Kernel_Name"])
+                    if name is None and "k_rate_" in raw:      # the calibration kernels of hipr_debug_valu_issue_rates: instruction count known by construction
+                        name = "rate_" + raw.split("k_rate_")[1].split("<")[0].strip()
                     if name is None:
                         continue
-                    sums[name] = sums.get(name, 0.0) + float(row["Counter_Value"])
-                    launches.setdefault(name, set()).add(row["Dispatch_Id"])
+                    sums[counter][name] = sums[counter].get(name, 0.0) + float(row["Counter_Value"])
+                    launches[counter].setdefault(name, set()).add(row["Dispatch_Id"])
+                    if counter == counters[0] and row.get("End_Timestamp") and row.get("Start_Timestamp"):      # the dispatch's duration under the profiler, once per dispatch
+                        durations[name] = durations.get(name, 0.0) + (float(row["End_Timestamp"]) - float(row["Start_Timestamp"])) * 1e-9
         shutil.rmtree(tmp, ignore_errors=True)
-        if r.returncode != 0 or not sums:
-            return {}, {"error": f"rocprofv3 --pmc {counter} exited with {r.returncode}: {r.stderr.decode(errors='replace')[-300:]}"}
-        totals[counter] = {n: (sums[n] / len(launches[n]), len(launches[n])) for n in sums}
+        if r.returncode != 0 or not any(sums.values()):
+            if counters is VALU_COUNTERS:      # the traffic passes stand without the VALU pass
+                totals["valu_error"] = f"rocprofv3 --pmc {label} exited with {r.returncode}: {r.stderr.decode(errors='replace')[-300:]}"
+                continue
+            return {}, {"error": f"rocprofv3 --pmc {label} exited with {r.returncode}: {r.stderr.decode(errors='replace')[-300:]}"}
+        for counter in counters:
+            totals[counter] = {n: (sums[counter][n] / len(launches[counter][n]), len(launches[counter][n])) for n in sums[counter]}
+        if counters is VALU_COUNTERS:
+            totals["valu_seconds"] = {n: (durations[n] / len(launches[counters[0]][n]), len(launches[counters[0]][n])) for n in durations}
     traffic, detail = {}, {}
     for name in set(totals["FETCH_SIZE"]) | set(totals["WRITE_SIZE"]):
+        if name.startswith("rate_"):
+            continue
         f_kib, f_n = totals["FETCH_SIZE"].get(name, (0.0, 0))
         w_kib, w_n = totals["WRITE_SIZE"].get(name, (0.0, 0))
         traffic[name] = (2.0 * f_kib + w_kib) * 1024.0
         detail[name] = {"FETCH_SIZE_KiB_per_launch": f_kib, "WRITE_SIZE_KiB_per_launch": w_kib, "launches_fetch_pass": f_n, "launches_write_pass": w_n}
-    return traffic, {"measured": "live: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child runs of this workload (2 steps each) before the timed run",
+    valu = {"error": totals["valu_error"]} if "valu_error" in totals else {c: {n: v[0] for n, v in totals.get(c, {}).items()} for c in VALU_COUNTERS + ("valu_seconds",)}
+    return traffic, {"measured": "live: rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE and --pmc " + " ".join(VALU_COUNTERS) + " child runs of this workload (2 steps each) before the timed run",
                      "formula": "(2 * FETCH_SIZE + WRITE_SIZE) * 1024 bytes per launch; calibration profiles/r03_fetch_calibration.txt", "side": "fabric (L2 memory side: Infinity Cache + HBM)",
-                     "seconds": time.perf_counter() - t0, "counters": detail, "stale": False}
+                     "seconds": time.perf_counter() - t0, "counters": detail, "valu_counters_per_launch": valu, "stale": False}
 
 
 def load_measured_traffic(key):
@@ -515,6 +545,118 @@ def rooflines_of(counters, times, per_ray, small, fused, samples_per_step, traff
     return rooflines, kernel_times
 
 
+def valu_roofline(name, kernel_text, seconds_per_launch, valu, rates, compute_units):
+    """The VALU roof beside the HBM one: wave64 VALU instructions per second of the dominant kernel against what the device issues of
+    v_fma_f32 chains, both measured by this run -- the counters by the SQ child pass, the peak by hipr_debug_valu_issue_rates in this process. The SQ counters are
+    calibrated on the rate kernel of the same pass (instruction count known by construction, VALU busy by construction)."""
+    if not valu or "error" in valu or name not in valu.get("SQ_INSTS_VALU", {}):
+        return {"bound": "valu", "kernel": kernel_text, "error": (valu or {}).get("error", "no SQ counter pass for this kernel")}
+    insts, lane_cycles, active = (valu[c].get(name, 0.0) for c in ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU"))
+    expected_rate_insts = compute_units * 8 * 4 * RATE_KERNEL_ITERATIONS * 8.0
+    rate_insts = valu["SQ_INSTS_VALU"].get("rate_fma", 0.0)
+    scale = expected_rate_insts / rate_insts if rate_insts > 0 else 1.0          # 1.0 when the counter sees every SIMD
+    rate_lanes = valu["SQ_THREAD_CYCLES_VALU"].get("rate_fma", 0.0) / rate_insts if rate_insts > 0 else 64.0
+    peak = rates["v_fma_f32"]
+    achieved = scale * insts / seconds_per_launch
+    entry = {"bound": "valu", "kernel": kernel_text, "achieved": achieved * 1e-9, "peak": peak * 1e-9, "unit": "G wave64 VALU instructions/s", "frac": achieved / peak,
+             "instructions_per_launch": scale * insts, "lanes_per_instruction": 64.0 * (lane_cycles / insts) / rate_lanes if insts > 0 and rate_lanes > 0 else None,
+             "peak_by_kind": {k: v * 1e-9 for k, v in rates.items()},
+             "peak_note": "v_fma_f32 chains, eight waves per SIMD (hipr_debug_valu_issue_rates, measured in this process); v_max_f32 / v_cvt_f32_ubyteN issue at the lower rates "
+                          "beside it, so a kernel made of all three saturates the pipe below frac 1",
+             "calibration": {"rate_kernel_instructions_expected": expected_rate_insts, "rate_kernel_instructions_counted": rate_insts, "scale": scale,
+                             "rate_kernel_lane_cycles_per_instruction": rate_lanes}}
+    secs = valu.get("valu_seconds", {})
+    rate_active = valu["SQ_ACTIVE_INST_VALU"].get("rate_fma", 0.0)
+    if secs.get(name) and secs.get("rate_fma") and rate_active > 0:
+        # share of time the VALU executes, relative to a kernel that does nothing else (both under the profiler, same pass)
+        entry["valu_busy"] = (active / secs[name]) / (rate_active / secs["rate_fma"])
+        entry["valu_busy_basis"] = "SQ_ACTIVE_INST_VALU per second of this kernel / of the v_fma_f32 rate kernel (same counter pass, dispatch timestamps)"
+    return entry
+
+
+def useful_traffic(name, counters, launches, samples_per_step):
+    """Bytes a launch of the kernel has to move whatever the caches do: results written once + queue records read once. Set against
+    roofline.traffic (what crossed the L2's memory side) it shows the re-reads and the partial-line / spill writes."""
+    n_closest, n_shadow, n_camera = counters["closest_rays"], counters["shadow_rays"], counters["camera_rays"]
+    if name in ("trace", "trace_closest", "trace_shadow"):
+        closest = n_closest if name != "trace_shadow" else 0
+        shadow = n_shadow if name != "trace_closest" else 0
+        writes = 16.0 * closest + 16.0 * shadow                 # a hit record per closest-hit ray; the radiance slot of a shadow ray's path
+        reads = 48.0 * closest + (48.0 + 16.0) * shadow        # ray records (origin, direction, slot / id) + the radiance slot read for the add
+        return {"writes": writes / launches, "reads": reads / launches, "bytes": (writes + reads) / launches,
+                "what": "per launch: 16 B hit per closest-hit ray + 16 B radiance per shadow ray written; 48 B ray record per ray + 16 B radiance per shadow ray read; the tree itself "
+                        "(10 MB at 251 k triangles) is compulsory once per launch at most and left out"}
+    return None
+
+
+XGMI_LINK_GBS = 153.0      # one xGMI link per peer, MI355X_MICROARCH.md
+
+
+def scaling_proxy(ctx, scene, bounces, args, device, t1_ms):
+    """The per-GPU shape of north_star's 8-GPU job, timed on the one GPU there is: the frame's 8 x 8 tiles dealt round robin to N
+    ranks (tile_stride N), every phase 0 .. N-1 rendered in turn by this device, the slowest phase standing for the step of an N-GPU node.
+      strong: the SAME job split N ways (spp_per_pass accumulations of the whole frame per step; `bench.py --gpus N --fixed-frame`);
+      weak:   N x the accumulations per step, so that a rank traces as many paths as the single GPU does (`bench.py --gpus N`, the default);
+      interactive: one accumulation per pass, split N ways (a camera move on an N-GPU node).
+    Not in it: the gather of the half4 tiles to rank 0 (bounded below from the xGMI link rate) and any imbalance between devices."""
+    import torch
+    from bifrost3d_amd import distributed
+    W, H, S0 = args.width, args.height, args.spp_per_pass
+
+    def phases(n, samples, timed, warm=1):
+        out, paths = [], 0
+        for phase in range(n):
+            ctx.set_frame(W, H, tile_phase=phase, tile_stride=n, samples_per_pass=samples)
+            # a rank of an N-way split writes its tiles compactly (pitch 0); the single GPU writes the frame
+            compact = torch.zeros((distributed.padded_pixels_per_rank(W, H, n), 4) if n > 1 else (H, W, 4), dtype=torch.float16, device=device)
+            pitch = 0 if n > 1 else W
+            torch.cuda.synchronize(device)
+            a = 0
+            for _ in range(warm):
+                ctx.render_pass(scene.camera(W, H, accumulations=a, max_bounce_count=bounces), compact.data_ptr(), pitch)
+                a += samples
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(timed):
+                ctx.render_pass(scene.camera(W, H, accumulations=a, max_bounce_count=bounces), compact.data_ptr(), pitch)
+                a += samples
+            ctx.synchronize()
+            out.append((time.perf_counter() - t0) / timed * 1e3)
+            paths = max(paths, ctx.owned_pixel_count() * samples)
+            del compact
+        return out, paths
+
+    frame_bytes = W * H * 8
+    proxy = {"strong": {}, "weak": {}, "interactive": {}, "t1_ms_per_step": t1_ms}
+    one_spp, _ = phases(1, 1, 16, warm=4)
+    for n in (1, 2, 4, 8):
+        gather_ms = (frame_bytes / n) / (XGMI_LINK_GBS * 1e9) * 1e3 if n > 1 else 0.0      # every peer sends its 1/N of the frame over its own link to rank 0
+        if n == 1:
+            proxy["strong"]["1"] = {"ms_per_step": t1_ms, "paths_per_gpu_per_step": W * H * S0, "predicted_speedup": 1.0, "predicted_efficiency": 1.0}
+            proxy["interactive"]["1"] = {"ms_per_pass": one_spp[0], "paths_per_gpu_per_pass": W * H, "predicted_speedup": 1.0}
+            continue
+        strong, strong_paths = phases(n, S0, 2)
+        weak, weak_paths = phases(n, S0 * n, 1)
+        inter, inter_paths = phases(n, 1, 16, warm=4)
+        proxy["strong"][str(n)] = {"ms_per_step": max(strong), "ms_per_step_by_phase": strong, "paths_per_gpu_per_step": strong_paths, "gather_ms_lower_bound": gather_ms,
+                                   "predicted_speedup": t1_ms / (max(strong) + gather_ms), "predicted_efficiency": t1_ms / (max(strong) + gather_ms) / n}
+        proxy["weak"][str(n)] = {"ms_per_step": max(weak), "ms_per_step_by_phase": weak, "paths_per_gpu_per_step": weak_paths, "gather_ms_lower_bound": gather_ms,
+                                 "predicted_speedup": n * t1_ms / (max(weak) + gather_ms), "predicted_efficiency": t1_ms / (max(weak) + gather_ms)}
+        proxy["interactive"][str(n)] = {"ms_per_pass": max(inter), "paths_per_gpu_per_pass": inter_paths, "predicted_speedup": one_spp[0] / (max(inter) + gather_ms)}
+    ctx.set_frame(W, H, tile_phase=0, tile_stride=1, samples_per_pass=S0)
+    # smallest per-GPU wavefront that kept 90 % of the single-GPU rate per path, over everything measured above
+    rate1 = W * H * S0 / t1_ms
+    points = [(v["paths_per_gpu_per_step"], v["paths_per_gpu_per_step"] / v["ms_per_step"] / rate1) for kind in ("strong", "weak") for v in proxy[kind].values()]
+    points += [(v["paths_per_gpu_per_pass"], v["paths_per_gpu_per_pass"] / v["ms_per_pass"] / rate1) for v in proxy["interactive"].values()]
+    points.sort()
+    proxy["rate_by_wavefront"] = [{"paths_per_gpu": p, "share_of_full_rate": r} for p, r in points]
+    enough = [p for p, r in points if r >= 0.9]
+    proxy["min_paths_per_gpu_for_90_percent"] = min(enough) if enough else None
+    proxy["note"] = ("one device renders every phase of an N-way round-robin tile split in turn; ms_per_step = the slowest phase; predicted_speedup = T(1) / (that + the gather's "
+                     f"lower bound, frame / N over one {XGMI_LINK_GBS:.0f} GB/s xGMI link per peer); measured on ONE GPU: no second device, no RCCL in it")
+    return proxy
+
+
 def measure(ctx, scene, scene_name, bounces, args, rank, world, device, steps, warmup, sync):
     """Instrumented passes (per-ray node / triangle counts), warmup, then exactly `steps` timed steps. Returns the figures of this rank."""
     import torch
@@ -582,6 +724,8 @@ def measure(ctx, scene, scene_name, bounces, args, rank, world, device, steps, w
 
     ctx.synchronize()
     counters, times = ctx.counters(), ctx.kernel_times()
+    if args.pmc_child:
+        ctx.valu_issue_rates()      # calibration kernels of the SQ pass: their instruction count is known by construction
     stats = torch.tensor([elapsed, counters["closest_rays"], counters["shadow_rays"], counters["camera_rays"]], dtype=torch.float64, device=device)
     if world > 1:
         if on_host:
@@ -673,7 +817,7 @@ def main():
     if os.environ.get("RANK") is not None and os.environ.get("HIPR_BENCH_TEST_HANG_RANK") in (os.environ.get("RANK"), "all"):
         time.sleep(3600)
     if args.pmc_child:      # a counter pass of measure_traffic_live: the timed region only
-        args.no_cpu_baseline = args.no_other_workloads = args.no_rmse = args.no_plugin = True
+        args.no_cpu_baseline = args.no_other_workloads = args.no_rmse = args.no_plugin = args.no_scaling_proxy = True
         args.pmc_traffic = "off"
     # roofline.traffic, measured by child processes under rocprofv3 BEFORE this process initialises the GPU (importing torch does not)
     live_traffic = None
@@ -745,6 +889,27 @@ def main():
                             "paths_per_gpu_per_step": int(main_figures["pixel_samples"] / args.steps / world),
                             "note": "ms_per_step per rank = that rank's own clock over the timed region (the line's ms_per_step is the maximum); gather_ms = rank 0's time in the "
                                     "final gather of the half4 tiles + the scatter kernel, inside the timed region"}
+        if world == 1 and not args.pmc_child:
+            # the VALU roof beside the HBM one, and the bytes the dominant kernel could not avoid
+            dominant = max(main_figures["roofline_by_kernel"], key=lambda n: main_figures["roofline_by_kernel"][n]["total_ms"])
+            entry = main_figures["roofline_by_kernel"][dominant]
+            try:
+                rates = ctx.valu_issue_rates()
+                valu = (live_traffic[1] or {}).get("valu_counters_per_launch") if live_traffic and live_traffic[0] else None
+                out["roofline_valu"] = valu_roofline(dominant, entry["kernel"], entry["avg_launch_ms"] * 1e-3, valu, rates, torch.cuda.get_device_properties(device).multi_processor_count)
+            except Exception as e:      # the line stands without it
+                out["roofline_valu"] = {"bound": "valu", "error": str(e)}
+            useful = useful_traffic(dominant, result["counters"], entry["launches"], main_figures["spp_per_step"])
+            if useful:
+                out["roofline"]["traffic_useful"] = useful
+                if out["roofline"].get("traffic"):
+                    out["roofline"]["traffic_over_useful"] = out["roofline"]["traffic"] / useful["bytes"]
+                    counters_detail = (main_figures["roofline"].get("traffic_source") or {}).get("counters", {}).get(dominant)
+                    if counters_detail:
+                        out["roofline"]["write_amplification"] = counters_detail["WRITE_SIZE_KiB_per_launch"] * 1024.0 / useful["writes"]
+            out["roofline"]["limiter"] = ("valu" if out["roofline_valu"].get("valu_busy", 0) >= 0.6 else "see roofline_valu") if "error" not in out["roofline_valu"] else None
+            if not args.no_scaling_proxy and not args.scene_file and not under_profiler:
+                out["scaling_proxy"] = scaling_proxy(ctx, scene, bounces, args, device, main_figures["ms_per_step"])
         if world == 1:
             copy_gbs = measured_copy_bandwidth(device)
             out["roofline"]["measured_copy_bandwidth"] = {"GB/s": copy_gbs, "what": "1 GiB device-to-device copy, bytes read + written, best of five (torch)",

@@ -142,7 +142,7 @@ C_ABI_SYMBOLS = (
     "hipr_group_create", "hipr_group_destroy", "hipr_group_size", "hipr_group_context", "hipr_group_gather_description", "hipr_group_upload_tables", "hipr_group_upload_scene",
     "hipr_group_set_scene_state", "hipr_group_set_entry_point", "hipr_group_use_scratch_accumulation", "hipr_group_set_frame", "hipr_group_set_samples_per_pass",
     "hipr_group_trace_pass", "hipr_group_accumulate_samples", "hipr_group_read_accumulation", "hipr_group_get_counters",
-    "hipr_debug_shading", "hipr_debug_light", "hipr_debug_generate", "hipr_debug_sobol", "hipr_debug_sample_offsets", "hipr_debug_trace_closest", "hipr_debug_trace_shadow",
+    "hipr_debug_shading", "hipr_debug_light", "hipr_debug_generate", "hipr_debug_sobol", "hipr_debug_valu_issue_rates", "hipr_debug_sample_offsets", "hipr_debug_trace_closest", "hipr_debug_trace_shadow",
 )
 
 
@@ -198,6 +198,7 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.hipr_get_kernel_times.argtypes = [vp, C.POINTER(HiprKernelTimes)]
     lib.hipr_debug_generate.argtypes = [vp, C.POINTER(HiprCameraState), c_u32, C.POINTER(c_f), C.POINTER(c_f), C.POINTER(c_u32)]
     lib.hipr_debug_sobol.argtypes = [vp, C.POINTER(c_u32), c_u32, C.POINTER(c_u32)]
+    lib.hipr_debug_valu_issue_rates.argtypes = [vp, C.POINTER(C.c_double)]
     lib.hipr_group_create.argtypes = [C.POINTER(C.c_int), c_u32, C.POINTER(vp)]
     lib.hipr_group_destroy.argtypes = [vp]
     lib.hipr_group_size.argtypes = [vp]; lib.hipr_group_size.restype = c_u32

@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <string>
@@ -109,8 +110,14 @@ void worker_loop(HiprGroup* g, uint32_t index) {
             work = w.work;
         }
         Member& m = g->members[index];
-        m.status = work(m, index);
-        m.message = m.status != HIPR_OK ? hipr_last_error() : "";
+        // an exception on this thread (std::bad_alloc in a host-side vector of an entry point) would end the process: it becomes the member's status
+        try {
+            m.status = work(m, index);
+            m.message = m.status != HIPR_OK ? hipr_last_error() : "";
+        } catch (const std::exception& e) {
+            m.status = HIPR_ERROR_OUT_OF_MEMORY;
+            m.message = std::string("exception on the member's worker thread: ") + e.what();
+        }
         {
             std::lock_guard<std::mutex> lock(w.mutex);
             if (--w.pending == 0) w.done.notify_one();

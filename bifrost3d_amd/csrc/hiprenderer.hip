@@ -1093,7 +1093,7 @@ int hipr_update_scene_geometry(HiprContext* c, const HiprSceneDesc* s) {
     if (validate_wide8(s, wide8_height, invalid, sizeof(invalid))) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_update_scene_geometry: %s", invalid);
     if (c->wide8.slot_count && (s->wide8_slot_count != c->wide8.slot_count || wide8_height != c->wide8_height))
         return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_update_scene_geometry: the 8-wide tree's topology changed");
-    for (int g = 0; g < MAX_WAVEFRONTS; ++g) if (c->wavefronts[g].stream) HIP_TRY(hipStreamSynchronize(c->wavefronts[g].stream));
+    if (int finish_status = finish_all(c)) return finish_status;      // pipelined passes included: no pending pass may go on over the new geometry
     hipStream_t st = c->stream;
     int r = 0;
     r |= c->nodes.upload(s->nodes, size_t(s->node_count) * sizeof(HiprBvhNode), st);
@@ -1594,6 +1594,56 @@ int hipr_debug_sobol(HiprContext* c, const uint32_t* triples, uint32_t n, uint32
     hipLaunchKernelGGL(k_debug_sobol, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->debug_a.as<uint32_t>(), n, c->debug_b.as<uint32_t>(), c->sobol_tables.as<uint32_t>());
     if (int finish_status = finish_all(c)) return finish_status;
     HIP_TRY(hipMemcpy(out_uint4, c->debug_b.ptr, size_t(n) * 16, hipMemcpyDeviceToHost));
+    return HIPR_OK;
+}
+
+// ---- the VALU roof, measured -----------------------------------------------------------------------------------------------------------------------
+#define HIPR_RATE_KERNEL(NAME, INSTR)                                                                                              \
+    __global__ __launch_bounds__(256) void NAME(uint32_t* out, const uint32_t* in, int iterations) {                                \
+        uint32_t a0 = in[threadIdx.x & 7], a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7; \
+        const uint32_t m = in[8 + (threadIdx.x & 1)], k = in[10 + (threadIdx.x & 1)];                                               \
+        for (int it = 0; it < iterations; ++it)                                                                                     \
+            asm volatile(INSTR(0) INSTR(1) INSTR(2) INSTR(3) INSTR(4) INSTR(5) INSTR(6) INSTR(7)                                    \
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(k));        \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;                                         \
+    }
+#define HIPR_RATE_FMA(k) "v_fma_f32 %" #k ", %" #k ", %8, %9\n"
+#define HIPR_RATE_MAX(k) "v_max_f32 %" #k ", %" #k ", %8\n"
+#define HIPR_RATE_CVT(k) "v_cvt_f32_ubyte1 %" #k ", %" #k "\n"
+HIPR_RATE_KERNEL(k_rate_fma, HIPR_RATE_FMA)
+HIPR_RATE_KERNEL(k_rate_max, HIPR_RATE_MAX)
+HIPR_RATE_KERNEL(k_rate_cvt, HIPR_RATE_CVT)
+
+int hipr_debug_valu_issue_rates(HiprContext* c, double* out3) {
+    if (int s = check_context(c)) return s;
+    if (!out3) return fail(HIPR_ERROR_INVALID_ARGUMENT, "null argument");
+    if (int finish_status = finish_all(c)) return finish_status;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+    const int blocks = prop.multiProcessorCount * 8, threads = 256, iterations = 4096;      // 8 blocks of 4 waves per CU: 8 waves per SIMD
+    const uint32_t seed[12] = {0x3f800000u, 0x3f810000u, 0x3f820000u, 0x3f830000u, 0x3f840000u, 0x3f850000u, 0x3f860000u, 0x3f870000u, 0x3f7fff00u, 0x3f7ffe00u, 0x33800000u, 0x33900000u};
+    if (int s = c->debug_a.upload(seed, sizeof(seed), c->stream)) return s;
+    if (int s = c->debug_b.resize(size_t(blocks) * threads * 4)) return s;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    typedef void (*RateKernel)(uint32_t*, const uint32_t*, int);
+    const RateKernel kernels[3] = {k_rate_fma, k_rate_max, k_rate_cvt};
+    for (int which = 0; which < 3; ++which) {
+        float best = 1e30f;
+        for (int repeat = 0; repeat < 4; ++repeat) {      // the first launch warms the clocks up
+            HIP_TRY(hipEventRecord(e0, c->stream));
+            hipLaunchKernelGGL(kernels[which], dim3(blocks), dim3(threads), 0, c->stream, c->debug_b.as<uint32_t>(), c->debug_a.as<uint32_t>(), iterations);
+            HIP_TRY(hipEventRecord(e1, c->stream));
+            HIP_TRY(hipEventSynchronize(e1));
+            float ms = 0.0f;
+            HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+            if (repeat > 0) best = std::min(best, ms);
+        }
+        out3[which] = double(blocks) * (threads / 64) * double(iterations) * 8.0 / (double(best) * 1e-3);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     return HIPR_OK;
 }
 

@@ -863,7 +863,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(tra
                 const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
 #endif
 #ifdef HIPR_EXTRA_NODE_LOADS
-                // Sensitivity experiment (tools/gpu_round3_b.sh): N more 16 B loads per lane from the node's own line -- no new cache line, no new miss, only more
+                // Sensitivity experiment (profiles/r03_ab_extra_node_loads.txt): N more 16 B loads per lane from the node's own line -- no new cache line, no new miss, only more
                 // work for the address / tag pipeline. The pointer is laundered so that the loads are not merged with the four above.
                 uint32_t extra_bits = 0u;
 #pragma unroll

@@ -16,7 +16,8 @@
 //     position p ^ octant, octant bit a = (1 / direction[a] < 0). A ray takes children from its current group lowest pending bit first, inner nodes and
 //     leaf records alike; when the group is empty it pops one from its stack (LDS, one 8-byte entry per lane and depth).
 //   * visiting a node: slab distances of the 8 quantised boxes, fma(float(q), A, B) with A = 2^(e - 127) * inv_d, B = fma(origin, inv_d, -ood) and
-//     origin = fma(float(m), grid_cell, grid_min); a child is hit if tnear <= tfar (tnear / tfar and the 3 ulp of slack as in the other searches). If any
+//     origin = fma(float(m), grid_cell, grid_min); tnear = max(entry distances, tmin), tfar = min(exit distances, tmax); a child is hit unless
+//     fma(tfar, 1.0000004f, -tnear) has its sign bit set (the 3 ulp of slack of the other searches, folded into the one rounding of the fma). If any
 //     child is hit, the current group is pushed when it still has pending children, and the node's hits become the current group.
 //   * visiting a record: triangle A = (a; e1, e2), then B = (a; e2, e3), each with the Moeller-Trumbore solve of kernels.h on the stored edges; the
 //     weights (1 - u - v, u, v) of the record's corners become the scene triangle's (u, v) through the record's selectors.
@@ -43,6 +44,9 @@ struct Wide8Scene {
 constexpr int WIDE8_STACK_SHALLOW = 12;      // 12 KB per block of two waves: twelve blocks per CU, six waves per SIMD
 #ifndef HIPR_WIDE8_WAVES
 #define HIPR_WIDE8_WAVES 6
+#endif
+#ifndef HIPR_WIDE8_SIGN_HITS
+#define HIPR_WIDE8_SIGN_HITS 1      // the hit children of a node from the sign bits of fma(tfar, slack, -tnear): the specification since round 4 (0: round 3's multiply + compare)
 #endif
 #ifndef HIPR_WIDE8_WAVES_LOW
 #define HIPR_WIDE8_WAVES_LOW 6
@@ -267,6 +271,24 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(wid
                 const uint32_t ny[2] = {py ? w1.z : w3.x, py ? w1.w : w3.y}, fy[2] = {py ? w3.x : w1.z, py ? w3.y : w1.w};
                 const uint32_t nz[2] = {pz ? w2.x : w3.z, pz ? w2.y : w3.w}, fz[2] = {pz ? w3.z : w2.x, pz ? w3.w : w2.y};
                 uint32_t h = 0u;
+#if HIPR_WIDE8_SIGN_HITS
+                // A child is missed when fma(tfar, 1 + 3 ulp, -tnear) is negative: the sign bits of the eight differences are shifted into one word
+                // (v_alignbit_b32: (h << 1) | (difference >> 31)), last child first, so that bit k stands for child k. One fma and one funnel shift
+                // per child where a multiply, a compare, a select and a third of an or used to be: 231 -> 219 VALU instructions per node visit,
+                // atrium trace 46.4 -> 45.5 ms per step (profiles/r04_ab_node_block.txt; the same table through an LDS byte table for the octant
+                // permutation: 46.1, not adopted).
+#pragma unroll
+                for (int k = 7; k >= 0; --k) {
+                    const int word = k >> 2, shift = 8 * (k & 3);
+                    const float x0 = fmaf(float((nx[word] >> shift) & 0xFFu), ax, bx), x1 = fmaf(float((fx[word] >> shift) & 0xFFu), ax, bx);
+                    const float y0 = fmaf(float((ny[word] >> shift) & 0xFFu), ay, by), y1 = fmaf(float((fy[word] >> shift) & 0xFFu), ay, by);
+                    const float z0 = fmaf(float((nz[word] >> shift) & 0xFFu), az, bz), z1 = fmaf(float((fz[word] >> shift) & 0xFFu), az, bz);
+                    const float tnear = fmaxf(fmaxf(x0, y0), fmaxf(z0, tmin));
+                    const float tfar = fminf(fminf(fminf(x1, y1), z1), tmax);
+                    h = __builtin_amdgcn_alignbit(h, __float_as_uint(fmaf(tfar, 1.0000004f, -tnear)), 31u);
+                }
+                h = ~h & (w0.w >> 24);
+#else
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const int word = k >> 2, shift = 8 * (k & 3);
@@ -279,6 +301,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(wid
                     h |= tnear <= tfar ? (1u << k) : 0u;
                 }
                 h &= w0.w >> 24;
+#endif
                 // bit k -> bit k ^ octant: three conditional swaps of neighbouring bits, pairs and nibbles
                 h = (octant & 1u) ? (((h & 0x55u) << 1) | ((h >> 1) & 0x55u)) : h;
                 h = (octant & 2u) ? (((h & 0x33u) << 2) | ((h >> 2) & 0x33u)) : h;

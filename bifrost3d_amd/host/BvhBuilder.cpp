@@ -676,7 +676,7 @@ double refit_bvh(BvhBuildResult& bvh, const std::vector<HiprTriangle>& triangles
         quantise_children(boxes, count, w);      // the non-empty children occupy the first `count` slots, as the build left them
         (void)refs;
     }
-    refit_wide8(bvh.wide8, OrderedTriangles{triangles.data(), nullptr, triangles.size()});
+    if (!refit_wide8(bvh.wide8, OrderedTriangles{triangles.data(), nullptr, triangles.size()})) return -1.0;      // the 8-wide tree asks for a rebuild
     return area;
 }
 

@@ -24,7 +24,8 @@ struct BvhBuildResult {
 BvhBuildResult build_bvh(const std::vector<HiprTriangle>& world_triangles, uint32_t max_depth = 62);
 
 // Transform-only update: refits every box of `bvh` (BVH2 child boxes and the wide nodes' quantised child boxes) to `triangles`, which are
-// the build's triangles in leaf order with new positions; topology and triangle order are kept. Returns bvh_child_area() of the result.
+// the build's triangles in leaf order with new positions; topology and triangle order are kept. Returns bvh_child_area() of the result, or a negative value when
+// the 8-wide tree could not be refitted (refit_wide8) and the caller has to rebuild.
 double refit_bvh(BvhBuildResult& bvh, const std::vector<HiprTriangle>& triangles_in_leaf_order);
 // Sum of the half-areas of all BVH2 child boxes: grows when a refit leaves the tree with overlapping, stretched boxes.
 double bvh_child_area(const BvhBuildResult& bvh);

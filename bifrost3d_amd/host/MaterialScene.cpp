@@ -86,18 +86,108 @@ Mesh revolved_sphere(const std::string& name, unsigned longitude_quads, unsigned
     return mesh;
 }
 
+// ---- the procedural shader ball ------------------------------------------------------------------------------------------------------------------
+// A stand-in for Resources/Shaderball.gltf (the Mori knob; not in this repository and not on the GPU box) that costs a ray what the asset costs it.
+// The asset, measured where it is (tests/test_loaders_cpu.py): 11 952 + 13 332 triangles in a 2 x 2 x 2 box holding FIVE to SIX times the area of the
+// enclosing sphere -- a thick outer shell with round openings, a ball inside it that is itself several layers, a base of radius 1.1 -- with
+// triangle edges between 0.0005 and 0.4 and aspect ratios of 20 at the 90th percentile. A ray visits 4.2 nodes and tests 4.8 triangles of it. The first
+// stand-in (one sphere over a squashed sphere, regular grid) cost 2.8 and 1.6. This one is built from the same ingredients as the asset:
+//   * layers: latitude-longitude patches of a sphere, outward or inward facing, with quads left out where a predicate says so (the openings);
+//   * an irregular tessellation: the grid's rows and columns are unevenly spaced, its meridians are helices and every vertex is moved inside its cell
+//     along the surface, so that triangles are long, slanted and of very different sizes while the shape stays the sphere's.
+// The shape parameters below were tuned until the oracle's counters on this scene matched the asset's within 10 % (enforced in the build container by
+// tests/test_loaders_cpu.py::test_material_scene_on_the_reference_shader_ball_against_the_stand_in).
+struct Patches {
+    std::vector<Vector3f> positions, normals;
+    std::vector<Vector2f> texcoords;
+    std::vector<Vector3ui> primitives;
+};
+
+inline float hash01(uint32_t a, uint32_t b, uint32_t seed) {
+    uint32_t h = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA77u ^ seed * 0xC2B2AE3Du;
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+    return float(h >> 8) * (1.0f / 16777216.0f);
+}
+
+// A layer: the part of the ellipsoid centre + scale * direction(theta, phi) whose quads `keep(direction of the quad's middle)` accepts, theta in
+// [theta0, theta1] of pi, the grid unevenly spaced (`unevenness` in [0, 1)) and jittered (`jitter` in cells). `inward`: the surface faces the centre.
+template <typename Keep>
+void add_layer(Patches& out, unsigned longitude_quads, unsigned latitude_quads, Vector3f centre, Vector3f scale, float theta0, float theta1, bool inward, float unevenness, float jitter,
+               uint32_t seed, Keep&& keep) {
+    // quads 1.56 times as wide (along a parallel) as they are high at equal counts: with the helical meridians below they become slanted slivers
+    longitude_quads = unsigned(longitude_quads / 0.8f + 0.5f); latitude_quads = unsigned(latitude_quads * 0.8f + 0.5f);
+    const float J_TWIST = 1.0f;      // the grid's meridians are helices: quads become slanted parallelograms whose boxes overlap their neighbours', as a sculpted mesh's do
+    const unsigned latitude_size = latitude_quads + 1, longitude_size = longitude_quads + 1;
+    const unsigned first_vertex = unsigned(out.positions.size());
+    auto direction = [](float theta, float phi) { const float s = std::sin(theta); return Vector3f(-s * std::sin(phi), std::cos(theta), s * std::cos(phi)); };
+    // uneven spacing: a smooth monotone warp of the unit interval, u + a sin(2 pi k u) / (2 pi k) has derivative 1 + a cos(.) > 0
+    auto warp = [&](float u, float k) { return u + unevenness * std::sin(2.0f * PI<float>() * k * u) / (2.0f * PI<float>() * k); };
+    for (unsigned y = 0; y < latitude_size; ++y)
+        for (unsigned x = 0; x < longitude_size; ++x) {
+            float u = float(x) / longitude_quads, v = float(y) / latitude_quads;
+            const bool seam = x == 0 || x == longitude_quads, rim = y == 0 || y == latitude_quads;
+            if (!seam) u += (hash01(x, y, seed) - 0.5f) * jitter / longitude_quads;
+            if (!rim) v += (hash01(y, x, seed ^ 0x51ED27u) - 0.5f) * jitter / latitude_quads;
+            u = warp(u, 3.0f); v = warp(v, 2.0f);
+            const float theta = (theta0 + (theta1 - theta0) * v) * PI<float>(), phi = (u + J_TWIST * v) * 2.0f * PI<float>();
+            const Vector3f d = direction(theta, phi);
+            out.positions.push_back(centre + Vector3f(d.x * scale.x, d.y * scale.y, d.z * scale.z));
+            const Vector3f n = normalize(Vector3f(d.x / scale.x, d.y / scale.y, d.z / scale.z));
+            out.normals.push_back(inward ? -n : n);
+            out.texcoords.push_back(Vector2f{u, theta0 + (theta1 - theta0) * v});
+        }
+    for (unsigned y = 0; y < latitude_quads; ++y)
+        for (unsigned x = 0; x < longitude_quads; ++x) {
+            const float theta = (theta0 + (theta1 - theta0) * (y + 0.5f) / latitude_quads) * PI<float>(), phi = ((x + 0.5f) / longitude_quads + J_TWIST * (y + 0.5f) / latitude_quads) * 2.0f * PI<float>();
+            if (!keep(direction(theta, phi))) continue;
+            const unsigned base = first_vertex + x + y * longitude_size;
+            const bool north_pole = y == 0 && theta0 == 0.0f, south_pole = y == latitude_quads - 1 && theta1 == 1.0f;      // the collapsed rows: one triangle per quad
+            const unsigned a = base, b = base + 1, c = base + longitude_size, d = base + longitude_size + 1;
+            if (!north_pole) out.primitives.push_back(inward ? Vector3ui{a, c, b} : Vector3ui{a, b, c});
+            if (!south_pole) out.primitives.push_back(inward ? Vector3ui{b, c, d} : Vector3ui{b, d, c});
+        }
+}
+
+Mesh mesh_of(const std::string& name, const Patches& patches) {
+    MeshFlags buffers = MeshFlag::Position; buffers |= MeshFlag::Normal; buffers |= MeshFlag::Texcoord;
+    Mesh mesh = Mesh(name, unsigned(patches.primitives.size()), unsigned(patches.positions.size()), buffers);
+    std::copy(patches.positions.begin(), patches.positions.end(), mesh.get_positions());
+    std::copy(patches.normals.begin(), patches.normals.end(), mesh.get_normals());
+    std::copy(patches.texcoords.begin(), patches.texcoords.end(), mesh.get_texcoords());
+    std::copy(patches.primitives.begin(), patches.primitives.end(), mesh.get_primitives());
+    mesh.compute_bounds();
+    return mesh;
+}
+
 SceneNode create_procedural_shader_ball(Material outer_material, Material inner_material) {
+    // tuned against the asset (see above): row / column spacing varies by 0.6, vertices move up to 0.3 cells, the grid's meridians make one turn from pole to pole
+    const float J_UNEVEN = 0.6f, J_JITTER = 0.6f;
     SceneNode ball_node = SceneNode("ShaderBall");
+    // Five round openings in the shell: four around the upper half, one on top (object space; the ball is scaled by two in the scene).
+    const Vector3f opening_axes[5] = {normalize(Vector3f(1, 0.45f, 1)), normalize(Vector3f(-1, 0.45f, 1)), normalize(Vector3f(1, 0.45f, -1)), normalize(Vector3f(-1, 0.45f, -1)), Vector3f(0, 1, 0)};
+    const float opening_cosine = std::cos(0.40f);
+    auto shell = [&](Vector3f d) { for (const Vector3f& axis : opening_axes) if (dot(d, axis) > opening_cosine) return false; return true; };
+    auto everywhere = [](Vector3f) { return true; };
+    const Vector3f centre = Vector3f(0, 0.06f, 0);
+
+    // The tested material ("Node5"): the shell's outside and inside faces and the base it stands on.
+    Patches outer;
+    add_layer(outer, 74, 46, centre, Vector3f(0.5f, 0.5f, 0.5f), 0.0f, 1.0f, false, J_UNEVEN, J_JITTER, 1u, shell);
+    add_layer(outer, 64, 42, centre, Vector3f(0.44f, 0.44f, 0.44f), 0.0f, 1.0f, true, J_UNEVEN, J_JITTER, 2u, shell);
+    add_layer(outer, 56, 20, Vector3f(0, -0.42f, 0), Vector3f(0.54f, 0.08f, 0.54f), 0.0f, 1.0f, false, J_UNEVEN, J_JITTER, 3u, everywhere);
     SceneNode outer_node = SceneNode("Node5");
-    MeshModel(outer_node, revolved_sphere("ShaderBallOuter", 96, 64), outer_material);
+    MeshModel(outer_node, mesh_of("ShaderBallOuter", outer), outer_material);
     outer_node.set_parent(ball_node);
 
-    // The rubber part: a flattened sphere under the ball that reaches out beyond it as a base.
-    Mesh base = revolved_sphere("ShaderBallBase", 104, 66);
-    const Matrix3x4f squash = {{{0.9f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.16f, 0.0f, -0.42f}, {0.0f, 0.0f, 0.9f, 0.0f}}};
-    MeshUtils::transform_mesh(base, squash);
+    // The rubber inside ("Node2"): a ball of three layers, the outer two grooved so that the ones below show.
+    Patches inner;
+    auto grooved = [](Vector3f d) { const float phi = std::atan2(d.x, d.z); return std::fmod(std::fabs(phi) * (8.0f / PI<float>()), 2.0f) < 1.4f; };
+    auto banded = [](Vector3f d) { return std::fmod((d.y + 1.0f) * 4.0f, 2.0f) < 1.5f; };
+    add_layer(inner, 84, 42, centre, Vector3f(0.365f, 0.365f, 0.365f), 0.0f, 1.0f, false, J_UNEVEN, J_JITTER, 4u, grooved);
+    add_layer(inner, 74, 42, centre, Vector3f(0.355f, 0.355f, 0.355f), 0.0f, 1.0f, false, J_UNEVEN, J_JITTER, 5u, banded);
+    add_layer(inner, 64, 42, centre, Vector3f(0.34f, 0.34f, 0.34f), 0.0f, 1.0f, false, J_UNEVEN, J_JITTER, 6u, everywhere);
     SceneNode inner_node = SceneNode("Node2");
-    MeshModel(inner_node, base, inner_material);
+    MeshModel(inner_node, mesh_of("ShaderBallInner", inner), inner_material);
     inner_node.set_parent(ball_node);
     return ball_node;
 }

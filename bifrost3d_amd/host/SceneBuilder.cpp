@@ -238,14 +238,24 @@ void SceneBuilder::finalize(uint32_t bvh_max_depth) {
 
 bool SceneBuilder::update_model_transforms(const std::vector<std::pair<uint32_t, Transform>>& model_transforms, double rebuild_threshold) {
     std::vector<bool> moved(m_instances.size(), false);
+    // Decided before anything is touched: does an update turn an instance inside out? Such an instance is drawn from its own index triples (two corners
+    // exchanged, index_offset_for), so the triangle array is rebuilt from the instances -- with EVERY update of the batch applied first; the caller is told
+    // "rebuilt" (false) and uploads a desc() that carries all the new poses.
+    bool flips = false;
     for (const auto& update : model_transforms)
         for (size_t i = 0; i < m_instances.size(); ++i)
             if (uint32_t(m_instances[i].instance_id) == ((1u << 30) | update.first)) {
                 Matrix3x4f m = to_matrix3x4(update.second);
-                if (mirrors(m.begin()) != mirrors(m_instances[i].object_to_world)) return false;      // the instance turns inside out: its index triples change, a rebuild
+                flips = flips || mirrors(m.begin()) != mirrors(m_instances[i].object_to_world);
                 std::memcpy(m_instances[i].object_to_world, m.begin(), sizeof(m_instances[i].object_to_world));
                 moved[i] = true;
             }
+    if (flips) {
+        for (size_t i = 0; i < m_instances.size(); ++i)
+            if (moved[i]) m_instances[i].index_offset = index_offset_for(m_instance_mesh[i], m_instances[i].object_to_world);
+        finalize(m_bvh_max_depth_limit);
+        return false;
+    }
     m_bounds = AABB::invalid();
     for (HiprTriangle& t : m_triangles) {
         if (moved[t.instance_index]) {
@@ -265,7 +275,7 @@ bool SceneBuilder::update_model_transforms(const std::vector<std::pair<uint32_t,
     }
     const double area = refit_bvh(m_bvh, m_triangles);
     for (int a = 0; a < 3; ++a) { m_desc.wide8_grid_min[a] = m_bvh.wide8.grid_min[a]; m_desc.wide8_grid_cell[a] = m_bvh.wide8.grid_cell[a]; }     // the refit moves the grid with the scene
-    if (m_built_bvh_area > 0.0 && area > rebuild_threshold * m_built_bvh_area) {
+    if (area < 0.0 || (m_built_bvh_area > 0.0 && area > rebuild_threshold * m_built_bvh_area)) {      // area < 0: a leaf record of the 8-wide tree could not be refitted
         finalize(m_bvh_max_depth_limit);      // the instances already carry the new transforms
         return false;
     }

@@ -677,8 +677,8 @@ Wide8Result build_wide8(const std::vector<HiprBvhNode>& nodes, const OrderedTria
     return result;
 }
 
-void refit_wide8(Wide8Result& tree, const OrderedTriangles& triangles) {
-    if (tree.slots.empty()) return;
+bool refit_wide8(Wide8Result& tree, const OrderedTriangles& triangles) {
+    if (tree.slots.empty()) return true;
     set_grid(triangles, tree);      // the moved scene's bounds: node origins must not be clamped at the ends of a stale grid
     std::vector<uint8_t> is_node(tree.slots.size(), 0);
     is_node[0] = 1;
@@ -700,7 +700,9 @@ void refit_wide8(Wide8Result& tree, const OrderedTriangles& triangles) {
             const uint32_t index_a = leaf.triangle[0], index_b = leaf.triangle[1];
             const int rotation_a = int((1 - int((leaf.flags >> 8) & 3u) + 3) % 3);
             HiprLeaf8 rebuilt;
-            if (!make_record(triangles, index_a, index_b, rotation_a, rebuilt)) make_record(triangles, index_a, HIPR_LEAF8_NONE, 0, rebuilt);   // cannot happen for a rigid move of one instance
+            // Pairing was decided on bit-identical WORLD positions: two distinct object-space vertices that rounded to one world position at build time may
+            // part after the move. The record cannot hold both triangles then; the caller rebuilds (a record of A alone would drop B from this tree only).
+            if (!make_record(triangles, index_a, index_b, rotation_a, rebuilt)) return false;
             leaf = rebuilt;
             exact[i] = triangle_box(triangles[index_a]);
             if (index_b != HIPR_LEAF8_NONE) exact[i].grow(triangle_box(triangles[index_b]));
@@ -718,6 +720,7 @@ void refit_wide8(Wide8Result& tree, const OrderedTriangles& triangles) {
         exact[i] = all;
         Collapse::quantise_node(boxes, valid, all, tree.grid_min, tree.grid_cell, n);
     }
+    return true;
 }
 
 } // namespace HIPRenderer

@@ -30,6 +30,7 @@ struct OrderedTriangles {
 Wide8Result build_wide8(const std::vector<HiprBvhNode>& nodes, const OrderedTriangles& triangles_in_leaf_order);
 
 // Transform-only update: same topology, new triangle positions. Rewrites every leaf record from `triangles_in_leaf_order` and requantises every node.
-void refit_wide8(Wide8Result& tree, const OrderedTriangles& triangles_in_leaf_order);
+// false: a paired record's shared corners are no longer bit-identical after the move -- the tree is stale and must be rebuilt (nothing else is wrong).
+bool refit_wide8(Wide8Result& tree, const OrderedTriangles& triangles_in_leaf_order);
 
 } // namespace HIPRenderer

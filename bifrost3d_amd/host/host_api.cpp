@@ -62,7 +62,14 @@ static void* create_material_scene(const std::string& shader_ball_path, unsigned
 static void* create_glass_scene(const std::string& resource_directory, unsigned variant);
 static void* create_opacity_scene(unsigned quads_per_edge, unsigned variant);
 
+// The builders hand a worker thread's exception (std::bad_alloc on a scene too large for the host) to the caller: every entry that reaches
+// finalize() / refit_bvh() turns it into its error value here -- nothing may unwind through the C boundary.
+static void* scene_create(const char* name, unsigned variant, unsigned param0, unsigned param1);
 void* hiprh_scene_create(const char* name, unsigned variant, unsigned param0, unsigned param1) {
+    try { return scene_create(name, variant, param0, param1); }
+    catch (const std::exception& e) { fprintf(stderr, "hiprh_scene_create: %s\n", e.what()); Bifrost::deallocate_all(); return nullptr; }
+}
+static void* scene_create(const char* name, unsigned variant, unsigned param0, unsigned param1) {
     if (!name) return nullptr;
     if (!std::strncmp(name, "material", 8) && (name[8] == 0 || name[8] == ':')) return create_material_scene(name[8] ? name + 9 : "", variant);
     if (!std::strncmp(name, "glass", 5) && (name[5] == 0 || name[5] == ':')) return create_glass_scene(name[5] ? name + 6 : "", variant);
@@ -207,7 +214,12 @@ static void* scene_load_with_environment(const char* path, const char* environme
 // SimpleViewer's main loop does per frame (apps/SimpleViewer/main.cpp:298-308). out[0] = milliseconds of the timed calls, out[1] = accumulations
 // reached, out[2] = flattened triangle count. max_batch: Renderer::set_max_batch_size (1 = one launch per accumulation, the reference's granularity).
 // Returns 0, or a negative number when the renderer cannot be created or a call fails. The Bifrost managers are scratch space here.
+static int renderer_bench(const char* data_directory, unsigned target_triangles, unsigned width, unsigned height, unsigned warmup_calls, unsigned calls, unsigned max_batch, double* out3);
 int hiprh_renderer_bench(const char* data_directory, unsigned target_triangles, unsigned width, unsigned height, unsigned warmup_calls, unsigned calls, unsigned max_batch, double* out3) {
+    try { return renderer_bench(data_directory, target_triangles, width, height, warmup_calls, calls, max_batch, out3); }
+    catch (const std::exception& e) { fprintf(stderr, "hiprh_renderer_bench: %s\n", e.what()); Bifrost::deallocate_all(); return -5; }
+}
+static int renderer_bench(const char* data_directory, unsigned target_triangles, unsigned width, unsigned height, unsigned warmup_calls, unsigned calls, unsigned max_batch, double* out3) {
     using namespace Bifrost;
     if (!data_directory || !out3 || !width || !height) return -1;
     deallocate_all();
@@ -302,7 +314,8 @@ size_t hiprh_png_load(const char* path, int flip, unsigned* width, unsigned* hei
 int hiprh_scene_move_model(void* scene, unsigned model_index, const float* translation3, const float* rotation4, float scale, double rebuild_threshold) {
     if (!scene || !translation3 || !rotation4) return -1;
     const Transform t(Vector3f(translation3[0], translation3[1], translation3[2]), Bifrost::Math::Quaternionf(rotation4[0], rotation4[1], rotation4[2], rotation4[3]), scale);
-    return static_cast<SceneBuilder*>(scene)->update_model_transforms({{model_index, t}}, rebuild_threshold > 0.0 ? rebuild_threshold : 1.5) ? 1 : 0;
+    try { return static_cast<SceneBuilder*>(scene)->update_model_transforms({{model_index, t}}, rebuild_threshold > 0.0 ? rebuild_threshold : 1.5) ? 1 : 0; }
+    catch (const std::exception& e) { fprintf(stderr, "hiprh_scene_move_model: %s\n", e.what()); return -1; }
 }
 
 void hiprh_scene_destroy(void* scene) { delete static_cast<SceneBuilder*>(scene); }
@@ -341,10 +354,13 @@ int hiprh_make_camera(const float* params14, unsigned width, unsigned height, un
 // Stand-alone BVH build over caller triangles (tests): returns a handle owning nodes + order.
 struct BvhHandle { BvhBuildResult result; };
 void* hiprh_bvh_build(const HiprTriangle* triangles, unsigned count, unsigned max_depth) {
-    std::vector<HiprTriangle> t(triangles, triangles + count);
-    BvhHandle* h = new BvhHandle();
-    h->result = build_bvh(t, max_depth);
-    return h;
+    BvhHandle* h = nullptr;
+    try {
+        std::vector<HiprTriangle> t(triangles, triangles + count);
+        h = new BvhHandle();
+        h->result = build_bvh(t, max_depth);
+        return h;
+    } catch (const std::exception& e) { fprintf(stderr, "hiprh_bvh_build: %s\n", e.what()); delete h; return nullptr; }
 }
 unsigned hiprh_bvh_node_count(void* h) { return unsigned(static_cast<BvhHandle*>(h)->result.nodes.size()); }
 unsigned hiprh_bvh_max_depth(void* h) { return static_cast<BvhHandle*>(h)->result.max_depth; }

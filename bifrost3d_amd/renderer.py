@@ -135,6 +135,12 @@ class Context:
         self._check(self.lib.hipr_get_kernel_times(self.handle, C.byref(t)), "hipr_get_kernel_times")
         return {name: dict(ms=t.milliseconds[i], launches=int(t.launches[i])) for i, name in enumerate(capi.HIPR_KERNEL_NAMES)}
 
+    def valu_issue_rates(self) -> dict:
+        """Wave64 instructions per second device-wide of v_fma_f32 / v_max_f32 / v_cvt_f32_ubyte1 chains (hipr_debug_valu_issue_rates)."""
+        out = (C.c_double * 3)()
+        self._check(self.lib.hipr_debug_valu_issue_rates(self.handle, out), "hipr_debug_valu_issue_rates")
+        return {"v_fma_f32": out[0], "v_max_f32": out[1], "v_cvt_f32_ubyte1": out[2]}
+
     def scatter_tiles(self, compact_ptr, rank_stride, rank_count, width, height, out_ptr, out_pitch):
         self._check(self.lib.hipr_scatter_tiles(self.handle, C.c_void_p(compact_ptr), rank_stride, rank_count, width, height, C.c_void_p(out_ptr), out_pitch),
                     "hipr_scatter_tiles")

@@ -511,6 +511,10 @@ int hipr_debug_shading(HiprContext* context, int shading_model, const float* par
  * pdf(light, position, direction), 0, 0, 0, 0. Host pointers; position3 is shared by the n inputs. */
 int hipr_debug_light(HiprContext* context, const HiprLight* light, const float* position3, const float* in_n3, uint32_t n, int mode, float* out_n8);
 int hipr_debug_sobol(HiprContext* context, const uint32_t* accumulation_pixelhash_dimension, uint32_t n, uint32_t* out_uint4);
+/* The VALU roof of the device the context runs on, measured (bench.py's roofline_valu; no reference counterpart): eight independent chains of one
+ * instruction per lane, eight waves per SIMD on every CU, best of three launches. out3[0] = v_fma_f32, out3[1] = v_max_f32, out3[2] = v_cvt_f32_ubyte1,
+ * each in wave64 instructions per second device-wide (tools/microbench/issue_rates.hip has the full table: profiles/r03_issue_rates.txt). */
+int hipr_debug_valu_issue_rates(HiprContext* context, double* out3);
 /* The 256 float4 reverse-Halton offsets the next event estimation candidates are drawn with, read back from the device
  * (g_random_sample_offsets, OR/Renderer.cpp:323-336). out_256x4: host pointer to 1024 floats. */
 int hipr_debug_sample_offsets(HiprContext* context, float* out_256x4);

@@ -345,7 +345,8 @@ Hit closest_hit_wide(const HiprSceneDesc& scene, const Ray& ray, uint32_t skip, 
 //     node that are still to be visited, `pending` bit p standing for the child in position p ^ octant. Children are taken from the current group lowest
 //     pending bit first -- the nearest octant first -- whether they are inner nodes or leaf records;
 //   * visiting an inner node tests its up to eight quantised child boxes (slab distances fma(float(q), A, B) with A = 2^(e - 127) * inv_d and
-//     B = fma(origin, inv_d, -ood), origin = fma(float(m), grid_cell, grid_min); tnear / tfar as for the other trees, same 3 ulp of slack); if any is hit the
+//     B = fma(origin, inv_d, -ood), origin = fma(float(m), grid_cell, grid_min); tnear / tfar as for the other trees; a child is hit unless
+//     fma(tfar, 1.0000004f, -tnear) is negative -- the other trees' 3 ulp of slack inside the one rounding of the fma, round 4); if any is hit the
 //     current group goes on the stack (when it still has pending children) and the node's hits become the current group;
 //   * visiting a leaf record tests triangle A = (a; e1, e2), then B = (a; e2, e3) if there is one, with the solve of intersect_triangle on the stored
 //     edges; the weights (w, u, v) = (1 - u - v, u, v) of the record's corners are mapped to the scene triangle's (u, v) by the record's selectors.
@@ -433,9 +434,9 @@ static inline void traverse_wide8(const HiprSceneDesc& scene, const Ray& ray, fl
                 hi[a] = fmaf(float(n.qhi[a][k]), A[a], B[a]);
             }
             const float tnear = fmaxf(fmaxf(fminf(lo[0], hi[0]), fminf(lo[1], hi[1])), fmaxf(fminf(lo[2], hi[2]), ray.tmin));
-            float tfar = fminf(fminf(fmaxf(lo[0], hi[0]), fmaxf(lo[1], hi[1])), fmaxf(lo[2], hi[2]));
-            tfar = fminf(tfar, tmax) * 1.0000004f;
-            if ((valid >> k & 1u) && tnear <= tfar)
+            const float tfar = fminf(fminf(fminf(fmaxf(lo[0], hi[0]), fmaxf(lo[1], hi[1])), fmaxf(lo[2], hi[2])), tmax);
+            // missed when tfar * (1 + 3 ulp) - tnear, rounded ONCE, is negative (its sign bit is what the device collects: csrc/wide8_kernels.h)
+            if ((valid >> k & 1u) && !std::signbit(fmaf(tfar, 1.0000004f, -tnear)))
                 hits |= 1u << (k ^ octant);
         }
         if (hits) {

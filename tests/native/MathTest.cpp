@@ -195,6 +195,32 @@ CPU_TEST_F(MathFixture, a_mirroring_instance_keeps_its_front_side) {
         EXPECT_TRUE(almost_equal(p1, from_triple, 4));
     }
     // a transform-only update that turns an instance inside out cannot be a refit: the triples change
-    EXPECT_TRUE(!scene.update_model_transforms({{1u, Transform(Vector3f(0, 1, 0), turned, -2.0f)}}));
+    // -- and "false" means REBUILT: desc() carries the new pose of every model of the batch (the flipped one and the one updated before it), the flipped
+    // instance points at the mirrored triples, and the world-space triangles agree with the instance matrices.
+    EXPECT_TRUE(!scene.update_model_transforms({{3u, Transform(Vector3f(-5, 2, 0), turned, -0.5f)}, {1u, Transform(Vector3f(0, 1, 0), turned, -2.0f)}}));
+    {
+        const HiprSceneDesc& r = scene.desc();
+        EXPECT_EQ(3u, r.triangle_count);
+        EXPECT_EQ(r.instances[0].index_offset, r.instances[1].index_offset);      // model 1 now shares the mirrored copy
+        EXPECT_FLOAT_EQ_EPS(1.0f, r.instances[0].object_to_world[7], 1e-6);                 // translation y of model 1
+        EXPECT_FLOAT_EQ_EPS(2.0f, r.instances[2].object_to_world[7], 1e-6);                 // and of model 3, updated in the same batch
+        for (uint32_t t = 0; t < r.triangle_count; ++t) {
+            const HiprTriangle& tri = r.triangles[t];
+            const HiprInstance& inst = r.instances[tri.instance_index];
+            const float* M = inst.object_to_world;
+            const uint32_t* idx = r.indices + 3 * size_t(inst.index_offset + tri.primitive_index);
+            const float* corners[3] = {tri.v0, tri.v1, tri.v2};
+            for (int k = 0; k < 3; ++k) {
+                const HiprVertexGeometry& g = r.geometry[inst.vertex_offset + idx[k]];
+                const Vector3f expected(M[0] * g.position[0] + M[1] * g.position[1] + M[2] * g.position[2] + M[3], M[4] * g.position[0] + M[5] * g.position[1] + M[6] * g.position[2] + M[7],
+                                        M[8] * g.position[0] + M[9] * g.position[1] + M[10] * g.position[2] + M[11]);
+                EXPECT_TRUE(almost_equal(Vector3f(corners[k][0], corners[k][1], corners[k][2]), expected, 4));
+            }
+            // the front side stays the object-space front side: geometric normal = R n / s
+            const float s = tri.instance_index == 0 ? -2.0f : (tri.instance_index == 1 ? -2.0f : -0.5f);
+            const Vector3f p0(tri.v0[0], tri.v0[1], tri.v0[2]), p1(tri.v1[0], tri.v1[1], tri.v1[2]), p2(tri.v2[0], tri.v2[1], tri.v2[2]);
+            EXPECT_TRUE(almost_equal(normalize(cross(p1 - p0, p2 - p0)), normalize(Vector3f(M[2], M[6], M[10]) / (s * s)), 64));
+        }
+    }
     EXPECT_TRUE(scene.update_model_transforms({{2u, Transform(Vector3f(5, 1, 0), turned, -3.0f)}}));
 }

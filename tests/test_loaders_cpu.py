@@ -345,10 +345,10 @@ def test_scene_load_reports_files_it_cannot_read(tmp_path):
 def test_material_scene_on_the_reference_shader_ball_against_the_stand_in():
     """apps/SimpleViewer/Scenes/Material.cpp:143-188 builds config 3 from Resources/Shaderball.gltf; the GPU box has no reference tree, so bench.py and the
     -m gpu tests render a procedural stand-in of the ball. Here, where the asset is, the scene is built from it through the same code path: the 8-wide tree's
-    search finds what the BVH2 search finds on it, and the stand-in is set against the real asset's figures: same triangle count (+-5 %), same share of rays that
-    hit, same rays per path, same mean radiance (+-15 ... 20 %) -- and, measured here and written down rather than hidden, a CHEAPER traversal: a ray visits
-    4.2 nodes and tests 4.8 triangles of the real ball's irregular mesh against 2.8 and 1.6 of the stand-in's regular grid, so config 3's Mrays/s on the
-    stand-in flatter the traversal by about that much (profiles/r03_config3_real_asset_statistics.txt)."""
+    search finds what the BVH2 search finds on it, and the stand-in is held to the real asset's figures: same triangle count (+-5 %), same share of rays that
+    hit, same rays per path, same mean radiance -- and, since round 4, the same COST per ray: node visits, triangle tests and shadow-ray node visits within
+    10 % of the asset's (4.3 / 5.0 / 3.5; round 3's regular-grid sphere cost 2.8 / 1.6 / 2.5 and flattered config 3's Mrays/s). The stand-in's layered shells,
+    openings and slanted, uneven tessellation (host/MaterialScene.cpp) were tuned against these counters; profiles/r04_config3_real_asset_statistics.txt."""
     from oracle_bindings import get_oracle
     Scene = host.Scene
     oracle = get_oracle(True)
@@ -356,7 +356,7 @@ def test_material_scene_on_the_reference_shader_ball_against_the_stand_in():
     stand_in = Scene("material")
     assert 170000 <= real.desc.triangle_count <= 185000                                   # 7 x (13 332 + 11 952) + the floor's 8
     assert abs(stand_in.desc.triangle_count - real.desc.triangle_count) <= 0.05 * real.desc.triangle_count
-    w, h, spp = 64, 36, 2
+    w, h, spp = 128, 72, 2
     figures = {}
     for name, scene in (("real", real), ("stand_in", stand_in)):
         cam = scene.camera(w, h, max_bounce_count=32)
@@ -366,7 +366,8 @@ def test_material_scene_on_the_reference_shader_ball_against_the_stand_in():
     print("CONFIG-3-STATISTICS", figures)
     for key, tolerance in (("hits", 0.15), ("rays_per_path", 0.2), ("mean", 0.2)):
         assert abs(figures["stand_in"][key] - figures["real"][key]) <= tolerance * figures["real"][key], (key, figures)
-    assert 0.5 <= figures["stand_in"]["nodes"] / figures["real"]["nodes"] <= 1.1 and 0.25 <= figures["stand_in"]["triangles"] / figures["real"]["triangles"] <= 1.1, figures
+    for key in ("nodes", "triangles", "shadow_nodes"):      # what a ray costs: within 10 % of the asset
+        assert abs(figures["stand_in"][key] - figures["real"][key]) <= 0.10 * figures["real"][key], (key, figures)
     # the real asset under both searches: same hits for the camera rays
     xy = np.stack(np.meshgrid(np.arange(w), np.arange(h)), axis=-1).reshape(-1, 2).astype(np.uint32)
     o, d = oracle.generate_rays(real.camera(w, h), w, h, 1, xy)

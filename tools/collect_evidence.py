@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Copies what tools/gpu_round3_final.sh left under gpurun_out/r3final/ into the committed evidence under profiles/ (names: profiles/README.md, Round 3).
-usage: python tools/collect_round3.py [gpurun_out/r3final]"""
+"""Copies what tools/gpu_evidence.sh <tag> left under gpurun_out/<tag>/ into the committed evidence under profiles/<tag>_* (names: profiles/README.md).
+usage: python tools/collect_evidence.py gpurun_out/r04 r04"""
 import json
 import re
 import shutil
@@ -8,7 +8,7 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-src = Path(sys.argv[1]) if len(sys.argv) > 1 else ROOT / "gpurun_out" / "r3final"
+src, TAG = Path(sys.argv[1]), sys.argv[2]
 profiles = ROOT / "profiles"
 
 
@@ -21,23 +21,23 @@ def one_line(source, target):
 
 
 lines = {}
-for source, target in (("bench_default.json", "r03_bench_final.json"), ("bench_under_rocprof.json", "r03_atrium_bench_under_rocprof.json"), ("bench_material.json", "r03_bench_material.json"),
-                       ("bench_cornell_diffuse.json", "r03_bench_cornell_diffuse.json"), ("bench_atrium10M_4k.json", "r03_bench_atrium10M_4k.json"),
-                       ("bench_atrium_1spp.json", "r03_bench_atrium_1spp.json"), ("bench_2rank_gloo_shared_device.json", "r03_bench_2rank_gloo_shared_device.json")):
+for source, target in (("bench_default.json", TAG + "_bench_final.json"), ("bench_under_rocprof.json", TAG + "_atrium_bench_under_rocprof.json"), ("bench_material.json", TAG + "_bench_material.json"),
+                       ("bench_cornell_diffuse.json", TAG + "_bench_cornell_diffuse.json"), ("bench_atrium10M_4k.json", TAG + "_bench_atrium10M_4k.json"),
+                       ("bench_atrium_1spp.json", TAG + "_bench_atrium_1spp.json"), ("bench_2rank_gloo_shared_device.json", TAG + "_bench_2rank_gloo_shared_device.json")):
     if (src / source).exists() and (src / source).stat().st_size:
         lines[target] = one_line(source, target)
 stats = sorted(src.glob("trace/**/*kernel_stats.csv"), key=lambda f: f.stat().st_mtime, reverse=True)      # the newest run
 if stats:
-    shutil.copy(stats[0], profiles / "r03_atrium_kernel_stats.csv")
+    shutil.copy(stats[0], profiles / (TAG + "_atrium_kernel_stats.csv"))
 for name in ("rmse_protocol_480x270.json", "rmse_protocol_160x90.json"):
     if (src / name).exists() and (src / name).stat().st_size:
-        shutil.copy(src / name, profiles / ("r03_" + name))
+        shutil.copy(src / name, profiles / (TAG + "_" + name))
 if (src / "trace_log.txt").exists():
-    shutil.copy(src / "trace_log.txt", profiles / "r03_atrium_trace_log.txt")
+    shutil.copy(src / "trace_log.txt", profiles / (TAG + "_atrium_trace_log.txt"))
 log = (src / "gpu_tests.log").read_text() if (src / "gpu_tests.log").exists() else ""
 metrics = [l for l in log.splitlines() if re.search(r"IMAGE-METRIC|DENOISER-METRIC|atrium: pixels within", l)]
 if metrics:
     tail = [l for l in log.splitlines() if re.search(r"\d+ passed", l)]
-    (profiles / "r03_image_metrics.txt").write_text("\n".join(metrics + tail) + "\n")
+    (profiles / (TAG + "_image_metrics.txt")).write_text("\n".join(metrics + tail) + "\n")
 for target, d in lines.items():
     print(f"{target:44} {d['value']:9.1f} {d['unit']:8} {d['ms_per_step']:8.2f} ms/step  roofline.frac {d.get('roofline', {}).get('frac')}")

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turns what tools/gpu_round2_profiles.sh left under gpurun_out/<dir>/ into the committed evidence under profiles/:
+"""Turns what tools/gpu_evidence.sh <tag> counters left under gpurun_out/<dir>/ into the committed evidence under profiles/:
   <tag>_<scene>_kernel_stats.csv          rocprofv3 --kernel-trace --stats summary
   <tag>_<scene>_bench_under_rocprof.json  the bench line of that same profiled run
   pmc_traffic.json                        HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes (tools/make_pmc_traffic.py)
@@ -75,7 +75,7 @@ def derived(c):
 
 if sums:
     lines = [f"# SQ / TCC / TCP counters of the atrium bench (bench.py --scene atrium --steps 2 --warmup 1, one wavefront), rocprofv3 --pmc, four separate passes",
-             "# (tools/profile_sq.sh, tools/gpu_round3_profiles.sh, tools/collect_profiles.py). Sums over all dispatches of a kernel in the run; SQ_*_CYCLES are quad-cycles summed over waves.",
+             "# (tools/profile_sq.sh, tools/gpu_evidence.sh, tools/collect_profiles.py). Sums over all dispatches of a kernel in the run; SQ_*_CYCLES are quad-cycles summed over waves.",
              "# derived: share of wave time = counter / SQ_WAVE_CYCLES; lanes per VALU instruction = SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU; L2 hit = TCC_HIT / TCC_REQ; L1 hit = 1 - TCP_TCC_READ_REQ / TCP_TOTAL_CACHE_ACCESSES",
              ""]
     limiters = {}

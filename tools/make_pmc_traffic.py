@@ -33,6 +33,8 @@ def bench_name(kernel: str):
     if "k_trace_persistent" in k or "k_trace_wide8" in k:   # template arguments <STACK, MODE, INSTRUMENT>; MODE 0 closest, 1 shadow, 2 fused
         args = k[k.index("<") + 1:k.rindex(">")].split(",") if "<" in k else []
         mode = args[1].strip() if len(args) > 1 else "2"
+        if len(args) > 2 and args[2].strip() == "true":      # the instrumented build (counting passes before the warm-up): not what the timed region runs
+            return None
         return {"0": "trace_closest", "1": "trace_shadow"}.get(mode, "trace")
     return None
 
