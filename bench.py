@@ -68,9 +68,9 @@ def parse_args(argv=None):
     p.add_argument("--bounces", type=int, default=None, help="max_bounce_count; default 4, and 32 for the viewer's built-in scenes (apps/SimpleViewer/main.cpp:353)")
     p.add_argument("--spp-per-pass", type=int, default=32, help="accumulations traced together per step and GPU (HiprFrameDesc::samples_per_pass)")
     p.add_argument("--wavefronts", type=int, default=0, choices=[0, 1, 2, 3, 4],
-                   help="0 (default): the library's choice by scene -- one wavefront for the persistent wide-BVH kernels (atrium, material scene: kernel durations are "
-                        "those of kernels running alone), two half-frame wavefronts on two streams for the small-scene kernels (Cornell box: one shades while the other "
-                        "traces, +9 ... +27 %%; per-kernel durations are then co-running durations)")
+                   help="0 (default): the library's choice -- two half-frame wavefronts on two streams for the small-scene kernels (Cornell box: one shades while the other "
+                        "traces) and, since round 4, for the persistent wide-BVH kernels from 2^24 paths per pass on (where one wavefront's launch drains the other's blocks "
+                        "move in: +4 %%), one below that. Per-kernel durations of co-running wavefronts overlap; the rooflines are priced on a one-wavefront leg")
     p.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                    help="gloo + --share-device runs the N > 1 code path with every rank on GPU 0 (functional test of tiling / gather / scatter on a 1-GPU box)")
     p.add_argument("--share-device", action="store_true")
@@ -218,10 +218,10 @@ def measure_traffic_live(argv):
         if skip:
             skip -= 1
             continue
-        if a in ("--steps", "--warmup", "--gpus", "--pmc-traffic", "--cpu-baseline-seconds", "--master-port", "--spawn-deadline"):
+        if a in ("--steps", "--warmup", "--gpus", "--pmc-traffic", "--cpu-baseline-seconds", "--master-port", "--spawn-deadline", "--wavefronts"):
             skip = 1
             continue
-        if a.split("=")[0] in ("--steps", "--warmup", "--gpus", "--pmc-traffic", "--cpu-baseline-seconds", "--master-port", "--spawn-deadline"):
+        if a.split("=")[0] in ("--steps", "--warmup", "--gpus", "--pmc-traffic", "--cpu-baseline-seconds", "--master-port", "--spawn-deadline", "--wavefronts"):
             continue
         passthrough.append(a)
     totals = {}
@@ -232,7 +232,7 @@ def measure_traffic_live(argv):
     for counters in passes:
         tmp = tempfile.mkdtemp(prefix="hipr_pmc_")
         cmd = [rocprof, "--pmc", *counters, "--output-format", "csv", "-d", tmp, "--", sys.executable, str(Path(__file__).resolve())] + passthrough + \
-              ["--pmc-child", "--steps", "2", "--warmup", "1", "--gpus", "1"]
+              ["--pmc-child", "--steps", "2", "--warmup", "1", "--gpus", "1", "--wavefronts", "1"]
         label = " ".join(counters)
         try:
             # a pass takes seconds (the first import of torch on a fresh box up to two minutes); its own process group, so that a pass that hangs is ended whole
@@ -357,6 +357,10 @@ def rmse_against_oracle(ctx, scene, bounces, spps=(8, 256), width=160, height=90
                          "share_of_squared_error_in_8_worst_pixels": float(worst / max((d ** 2).sum(), 1e-300)),
                          "rmse_rgb_without_8_worst_pixels": float(np.sqrt(max((d ** 2).sum() - worst, 0.0) / (3.0 * (len(d) - 8))))}
         stem = ROOT / "profiles" / "converged" / f"{converged_name}_{width}x{height}_acc{spp}_{17 * spp}" if converged_name else None
+        if stem is not None and not Path(str(stem) + ".npy").exists() or (stem is not None and Path(str(stem) + ".json").exists() and
+                                                                           json.loads(Path(str(stem) + ".json").read_text()).get("triangles") != int(scene.desc.triangle_count)):
+            # atriums other than the headline one are filed under their triangle count (tools/converged_reference.py)
+            stem = ROOT / "profiles" / "converged" / f"{converged_name}{int(scene.desc.triangle_count)}_{width}x{height}_acc{spp}_{17 * spp}"
         if stem is not None and Path(str(stem) + ".npy").exists() and Path(str(stem) + ".json").exists():
             meta = json.loads(Path(str(stem) + ".json").read_text())
             if meta.get("triangles") == int(scene.desc.triangle_count) and meta.get("bounces") == bounces:      # any of the oracle's searches converges to the same image
@@ -663,7 +667,15 @@ def measure(ctx, scene, scene_name, bounces, args, rank, world, device, steps, w
     import torch.distributed as dist
     from bifrost3d_amd import capi, distributed
     W, H = args.width, args.height
-    S = args.spp_per_pass * (1 if args.fixed_frame else world)
+    # Accumulations a rank traces per pass. Weak scaling (the default): N x the single GPU's, so that a rank's wavefront is as large as the single GPU's.
+    # --fixed-frame (strong scaling: the same `steps` x spp_per_pass accumulations of the whole frame, every rank its tiles): a rank of N holds 1 / N of the
+    # pixels, so it takes N steps' worth of accumulations per pass where the step count allows -- the wavefront the scaling proxy shows it needs (a pass
+    # of 8 M paths runs at 79 %% of the rate of one of 66 M: scaling_proxy.rate_by_wavefront) -- and makes steps / batch passes.
+    batch = 1
+    if args.fixed_frame and world > 1:
+        batch = max(g for g in range(1, world + 1) if steps % g == 0 and warmup % g == 0) if warmup else max(g for g in range(1, world + 1) if steps % g == 0)
+    S = args.spp_per_pass * (batch if args.fixed_frame else world)
+    steps_run, warmup_run = steps // batch, warmup // batch
     on_host = world > 1 and args.dist_backend == "gloo"
     ctx.upload_scene(scene)
     ctx.set_wavefront_count(args.wavefronts)
@@ -703,7 +715,7 @@ def measure(ctx, scene, scene_name, bounces, args, rank, world, device, steps, w
                "shadow_nodes": ic["shadow_nodes"] / max(1, ic["shadow_rays"]), "shadow_triangles": ic["shadow_triangles"] / max(1, ic["shadow_rays"])}
 
     a = 2 * S
-    for _ in range(warmup):
+    for _ in range(warmup_run):
         run_pass(a)
         a += S
     finish_frame()
@@ -713,7 +725,7 @@ def measure(ctx, scene, scene_name, bounces, args, rank, world, device, steps, w
 
     sync()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for _ in range(steps_run):
         run_pass(a)
         a += S
     t_gather = time.perf_counter()
@@ -737,15 +749,15 @@ def measure(ctx, scene, scene_name, bounces, args, rank, world, device, steps, w
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
         elapsed = float(mx[0])
     total = {"closest_rays": float(stats[1]), "shadow_rays": float(stats[2]), "camera_rays": float(stats[3])}
-    result = {"elapsed": elapsed, "total": total, "counters": counters, "times": times, "per_ray": per_ray, "S": S, "gather_ms": gather_ms,
+    result = {"elapsed": elapsed, "total": total, "counters": counters, "times": times, "per_ray": per_ray, "S": S, "gather_ms": gather_ms, "passes": steps_run, "steps_per_pass": batch,
               "rank_elapsed": [float(t[0]) for t in per_rank] if world > 1 else [elapsed]}
     if rank == 0:
         result["frame_ok"] = bool(torch.isfinite(frame.float()).all().item()) and float(frame[..., :3].float().mean()) > 0
         result["small"] = ctx.trace_variant() == capi.TRACE_EXHAUSTIVE
         result["fused"] = ctx.trace_is_fused()
         result["wide8"] = ctx.trace_variant() == capi.TRACE_WIDE8_PERSISTENT
-    result["wavefronts"] = args.wavefronts if args.wavefronts else (1 if ctx.trace_is_fused() else 2)
-    if world == 1 and result.get("wide8") and not args.pmc_child and not getattr(args, "under_profiler", False):      # kept out of profiled runs: their per-kernel averages are the line's own launches
+    result["wavefronts"] = ctx.wavefront_count()
+    if world == 1 and result.get("wide8") and not args.pmc_child and not getattr(args, "under_profiler", False) and not getattr(args, "alone_leg", False):      # kept out of profiled runs: their per-kernel averages are the line's own launches
         # The same frames with every refused closest hit retraced, as the reference does it (hipr_set_backface_culling 0): a short run beside the line's own,
         # for the ray count and the time the stepping saves. Outside the timed region.
         ctx.set_backface_culling(False)
@@ -771,7 +783,7 @@ def measure(ctx, scene, scene_name, bounces, args, rank, world, device, steps, w
 
 def summarise(result, scene_name, scene_text, bounces, args, world, steps, live_traffic=None):
     """The figures of one measured workload as the bench line reports them (rank 0)."""
-    W, H, S = args.width, args.height, result["S"]
+    W, H, S = args.width, args.height, result["S"] // result.get("steps_per_pass", 1)      # accumulations per STEP (a fixed-frame rank batches several steps into a pass)
     key = f"{scene_name}:{W}x{H}:spp{args.spp_per_pass}:bounces{bounces}"
     if scene_name == "atrium":
         key += f":tris{args.atrium_triangles}"
@@ -784,7 +796,7 @@ def summarise(result, scene_name, scene_text, bounces, args, world, steps, live_
             traffic, traffic_source = load_measured_traffic(key)
             if live_traffic and traffic_source is not None:
                 traffic_source["live_measurement_failed"] = live_traffic[1]
-    rooflines, kernel_times = rooflines_of(result["counters"], result["times"], result["per_ray"], result["small"], result["fused"], S, traffic,
+    rooflines, kernel_times = rooflines_of(result["counters"], result["times"], result["per_ray"], result["small"], result["fused"], result["S"], traffic,
                                            triangle_bytes=32.0 if result.get("wide8") else 48.0)   # a 64 B leaf record holds two triangles
     dominant = max(rooflines, key=lambda n: rooflines[n]["total_ms"])
     roofline = dict(rooflines[dominant])
@@ -866,8 +878,29 @@ def main():
     ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
     result = measure(ctx, scene, scene_name, bounces, args, rank, world, device, args.steps, args.warmup, sync)
 
+    alone = None
+    if world == 1 and result["wavefronts"] > 1 and not args.pmc_child:
+        # The timed region ran co-running wavefronts: its per-launch HIP-event durations are those of kernels sharing the device. The rooflines price a KERNEL:
+        # two more steps with one wavefront -- every kernel alone on the device, HIP events on its launch stream -- right after the timed region, the same
+        # shape the counter passes and the committed rocprofv3 --stats profile run in.
+        import copy
+        alone_args = copy.copy(args)
+        alone_args.wavefronts, alone_args.alone_leg = 1, True
+        alone = measure(ctx, scene, scene_name, bounces, alone_args, 0, 1, device, 2, 1, sync)
+        ctx.set_wavefront_count(args.wavefronts)
     if rank == 0:
-        main_figures = summarise(result, scene_name, scene_text, bounces, args, world, args.steps, live_traffic)
+        main_figures = summarise(result, scene_name, scene_text, bounces, args, world, args.steps, None if alone else live_traffic)
+        if alone:
+            alone_figures = summarise(alone, scene_name, scene_text, bounces, args, 1, 2, live_traffic)
+            timed = main_figures["roofline_by_kernel"]
+            main_figures["roofline"], main_figures["roofline_by_kernel"] = alone_figures["roofline"], alone_figures["roofline_by_kernel"]
+            dominant = max(alone_figures["roofline_by_kernel"], key=lambda n: alone_figures["roofline_by_kernel"][n]["total_ms"])
+            main_figures["roofline"]["duration_source"] = ("2 steps with ONE wavefront right after the timed region: the kernel alone on the device (HIP events on its launch stream), as in the "
+                                                           "counter passes and the committed rocprofv3 --stats profile. The timed region runs two co-running half-frame wavefronts; its own "
+                                                           "per-launch figures are under timed_region")
+            main_figures["roofline"]["timed_region"] = {k: timed[dominant].get(k) for k in ("avg_launch_ms", "launches", "total_ms", "achieved_model", "frac_model")} if dominant in timed else None
+            main_figures["roofline"]["alone_ms_per_step"] = alone_figures["ms_per_step"]
+            main_figures["kernel_ms_per_step_alone"] = alone_figures["kernel_ms_per_step"]
         out = {
             "metric": METRIC, "value": main_figures["value"], "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": main_figures["ms_per_step"], "higher_is_better": True, "scaling": "strong" if args.fixed_frame and world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -879,6 +912,9 @@ def main():
                        "rmse_note": "no OptiX image exists or can be produced here (DESIGN.md); rmse_vs_oracle compares with the pinned CPU oracle at equal spp and seed"},
             "roofline": main_figures["roofline"], "roofline_by_kernel": main_figures["roofline_by_kernel"], "kernel_ms_per_step": main_figures["kernel_ms_per_step"],
         }
+        if "kernel_ms_per_step_alone" in main_figures:
+            out["kernel_ms_per_step_alone"] = main_figures["kernel_ms_per_step_alone"]
+            out["kernel_ms_per_step_note"] = "kernel_ms_per_step sums HIP-event durations of launches that overlap the other wavefront's (it exceeds ms_per_step); kernel_ms_per_step_alone: one wavefront"
         if result.get("wide8"):
             out["config"]["backface_culling"] = ("hipr_set_backface_culling 1 (the default): the 8-wide traversal steps over closest hits on the back of one-sided surfaces instead of "
                                                   "handing them to the hit program to be refused and retraced; rays counted are the BVH queries actually made")
@@ -886,6 +922,7 @@ def main():
             out["retrace_mode"] = result["retrace_mode"]
         if world > 1:
             out["ranks"] = {"ms_per_step": [e / args.steps * 1e3 for e in result["rank_elapsed"]], "gather_ms": result["gather_ms"],
+                            "passes": result["passes"], "steps_per_pass": result["steps_per_pass"], "accumulations_per_pass_per_rank": result["S"],
                             "paths_per_gpu_per_step": int(main_figures["pixel_samples"] / args.steps / world),
                             "note": "ms_per_step per rank = that rank's own clock over the timed region (the line's ms_per_step is the maximum); gather_ms = rank 0's time in the "
                                     "final gather of the half4 tiles + the scatter kernel, inside the timed region"}
@@ -899,7 +936,7 @@ def main():
                 out["roofline_valu"] = valu_roofline(dominant, entry["kernel"], entry["avg_launch_ms"] * 1e-3, valu, rates, torch.cuda.get_device_properties(device).multi_processor_count)
             except Exception as e:      # the line stands without it
                 out["roofline_valu"] = {"bound": "valu", "error": str(e)}
-            useful = useful_traffic(dominant, result["counters"], entry["launches"], main_figures["spp_per_step"])
+            useful = useful_traffic(dominant, (alone or result)["counters"], entry["launches"], main_figures["spp_per_step"])
             if useful:
                 out["roofline"]["traffic_useful"] = useful
                 if out["roofline"].get("traffic"):

@@ -138,7 +138,7 @@ C_ABI_SYMBOLS = (
     "hipr_set_frame", "hipr_owned_pixel_count",
     "hipr_render_pass", "hipr_set_samples_per_pass", "hipr_trace_pass", "hipr_accumulate_samples", "hipr_read_accumulation", "hipr_scatter_tiles", "hipr_synchronize", "hipr_get_counters",
     "hipr_device_malloc", "hipr_device_free", "hipr_device_memset", "hipr_copy_to_host", "hipr_present_flipped",
-    "hipr_reset_counters", "hipr_set_wavefront_count", "hipr_get_trace_variant", "hipr_set_trace_variant", "hipr_set_pass_pipelining", "hipr_set_backface_culling", "hipr_set_instrumentation", "hipr_reset_timers", "hipr_get_kernel_times",
+    "hipr_reset_counters", "hipr_set_wavefront_count", "hipr_get_wavefront_count", "hipr_get_trace_variant", "hipr_set_trace_variant", "hipr_set_pass_pipelining", "hipr_set_backface_culling", "hipr_set_instrumentation", "hipr_reset_timers", "hipr_get_kernel_times",
     "hipr_group_create", "hipr_group_destroy", "hipr_group_size", "hipr_group_context", "hipr_group_gather_description", "hipr_group_upload_tables", "hipr_group_upload_scene",
     "hipr_group_set_scene_state", "hipr_group_set_entry_point", "hipr_group_use_scratch_accumulation", "hipr_group_set_frame", "hipr_group_set_samples_per_pass",
     "hipr_group_trace_pass", "hipr_group_accumulate_samples", "hipr_group_read_accumulation", "hipr_group_get_counters",

@@ -169,8 +169,16 @@ struct HiprContext {
     // persistent kernels walk the compressed 4-wide BVH; without one (HiprSceneDesc::wide_nodes == NULL) the plain BVH2 kernels serve every scene
     // Two half-frame wavefronts on two streams overlap one half's shading with the other's tracing. That pays where the trace kernels are short
     // and light (exhaustive search / BVH2: Cornell +9 % ... +27 %); the persistent wide-BVH kernels fill the register file on their own, the
-    // other wavefront's blocks then wait for residency and nothing is gained (atrium 88.4 vs 88.8 ms, material 24.9 vs 25.1 ms per step): one.
-    int wavefronts_wanted() const { return wavefront_limit > 0 ? wavefront_limit : (scene_ready && use_persistent() ? 1 : 2); }
+    // other wavefront's blocks then wait for residency and nothing was gained with round 2's kernels (atrium 88.4 vs 88.8 ms, material 24.9 vs 25.1 ms
+    // per step). With round 4's (profiles/r04_ab_wavefronts.txt) two wavefronts pay on every pass of tens of millions of paths -- atrium 63.4 -> 60.6 ms
+    // per step, material 37.0 -> 35.7, 10 M triangles at 4K 91.8 -> 87.9: where one wavefront's launch drains, the other's blocks move in -- three and four do not
+    // (62.0, 64.9), and a pass of 2 M paths (one accumulation per pass) loses 8 % to the halved launches: two from 2^24 path slots per pass on, else one.
+    static constexpr uint64_t TWO_WAVEFRONTS_FROM_SLOTS = 1ull << 24;
+    int wavefronts_wanted() const {
+        if (wavefront_limit > 0) return wavefront_limit;
+        if (scene_ready && use_persistent()) return frame_ready && uint64_t(frame.owned_tiles) * 64u * frame.samples_per_pass >= TWO_WAVEFRONTS_FROM_SLOTS ? 2 : 1;
+        return 2;
+    }
     // The search of the uploaded scene, fixed when it is uploaded (hipr_set_trace_variant / HIPR_TRACE_VARIANT name a request for the NEXT upload).
     int chosen_variant = HIPR_TRACE_BVH2;
     void choose_variant() {
@@ -1397,6 +1405,14 @@ int hipr_set_wavefront_count(HiprContext* c, int count) {
     if (!c) return fail(HIPR_ERROR_INVALID_ARGUMENT, "null context");
     if (count < 0 || count > MAX_WAVEFRONTS) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_set_wavefront_count: %d is outside [0, %d]", count, MAX_WAVEFRONTS);
     c->wavefront_limit = count;   // 0: by scene; takes effect with the next pass
+    return HIPR_OK;
+}
+
+int hipr_get_wavefront_count(HiprContext* c, int* out_count) {
+    if (!c || !out_count) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_get_wavefront_count: null argument");
+    // what the NEXT pass runs as: the partition is redone at its start when the rule's answer changed (scene uploaded, limit set since hipr_set_frame)
+    const uint64_t slots = uint64_t(c->frame.owned_tiles) * 64u * c->frame.samples_per_pass;
+    *out_count = c->frame_ready ? int(std::max<uint64_t>(1, std::min<uint64_t>(uint64_t(c->wavefronts_wanted()), slots / 65536u))) : 0;
     return HIPR_OK;
 }
 

@@ -104,6 +104,11 @@ class Context:
     def reset_timers(self):
         self._check(self.lib.hipr_reset_timers(self.handle), "hipr_reset_timers")
 
+    def wavefront_count(self) -> int:
+        n = C.c_int()
+        self._check(self.lib.hipr_get_wavefront_count(self.handle, C.byref(n)), "hipr_get_wavefront_count")
+        return n.value
+
     def set_wavefront_count(self, count: int):
         self._check(self.lib.hipr_set_wavefront_count(self.handle, count), "hipr_set_wavefront_count")
 

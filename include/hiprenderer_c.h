@@ -456,6 +456,10 @@ int hipr_reset_counters(HiprContext* context);
  * HIPR_WAVEFRONTS) chooses by scene: two for scenes traced by the exhaustive / BVH2 kernels (+9 % ... +27 % on the Cornell box), one for the
  * persistent wide-BVH kernels, which fill the machine alone (measured: no gain, and per-kernel timers then time kernels that ran alone). */
 int hipr_set_wavefront_count(HiprContext* context, int count);
+/* The number of wavefronts the next pass runs as under the current frame, scene and limit: with the limit at 0 the library takes two for the persistent
+ * kernels from 2^24 path slots per pass on (where one wavefront's launch drains, the other's blocks move in: profiles/r04_ab_wavefronts.txt), one below,
+ * two for the small-scene kernels. 0 before hipr_set_frame. */
+int hipr_get_wavefront_count(HiprContext* context, int* out_count);
 /* How the uploaded scene is traced (chosen from its size; HIPR_TRACE_VARIANT overrides for experiments):
  *   HIPR_TRACE_BVH2             BVH2 kernels, one ray per lane (k_trace_closest / k_trace_shadow)
  *   HIPR_TRACE_WIDE_PERSISTENT  more than 64 BVH2 nodes: persistent kernels over the compressed 4-wide BVH; from bounce 1 on the

@@ -36,6 +36,18 @@ def test_bench_line_contract_single_gpu():
     assert roofline["traffic"] and roofline["traffic_source"]["measured"].startswith("live"), roofline.get("traffic_source")
     assert roofline["achieved"] == pytest.approx(roofline["traffic"] / (roofline["avg_launch_ms"] * 1e-3) / 1e9)
     assert "frac_model" in roofline and "observed_limiter" in roofline
+    # round 4: the VALU roof beside the HBM one (counters from a third live pass, the peak measured in the timed process), the bytes the kernel could not avoid,
+    # and the one-GPU proxy of the N-way tile split
+    valu = line["roofline_valu"]
+    assert valu["bound"] == "valu" and "error" not in valu, valu
+    assert 0.0 < valu["frac"] <= 1.2 and valu["frac"] == pytest.approx(valu["achieved"] / valu["peak"]) and 8.0 <= valu["lanes_per_instruction"] <= 64.0
+    assert 0.98 <= valu["calibration"]["scale"] <= 1.02          # SQ_INSTS_VALU counts the rate kernel's instructions to within 2 %
+    assert roofline["traffic_useful"]["bytes"] > 0 and roofline["traffic_over_useful"] >= 0.5 and roofline["write_amplification"] > 0
+    proxy = line["scaling_proxy"]
+    for kind in ("strong", "weak", "interactive"):
+        assert set(proxy[kind]) >= {"2", "4", "8"}
+    assert proxy["strong"]["8"]["paths_per_gpu_per_step"] * 8 == pytest.approx(proxy["strong"]["1"]["paths_per_gpu_per_step"], rel=0.02)
+    assert 1.0 < proxy["strong"]["8"]["predicted_speedup"] <= 8.5 and 0.3 < proxy["weak"]["8"]["predicted_efficiency"] <= 1.1
     # the same frames with every refused hit retraced, timed beside the line: more rays (the atrium's one-sided colonnade and drapes seen from behind), more time
     retrace = line["retrace_mode"]
     assert "backface_culling" in line["config"]

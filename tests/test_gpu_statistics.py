@@ -1,0 +1,84 @@
+"""The statistical tolerance of the lit images, under test (SURVEY.md 8(d) RMSE protocol).
+
+The shade kernel is built like the reference's --use_fast_math PTX (hardware sin / cos / pow / divide), the oracle with libm: single paths take another
+discrete decision now and then, so the lit images of the two differ at equal seed -- by zero-mean noise, as profiles/r03_rmse_protocol_*.json showed once.
+Here that is an assertion, on the 17.5 k- and the 251 k-triangle atrium at 160 x 90 x 64 spp (seconds of oracle on the box's host cores):
+
+  * no bias: per channel, |mean over the pixels of (device - oracle)| <= 3 standard errors of that mean;
+  * same distance to the truth: RMSE(device, converged) and RMSE(oracle, converged) agree within 1 %, where `converged` is the oracle's image of 4096
+    DISJOINT accumulations [256, 4352) committed under profiles/converged/ (tools/converged_reference.py) -- a bias would put one of them farther away;
+  * and the equal-seed RMSE itself stays under twice what was measured when the test was written.
+Metric: sqrt(mean over pixels and channels of the squared difference), and the reference's own ImageOperations::Compare::rms
+(extensions/ImageOperations/ImageOperations/Compare.h:23-43: the luminance of the absolute difference) beside it.
+"""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from bifrost3d_amd.host import Scene
+
+pytestmark = pytest.mark.gpu
+
+ROOT = Path(__file__).resolve().parent.parent
+W, H, SPP, BOUNCES = 160, 90, 64, 4
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from bifrost3d_amd.renderer import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def oracle_q():
+    from oracle_bindings import get_oracle
+    return get_oracle(True)
+
+
+def compare_rms(a, b):
+    d = np.abs(a - b)
+    luminance = 0.2126 * d[..., 0] + 0.7152 * d[..., 1] + 0.0722 * d[..., 2]
+    return float(np.sqrt(np.mean(luminance ** 2)))
+
+
+def rmse(a, b):
+    return float(np.sqrt(np.mean((a - b) ** 2)))
+
+
+# (atrium triangle target, converged file stem, equal-seed RMSE measured on the MI355X when the test was written)
+CASES = [(20000, "atrium17502_160x90_acc256_4352", None), (260000, "atrium_160x90_acc256_4352", None)]
+
+
+@pytest.mark.parametrize("target, stem, measured", CASES, ids=["atrium17k", "atrium251k"])
+def test_equal_seed_difference_is_unbiased_noise(ctx, oracle_q, target, stem, measured):
+    meta = json.loads((ROOT / "profiles" / "converged" / (stem + ".json")).read_text())
+    converged = np.load(ROOT / "profiles" / "converged" / (stem + ".npy")).astype(np.float64)
+    scene = Scene("atrium", param0=target, param1=1)
+    assert int(scene.desc.triangle_count) == meta["triangles"] and meta["bounces"] == BOUNCES and meta["accumulations"][0] >= SPP      # disjoint from [0, SPP)
+    ctx.upload_scene(scene)
+    ctx.set_frame(W, H, 0, 1, 32)
+    for a in range(0, SPP, 32):
+        ctx.render_pass(scene.camera(W, H, accumulations=a, max_bounce_count=BOUNCES))
+    ctx.synchronize()
+    gpu = ctx.read_accumulation()[..., :3].astype(np.float64)
+    cpu, _, _ = oracle_q.render(scene.desc, scene.state, scene.camera(W, H, max_bounce_count=BOUNCES), W, H, SPP, use_bvh=ctx.oracle_search())
+    cpu = cpu[..., :3].astype(np.float64)
+    assert np.isfinite(gpu).all()
+
+    d = (gpu - cpu).reshape(-1, 3)
+    mean, standard_error = d.mean(axis=0), d.std(axis=0) / np.sqrt(d.shape[0])
+    equal_seed = rmse(gpu, cpu)
+    to_truth_device, to_truth_oracle = rmse(gpu, converged), rmse(cpu, converged)
+    print(f"STATISTICS {stem}: equal-seed RMSE {equal_seed:.3e} (Compare::rms {compare_rms(gpu, cpu):.3e}), mean radiance {cpu.mean():.4f}; mean signed difference "
+          f"{mean} +- {standard_error} ({np.abs(mean) / standard_error} sigma); RMSE to the converged image: device {to_truth_device:.6f}, oracle {to_truth_oracle:.6f} "
+          f"(ratio {to_truth_device / to_truth_oracle:.5f})")
+    assert np.all(np.abs(mean) <= 3.0 * standard_error), (mean, standard_error)
+    assert abs(to_truth_device - to_truth_oracle) <= 0.01 * to_truth_oracle, (to_truth_device, to_truth_oracle)
+    # two estimators of one integral at 64 spp: their distance to the truth is the Monte Carlo noise, an order of magnitude above their mutual difference
+    assert equal_seed <= 0.25 * to_truth_oracle, (equal_seed, to_truth_oracle)
+    if measured is not None:
+        assert equal_seed <= 2.0 * measured, (equal_seed, measured)

@@ -59,7 +59,6 @@ def main():
     name = args.scene if args.scene != "atrium" or args.atrium_triangles == 260000 else f"atrium{int(scene.desc.triangle_count)}"      # the headline atrium keeps its plain name
     stem = ROOT / "profiles" / "converged" / f"{name}_{w}x{h}_acc{first}_{last}"
     np.save(str(stem) + ".npy", tail.astype(np.float32))
-    np.save(str(ROOT / "profiles" / "converged" / f"{name}_{w}x{h}_acc0_{first}_oracle.npy"), head.astype(np.float32))
     json.dump({"scene": args.scene, "triangles": int(scene.desc.triangle_count), "frame": [w, h], "accumulations": [first, last], "bounces": args.bounces, "search": args.search,
                "quantized_tables": True, "seconds": time.time() - t0, "threads": args.threads, "mean_radiance": float(tail.mean())}, open(str(stem) + ".json", "w"), indent=1)
     print("wrote", stem)

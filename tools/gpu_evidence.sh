@@ -35,8 +35,8 @@ for part in $parts; do
         python bench.py --spp-per-pass 1 --steps 64 --warmup 8 $quiet --no-rmse > $out/bench_atrium_1spp.json 2> $out/bench_atrium_1spp.err
         python bench.py --gpus 2 --share-device --dist-backend gloo --steps 4 --warmup 1 --no-rmse > $out/bench_2rank_gloo_shared_device.json 2> $out/bench_2rank.err ;;
     rmse)
-        timeout 1500 python tools/rmse_protocol.py --size 480x270 --out $out/rmse_protocol_480x270.json > $out/rmse_480.log 2>&1
-        timeout 600 python tools/rmse_protocol.py --size 160x90 --out $out/rmse_protocol_160x90.json > $out/rmse_160.log 2>&1 ;;
+        timeout 1800 python tools/rmse_protocol.py --size 480x270 --decay-to 1024 --out $out/rmse_protocol_480x270.json > $out/rmse_480.log 2>&1
+        timeout 900 python tools/rmse_protocol.py --size 160x90 --decay-to 4096 --out $out/rmse_protocol_160x90.json > $out/rmse_160.log 2>&1 ;;
     tests)
         timeout 2400 python -m pytest tests -m gpu -q -s > $out/gpu_tests.log 2>&1; grep -E "passed|failed" $out/gpu_tests.log | tail -2
         python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 ;;

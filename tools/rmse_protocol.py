@@ -41,6 +41,7 @@ def main():
     p.add_argument("--factor", type=int, default=16)
     p.add_argument("--bounces", type=int, default=4)
     p.add_argument("--worst", type=int, default=8)
+    p.add_argument("--decay-to", type=int, default=1024, help="largest sample count of the decay table (64, 256, 1024, ...); 0: none")
     p.add_argument("--out", default=None)
     args = p.parse_args()
     from bifrost3d_amd.host import Scene
@@ -108,6 +109,40 @@ def main():
                    "share_of_squared_error_in_worst_pixels": float((d ** 2).sum(axis=-1).ravel()[worst_flat].sum() / (d ** 2).sum()),
                    "rmse_rgb_without_worst_pixels": float(np.sqrt(((d ** 2).sum() - (d ** 2).sum(axis=-1).ravel()[worst_flat].sum()) / (3.0 * (n - len(worst_flat))))),
                    "pixels_beyond_1e-3_relative": int(((np.abs(d) / (np.abs(cpu) + 1e-3)).max(axis=-1) > 1e-3).sum()), "pixels": int(n)}
+
+    # ---- how the equal-seed difference decays with the sample count, and how heavy its tails are. Zero-mean noise of finite variance falls as 1 / sqrt(spp) and
+    # its per-pixel distribution tends to a Gaussian (kurtosis 3); rare large per-sample differences (a path that takes another discrete decision under
+    # the shade kernel's approximate arithmetic: one sample of a pixel differs by O(1)) make it heavy-tailed -- a few pixels carry the sum of squares, the
+    # RMSE falls more slowly than 1 / sqrt(spp) until every pixel has had its share of such samples, and the MEAN stays where it is.
+    if args.decay_to > spp:
+        ctx.set_frame(w, h, 0, 1, 32)           # start over: the running means are read at the checkpoints
+        accum = None
+        done = 0
+        checkpoints = []
+        c = 64
+        while c <= args.decay_to:
+            checkpoints.append(c)
+            c *= 4
+        decay = []
+        for checkpoint in checkpoints:
+            for a in range(done, checkpoint, 32):
+                ctx.render_pass(cam(a))
+            ctx.synchronize()
+            g = ctx.read_accumulation()[..., :3].astype(np.float64)
+            accum, _ = oracle_image(done, checkpoint - done, accum=accum)
+            o = accum[..., :3].astype(np.float64)
+            done = checkpoint
+            dd = (g - o)
+            per_pixel = (dd ** 2).sum(axis=-1).ravel()
+            top = np.sort(per_pixel)[::-1]
+            flat = dd.ravel()
+            decay.append({"spp": checkpoint, **rms_pair(g, o), "kurtosis": float(np.mean(flat ** 4) / max(np.mean(flat ** 2) ** 2, 1e-300)),
+                          "share_of_squared_error_in_the_worst_1_percent_of_pixels": float(top[:max(1, len(top) // 100)].sum() / max(per_pixel.sum(), 1e-300)),
+                          "median_absolute_difference": float(np.median(np.abs(flat))), "mean_signed_difference": float(flat.mean()),
+                          "standard_error_of_the_mean": float(flat.std() / np.sqrt(len(flat)))})
+        for k in range(1, len(decay)):
+            decay[k]["rmse_ratio_to_previous"] = decay[k - 1]["rmse_rgb"] / decay[k]["rmse_rgb"]      # 2.0 for 1 / sqrt(spp) at 4 x the samples
+        out["decay"] = decay
 
     # ---- the worst pixels, sample by sample
     ys, xs = np.unravel_index(worst_flat, (h, w))
