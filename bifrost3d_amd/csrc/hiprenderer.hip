@@ -78,9 +78,9 @@ struct Wavefront {
     hipStream_t stream = nullptr;       // wavefront 0 runs on the context stream, the others on their own
     hipStream_t own_stream = nullptr;
     hipEvent_t shade_done[2] = {nullptr, nullptr}, counts_copied[2] = {nullptr, nullptr}, finished = nullptr;   // by bounce parity: two bounces are in flight
-    DeviceBuffer path[2][4], hits, shadow[3], queue_counts, order, nee_flags;   // queue_counts: COUNT_LINES 64 B lines (see there); order: k_classify_hits' listing of a bounce's rays
+    DeviceBuffer path[2][4], hits, shadow[3], queue_counts, order, order_coat, nee_flags;   // queue_counts: COUNT_LINES 64 B lines (see there); order: k_classify_hits' listing of a bounce's rays
     uint32_t* host_counts = nullptr;    // pinned: {continuing paths, shadow rays} per bounce parity, [4] staging word
-    uint32_t first_slot = 0, n_slots = 0;
+    uint32_t first_slot = 0, n_slots = 0;      // first_slot: the wavefront's phase in the round-robin deal of 64-slot groups (partition_path_slots)
 
     PathState path_state(int which) const {
         return {path[which][0].as<float4>(), path[which][1].as<float4>(), path[which][2].as<float4>(), path[which][3].as<uint4>()};
@@ -122,6 +122,8 @@ struct HiprContext {
     Wide8Scene wide8 = {};              // the 8-wide tree with leaf records: what the persistent kernels walk when the scene brings one
     uint32_t wide8_height = 0;
     DeviceBuffer nodes, triangles, instances, indices, geometry, texcoords, tints, emissions, materials, lights, textures, texels;
+    DeviceBuffer triangle_class;        // one byte per triangle for the listing pass (k_classify_hits): bit 0 = its material is coated
+    bool any_coated_triangle = false, shade_classes = false;     // HIPR_SHADE_CLASSES=1: coated surface hits listed apart (built and measured in round 4: no gain, profiles/r04_ab_shade_classes.txt)
     DeviceBuffer ggx_rho, dielectric_rho, alpha, sample_offsets, sobol_tables;
     DeviceScene scene = {};
     bool tables_ready = false, scene_ready = false;
@@ -444,21 +446,24 @@ void launch_trace_fused(HiprContext* c, const Wavefront& w, const PathState& in,
 void launch_shade(HiprContext* c, const Wavefront& w, const HiprCameraState& camera, int cur, uint32_t alive, const uint32_t* in_count, uint32_t* out_counts, uint32_t* zero_pair) {
     // The rays of the bounce listed by kind (kernels.h k_classify_hits): the shade kernel's batches then hold surface hits only, or none.
     const uint32_t* order = nullptr;
+    const unsigned long long* listed = nullptr;
     // Pays where a good share of a bounce's rays did not hit a surface (the atrium's open roof: shade 23.3 -> 21.4 ms per step) and costs a pass over the hits
     // where nearly all did (the closed Cornell box: +7 %): on for the scenes of the persistent kernels, which are the large ones.
     // A bounce of a few thousand paths runs one wave per SIMD at most: the order they are taken in changes nothing, the listing pass would cost a launch.
     uint32_t* taken_words = w.queue_counts.as<uint32_t>() + COUNT_PAIR_STRIDE * COUNT_PAIRS;
     if (c->shade_ordered && c->use_persistent() && c->entry == HIPR_ENTRY_PATH_TRACING && alive >= c->shade_ordered_from) {
         unsigned long long* taken = reinterpret_cast<unsigned long long*>(taken_words + COUNT_PAIR_STRIDE * cur);
-        hipLaunchKernelGGL(k_classify_hits, dim3(grid_for(alive, 256u * CLASSIFY_ROUNDS, uint32_t(c->cu_count) * 8u)), dim3(256), 0, w.stream, w.hits.as<float4>(), in_count, w.order.as<uint32_t>(), taken);
+        hipLaunchKernelGGL(k_classify_hits, dim3(grid_for(alive, 256u * CLASSIFY_ROUNDS, uint32_t(c->cu_count) * 8u)), dim3(256), 0, w.stream, w.hits.as<float4>(), in_count, w.order.as<uint32_t>(), taken,
+                           c->shade_classes && c->any_coated_triangle ? c->triangle_class.as<unsigned char>() : nullptr, w.order_coat.as<uint32_t>());
         order = w.order.as<uint32_t>();
+        listed = taken;
     }
     // persistent blocks: three per CU stay resident (3 waves per SIMD), each walks the queue with a grid stride, one batch ahead on its inputs
     // measured: the Default / Transmissive kernels gain from a third wave per SIMD (atrium 29.4 -> 25.9 ms of shading per step), the lighter all-Diffuse
     // kernel loses (Cornell 18 390 -> 17 194 Mrays/s)
     const bool split = c->shade_split && c->entry == HIPR_ENTRY_PATH_TRACING && c->scene.light_count != 0 && w.nee_flags.ptr;
     const uint32_t blocks_per_cu = c->shade_blocks_per_cu > 0 ? uint32_t(c->shade_blocks_per_cu) : (split ? uint32_t(HIPR_SHADE_SPLIT_WAVES) : (c->shading_models == 2 ? 2u : 3u));
-    ShadeLaunch a = {grid_for(alive, SHADE_BLOCK, uint32_t(c->cu_count) * blocks_per_cu), w.stream, c->scene, camera, c->entry, w.path_state(cur), w.hits.as<float4>(), order, w.path_state(1 - cur),
+    ShadeLaunch a = {grid_for(alive, SHADE_BLOCK, uint32_t(c->cu_count) * blocks_per_cu), w.stream, c->scene, camera, c->entry, w.path_state(cur), w.hits.as<float4>(), order, w.order_coat.as<uint32_t>(), listed, w.path_state(1 - cur),
                      w.shadow_queue(), c->radiance.as<float4>(), in_count, reinterpret_cast<unsigned long long*>(out_counts), reinterpret_cast<unsigned long long*>(zero_pair),
                      reinterpret_cast<unsigned long long*>(taken_words + COUNT_PAIR_STRIDE * (1 - cur)), split ? w.nee_flags.as<unsigned char>() : nullptr,
                      c->counters.as<DeviceCounters>()};
@@ -475,24 +480,27 @@ int partition_path_slots(HiprContext* c) {
     int r = 0;
     c->partitioned_for = c->wavefronts_wanted();
     c->wavefront_count = int(std::max<uint64_t>(1, std::min<uint64_t>(uint64_t(c->partitioned_for), slots / 65536u)));
-    const uint64_t share = ((slots + c->wavefront_count - 1) / c->wavefront_count + 63) / 64 * 64;
+    // The slots are dealt to the wavefronts in groups of 64 (one wave of camera rays), round robin: with the pixel-major slot order every wavefront then
+    // covers the whole frame evenly -- contiguous halves would be the top and the bottom of the image, one of them done with its deep bounces long before
+    // the other (material scene: +2.3 % step time with halves). Queue entry i of wavefront g is slot ((i / 64) * G + g) * 64 + i % 64 (k_generate).
+    const uint64_t groups = slots / 64u;      // owned_tiles * 64 * samples: a multiple of 64
     for (int g = 0; g < MAX_WAVEFRONTS; ++g) {
         Wavefront& w = c->wavefronts[g];
-        const uint64_t first = std::min<uint64_t>(slots, share * g);
-        w.first_slot = uint32_t(first);
-        w.n_slots = g >= c->wavefront_count ? 0u : uint32_t(std::min<uint64_t>(share, slots - first));
+        w.first_slot = uint32_t(g);           // the wavefront's phase in the deal
+        w.n_slots = g >= c->wavefront_count ? 0u : uint32_t((groups + uint64_t(c->wavefront_count) - 1u - uint64_t(g)) / uint64_t(c->wavefront_count) * 64u);
         const bool second_slot = g == 1 && c->wavefront_count == 1 && c->pipeline_passes && c->partitioned_for == 1;    // the other pass slot: a copy of wavefront 0's share
         if (second_slot) { w.first_slot = c->wavefronts[0].first_slot; w.n_slots = c->wavefronts[0].n_slots; }
         const size_t bytes = size_t(std::max(w.n_slots, 64u)) * 16;
         if (g >= c->wavefront_count && !second_slot) {   // queues of wavefronts this pass size does not use go back to the allocator
             for (auto& buffers : w.path) for (DeviceBuffer& b : buffers) b.release();
-            w.hits.release(); w.order.release(); w.nee_flags.release();
+            w.hits.release(); w.order.release(); w.order_coat.release(); w.nee_flags.release();
             for (DeviceBuffer& b : w.shadow) b.release();
             continue;
         }
         for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) r |= w.path[i][j].resize(bytes);
         r |= w.hits.resize(bytes);
         r |= w.order.resize(bytes / 4);
+        r |= w.order_coat.resize(bytes / 4);
         if (c->shade_split) r |= w.nee_flags.resize(bytes / 16);
         for (int j = 0; j < 3; ++j) r |= w.shadow[j].resize(bytes);
     }
@@ -829,6 +837,18 @@ int build_derived_geometry(HiprContext* c, const HiprSceneDesc* s) {
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(st));
     }
+    // the listing pass's class of every triangle (k_classify_hits): bit 0 = the material of its instance carries a coat
+    c->any_coated_triangle = false;
+    if (s->triangle_count) {
+        std::vector<unsigned char> classes(s->triangle_count, 0);
+        for (uint32_t t = 0; t < s->triangle_count; ++t) {
+            const HiprMaterial& m = s->materials[s->instances[s->triangles[t].instance_index].material_index];
+            classes[t] = m.coat != 0 ? 1 : 0;
+            c->any_coated_triangle = c->any_coated_triangle || classes[t] != 0;
+        }
+        if (c->triangle_class.upload(classes.data(), classes.size(), st)) return HIPR_ERROR_OUT_OF_MEMORY;
+        HIP_TRY(hipStreamSynchronize(st));
+    }
     d.trace_items = nullptr;
     d.trace_item_count = 0;
     if (s->triangle_count && (s->triangle_count <= SMALL_SCENE_TRIANGLES || c->trace_variant == HIPR_TRACE_EXHAUSTIVE)) {
@@ -896,6 +916,7 @@ int hipr_create(int device_id, HiprContext** out_context) {
     if (const char* v = getenv("HIPR_BLOCKS_PER_CU")) c->blocks_per_cu_override = atoi(v);
     if (const char* v = getenv("HIPR_WAVEFRONTS")) c->wavefront_limit = std::max(0, std::min(MAX_WAVEFRONTS, atoi(v)));
     if (const char* v = getenv("HIPR_TRACE_LOG")) c->trace_log = atoi(v) != 0;
+    if (const char* v = getenv("HIPR_SHADE_CLASSES")) c->shade_classes = atoi(v) != 0;
     if (const char* v = getenv("HIPR_SHADE_ORDERED")) c->shade_ordered = atoi(v) != 0;
     if (const char* v = getenv("HIPR_SHADE_SPLIT")) c->shade_split = atoi(v) != 0;
     if (const char* v = getenv("HIPR_BACKFACE_CULLING")) c->cull_backfaces = atoi(v) != 0;
@@ -1270,7 +1291,7 @@ int hipr_trace_pass(HiprContext* c, const HiprCameraState* camera) {
         HIP_TRY(hipMemcpyAsync(w.queue_counts.as<uint32_t>(), w.host_counts + 8, COUNT_LINES * COUNT_PAIR_STRIDE * sizeof(uint32_t), hipMemcpyHostToDevice, w.stream));
         c->break_chain(w.stream);
         c->begin_timed(HIPR_KERNEL_GENERATE, w.stream);
-        hipLaunchKernelGGL(k_generate, dim3((w.n_slots + 255) / 256), dim3(256), 0, w.stream, f, *camera, w.path_state(0), c->radiance.as<float4>(), w.first_slot, w.n_slots);
+        hipLaunchKernelGGL(k_generate, dim3((w.n_slots + 255) / 256), dim3(256), 0, w.stream, f, *camera, w.path_state(0), c->radiance.as<float4>(), w.first_slot, uint32_t(pipelined ? 1 : c->wavefront_count), w.n_slots);
         c->end_timed(w.stream);
         alive[g] = w.n_slots;
         running[g] = true;
@@ -1555,7 +1576,7 @@ int hipr_debug_generate(HiprContext* c, const HiprCameraState* camera, uint32_t 
     DeviceBuffer bo, bd, bt, bm, br;
     if (bo.resize(size_t(n) * 16) | bd.resize(size_t(n) * 16) | bt.resize(size_t(n) * 16) | bm.resize(size_t(n) * 16) | br.resize(size_t(n) * 16)) return HIPR_ERROR_OUT_OF_MEMORY;
     const PathState out = {bo.as<float4>(), bd.as<float4>(), bt.as<float4>(), bm.as<uint4>()};
-    hipLaunchKernelGGL(k_generate, dim3((n + 255) / 256), dim3(256), 0, c->stream, f, cam, out, br.as<float4>(), 0u, n);
+    hipLaunchKernelGGL(k_generate, dim3((n + 255) / 256), dim3(256), 0, c->stream, f, cam, out, br.as<float4>(), 0u, 1u, n);
     if (int finish_status = finish_all(c)) return finish_status;
     if (out_origin_tmin) HIP_TRY(hipMemcpy(out_origin_tmin, bo.ptr, size_t(n) * 16, hipMemcpyDeviceToHost));
     if (out_direction) HIP_TRY(hipMemcpy(out_direction, bd.ptr, size_t(n) * 16, hipMemcpyDeviceToHost));

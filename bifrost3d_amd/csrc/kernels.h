@@ -92,6 +92,9 @@ struct ShadowQueue {
     float4* radiance;     // rgb, unused
 };
 
+#ifndef HIPR_PIXEL_MAJOR_SLOTS
+#define HIPR_PIXEL_MAJOR_SLOTS 1
+#endif
 struct FrameInfo {
     uint32_t width, height, tiles_x, tiles_total, tile_phase, tile_stride, owned_tiles, samples_per_pass;
 };
@@ -144,13 +147,22 @@ HD void camera_ray(const HiprCameraState& cam, uint32_t x, uint32_t y, uint32_t 
 }
 
 #ifndef HIPR_SHADE_TU
-// Camera rays of the path slots [first_slot, first_slot + n_paths) of the pass into queue entries [0, n_paths) of one wavefront.
-__global__ __launch_bounds__(256) void k_generate(FrameInfo frame, HiprCameraState cam, PathState out, float4* radiance, uint32_t first_slot, uint32_t n_paths) {
+// Camera rays of one wavefront's path slots into its queue entries [0, n_paths): the slots are dealt to the wavefronts in groups of 64, round robin
+// (wavefront `phase` of `wavefronts`).
+__global__ __launch_bounds__(256) void k_generate(FrameInfo frame, HiprCameraState cam, PathState out, float4* radiance, uint32_t phase, uint32_t wavefronts, uint32_t n_paths) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n_paths) return;
-    const uint32_t p = first_slot + i;
+    const uint32_t p = ((i >> 6) * wavefronts + phase) * 64u + (i & 63u);
+    // Path slot p <-> (owned pixel k, sample s of the pass). Pixel-major since round 4, p = k * samples_per_pass + s: the samples of a pixel sit side by
+    // side in the queue, so a wave of camera rays is one or two pixels' worth of near-identical rays -- its lanes walk the tree in step (no lane waits for
+    // the other kind of item), fetch the same nodes, and shade one material -- and the radiance slots of a pixel are one contiguous run for k_accumulate.
+    // Round 3's sample-major order (p = s * owned pixels + k) put 64 neighbouring PIXELS of one sample in a wave. profiles/r04_ab_slot_order.txt.
+#if HIPR_PIXEL_MAJOR_SLOTS
+    uint32_t k = p / frame.samples_per_pass, s = p - k * frame.samples_per_pass;
+#else
     uint32_t per_sample = frame.owned_tiles * 64u;
     uint32_t s = p / per_sample, k = p - s * per_sample;
+#endif
     uint32_t x, y;
     bool valid = owned_pixel(frame, k, x, y);
     uint32_t accumulation = cam.accumulations + s;
@@ -1012,47 +1024,66 @@ __global__ __launch_bounds__(256) void k_build_shade_triangles(DeviceScene sc, f
 // keep their order), so that all but one or two of the shade kernel's batches are of one kind. Which rays are shaded, and what each yields, is unchanged.
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t CLASSIFY_ROUNDS = 16;      // rounds of 256 rays a block lists per reservation: 4096 rays per atomic (one 64-bit atomic on one address costs ~8 ns device-wide)
+// Round 4: the surface hits are listed in two classes. The shade kernel's instruction stream forks on the material where a COAT is present -- a second
+// specular layer: make_default prepares it, every BSDF evaluation (three light candidates and the sample) adds its lobe -- and a wave that holds one
+// coated hit among its 64 walks that code for all of them (atrium: 4 of 25 materials are coated, i.e. nearly every wave of 64 mixed hits). `triangle_class`
+// holds one byte per scene triangle (bit 0: its material has a coat; written at upload), the coated hits go to a list of their own (`order_coat`, counted in
+// taken[1]) and the shade kernel takes the entries as [plain surface hits | coated surface hits | everything else]: order[j] for j < plain,
+// order_coat[j - plain] for the next `coated`, order[j] again behind them (the others were listed from the back of `order`: they end at n - 1).
+// MEASURED (profiles/r04_ab_shade_classes.txt): frames bit-identical (tests/test_gpu_coverage.py), atrium shade 17.1 -> 17.3 ms per step: only 4.6 % of the
+// atrium's surface hits are coated (the four coated materials cover little area), so 95 % of the waves did skip the coat code -- and the byte gather per
+// hit in this pass cost more than that code did. Off by default (HIPR_SHADE_CLASSES=1 turns it on); the listing is then round 3's two kinds.
 __global__ __launch_bounds__(256) void k_classify_hits(const float4* __restrict__ hits, const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ order,
-                                                       unsigned long long* taken /* low word: surface hits listed, high word: others listed */) {
-    __shared__ uint32_t s_surface[4], s_other[4];
+                                                       unsigned long long* taken /* [0] low word: plain surface hits listed, high word: others listed; [1]: coated surface hits listed */,
+                                                       const unsigned char* __restrict__ triangle_class, uint32_t* __restrict__ order_coat) {
+    __shared__ uint32_t s_surface[4], s_other[4], s_coat[4];
     __shared__ unsigned long long s_base;
+    __shared__ uint32_t s_coat_base;
     const uint32_t n = *count_ptr;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
     for (uint32_t chunk = blockIdx.x * (256u * CLASSIFY_ROUNDS); chunk < n; chunk += gridDim.x * (256u * CLASSIFY_ROUNDS)) {
         // pass 1: what the chunk holds, one bit per round and thread
-        uint32_t surface_bits = 0u, valid_bits = 0u;
+        uint32_t surface_bits = 0u, valid_bits = 0u, coat_bits = 0u;
 #pragma unroll
         for (uint32_t r = 0; r < CLASSIFY_ROUNDS; ++r) {
             const uint32_t i = chunk + r * 256u + threadIdx.x;
             const uint32_t id = i < n ? __float_as_uint(hits[i].w) : HIPR_HIT_MISS;
-            surface_bits |= (i < n && id != HIPR_HIT_MISS && !(id & HIPR_HIT_LIGHT)) ? (1u << r) : 0u;
+            const bool surface = i < n && id != HIPR_HIT_MISS && !(id & HIPR_HIT_LIGHT);
+            const bool coated = surface && triangle_class != nullptr && (triangle_class[id] & 1u);
+            surface_bits |= (surface && !coated) ? (1u << r) : 0u;
+            coat_bits |= coated ? (1u << r) : 0u;
             valid_bits |= i < n ? (1u << r) : 0u;
         }
-        uint32_t surfaces = uint32_t(__popc(surface_bits)), others = uint32_t(__popc(valid_bits & ~surface_bits));
-        for (int off = 32; off > 0; off >>= 1) { surfaces += __shfl_xor(surfaces, off); others += __shfl_xor(others, off); }
-        if (lane == 0) { s_surface[wave] = surfaces; s_other[wave] = others; }
+        uint32_t surfaces = uint32_t(__popc(surface_bits)), coats = uint32_t(__popc(coat_bits)), others = uint32_t(__popc(valid_bits & ~(surface_bits | coat_bits)));
+        for (int off = 32; off > 0; off >>= 1) { surfaces += __shfl_xor(surfaces, off); others += __shfl_xor(others, off); coats += __shfl_xor(coats, off); }
+        if (lane == 0) { s_surface[wave] = surfaces; s_other[wave] = others; s_coat[wave] = coats; }
         __syncthreads();
-        if (threadIdx.x == 0) s_base = atomicAdd(taken, (unsigned long long)(s_surface[0] + s_surface[1] + s_surface[2] + s_surface[3]) |
-                                                         (unsigned long long)(s_other[0] + s_other[1] + s_other[2] + s_other[3]) << 32);
+        if (threadIdx.x == 0) {
+            s_base = atomicAdd(taken, (unsigned long long)(s_surface[0] + s_surface[1] + s_surface[2] + s_surface[3]) |
+                                      (unsigned long long)(s_other[0] + s_other[1] + s_other[2] + s_other[3]) << 32);
+            const uint32_t block_coats = s_coat[0] + s_coat[1] + s_coat[2] + s_coat[3];
+            s_coat_base = block_coats ? uint32_t(atomicAdd(taken + 1, (unsigned long long)block_coats)) : 0u;
+        }
         __syncthreads();
-        // pass 2: places inside the block's two ranges, rays in (round, thread) order
-        uint32_t front = uint32_t(s_base), back = uint32_t(s_base >> 32);
+        // pass 2: places inside the block's ranges, rays in (round, thread) order
+        uint32_t front = uint32_t(s_base), back = uint32_t(s_base >> 32), coat_front = s_coat_base;
 #pragma unroll
         for (uint32_t r = 0; r < CLASSIFY_ROUNDS; ++r) {
-            const bool surface = (surface_bits >> r) & 1u, other = ((valid_bits & ~surface_bits) >> r) & 1u;
-            const unsigned long long surface_mask = wave_ballot(surface), other_mask = wave_ballot(other);
-            if (lane == 0) { s_surface[wave] = uint32_t(__popcll(surface_mask)); s_other[wave] = uint32_t(__popcll(other_mask)); }
+            const bool surface = (surface_bits >> r) & 1u, coated = (coat_bits >> r) & 1u, other = ((valid_bits & ~(surface_bits | coat_bits)) >> r) & 1u;
+            const unsigned long long surface_mask = wave_ballot(surface), other_mask = wave_ballot(other), coat_mask = wave_ballot(coated);
+            if (lane == 0) { s_surface[wave] = uint32_t(__popcll(surface_mask)); s_other[wave] = uint32_t(__popcll(other_mask)); s_coat[wave] = uint32_t(__popcll(coat_mask)); }
             __syncthreads();
-            uint32_t before_surface = 0, before_other = 0, round_surface = 0, round_other = 0;
+            uint32_t before_surface = 0, before_other = 0, before_coat = 0, round_surface = 0, round_other = 0, round_coat = 0;
             for (uint32_t w = 0; w < 4; ++w) {
-                before_surface += w < wave ? s_surface[w] : 0u; before_other += w < wave ? s_other[w] : 0u;
-                round_surface += s_surface[w]; round_other += s_other[w];
+                before_surface += w < wave ? s_surface[w] : 0u; before_other += w < wave ? s_other[w] : 0u; before_coat += w < wave ? s_coat[w] : 0u;
+                round_surface += s_surface[w]; round_other += s_other[w]; round_coat += s_coat[w];
             }
             const uint32_t i = chunk + r * 256u + threadIdx.x;
             if (surface) order[front + before_surface + uint32_t(__popcll(surface_mask & lt))] = i;
+            if (coated) order_coat[coat_front + before_coat + uint32_t(__popcll(coat_mask & lt))] = i;
             if (other) order[n - 1u - (back + before_other + uint32_t(__popcll(other_mask & lt)))] = i;
-            front += round_surface; back += round_other;
+            front += round_surface; back += round_other; coat_front += round_coat;
             __syncthreads();
         }
     }
@@ -1073,9 +1104,41 @@ __global__ __launch_bounds__(256) void k_accumulate(FrameInfo frame, uint32_t fi
                                                      double4* accumulation, ushort4* out, uint32_t out_pitch, float depth_normalizer) {
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
     const uint32_t per_sample = frame.owned_tiles * 64u;
-    if (k >= per_sample) return;
-    uint32_t x, y;
-    if (!owned_pixel(frame, k, x, y)) return;
+    uint32_t x = 0, y = 0;
+    const bool mine = k < per_sample && owned_pixel(frame, k, x, y);
+#if HIPR_PIXEL_MAJOR_SLOTS
+    // The block's 256 pixels hold their samples in 256 runs of samples_per_pass float4 (pixel-major slots). A thread reading its own run 16 bytes at a time
+    // makes every load of a wave touch 64 lines (measured: 1.0 ms per 32-sample pass at 1080p against 0.2 ms for the sample-major order); so the block brings
+    // eight samples of all its pixels at a time through LDS -- consecutive threads load consecutive float4 of a run, 128 contiguous bytes per pixel -- and every
+    // thread then folds its own eight IN ORDER (the running mean is order dependent: accumulation a before a + 1).
+    constexpr uint32_t CHUNK = 8, ROW = CHUNK + 1;      // one float4 of padding per pixel row: the threads' reads of column c fall on different banks
+    __shared__ float4 s_tile[256 * ROW];
+    double4 acc = mine ? accumulation[k] : double4{0, 0, 0, 0};
+    const size_t block_first = size_t(blockIdx.x) * 256u * frame.samples_per_pass + first_sample;
+    for (uint32_t c0 = 0; c0 < sample_count; c0 += CHUNK) {
+        const uint32_t columns = min(CHUNK, sample_count - c0);
+        for (uint32_t e = threadIdx.x; e < 256u * columns; e += 256u) {
+            const uint32_t row = e / columns, column = e - row * columns;
+            if (blockIdx.x * 256u + row < per_sample) s_tile[row * ROW + column] = radiance[block_first + size_t(row) * frame.samples_per_pass + c0 + column];
+        }
+        __syncthreads();
+        if (mine)
+            for (uint32_t c = 0; c < columns; ++c) {
+                const float4 r = s_tile[threadIdx.x * ROW + c];
+                const uint32_t a = first_accumulation + c0 + c;
+                if (a != 0) {
+                    const double t = 1.0 / (a + 1.0);
+                    acc.x = acc.x + (double(r.x) - acc.x) * t;
+                    acc.y = acc.y + (double(r.y) - acc.y) * t;
+                    acc.z = acc.z + (double(r.z) - acc.z) * t;
+                } else { acc.x = r.x; acc.y = r.y; acc.z = r.z; }
+                acc.w = 1.0;
+            }
+        __syncthreads();
+    }
+    if (!mine) return;
+#else
+    if (!mine) return;
     double4 acc = accumulation[k];
     for (uint32_t s = 0; s < sample_count; ++s) {
         const float4 r = radiance[(first_sample + s) * per_sample + k];
@@ -1088,6 +1151,7 @@ __global__ __launch_bounds__(256) void k_accumulate(FrameInfo frame, uint32_t fi
         } else { acc.x = r.x; acc.y = r.y; acc.z = r.z; }
         acc.w = 1.0;
     }
+#endif
     accumulation[k] = acc;
     if (out) {
         const size_t dst = frame.tile_stride == 1 ? size_t(x) + size_t(y) * out_pitch : size_t(k);

@@ -14,6 +14,8 @@ struct ShadeLaunch {
     PathState in;
     const float4* hits;
     const uint32_t* order;     // k_classify_hits: the queue entries in the order the kernel takes them (surface hits first); nullptr = queue order
+    const uint32_t* order_coat;               // the coated surface hits, listed apart
+    const unsigned long long* listed;         // k_classify_hits' counters of this bounce: [0] low word = plain surface hits, [1] = coated surface hits
     PathState out;
     ShadowQueue shadows;
     float4* radiance;

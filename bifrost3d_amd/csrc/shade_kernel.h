@@ -304,7 +304,13 @@ HD ShadeInputs shade_fetch_inputs(const PathState& in, const float4* hits, uint3
     return r;
 }
 // The queue entry that place j of the shading order holds (k_classify_hits; the queue's own order without it).
-HD uint32_t shade_entry(const uint32_t* order, uint32_t j, uint32_t n) { return j < n ? (order ? order[j] : j) : HIPR_DEAD_SLOT; }
+// The queue entry the kernel takes j-th: queue order, or k_classify_hits' listing [plain surface hits | coated surface hits | everything else].
+struct ShadeOrder { const uint32_t* order; const uint32_t* order_coat; uint32_t plain, coated; };
+HD uint32_t shade_entry(const ShadeOrder& o, uint32_t j, uint32_t n) {
+    if (j >= n) return HIPR_DEAD_SLOT;
+    if (!o.order) return j;
+    return (j >= o.plain && j - o.plain < o.coated) ? o.order_coat[j - o.plain] : o.order[j];
+}
 HD bool shade_hits_triangle(const ShadeInputs& in) {
     const uint32_t id = __float_as_uint(in.hit.w);
     return in.meta.x != HIPR_DEAD_SLOT && id != HIPR_HIT_MISS && !(id & HIPR_HIT_LIGHT);
@@ -342,7 +348,7 @@ HD HiprMaterial shade_fetch_material(const DeviceScene& sc, const ShadeInputs& i
 constexpr uint32_t SHADE_LDS_LIGHTS = 32;   // light arrays up to this size are copied to LDS (1.5 KB); larger ones are read from global memory
 constexpr int shade_waves_per_simd(int part) { return part == SHADE_PART_ALL ? HIPR_SHADE_WAVES : HIPR_SHADE_SPLIT_WAVES; }
 template <int MODELS, bool AOV, int PART>
-__global__ __launch_bounds__(SHADE_BLOCK, shade_waves_per_simd(PART)) void k_shade(DeviceScene sc, HiprCameraState cam, int entry, PathState in, const float4* hits, const uint32_t* order, PathState out,
+__global__ __launch_bounds__(SHADE_BLOCK, shade_waves_per_simd(PART)) void k_shade(DeviceScene sc, HiprCameraState cam, int entry, PathState in, const float4* hits, const uint32_t* order_list, const uint32_t* order_coat, const unsigned long long* listed, PathState out,
                                                         ShadowQueue shadows, float4* radiance, const uint32_t* count_ptr, unsigned long long* out_counts,
                                                         unsigned long long* zero_a, unsigned long long* zero_b, unsigned char* nee_flags, DeviceCounters* counters) {
 #if HIPR_SHADE_ONE_BARRIER
@@ -361,11 +367,13 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_waves_per_simd(PART)) void k_sha
     __shared__ HiprLight s_lights[SHADE_LDS_LIGHTS];
 #endif
     const uint32_t n = *count_ptr;
+    ShadeOrder order = {order_list, order_coat, 0u, 0u};
+    if (order_list && listed) { order.plain = uint32_t(listed[0]); order.coated = uint32_t(listed[1]); }      // k_classify_hits has run on this stream
     // The counters the NEXT bounce's kernels fill start from zero; nothing on the device reads or writes them while this kernel runs (hiprenderer.hip
     // enqueue_bounce). A fill command in the stream for each costs more than this whole kernel does on a bounce of a few thousand paths.
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (zero_a) *zero_a = 0ull;
-        if (zero_b) *zero_b = 0ull;
+        if (zero_b) { zero_b[0] = 0ull; zero_b[1] = 0ull; }      // the listing pass's two counters of the next bounce
     }
     if (blockIdx.x * SHADE_BLOCK >= n) return;
     const uint32_t stride = gridDim.x * SHADE_BLOCK;
