@@ -9,22 +9,35 @@ fresh child per rank, never a re-exec -- and forwards rank 0's line.
 Workload (the north-star configuration, BASELINE.json configs[3] on ONE GPU at N = 1): the 251 k-triangle procedural atrium
 (the Sponza-class stand-in of SURVEY.md 8d: the reference ships no Sponza and there is no network), DefaultShading materials,
 1920 x 1080, max_bounce_count 4, next event estimation over 3 RIS candidates. A "step" is one pass of the hot path over one batch:
-32 accumulations of the frame traced together (66 355 200 camera paths followed to completion), folded one by one into the
-f64 running mean and written as half4; the default 8 steps are the 256 spp of the metric. The reference traces one accumulation
-per launch; batching is a property of the wavefront design (bit-identical image for any batch size, tested), `--spp-per-pass 1`
+64 accumulations of the frame traced together (132 710 400 camera paths followed to completion, as two co-running wavefronts), folded one
+by one into the f64 running mean and written as half4; four steps are the 256 spp of the metric (`ms_per_256spp_frame`), the default 8 steps two
+such frames. Round 3 took 32 per step; 64 give 2 % more rays per second and 128 nothing more (profiles/r04_ab_spp_per_pass.txt). The reference traces
+one accumulation per launch; batching is a property of the wavefront design (bit-identical image for any batch size, tested), `--spp-per-pass 1`
 reproduces launch-per-accumulation. Inputs (scene, BVH, tables) are resident in HBM before the timed region, the frame stays in HBM.
 
-N > 1: tiles of 8 x 8 pixels are dealt round-robin to the ranks and a step traces N x 32 accumulations, so every GPU keeps
-66 355 200 paths per step ("weak" scaling, no data-path collective); the timed region ends with the RCCL gather of the half4
-tiles to rank 0 and the scatter kernel that assembles the frame.
+N > 1: tiles of 8 x 8 pixels are dealt round-robin to the ranks and a step traces N x 64 accumulations, so every GPU keeps
+132 710 400 paths per step ("weak" scaling, no data-path collective); the timed region ends with the RCCL gather of the half4
+tiles to rank 0 and the scatter kernel that assembles the frame. `--fixed-frame` splits the SAME steps over the ranks (strong scaling); a rank then
+batches up to N steps' worth of accumulations into a pass, so that its wavefront stays as large as the single GPU's (scaling_proxy says why).
 
 The ONE JSON line rank 0 prints carries the contract keys plus
-  roofline          the kernel with the largest total time in the timed region. `traffic` = bytes that crossed the L2's memory side per launch, from
-                    rocprofv3 counters: (2 * FETCH_SIZE + WRITE_SIZE) * 1024, measured by two child runs of this workload under `rocprofv3 --pmc` before the
-                    timed run (fallback: profiles/pmc_traffic.json), calibrated on this renderer's access patterns (profiles/r03_fetch_calibration.txt);
-                    `achieved` = traffic / HIP-event launch duration, `frac` = achieved / 8 TB/s -- always <= 1. `achieved_model` / `frac_model` price
-                    SURVEY.md 8d's ALGORITHMIC bytes (every node visit 64 B, ...) the same way: an upper bound that counts cache hits and may pass 1.
-                    `observed_limiter` from the SQ / TA counter passes under profiles/;
+  roofline          the kernel with the largest total time. `traffic` = bytes that crossed the L2's memory side per launch, from rocprofv3 counters:
+                    (2 * FETCH_SIZE + WRITE_SIZE) * 1024, measured by child runs of this workload under `rocprofv3 --pmc` before the timed run (fallback:
+                    profiles/pmc_traffic.json), calibrated on this renderer's access patterns (profiles/r03_fetch_calibration.txt); launches of the
+                    INSTRUMENTED build of the kernel (the counting passes) are not in the average (round 3 had them in: 0.38; without: 0.25).
+                    `achieved` = traffic / HIP-event launch duration, `frac` = achieved / 8 TB/s -- always <= 1. The timed region runs two co-running
+                    wavefronts, whose launches overlap: the durations the rooflines use are those of a ONE-wavefront leg of two steps right after it
+                    (`duration_source`; the timed region's own are under `timed_region`). `achieved_model` / `frac_model` price SURVEY.md 8d's
+                    ALGORITHMIC bytes (every node visit 64 B, ...) the same way: an upper bound that counts cache hits and may pass 1.
+                    `traffic_useful` = the bytes a launch cannot avoid (results written once, queue records read once), `traffic_over_useful`,
+                    `write_amplification` = WRITE_SIZE / useful writes;
+  roofline_valu     the VALU roof of the same kernel, which is what bounds it: wave64 VALU instructions per second (SQ_INSTS_VALU of a third live
+                    counter pass, calibrated on a rate kernel of known instruction count in the same pass) against the v_fma_f32 issue rate measured
+                    in this process (hipr_debug_valu_issue_rates), lanes per instruction, and `valu_busy` = SQ_ACTIVE_INST_VALU per second relative
+                    to a kernel that does nothing but issue VALU;
+  scaling_proxy     the per-GPU shape of the N-way tile split, timed on the one GPU: every phase of a tile_stride-N split rendered in turn, the slowest
+                    standing for the step of an N-GPU node; strong / weak / one accumulation per pass, the rate by wavefront size and the smallest
+                    wavefront that keeps 90 % of the full rate;
   cpu_baseline      the SmallPT restatement (BASELINE config 1) on the host cores, plus `c2`: the oracle's render of config 2 (Cornell,
                     all Diffuse) at reduced size next to the device's, equal ray counters, like-for-like Mrays/s (N = 1 only);
   other_workloads   BASELINE configs[1] (Cornell, all Diffuse) and configs[2] (material scene, 32 bounces) measured the same way after
@@ -66,7 +79,7 @@ def parse_args(argv=None):
                    "not the headline workload: the line's config.workload names the file")
     p.add_argument("--atrium-triangles", type=int, default=260000)
     p.add_argument("--bounces", type=int, default=None, help="max_bounce_count; default 4, and 32 for the viewer's built-in scenes (apps/SimpleViewer/main.cpp:353)")
-    p.add_argument("--spp-per-pass", type=int, default=32, help="accumulations traced together per step and GPU (HiprFrameDesc::samples_per_pass)")
+    p.add_argument("--spp-per-pass", type=int, default=64, help="accumulations traced together per step and GPU (HiprFrameDesc::samples_per_pass)")
     p.add_argument("--wavefronts", type=int, default=0, choices=[0, 1, 2, 3, 4],
                    help="0 (default): the library's choice -- two half-frame wavefronts on two streams for the small-scene kernels (Cornell box: one shades while the other "
                         "traces) and, since round 4, for the persistent wide-BVH kernels from 2^24 paths per pass on (where one wavefront's launch drains the other's blocks "
@@ -428,7 +441,7 @@ def cpu_baseline_c2(ctx, seconds: float):
 def plugin_renderer_figures(ctx, args, main_figures):
     """The same workload through the plugin class a Bifrost application holds: the atrium built in the Bifrost managers, pulled by
     HIPRenderer::Renderer::handle_updates, one blocking Renderer::render() per accumulation into a device render target (host/host_api.cpp
-    hiprh_renderer_bench). render() traces ahead in batches of up to 32 accumulations and folds one per call (bit-identical frames, tested);
+    hiprh_renderer_bench). render() traces ahead in batches of up to 64 accumulations and folds one per call (bit-identical frames, tested);
     `one_launch_per_accumulation` is the same loop at the reference's launch granularity. Rays per accumulation are those of the main
     measurement (same scene, camera and frame; the ray counts are deterministic)."""
     from bifrost3d_amd.host import renderer_bench
@@ -437,7 +450,7 @@ def plugin_renderer_figures(ctx, args, main_figures):
     out = {}
     import ctypes
     libc = ctypes.CDLL(None)
-    for key, max_batch, warmup, calls in (("batched", 32, 128, 128), ("one_launch_per_accumulation", 1, 4, 16)):
+    for key, max_batch, warmup, calls in (("batched", 64, 128, 128), ("one_launch_per_accumulation", 1, 4, 16)):
         r = renderer_bench(args.atrium_triangles, args.width, args.height, warmup, calls, max_batch)
         libc.fflush(None)      # the renderer announces its device with printf like the reference does (OR/Renderer.cpp:300); stdout is stderr here (main)
         ms = r["milliseconds"] / r["calls"]
@@ -596,6 +609,15 @@ def useful_traffic(name, counters, launches, samples_per_step):
 XGMI_LINK_GBS = 153.0      # one xGMI link per peer, MI355X_MICROARCH.md
 
 
+def fixed_frame_batch(steps: int, warmup: int, world: int) -> int:
+    """--fixed-frame: how many steps' worth of accumulations a rank traces per pass -- the largest g <= world that divides both the timed and the warm-up
+    step counts, so that exactly `steps` steps are timed after exactly `warmup` (a rank of N holds 1 / N of the pixels: N steps per pass make its wavefront
+    the single GPU's)."""
+    if world <= 1:
+        return 1
+    return max(g for g in range(1, world + 1) if steps % g == 0 and (warmup == 0 or warmup % g == 0))
+
+
 def scaling_proxy(ctx, scene, bounces, args, device, t1_ms):
     """The per-GPU shape of north_star's 8-GPU job, timed on the one GPU there is: the frame's 8 x 8 tiles dealt round robin to N
     ranks (tile_stride N), every phase 0 .. N-1 rendered in turn by this device, the slowest phase standing for the step of an N-GPU node.
@@ -671,9 +693,7 @@ def measure(ctx, scene, scene_name, bounces, args, rank, world, device, steps, w
     # --fixed-frame (strong scaling: the same `steps` x spp_per_pass accumulations of the whole frame, every rank its tiles): a rank of N holds 1 / N of the
     # pixels, so it takes N steps' worth of accumulations per pass where the step count allows -- the wavefront the scaling proxy shows it needs (a pass
     # of 8 M paths runs at 79 %% of the rate of one of 66 M: scaling_proxy.rate_by_wavefront) -- and makes steps / batch passes.
-    batch = 1
-    if args.fixed_frame and world > 1:
-        batch = max(g for g in range(1, world + 1) if steps % g == 0 and warmup % g == 0) if warmup else max(g for g in range(1, world + 1) if steps % g == 0)
+    batch = fixed_frame_batch(steps, warmup, world) if args.fixed_frame else 1
     S = args.spp_per_pass * (batch if args.fixed_frame else world)
     steps_run, warmup_run = steps // batch, warmup // batch
     on_host = world > 1 and args.dist_backend == "gloo"

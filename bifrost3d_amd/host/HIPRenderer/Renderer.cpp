@@ -203,7 +203,7 @@ struct Renderer::Implementation {
         void *noisy_frame = nullptr, *albedo_frame = nullptr;
         size_t feature_frame_pixels = 0;
     };
-    unsigned int max_batch_size = 32;   // accumulations traced together at most (set_max_batch_size; 1 = the reference's one launch per accumulation)
+    unsigned int max_batch_size = 64;   // accumulations traced together at most (64: 2 % more rays per second than 32 on the 1080p atrium, 128 gains nothing more: profiles/r04_ab_spp_per_pass.txt) (set_max_batch_size; 1 = the reference's one launch per accumulation)
     std::vector<CameraState> per_camera_state = std::vector<CameraState>(1);
     AIDenoiserFlags AI_denoiser_flags = AIDenoiserFlag::Default;
     PathRegularizationSettings path_regularization = {0.5f, 0.0f};   // OR/Renderer.cpp:482-483

@@ -493,7 +493,7 @@ GPU_TEST_F(RendererFixture, batched_tracing_returns_the_images_of_one_launch_per
     renderer->set_max_bounce_count(camera_ID, 4);
     renderer->handle_updates();
     reset_all_change_notifications();
-    EXPECT_EQ(32u, renderer->get_max_batch_size());
+    EXPECT_EQ(64u, renderer->get_max_batch_size());
 
     const int calls = 44;
     auto run = [&](unsigned int max_batch, std::vector<std::vector<double>>& accumulations, std::vector<std::vector<half4>>& frames) {

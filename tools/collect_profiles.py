@@ -19,8 +19,8 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 src, tag = Path(sys.argv[1]), sys.argv[2]
 profiles = ROOT / "profiles"
-KEYS = {"atrium": "atrium:1920x1080:spp32:bounces4:tris260000:wf1", "cornell_diffuse": "cornell_diffuse:1920x1080:spp32:bounces4:wf2",
-        "material": "material:1920x1080:spp32:bounces32:wf1"}
+KEYS = {"atrium": "atrium:1920x1080:spp64:bounces4:tris260000:wf1", "cornell_diffuse": "cornell_diffuse:1920x1080:spp64:bounces4:wf1",
+        "material": "material:1920x1080:spp64:bounces32:wf1"}      # the one-wavefront legs (tools/gpu_evidence.sh counters)
 
 for scene, key in KEYS.items():
     d = src / scene

@@ -3,7 +3,8 @@
 #   tools/gpu_evidence.sh <tag> [part ...]        e.g. gpurun -- 'bash tools/gpu_evidence.sh r04 bench stats tests'
 # parts (default: all, in this order)
 #   bench     the default `python bench.py` line (what the driver runs)
-#   stats     rocprofv3 --kernel-trace --stats of the same command
+#   stats     rocprofv3 --kernel-trace --stats of the same workload with ONE wavefront (every kernel alone on the device: the durations the bench line's
+#             rooflines are priced on; the timed region of the default line runs two co-running wavefronts whose launches overlap)
 #   workloads the other BASELINE configurations (material, cornell_diffuse, 10 M triangles at 4K, 1 spp per pass, two ranks on one device)
 #   rmse      tools/rmse_protocol.py at 480x270 and 160x90
 #   tests     the GPU suite with image metrics, then smoke()
@@ -24,7 +25,7 @@ for part in $parts; do
         python bench.py > $out/bench_default.json 2> $out/bench_default.err; tail -c 600 $out/bench_default.json ;;
     stats)
         cd /tmp
-        timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $root/bench.py $quiet --no-rmse --pmc-traffic off > $out/bench_under_rocprof.json 2> $out/bench_under_rocprof.err
+        timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $root/bench.py $quiet --no-rmse --pmc-traffic off --wavefronts 1 > $out/bench_under_rocprof.json 2> $out/bench_under_rocprof.err
         cd $root
         find $out/trace -name "*kernel_trace.csv" -size +8M -delete ;;
     workloads)
@@ -44,9 +45,9 @@ for part in $parts; do
         HIPR_TRACE_LOG=1 timeout 600 python tools/trace_log_probe.py atrium 32 1 > $out/trace_log.txt 2>&1 ;;
     counters)
         for scene in atrium cornell_diffuse material; do
-            bash tools/profile_round.sh $tag/$scene --scene $scene --steps 4 --warmup 1 > $out/${scene}_profile.log 2>&1
+            bash tools/profile_round.sh $tag/$scene --scene $scene --steps 4 --warmup 1 --wavefronts 1 > $out/${scene}_profile.log 2>&1
         done
-        bash tools/profile_sq.sh $tag/sq_atrium --scene atrium --steps 2 --warmup 1 > $out/sq.log 2>&1
+        bash tools/profile_sq.sh $tag/sq_atrium --scene atrium --steps 2 --warmup 1 --wavefronts 1 > $out/sq.log 2>&1
         for d in sq1 sq2 tcc tcp; do python tools/pmc_summary.py $out/sq_atrium/$d k_shade k_trace_wide8 k_generate k_accumulate k_classify_hits > $out/sq_atrium_$d.txt; done
         find $out -name "*.csv" -size +3M -delete
         find $out -name "*agent_info.csv" -delete ;;
