@@ -42,7 +42,8 @@ def test_bench_line_contract_single_gpu():
     assert valu["bound"] == "valu" and "error" not in valu, valu
     assert 0.0 < valu["frac"] <= 1.2 and valu["frac"] == pytest.approx(valu["achieved"] / valu["peak"]) and 8.0 <= valu["lanes_per_instruction"] <= 64.0
     assert 0.98 <= valu["calibration"]["scale"] <= 1.02          # SQ_INSTS_VALU counts the rate kernel's instructions to within 2 %
-    assert roofline["traffic_useful"]["bytes"] > 0 and roofline["traffic_over_useful"] >= 0.5 and roofline["write_amplification"] > 0
+    if "trace" in roofline["kernel"]:      # the unavoidable bytes are defined for the trace kernels (the dominant one here)
+        assert roofline["traffic_useful"]["bytes"] > 0 and roofline["traffic_over_useful"] >= 0.5 and roofline["write_amplification"] > 0
     proxy = line["scaling_proxy"]
     for kind in ("strong", "weak", "interactive"):
         assert set(proxy[kind]) >= {"2", "4", "8"}
