@@ -177,7 +177,8 @@ def main():
         pixels.append(entry)
     out["worst_pixels"] = pixels
     ctx.close()
-    text = json.dumps(out, indent=1)
+    # one line per top-level key: the per-sample tables of the worst pixels are data, not prose (thousands of lines per file bloat every diff)
+    text = "{\n" + ",\n".join(f" {json.dumps(k)}: {json.dumps(v, separators=(', ', ': '))}" for k, v in out.items()) + "\n}"
     if args.out:
         Path(args.out).write_text(text + "\n")
     print(text)
