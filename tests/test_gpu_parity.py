@@ -370,6 +370,37 @@ def test_wavefront_count_does_not_change_the_image(ctx, cornell, atrium, scene_n
             assert counters[1][key] == counters[count][key], (count, key)
 
 
+def test_slot_order_and_the_deal_to_the_wavefronts_do_not_change_the_image(ctx, atrium):
+    """Round 4: path slots are pixel-major (slot = pixel * samples_per_pass + sample) and dealt to the wavefronts in groups of 64, round robin; k_accumulate
+    brings the samples of 256 pixels through LDS eight at a time. None of it may show: a frame whose size is no multiple of the 8 x 8 tiles, samples per pass
+    that neither divide 64 nor fit one LDS chunk (3, 5, 30), one to three wavefronts -- the running mean equals the one of single-sample passes on one
+    wavefront, bit for bit, and so do the ray counters; folding a traced pass in two parts (hipr_accumulate_samples) gives the same frame as folding it at once."""
+    import ctypes as C
+    w, h, accumulations = 652, 412, 30           # 82 x 52 tiles, the last column and row partly outside the frame
+    try:
+        ctx.set_wavefront_count(1)
+        reference, reference_counters = render_gpu(ctx, atrium, w, h, accumulations, 4, samples_per_pass=1)
+        for samples, count in ((3, 2), (5, 3), (30, 2), (15, 1)):
+            ctx.set_wavefront_count(count)
+            image, counters = render_gpu(ctx, atrium, w, h, accumulations, 4, samples_per_pass=samples)
+            assert np.array_equal(image, reference), (samples, count)
+            for key in ("camera_rays", "closest_rays", "shadow_rays", "shaded_hits"):
+                assert counters[key] == reference_counters[key], (samples, count, key)
+        # a pass of 10 traced once and folded as 4 + 6 samples
+        ctx.set_wavefront_count(2)
+        ctx.upload_scene(atrium)
+        ctx.set_frame(w, h, 0, 1, 10)
+        for first in range(0, accumulations, 10):
+            cam = atrium.camera(w, h, accumulations=first, max_bounce_count=4)
+            ctx._check(ctx.lib.hipr_trace_pass(ctx.handle, C.byref(cam)), "hipr_trace_pass")
+            ctx._check(ctx.lib.hipr_accumulate_samples(ctx.handle, 0, 4, first, None, 0, 0), "hipr_accumulate_samples")
+            ctx._check(ctx.lib.hipr_accumulate_samples(ctx.handle, 4, 6, first + 4, None, 0, 1), "hipr_accumulate_samples")
+        assert np.array_equal(ctx.read_accumulation(), reference)
+    finally:
+        ctx.set_wavefront_count(0)
+        ctx.set_frame(w, h)
+
+
 def test_tessellated_cornell_renders_the_same_image(ctx, oracle_q, cornell_tessellated):
     """The BVH2 kernels end to end: the tessellated box is the same surface set, so the image matches the oracle's (BVH2) render
     of it under the usual statistical bar."""
