@@ -21,10 +21,11 @@
 //     child is hit, the current group is pushed when it still has pending children, and the node's hits become the current group.
 //   * visiting a record: triangle A = (a; e1, e2), then B = (a; e2, e3), each with the Moeller-Trumbore solve of kernels.h on the stored edges; the
 //     weights (1 - u - v, u, v) of the record's corners become the scene triangle's (u, v) through the record's selectors.
-// Tried and not adopted (round 3): TWO rays per lane, the lane bringing forward whichever of its rays has an item of the kind the wave is working on
-// (tools/experiments/wide8_kernels_two_rays_per_lane.h.txt; per-ray order unchanged, the parity tests pass with it). The wave's instructions would find
-// ~56 instead of 38 lanes with work, but the second set of ray registers (26 per lane) does not fit next to the node block's ~50 temporaries: at four
-// waves per SIMD the compiler still spills 114 VGPRs and the atrium's trace time goes from 50.2 to 83.0 ms per step (profiles/r03_ab_two_rays_per_lane.txt).
+// Tried and not adopted: TWO rays per lane, the lane bringing forward whichever of its rays has an item of the kind the wave is working on
+// (tools/experiments/wide8_dual_kernels.h.txt; per-ray order unchanged, the parity tests pass with it). The wave's instructions find more lanes with work,
+// but the second set of ray registers (26 per lane) does not fit next to the node block's temporaries: at four waves per SIMD the compiler spills 114-128
+// VGPRs (round 3: 50.2 -> 83.0 ms per atrium step), and at three waves, where nothing spills, three instruction streams per SIMD do not cover the chain
+// vote -> exchange -> gather -> test (round 4: 45.9 -> 63.1 ms; profiles/r04_ab_two_rays_three_waves.txt).
 // The wave-level machinery (persistent waves claiming 64-ray chunks from sharded counters, refilling idle lanes, one KIND of item per iteration chosen by
 // a wave vote, fused closest-hit + shadow launches) is that of k_trace_persistent (kernels.h), which remains for the 4-wide tree.
 #pragma once
