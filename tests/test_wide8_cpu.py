@@ -446,3 +446,16 @@ def test_one_sided_flags_follow_the_materials(oracle):
     finally:
         d.triangles[victim].flags &= ~capi.TRIANGLE_ONE_SIDED
     assert capi.load_library().hipr_validate_scene(C.byref(d)) == 0
+
+
+def test_the_reinsertion_optimised_bvh2_passes_this_suite():
+    """host/BvhOptimizer.cpp (opt-in, HIPR_BVH_REINSERTION = passes): subtrees of the finished BVH2 are taken out and hung where the SAH cost falls most before the
+    tree is collapsed. Whatever it does to the topology, the tree must stay a valid one: this file's checks (records pair triangles that share an edge, quantised
+    boxes contain what is below them, the oracle's search over the 8-wide tree equals its other searches and its brute force, refit keeps the topology) run again
+    in a process that builds every scene with three passes of it. The switch is read once per process, hence the child."""
+    import os, subprocess, sys
+    env = dict(os.environ, HIPR_BVH_REINSERTION="3")
+    env.pop("PYTEST_CURRENT_TEST", None)
+    done = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-k", "not reinsertion_optimised", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
+    assert done.returncode == 0, done.stdout[-2000:] + done.stderr[-1000:]
+    assert "passed" in done.stdout
