@@ -122,6 +122,8 @@ struct HiprContext {
     Wide8Scene wide8 = {};              // the 8-wide tree with leaf records: what the persistent kernels walk when the scene brings one
     uint32_t wide8_height = 0;
     DeviceBuffer nodes, triangles, instances, indices, geometry, texcoords, tints, emissions, materials, lights, textures, texels;
+    bool all_triangles_opaque = false;  // no triangle of the uploaded scene needs its material's coverage sampled (HIPR_TRIANGLE_OPAQUE on all): k_trace_wide8<..., COVERAGE = false>
+    bool lean_trace = true;             // HIPR_LEAN_TRACE=0: always the full kernel
     DeviceBuffer triangle_class;        // one byte per triangle for the listing pass (k_classify_hits): bit 0 = its material is coated
     bool any_coated_triangle = false, shade_classes = false;     // HIPR_SHADE_CLASSES=1: coated surface hits listed apart (built and measured in round 4: no gain, profiles/r04_ab_shade_classes.txt)
     DeviceBuffer ggx_rho, dielectric_rho, alpha, sample_offsets, sobol_tables;
@@ -372,6 +374,11 @@ void launch_wide8(HiprContext* c, const Wavefront& w, const PathState& in, const
     // pipelined passes: one block slot per CU stays free, so that the other slot's tail launches find room next to this pass's persistent blocks
     uint32_t grid = uint32_t(c->cu_count) * uint32_t(c->pipelining_now && per_cu > 2 ? per_cu - c->pipeline_spare_blocks : per_cu);
     grid = std::max(1u, std::min(grid, (upper_bound + 63u) / 64u / waves_per_block + 1u));
+    // scenes whose triangles are all statically opaque run the kernel without the coverage code (closest-only launches never reach it anyway)
+    if (!INSTRUMENT && MODE != TRACE_CLOSEST && c->all_triangles_opaque && c->lean_trace)
+        hipLaunchKernelGGL((k_trace_wide8<STACK, MODE, INSTRUMENT, false>), dim3(grid), dim3(TRACE_BLOCK), 0, w.stream, c->scene, c->wide8, in, w.hits.as<float4>(), w.shadow_queue(),
+                           c->radiance.as<float4>(), closest_count, shadow_count, next_work_counter(c), c->refill_below, c->counters.as<DeviceCounters>());
+    else
     hipLaunchKernelGGL((k_trace_wide8<STACK, MODE, INSTRUMENT>), dim3(grid), dim3(TRACE_BLOCK), 0, w.stream, c->scene, c->wide8, in, w.hits.as<float4>(), w.shadow_queue(),
                        c->radiance.as<float4>(), closest_count, shadow_count, next_work_counter(c), c->refill_below, c->counters.as<DeviceCounters>());
 }
@@ -839,6 +846,8 @@ int build_derived_geometry(HiprContext* c, const HiprSceneDesc* s) {
     }
     // the listing pass's class of every triangle (k_classify_hits): bit 0 = the material of its instance carries a coat
     c->any_coated_triangle = false;
+    c->all_triangles_opaque = true;
+    for (uint32_t t = 0; t < s->triangle_count; ++t) c->all_triangles_opaque = c->all_triangles_opaque && (s->triangles[t].flags & HIPR_TRIANGLE_OPAQUE) != 0;
     if (s->triangle_count) {
         std::vector<unsigned char> classes(s->triangle_count, 0);
         for (uint32_t t = 0; t < s->triangle_count; ++t) {
@@ -917,6 +926,7 @@ int hipr_create(int device_id, HiprContext** out_context) {
     if (const char* v = getenv("HIPR_WAVEFRONTS")) c->wavefront_limit = std::max(0, std::min(MAX_WAVEFRONTS, atoi(v)));
     if (const char* v = getenv("HIPR_TRACE_LOG")) c->trace_log = atoi(v) != 0;
     if (const char* v = getenv("HIPR_SHADE_CLASSES")) c->shade_classes = atoi(v) != 0;
+    if (const char* v = getenv("HIPR_LEAN_TRACE")) c->lean_trace = atoi(v) != 0;
     if (const char* v = getenv("HIPR_SHADE_ORDERED")) c->shade_ordered = atoi(v) != 0;
     if (const char* v = getenv("HIPR_SHADE_SPLIT")) c->shade_split = atoi(v) != 0;
     if (const char* v = getenv("HIPR_BACKFACE_CULLING")) c->cull_backfaces = atoi(v) != 0;

@@ -54,7 +54,10 @@ constexpr int WIDE8_STACK_SHALLOW = 12;      // 12 KB per block of two waves: tw
 #endif
 HD constexpr int wide8_waves_per_simd(int stack_entries) { return stack_entries <= 8 ? HIPR_WIDE8_WAVES_LOW : (stack_entries <= 12 ? HIPR_WIDE8_WAVES : (stack_entries <= 16 ? 5 : 4)); }
 
-template <int STACK, int MODE, bool INSTRUMENT>
+// COVERAGE: the scene holds triangles that are not statically opaque (coverage textures, cut-outs, partial coverage): a shadow ray that hits one samples its material's
+// coverage. Scenes without any (the common case; decided at upload) run the instantiation without that code: it is a fifth of the kernel's instructions and, though never
+// executed there, it weighs on the register allocation of the loop around it (profiles/r04_ab_trace_without_coverage.txt).
+template <int STACK, int MODE, bool INSTRUMENT, bool COVERAGE = true>
 __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(wide8_waves_per_simd(STACK)))) void k_trace_wide8(DeviceScene sc, Wide8Scene tree, PathState in, float4* hits, ShadowQueue q,
         float4* radiance, const uint32_t* closest_count_ptr, const uint32_t* shadow_count_ptr, uint32_t* work_counter, int refill_below, DeviceCounters* counters) {
     __shared__ uint2 s_stack[STACK * TRACE_BLOCK];
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(wid
                             if constexpr (MODE != TRACE_CLOSEST) {
                                 if (is_shadow && hit && t > tmin && t < tmax) {
                                     float coverage = 1.0f;
-                                    if (!(flags >> which & 1u)) {
+                                    if (COVERAGE && !(flags >> which & 1u)) {
                                         const float4 tc = sc.triangles[3 * size_t(id) + 2];       // instance and primitive of the scene triangle
                                         const HiprInstance& inst = sc.instances[__float_as_uint(tc.y)];
                                         coverage = material_coverage(sc, sc.materials[inst.material_index], triangle_texcoord(sc, inst, __float_as_uint(tc.z), u, v));
