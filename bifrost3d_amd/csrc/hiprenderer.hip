@@ -124,6 +124,8 @@ struct HiprContext {
     DeviceBuffer nodes, triangles, instances, indices, geometry, texcoords, tints, emissions, materials, lights, textures, texels;
     bool all_triangles_opaque = false;  // no triangle of the uploaded scene needs its material's coverage sampled (HIPR_TRIANGLE_OPAQUE on all): k_trace_wide8<..., COVERAGE = false>
     bool lean_trace = true;             // HIPR_LEAN_TRACE=0: always the full kernel
+    bool scene_has_textures = true;     // a material references a texture, or the scene brings an environment map / presampled environment light: k_shade<..., TEXTURES = true>
+    bool lean_shade = true;             // HIPR_LEAN_SHADE=0: always the full kernel
     DeviceBuffer triangle_class;        // one byte per triangle for the listing pass (k_classify_hits): bit 0 = its material is coated
     bool any_coated_triangle = false, shade_classes = false;     // HIPR_SHADE_CLASSES=1: coated surface hits listed apart (built and measured in round 4: no gain, profiles/r04_ab_shade_classes.txt)
     DeviceBuffer ggx_rho, dielectric_rho, alpha, sample_offsets, sobol_tables;
@@ -473,7 +475,7 @@ void launch_shade(HiprContext* c, const Wavefront& w, const HiprCameraState& cam
     ShadeLaunch a = {grid_for(alive, SHADE_BLOCK, uint32_t(c->cu_count) * blocks_per_cu), w.stream, c->scene, camera, c->entry, w.path_state(cur), w.hits.as<float4>(), order, w.order_coat.as<uint32_t>(), listed, w.path_state(1 - cur),
                      w.shadow_queue(), c->radiance.as<float4>(), in_count, reinterpret_cast<unsigned long long*>(out_counts), reinterpret_cast<unsigned long long*>(zero_pair),
                      reinterpret_cast<unsigned long long*>(taken_words + COUNT_PAIR_STRIDE * (1 - cur)), split ? w.nee_flags.as<unsigned char>() : nullptr,
-                     c->counters.as<DeviceCounters>()};
+                     c->counters.as<DeviceCounters>(), c->scene_has_textures || !c->lean_shade};
     hipr::launch_shade(c->shading_models, a);
 }
 
@@ -845,6 +847,12 @@ int build_derived_geometry(HiprContext* c, const HiprSceneDesc* s) {
         HIP_TRY(hipStreamSynchronize(st));
     }
     // the listing pass's class of every triangle (k_classify_hits): bit 0 = the material of its instance carries a coat
+    c->scene_has_textures = s->environment != nullptr;
+    for (uint32_t m = 0; m < s->material_count; ++m) {
+        const HiprMaterial& material = s->materials[m];
+        c->scene_has_textures = c->scene_has_textures || material.tint_roughness_texture_ID || material.roughness_texture_ID || material.metallic_texture_ID || material.coverage_texture_ID;
+    }
+    for (uint32_t l = 0; l < s->light_count; ++l) c->scene_has_textures = c->scene_has_textures || (s->lights[l].flags & HIPR_LIGHT_TYPE_MASK) == HIPR_LIGHT_PRESAMPLED_ENVIRONMENT;
     c->any_coated_triangle = false;
     c->all_triangles_opaque = true;
     for (uint32_t t = 0; t < s->triangle_count; ++t) c->all_triangles_opaque = c->all_triangles_opaque && (s->triangles[t].flags & HIPR_TRIANGLE_OPAQUE) != 0;
@@ -927,6 +935,7 @@ int hipr_create(int device_id, HiprContext** out_context) {
     if (const char* v = getenv("HIPR_TRACE_LOG")) c->trace_log = atoi(v) != 0;
     if (const char* v = getenv("HIPR_SHADE_CLASSES")) c->shade_classes = atoi(v) != 0;
     if (const char* v = getenv("HIPR_LEAN_TRACE")) c->lean_trace = atoi(v) != 0;
+    if (const char* v = getenv("HIPR_LEAN_SHADE")) c->lean_shade = atoi(v) != 0;
     if (const char* v = getenv("HIPR_SHADE_ORDERED")) c->shade_ordered = atoi(v) != 0;
     if (const char* v = getenv("HIPR_SHADE_SPLIT")) c->shade_split = atoi(v) != 0;
     if (const char* v = getenv("HIPR_BACKFACE_CULLING")) c->cull_backfaces = atoi(v) != 0;

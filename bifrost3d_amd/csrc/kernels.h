@@ -416,6 +416,12 @@ HD float material_coverage(const DeviceScene& sc, const HiprMaterial& m, f2 uv) 
     return m.coverage * tex;
 }
 
+// the same for a material known to carry no coverage texture (the shade kernel's instantiation for scenes without textures)
+HD float material_coverage_untextured(const HiprMaterial& m) {
+    if (m.flags & HIPR_MATERIAL_CUTOUT) return 1.0f < m.coverage ? 0.0f : 1.0f;
+    return m.coverage;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Presampled environment light (ORS/LightSources/PresampledEnvironmentLightImpl.h:18-41, OR/Utils.h:288-292)
 // ---------------------------------------------------------------------------------------------

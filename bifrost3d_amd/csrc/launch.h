@@ -25,6 +25,7 @@ struct ShadeLaunch {
     unsigned long long* zero_b;
     unsigned char* nee_flags;         // one byte per queue entry: non-null runs the kernel as its two halves (shade_kernel.h SHADE_PART_*)
     DeviceCounters* counters;
+    bool textures;                    // the scene holds textures or an environment map (false: k_shade<..., TEXTURES = false>)
 };
 
 void launch_shade(int shading_models, const ShadeLaunch& args);

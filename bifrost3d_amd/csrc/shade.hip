@@ -8,17 +8,24 @@
 
 namespace hipr {
 
-template <int MODELS, bool AOV>
-static void launch_models(const ShadeLaunch& a) {
+template <int MODELS, bool AOV, bool TEXTURES>
+static void launch_models_with(const ShadeLaunch& a) {
     if (!AOV && a.nee_flags) {     // the two halves, one after the other (shade_kernel.h SHADE_PART_*)
-        hipLaunchKernelGGL((k_shade<MODELS, AOV, SHADE_PART_NEE>), dim3(a.grid), dim3(SHADE_BLOCK), 0, a.stream, a.scene, a.camera, a.entry, a.in, a.hits, a.order, a.order_coat, a.listed, a.out, a.shadows,
-                           a.radiance, a.in_count, a.out_counts, nullptr, nullptr, a.nee_flags, a.counters);
-        hipLaunchKernelGGL((k_shade<MODELS, AOV, SHADE_PART_BSDF>), dim3(a.grid), dim3(SHADE_BLOCK), 0, a.stream, a.scene, a.camera, a.entry, a.in, a.hits, a.order, a.order_coat, a.listed, a.out, a.shadows,
-                           a.radiance, a.in_count, a.out_counts, a.zero_a, a.zero_b, a.nee_flags, a.counters);
+        hipLaunchKernelGGL((k_shade<MODELS, AOV, SHADE_PART_NEE, TEXTURES>), dim3(a.grid), dim3(SHADE_BLOCK), 0, a.stream, a.scene, a.camera, a.entry, a.in, a.hits, a.order, a.order_coat, a.listed, a.out,
+                           a.shadows, a.radiance, a.in_count, a.out_counts, nullptr, nullptr, a.nee_flags, a.counters);
+        hipLaunchKernelGGL((k_shade<MODELS, AOV, SHADE_PART_BSDF, TEXTURES>), dim3(a.grid), dim3(SHADE_BLOCK), 0, a.stream, a.scene, a.camera, a.entry, a.in, a.hits, a.order, a.order_coat, a.listed, a.out,
+                           a.shadows, a.radiance, a.in_count, a.out_counts, a.zero_a, a.zero_b, a.nee_flags, a.counters);
         return;
     }
-    hipLaunchKernelGGL((k_shade<MODELS, AOV, SHADE_PART_ALL>), dim3(a.grid), dim3(SHADE_BLOCK), 0, a.stream, a.scene, a.camera, a.entry, a.in, a.hits, a.order, a.order_coat, a.listed, a.out, a.shadows, a.radiance,
-                       a.in_count, a.out_counts, a.zero_a, a.zero_b, nullptr, a.counters);
+    hipLaunchKernelGGL((k_shade<MODELS, AOV, SHADE_PART_ALL, TEXTURES>), dim3(a.grid), dim3(SHADE_BLOCK), 0, a.stream, a.scene, a.camera, a.entry, a.in, a.hits, a.order, a.order_coat, a.listed, a.out, a.shadows,
+                       a.radiance, a.in_count, a.out_counts, a.zero_a, a.zero_b, nullptr, a.counters);
+}
+
+// Scenes without a texture or an environment map run the instantiation without the samplers (shade_kernel.h TEXTURES); the AOV entries keep the one generic kernel.
+template <int MODELS, bool AOV>
+static void launch_models(const ShadeLaunch& a) {
+    if (!AOV && !a.textures) launch_models_with<MODELS, AOV, false>(a);
+    else launch_models_with<MODELS, AOV, true>(a);
 }
 
 // The kernel is instantiated per set of shading models the uploaded scene uses (bit 0 Default, 1 Diffuse, 2 Transmissive).

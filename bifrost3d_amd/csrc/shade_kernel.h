@@ -51,7 +51,10 @@ struct ShadeGeometry {
     float4 s0, s1, s2, s3, s4, s5;     // shading record (k_build_shade_triangles)
 };
 
-template <int MODELS, bool AOV, int PART = SHADE_PART_ALL>
+// TEXTURES: the scene holds textures or an environment map. Scenes with neither (decided at upload) run the instantiation without the samplers -- four inlined copies of
+// sample_texture, the environment lookups -- which are never executed there but cost the kernel 43 spilled scalar registers (round 4, profiles/r04_ab_shade_without_textures.txt:
+// atrium shade 32.9 -> 31.6 ms per 64 accumulations, Cornell all-Diffuse step -2.8 %).
+template <int MODELS, bool AOV, int PART = SHADE_PART_ALL, bool TEXTURES = true>
 HD void shade_path(const DeviceScene& sc, const HiprCameraState& cam, int entry, const uint32_t* sobol_lds, f3 ro, f3 rd, float bsdf_pdf, f3 throughput, uint32_t bounces,
                    uint32_t last_triangle, uint32_t pixel_hash, uint32_t accumulation, float4 hit, const ShadeGeometry& geo, const HiprMaterial& mp, bool nee_kept_a_sample,
                    ShadeOutput& out) {
@@ -66,7 +69,7 @@ HD void shade_path(const DeviceScene& sc, const HiprCameraState& cam, int entry,
         }
         // miss program (SimpleRGPs.cu:349-362): the tint, or the environment map weighted against the BSDF sample that got here
         f3 environment = mk3(sc.env_tint[0], sc.env_tint[1], sc.env_tint[2]);
-        if (sc.env_map_ID) {
+        if (TEXTURES && sc.env_map_ID) {
             environment = environment_evaluate(sc, rd);
             if (pdf_valid_not_delta(bsdf_pdf)) environment *= balance_heuristic(pdf_value(bsdf_pdf), pdf_value(environment_pdf(sc, rd)));
         }
@@ -105,7 +108,7 @@ HD void shade_path(const DeviceScene& sc, const HiprCameraState& cam, int entry,
     const bool backside_cull = !hit_from_front && !thin_walled && !transmissive;
 
     const f4 bsdf_u = sobol4f_tables(accumulation, pixel_hash, 8u * bounces + 2u, sobol_lds);   // BSDF dimension, always drawn
-    const float coverage = material_coverage(sc, mp, texcoord);
+    const float coverage = TEXTURES ? material_coverage(sc, mp, texcoord) : material_coverage_untextured(mp);
     if (backside_cull || coverage < bsdf_u.w) {
         // rejected hit: same ray, tmin bumped past it, counters untouched (MonteCarlo.cu:159-164)
         if (PART == SHADE_PART_NEE) return;
@@ -147,14 +150,14 @@ HD void shade_path(const DeviceScene& sc, const HiprCameraState& cam, int entry,
 
     // --- material ---------------------------------------------------------------------------------
     f4 tr = {mp.tint[0], mp.tint[1], mp.tint[2], mp.roughness};
-    if (mp.tint_roughness_texture_ID) tr = tr * sample_texture(sc, mp.tint_roughness_texture_ID, texcoord);
-    if (mp.roughness_texture_ID) tr.w *= sample_texture(sc, mp.roughness_texture_ID, texcoord).x;
+    if (TEXTURES && mp.tint_roughness_texture_ID) tr = tr * sample_texture(sc, mp.tint_roughness_texture_ID, texcoord);
+    if (TEXTURES && mp.roughness_texture_ID) tr.w *= sample_texture(sc, mp.roughness_texture_ID, texcoord).x;
     tr = tr * tint_scale;
     MaterialInputs in;
     in.tint = {tr.x, tr.y, tr.z};
     in.roughness = tr.w;
     in.specularity = mp.specularity;
-    in.metallic = mp.metallic_texture_ID ? mp.metallic * sample_texture(sc, mp.metallic_texture_ID, texcoord).x : mp.metallic;
+    in.metallic = (TEXTURES && mp.metallic_texture_ID) ? mp.metallic * sample_texture(sc, mp.metallic_texture_ID, texcoord).x : mp.metallic;
     in.coat = mp.coat / 65535.0f;
     in.coat_roughness = mp.coat_roughness / 65535.0f;
     // PathRegularizationSettings::PDF_scale_at_accumulation (OR/PublicTypes.h:44), per path: a pass may carry several accumulations
@@ -229,7 +232,7 @@ HD void shade_path(const DeviceScene& sc, const HiprCameraState& cam, int entry,
             int li = int(r.z * light_count);
             li = li > light_count - 1 ? light_count - 1 : li;
             LightSample c;
-            if ((sc.lights[li].flags & HIPR_LIGHT_TYPE_MASK) == HIPR_LIGHT_PRESAMPLED_ENVIRONMENT) {   // table lookup, PresampledEnvironmentLightImpl.h:22-27
+            if (TEXTURES && (sc.lights[li].flags & HIPR_LIGHT_TYPE_MASK) == HIPR_LIGHT_PRESAMPLED_ENVIRONMENT) {   // table lookup, PresampledEnvironmentLightImpl.h:22-27
                 int index = int(r.x * float(sc.env_sample_count));
                 index = index > int(sc.env_sample_count) - 1 ? int(sc.env_sample_count) - 1 : index;
                 const float4 a = sc.env_samples[2 * index], b = sc.env_samples[2 * index + 1];
@@ -347,7 +350,7 @@ HD HiprMaterial shade_fetch_material(const DeviceScene& sc, const ShadeInputs& i
 #endif
 constexpr uint32_t SHADE_LDS_LIGHTS = 32;   // light arrays up to this size are copied to LDS (1.5 KB); larger ones are read from global memory
 constexpr int shade_waves_per_simd(int part) { return part == SHADE_PART_ALL ? HIPR_SHADE_WAVES : HIPR_SHADE_SPLIT_WAVES; }
-template <int MODELS, bool AOV, int PART>
+template <int MODELS, bool AOV, int PART, bool TEXTURES = true>
 __global__ __launch_bounds__(SHADE_BLOCK, shade_waves_per_simd(PART)) void k_shade(DeviceScene sc, HiprCameraState cam, int entry, PathState in, const float4* hits, const uint32_t* order_list, const uint32_t* order_coat, const unsigned long long* listed, PathState out,
                                                         ShadowQueue shadows, float4* radiance, const uint32_t* count_ptr, unsigned long long* out_counts,
                                                         unsigned long long* zero_a, unsigned long long* zero_b, unsigned char* nee_flags, DeviceCounters* counters) {
@@ -414,7 +417,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_waves_per_simd(PART)) void k_sha
         if (slot != HIPR_DEAD_SLOT) {
             bool nee_kept_a_sample = false;
             if (PART == SHADE_PART_BSDF && shade_hits_triangle(cur)) nee_kept_a_sample = nee_flags[cur.entry] != 0;   // written for every accepted hit; read by those only
-            shade_path<MODELS, AOV, PART>(sc, cam, entry, s_sobol, mk3(cur.o.x, cur.o.y, cur.o.z), mk3(cur.d.x, cur.d.y, cur.d.z), cur.d.w, mk3(cur.t.x, cur.t.y, cur.t.z),
+            shade_path<MODELS, AOV, PART, TEXTURES>(sc, cam, entry, s_sobol, mk3(cur.o.x, cur.o.y, cur.o.z), mk3(cur.d.x, cur.d.y, cur.d.z), cur.d.w, mk3(cur.t.x, cur.t.y, cur.t.z),
                                           __float_as_uint(cur.t.w), cur.meta.y, pixel_hash, accumulation, cur.hit, geo, mat, nee_kept_a_sample, so);
             if (PART == SHADE_PART_NEE && so.nee_reached) nee_flags[cur.entry] = so.nee_valid ? 1 : 0;
             if (so.add_radiance.x != 0.0f || so.add_radiance.y != 0.0f || so.add_radiance.z != 0.0f) {
