@@ -35,7 +35,7 @@ for name in ("rmse_protocol_480x270.json", "rmse_protocol_160x90.json"):
 if (src / "trace_log.txt").exists():
     shutil.copy(src / "trace_log.txt", profiles / (TAG + "_atrium_trace_log.txt"))
 log = (src / "gpu_tests.log").read_text() if (src / "gpu_tests.log").exists() else ""
-metrics = [l for l in log.splitlines() if re.search(r"IMAGE-METRIC|DENOISER-METRIC|atrium: pixels within", l)]
+metrics = [l for l in log.splitlines() if re.search(r"IMAGE-METRIC|DENOISER-METRIC|STATISTICS|atrium: pixels within", l)]
 if metrics:
     tail = [l for l in log.splitlines() if re.search(r"\d+ passed", l)]
     (profiles / (TAG + "_image_metrics.txt")).write_text("\n".join(metrics + tail) + "\n")
