@@ -372,6 +372,47 @@ def test_frames_do_not_depend_on_the_listing_of_the_hits(oracle_q):
         assert c0[key] == c1[key] == c2[key], key
 
 
+def test_the_kernel_instantiations_without_unreachable_code_render_the_same(oracle_q):
+    """Round 4: scenes whose triangles are all statically opaque are traced by k_trace_wide8<..., COVERAGE = false> (no texture-coverage code), scenes without a texture or an
+    environment map are shaded by k_shade<..., TEXTURES = false> (no samplers). The traversal's results do not depend on the instantiation: with the full trace kernel forced
+    (HIPR_LEAN_TRACE=0) the frame is the same bit for bit and so are the counters. The two shade instantiations are the same source compiled twice with fast-math contraction, so
+    their frames agree to rounding, not to the bit: RMSE far below the equal-seed difference to the oracle; and the scene that does bring a texture (the material scene's floor)
+    must not take the instantiation without samplers -- its image bar against the oracle is test_material_scene_image_matches_oracle's."""
+    import os
+    from bifrost3d_amd.renderer import Context
+    scene = Scene("atrium", param0=20000, param1=3)
+    w, h, batch, passes = 160, 96, 4, 2
+    frames = []
+    for settings in (dict(), dict(HIPR_LEAN_TRACE="0"), dict(HIPR_LEAN_SHADE="0")):
+        saved = {k: os.environ.get(k) for k in ("HIPR_LEAN_TRACE", "HIPR_LEAN_SHADE")}
+        os.environ.update(settings)
+        try:
+            c = Context(0)
+        finally:
+            for k, v in saved.items():
+                if v is None: os.environ.pop(k, None)
+                else: os.environ[k] = v
+        try:
+            c.upload_scene(scene)
+            c.set_frame(w, h, 0, 1, batch)
+            c.reset_counters()
+            for p in range(passes):
+                c.render_pass(scene.camera(w, h, accumulations=p * batch, max_bounce_count=4))
+            c.synchronize()
+            frames.append((c.read_accumulation(), c.counters()))
+        finally:
+            c.close()
+    (lean, c0), (full_trace, c1), (full_shade, c2) = frames
+    assert np.array_equal(lean, full_trace)
+    for key in ("closest_rays", "shadow_rays", "shaded_hits", "camera_rays"):
+        assert c0[key] == c1[key], key
+    difference = float(np.sqrt(np.mean((lean[..., :3] - full_shade[..., :3]) ** 2)))
+    print(f"IMAGE-METRIC lean vs full shade kernel: rmse {difference:.3e} of a mean of {float(lean[..., :3].mean()):.3f}")
+    assert np.isfinite(lean).all() and difference <= 1e-4 * float(lean[..., :3].mean())      # measured 2.5e-8 of a mean of 0.93
+    for key in ("closest_rays", "shadow_rays", "shaded_hits"):
+        assert abs(c0[key] - c2[key]) <= max(4, c0[key] // 1000), key
+
+
 def test_million_triangle_scene(ctx, oracle_q):
     """BASELINE config 5's shape at test size: the 1 M-triangle atrium (seed 2), wide BVH of 250 k nodes. Stage parity bit-exact with
     counters, a small image against the oracle, and at 3840 x 2160 the size-independent properties (finite, every camera path
