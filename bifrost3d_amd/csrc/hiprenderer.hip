@@ -462,8 +462,12 @@ void launch_shade(HiprContext* c, const Wavefront& w, const HiprCameraState& cam
     uint32_t* taken_words = w.queue_counts.as<uint32_t>() + COUNT_PAIR_STRIDE * COUNT_PAIRS;
     if (c->shade_ordered && c->use_persistent() && c->entry == HIPR_ENTRY_PATH_TRACING && alive >= c->shade_ordered_from) {
         unsigned long long* taken = reinterpret_cast<unsigned long long*>(taken_words + COUNT_PAIR_STRIDE * cur);
-        hipLaunchKernelGGL(k_classify_hits, dim3(grid_for(alive, 256u * CLASSIFY_ROUNDS, uint32_t(c->cu_count) * 8u)), dim3(256), 0, w.stream, w.hits.as<float4>(), in_count, w.order.as<uint32_t>(), taken,
-                           c->shade_classes && c->any_coated_triangle ? c->triangle_class.as<unsigned char>() : nullptr, w.order_coat.as<uint32_t>());
+        if (c->shade_classes && c->any_coated_triangle)
+            hipLaunchKernelGGL(k_classify_hits<true>, dim3(grid_for(alive, 256u * CLASSIFY_ROUNDS, uint32_t(c->cu_count) * 8u)), dim3(256), 0, w.stream, w.hits.as<float4>(), in_count, w.order.as<uint32_t>(), taken,
+                               c->triangle_class.as<unsigned char>(), w.order_coat.as<uint32_t>());
+        else
+            hipLaunchKernelGGL(k_classify_hits<false>, dim3(grid_for(alive, 256u * CLASSIFY_ROUNDS, uint32_t(c->cu_count) * 8u)), dim3(256), 0, w.stream, w.hits.as<float4>(), in_count, w.order.as<uint32_t>(), taken,
+                               (const unsigned char*)nullptr, w.order_coat.as<uint32_t>());
         order = w.order.as<uint32_t>();
         listed = taken;
     }

@@ -1039,6 +1039,7 @@ constexpr uint32_t CLASSIFY_ROUNDS = 16;      // rounds of 256 rays a block list
 // MEASURED (profiles/r04_ab_shade_classes.txt): frames bit-identical (tests/test_gpu_coverage.py), atrium shade 17.1 -> 17.3 ms per step: only 4.6 % of the
 // atrium's surface hits are coated (the four coated materials cover little area), so 95 % of the waves did skip the coat code -- and the byte gather per
 // hit in this pass cost more than that code did. Off by default (HIPR_SHADE_CLASSES=1 turns it on); the listing is then round 3's two kinds.
+template <bool CLASSES>
 __global__ __launch_bounds__(256) void k_classify_hits(const float4* __restrict__ hits, const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ order,
                                                        unsigned long long* taken /* [0] low word: plain surface hits listed, high word: others listed; [1]: coated surface hits listed */,
                                                        const unsigned char* __restrict__ triangle_class, uint32_t* __restrict__ order_coat) {
@@ -1056,7 +1057,7 @@ __global__ __launch_bounds__(256) void k_classify_hits(const float4* __restrict_
             const uint32_t i = chunk + r * 256u + threadIdx.x;
             const uint32_t id = i < n ? __float_as_uint(hits[i].w) : HIPR_HIT_MISS;
             const bool surface = i < n && id != HIPR_HIT_MISS && !(id & HIPR_HIT_LIGHT);
-            const bool coated = surface && triangle_class != nullptr && (triangle_class[id] & 1u);
+            const bool coated = CLASSES && surface && (triangle_class[id] & 1u);
             surface_bits |= (surface && !coated) ? (1u << r) : 0u;
             coat_bits |= coated ? (1u << r) : 0u;
             valid_bits |= i < n ? (1u << r) : 0u;
@@ -1068,7 +1069,7 @@ __global__ __launch_bounds__(256) void k_classify_hits(const float4* __restrict_
         if (threadIdx.x == 0) {
             s_base = atomicAdd(taken, (unsigned long long)(s_surface[0] + s_surface[1] + s_surface[2] + s_surface[3]) |
                                       (unsigned long long)(s_other[0] + s_other[1] + s_other[2] + s_other[3]) << 32);
-            const uint32_t block_coats = s_coat[0] + s_coat[1] + s_coat[2] + s_coat[3];
+            const uint32_t block_coats = CLASSES ? s_coat[0] + s_coat[1] + s_coat[2] + s_coat[3] : 0u;
             s_coat_base = block_coats ? uint32_t(atomicAdd(taken + 1, (unsigned long long)block_coats)) : 0u;
         }
         __syncthreads();
@@ -1077,7 +1078,7 @@ __global__ __launch_bounds__(256) void k_classify_hits(const float4* __restrict_
 #pragma unroll
         for (uint32_t r = 0; r < CLASSIFY_ROUNDS; ++r) {
             const bool surface = (surface_bits >> r) & 1u, coated = (coat_bits >> r) & 1u, other = ((valid_bits & ~(surface_bits | coat_bits)) >> r) & 1u;
-            const unsigned long long surface_mask = wave_ballot(surface), other_mask = wave_ballot(other), coat_mask = wave_ballot(coated);
+            const unsigned long long surface_mask = wave_ballot(surface), other_mask = wave_ballot(other), coat_mask = CLASSES ? wave_ballot(coated) : 0ull;
             if (lane == 0) { s_surface[wave] = uint32_t(__popcll(surface_mask)); s_other[wave] = uint32_t(__popcll(other_mask)); s_coat[wave] = uint32_t(__popcll(coat_mask)); }
             __syncthreads();
             uint32_t before_surface = 0, before_other = 0, before_coat = 0, round_surface = 0, round_other = 0, round_coat = 0;
@@ -1087,7 +1088,7 @@ __global__ __launch_bounds__(256) void k_classify_hits(const float4* __restrict_
             }
             const uint32_t i = chunk + r * 256u + threadIdx.x;
             if (surface) order[front + before_surface + uint32_t(__popcll(surface_mask & lt))] = i;
-            if (coated) order_coat[coat_front + before_coat + uint32_t(__popcll(coat_mask & lt))] = i;
+            if (CLASSES && coated) order_coat[coat_front + before_coat + uint32_t(__popcll(coat_mask & lt))] = i;
             if (other) order[n - 1u - (back + before_other + uint32_t(__popcll(other_mask & lt)))] = i;
             front += round_surface; back += round_other; coat_front += round_coat;
             __syncthreads();
