@@ -78,7 +78,7 @@ struct Wavefront {
     hipStream_t stream = nullptr;       // wavefront 0 runs on the context stream, the others on their own
     hipStream_t own_stream = nullptr;
     hipEvent_t shade_done[2] = {nullptr, nullptr}, counts_copied[2] = {nullptr, nullptr}, finished = nullptr;   // by bounce parity: two bounces are in flight
-    DeviceBuffer path[2][4], hits, shadow[3], queue_counts, order, order_coat, nee_flags;   // queue_counts: COUNT_LINES 64 B lines (see there); order: k_classify_hits' listing of a bounce's rays
+    DeviceBuffer path[2][4], hits, shadow[3], queue_counts, order, order_coat, nee_flags, sort_keys[2], sort_order, sort_temp;     // sort_*: ray_sort.hip (HIPR_COHERENCE_SORT=1)   // queue_counts: COUNT_LINES 64 B lines (see there); order: k_classify_hits' listing of a bounce's rays
     uint32_t* host_counts = nullptr;    // pinned: {continuing paths, shadow rays} per bounce parity, [4] staging word
     uint32_t first_slot = 0, n_slots = 0;      // first_slot: the wavefront's phase in the round-robin deal of 64-slot groups (partition_path_slots)
 
@@ -88,7 +88,8 @@ struct Wavefront {
     ShadowQueue shadow_queue() const { return {shadow[0].as<float4>(), shadow[1].as<float4>(), shadow[2].as<float4>()}; }
     void release() {
         for (auto& buffers : path) for (DeviceBuffer& b : buffers) b.release();
-        hits.release(); queue_counts.release(); order.release(); nee_flags.release();
+        hits.release(); queue_counts.release(); order.release(); order_coat.release(); nee_flags.release();
+        sort_keys[0].release(); sort_keys[1].release(); sort_order.release(); sort_temp.release();
         for (DeviceBuffer& b : shadow) b.release();
         for (hipEvent_t e : shade_done) if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : counts_copied) if (e) (void)hipEventDestroy(e);
@@ -127,6 +128,7 @@ struct HiprContext {
     bool scene_has_textures = true;     // a material references a texture, or the scene brings an environment map / presampled environment light: k_shade<..., TEXTURES = true>
     bool lean_shade = true;             // HIPR_LEAN_SHADE=0: always the full kernel
     DeviceBuffer triangle_class;        // one byte per triangle for the listing pass (k_classify_hits): bit 0 = its material is coated
+    bool coherence_sort = false;        // HIPR_COHERENCE_SORT=1: the rays of a fused trace launch are taken by (origin cell, octant), ray_sort.hip (built and measured in round 4: profiles/r04_ab_coherence_sort.txt)
     bool any_coated_triangle = false, shade_classes = false;     // HIPR_SHADE_CLASSES=1: coated surface hits listed apart (built and measured in round 4: no gain, profiles/r04_ab_shade_classes.txt)
     DeviceBuffer ggx_rho, dielectric_rho, alpha, sample_offsets, sobol_tables;
     DeviceScene scene = {};
@@ -363,7 +365,7 @@ void launch_persistent(HiprContext* c, const Wavefront& w, const PathState& in, 
 
 // One persistent launch over the 8-wide tree (wide8_kernels.h). The LDS stack is sized by the tree's height: a ray keeps at most one group per level.
 template <int STACK, int MODE, bool INSTRUMENT>
-void launch_wide8(HiprContext* c, const Wavefront& w, const PathState& in, const uint32_t* closest_count, const uint32_t* shadow_count, uint32_t upper_bound, int bucket) {
+void launch_wide8(HiprContext* c, const Wavefront& w, const PathState& in, const uint32_t* closest_count, const uint32_t* shadow_count, uint32_t upper_bound, int bucket, const uint32_t* sorted = nullptr) {
     int& per_cu = c->wide8_blocks_per_cu[MODE][bucket];
     if (per_cu == 0) {
         int blocks = 0;
@@ -376,6 +378,15 @@ void launch_wide8(HiprContext* c, const Wavefront& w, const PathState& in, const
     // pipelined passes: one block slot per CU stays free, so that the other slot's tail launches find room next to this pass's persistent blocks
     uint32_t grid = uint32_t(c->cu_count) * uint32_t(c->pipelining_now && per_cu > 2 ? per_cu - c->pipeline_spare_blocks : per_cu);
     grid = std::max(1u, std::min(grid, (upper_bound + 63u) / 64u / waves_per_block + 1u));
+    if constexpr (MODE == TRACE_FUSED && !INSTRUMENT) if (sorted) {     // ray_sort.hip listed the launch's rays
+        if (c->all_triangles_opaque && c->lean_trace)
+            hipLaunchKernelGGL((k_trace_wide8<STACK, MODE, INSTRUMENT, false, true>), dim3(grid), dim3(TRACE_BLOCK), 0, w.stream, c->scene, c->wide8, in, w.hits.as<float4>(), w.shadow_queue(),
+                               c->radiance.as<float4>(), closest_count, shadow_count, next_work_counter(c), c->refill_below, c->counters.as<DeviceCounters>(), sorted);
+        else
+            hipLaunchKernelGGL((k_trace_wide8<STACK, MODE, INSTRUMENT, true, true>), dim3(grid), dim3(TRACE_BLOCK), 0, w.stream, c->scene, c->wide8, in, w.hits.as<float4>(), w.shadow_queue(),
+                               c->radiance.as<float4>(), closest_count, shadow_count, next_work_counter(c), c->refill_below, c->counters.as<DeviceCounters>(), sorted);
+        return;
+    }
     // scenes whose triangles are all statically opaque run the kernel without the coverage code (closest-only launches never reach it anyway)
     if (!INSTRUMENT && MODE != TRACE_CLOSEST && c->all_triangles_opaque && c->lean_trace)
         hipLaunchKernelGGL((k_trace_wide8<STACK, MODE, INSTRUMENT, false>), dim3(grid), dim3(TRACE_BLOCK), 0, w.stream, c->scene, c->wide8, in, w.hits.as<float4>(), w.shadow_queue(),
@@ -386,19 +397,19 @@ void launch_wide8(HiprContext* c, const Wavefront& w, const PathState& in, const
 }
 
 template <int MODE, bool INSTRUMENT>
-void launch_persistent_for_stack(HiprContext* c, const Wavefront& w, const PathState& in, const uint32_t* closest_count, const uint32_t* shadow_count, uint32_t upper_bound) {
+void launch_persistent_for_stack(HiprContext* c, const Wavefront& w, const PathState& in, const uint32_t* closest_count, const uint32_t* shadow_count, uint32_t upper_bound, const uint32_t* sorted = nullptr) {
     // LDS stack entries by the worst case of the wide tree. Trees that need up to 32 entries run with 16 in LDS and the rest in a per-lane scratch
     // array (traversals rarely get past 16): 4 KB of LDS per wave instead of 8 lets a sixth wave per SIMD stay resident, and the kernel is bound by
     // the latency of its dependent gathers (atrium, 260 k triangles: 61.0 -> 57.7 ms of trace time per step). Deeper trees (the 10 M triangle
     // atrium) spill often enough that 32 LDS entries + scratch is the faster split (116.7 vs 119.9 ms).
     if (c->use_wide8()) {       // height h: at most h - 1 groups wait on the stack
 #if HIPR_WIDE8_LOW_BUCKET
-        if (c->wide8_height <= 9u) launch_wide8<8, MODE, INSTRUMENT>(c, w, in, closest_count, shadow_count, upper_bound, 3);
+        if (c->wide8_height <= 9u) launch_wide8<8, MODE, INSTRUMENT>(c, w, in, closest_count, shadow_count, upper_bound, 3, sorted);
         else
 #endif
-        if (c->wide8_height <= uint32_t(WIDE8_STACK_SHALLOW) + 1u) launch_wide8<WIDE8_STACK_SHALLOW, MODE, INSTRUMENT>(c, w, in, closest_count, shadow_count, upper_bound, 0);
-        else if (c->wide8_height <= 17u) launch_wide8<16, MODE, INSTRUMENT>(c, w, in, closest_count, shadow_count, upper_bound, 1);
-        else launch_wide8<32, MODE, INSTRUMENT>(c, w, in, closest_count, shadow_count, upper_bound, 2);
+        if (c->wide8_height <= uint32_t(WIDE8_STACK_SHALLOW) + 1u) launch_wide8<WIDE8_STACK_SHALLOW, MODE, INSTRUMENT>(c, w, in, closest_count, shadow_count, upper_bound, 0, sorted);
+        else if (c->wide8_height <= 17u) launch_wide8<16, MODE, INSTRUMENT>(c, w, in, closest_count, shadow_count, upper_bound, 1, sorted);
+        else launch_wide8<32, MODE, INSTRUMENT>(c, w, in, closest_count, shadow_count, upper_bound, 2, sorted);
         return;
     }
 #ifndef HIPR_STACK_MID
@@ -449,7 +460,15 @@ void launch_trace_shadow(HiprContext* c, const Wavefront& w, const uint32_t* cou
 // The closest-hit rays of this bounce and the shadow rays the previous bounce queued, as one persistent launch.
 template <bool INSTRUMENT>
 void launch_trace_fused(HiprContext* c, const Wavefront& w, const PathState& in, const uint32_t* closest_count, const uint32_t* shadow_count, uint32_t upper_bound) {
-    launch_persistent_for_stack<TRACE_FUSED, INSTRUMENT>(c, w, in, closest_count, shadow_count, upper_bound);
+    const uint32_t* sorted = nullptr;
+    if (!INSTRUMENT && c->coherence_sort && c->use_wide8() && w.sort_order.ptr) {
+        const ShadowQueue q = w.shadow_queue();
+        hipr::RaySortLaunch a = {w.stream, in.o_tmin, in.d_pdf, q.o_tmax, q.d_slot, closest_count, shadow_count, std::min(upper_bound, 2u * std::max(w.n_slots, 64u)), {}, {},
+                                 w.sort_keys[0].as<uint16_t>(), w.sort_keys[1].as<uint16_t>(), w.sort_order.as<uint32_t>(), w.sort_temp.ptr, w.sort_temp.bytes};
+        for (int k = 0; k < 3; ++k) { a.grid_min[k] = c->wide8.grid_min[k]; a.cells_per_unit[k] = 16.0f / (c->wide8.grid_cell[k] * 2097152.0f); }
+        if (hipr::launch_ray_sort(a) == 0) sorted = w.sort_order.as<uint32_t>();
+    }
+    launch_persistent_for_stack<TRACE_FUSED, INSTRUMENT>(c, w, in, closest_count, shadow_count, upper_bound, sorted);
 }
 
 void launch_shade(HiprContext* c, const Wavefront& w, const HiprCameraState& camera, int cur, uint32_t alive, const uint32_t* in_count, uint32_t* out_counts, uint32_t* zero_pair) {
@@ -507,6 +526,7 @@ int partition_path_slots(HiprContext* c) {
         if (g >= c->wavefront_count && !second_slot) {   // queues of wavefronts this pass size does not use go back to the allocator
             for (auto& buffers : w.path) for (DeviceBuffer& b : buffers) b.release();
             w.hits.release(); w.order.release(); w.order_coat.release(); w.nee_flags.release();
+            w.sort_keys[0].release(); w.sort_keys[1].release(); w.sort_order.release(); w.sort_temp.release();
             for (DeviceBuffer& b : w.shadow) b.release();
             continue;
         }
@@ -515,6 +535,11 @@ int partition_path_slots(HiprContext* c) {
         r |= w.order.resize(bytes / 4);
         r |= w.order_coat.resize(bytes / 4);
         if (c->shade_split) r |= w.nee_flags.resize(bytes / 16);
+        if (c->coherence_sort) {      // both queues of a fused launch: 2 x n_slots entries
+            const size_t entries = bytes / 16 * 2;
+            r |= w.sort_keys[0].resize(entries * 2); r |= w.sort_keys[1].resize(entries * 2); r |= w.sort_order.resize(entries * 4);
+            r |= w.sort_temp.resize(hipr::ray_sort_temp_bytes(uint32_t(entries)));
+        }
         for (int j = 0; j < 3; ++j) r |= w.shadow[j].resize(bytes);
     }
     const bool two_slots = c->wavefront_count == 1 && c->pipeline_passes && c->partitioned_for == 1;
@@ -938,6 +963,7 @@ int hipr_create(int device_id, HiprContext** out_context) {
     if (const char* v = getenv("HIPR_WAVEFRONTS")) c->wavefront_limit = std::max(0, std::min(MAX_WAVEFRONTS, atoi(v)));
     if (const char* v = getenv("HIPR_TRACE_LOG")) c->trace_log = atoi(v) != 0;
     if (const char* v = getenv("HIPR_SHADE_CLASSES")) c->shade_classes = atoi(v) != 0;
+    if (const char* v = getenv("HIPR_COHERENCE_SORT")) c->coherence_sort = atoi(v) != 0;
     if (const char* v = getenv("HIPR_LEAN_TRACE")) c->lean_trace = atoi(v) != 0;
     if (const char* v = getenv("HIPR_LEAN_SHADE")) c->lean_shade = atoi(v) != 0;
     if (const char* v = getenv("HIPR_SHADE_ORDERED")) c->shade_ordered = atoi(v) != 0;

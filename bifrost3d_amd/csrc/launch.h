@@ -30,6 +30,21 @@ struct ShadeLaunch {
 
 void launch_shade(int shading_models, const ShadeLaunch& args);
 
+// ray_sort.hip: the rays of one fused trace launch listed by (kind, origin cell, direction octant). All pointers are device pointers.
+struct RaySortLaunch {
+    hipStream_t stream;
+    const float4 *closest_o, *closest_d, *shadow_o, *shadow_d;     // the two queues' origins and directions
+    const uint32_t *closest_count, *shadow_count;
+    uint32_t capacity;                       // entries listed: an upper bound of closest + shadow rays known to the host
+    float grid_min[3], cells_per_unit[3];    // 16 cells over the scene's bounds per axis
+    uint16_t *keys, *keys_sorted;            // capacity entries each
+    uint32_t* order;                         // capacity entries: order[i] = index into the closest queue, or closest count + index into the shadow queue
+    void* temp;
+    size_t temp_bytes;                       // ray_sort_temp_bytes(capacity) or more
+};
+size_t ray_sort_temp_bytes(uint32_t capacity);
+int launch_ray_sort(const RaySortLaunch& args);      // 0, or the hipError_t of the sort
+
 // All pointers are device pointers; see k_debug_shading (shade.hip).
 void launch_debug_light(hipStream_t stream, const HiprLight& light, const float* position3, const float* in_n3, int n, int mode, float* out_n8);
 void launch_debug_shading(hipStream_t stream, const DeviceTables& tables, int model, const float* params10, const float* wo_n3, const float* in_n3, int n, int mode,

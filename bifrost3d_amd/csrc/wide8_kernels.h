@@ -57,9 +57,12 @@ HD constexpr int wide8_waves_per_simd(int stack_entries) { return stack_entries 
 // COVERAGE: the scene holds triangles that are not statically opaque (coverage textures, cut-outs, partial coverage): a shadow ray that hits one samples its material's
 // coverage. Scenes without any (the common case; decided at upload) run the instantiation without that code: it is a fifth of the kernel's instructions and, though never
 // executed there, it weighs on the register allocation of the loop around it (profiles/r04_ab_trace_without_coverage.txt).
-template <int STACK, int MODE, bool INSTRUMENT, bool COVERAGE = true>
+// SORTED: the rays are taken in the order of `sorted` (ray_sort.hip: closest-hit rays first, each kind by origin cell and direction octant) instead of queue order;
+// every result is stored where it is in queue order, so nothing downstream sees the difference.
+template <int STACK, int MODE, bool INSTRUMENT, bool COVERAGE = true, bool SORTED = false>
 __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(wide8_waves_per_simd(STACK)))) void k_trace_wide8(DeviceScene sc, Wide8Scene tree, PathState in, float4* hits, ShadowQueue q,
-        float4* radiance, const uint32_t* closest_count_ptr, const uint32_t* shadow_count_ptr, uint32_t* work_counter, int refill_below, DeviceCounters* counters) {
+        float4* radiance, const uint32_t* closest_count_ptr, const uint32_t* shadow_count_ptr, uint32_t* work_counter, int refill_below, DeviceCounters* counters,
+        const uint32_t* sorted = nullptr) {
     __shared__ uint2 s_stack[STACK * TRACE_BLOCK];
     uint2* stack = s_stack + threadIdx.x;
     const uint32_t n_closest = MODE != TRACE_SHADOW ? *closest_count_ptr : 0u;
@@ -141,9 +144,10 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(wid
                     bool dead = false;
                     float4 ro, rdv;
                     if (MODE == TRACE_FUSED) is_shadow = idx >= n_closest;
+                    const uint32_t entry = SORTED ? sorted[idx] : idx;
                     if (is_shadow) {
                         if constexpr (MODE != TRACE_CLOSEST) {
-                            const uint32_t si = idx - n_closest;
+                            const uint32_t si = entry - n_closest;
                             ray_index = si;
                             ro = q.o_tmax[si]; rdv = q.d_slot[si];
                             const float4 rr = q.radiance[si];
@@ -152,15 +156,15 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(wid
                             tmin = 0.0f; tmax = ro.w;
                         }
                     } else if constexpr (MODE != TRACE_SHADOW) {
-                        ray_index = idx;
-                        const uint4 meta = in.meta[idx];
+                        ray_index = entry;
+                        const uint4 meta = in.meta[entry];
                         dead = meta.x == HIPR_DEAD_SLOT;
                         pay_k = meta.y;
-                        ro = in.o_tmin[idx]; rdv = in.d_pdf[idx];
+                        ro = in.o_tmin[entry]; rdv = in.d_pdf[entry];
                         tmin = ro.w; tmax = __builtin_inff();
                         pay_x = pay_y = 0.0f; pay_z = __uint_as_float(HIPR_HIT_MISS);
                     }
-                    if (dead) hits[idx] = make_float4(0, 0, 0, __uint_as_float(HIPR_HIT_MISS));
+                    if (dead) hits[entry] = make_float4(0, 0, 0, __uint_as_float(HIPR_HIT_MISS));
                     else {
                         o = mk3(ro.x, ro.y, ro.z); d = mk3(rdv.x, rdv.y, rdv.z);
                         const f3 sd = {fabsf(d.x) > 1e-20f ? d.x : copysignf(1e-20f, d.x), fabsf(d.y) > 1e-20f ? d.y : copysignf(1e-20f, d.y),
