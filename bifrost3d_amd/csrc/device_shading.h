@@ -571,6 +571,126 @@ HD Shading make_transmissive(const DeviceTables& t, const MaterialInputs& m, flo
     return s;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The terms of the BSDFs above that depend on the outgoing direction and the material only. A hit evaluates its shading four times -- three light
+// candidates and the BSDF sample's other lobes -- with the same wo: the terms are computed once per hit (round 4; the compiler hoisted them out of the
+// candidate loop by itself but computed them again, up to three times, in the sampling code behind it). Same expressions in the same order as the
+// functions they are taken from.
+// ---------------------------------------------------------------------------------------------
+struct OrenNayarTerms {
+    float roughness, B, pi_A;        // evaluate: single = pi_A * (1 + roughness * s_over_t)
+    float m_o, recip_den;            //           multi = m_o * |1 - EF_i| * recip_den, m_o = (ms_rho / pi) * |1 - EF_o|
+    float A;
+    float up, cp;                    // uniform / CLTC mixture
+    float Xx, Xy;                    // cltc::tangents: X; Y = (-X.y, X.x)
+    float a, b, c, d, amb, det, s;   // cltc::coefficients, amb = a - b d, det = c amb, s = (1 + 1 / sqrt(d^2 + 1)) / 2
+};
+HD OrenNayarTerms oren_nayar_terms(float roughness, f3 wo) {
+    OrenNayarTerms t;
+    const float c2 = 2.0f / 3.0f - 28.0f / (15.0f * HIPR_PI);
+    t.roughness = roughness;
+    t.A = 1.0f / (1.0f + HIPR_FON_C1 * roughness);
+    t.B = roughness * t.A;
+    t.pi_A = HIPR_RECIP_PI * t.A;
+    const float EF_o = oren_nayar::E_FON_approx(wo.z, t.A, t.B);
+    const float avg_EF = t.A * (1.0f + c2 * roughness);
+    const float ms_rho = avg_EF / (1.0f - (1.0f - avg_EF));
+    t.m_o = (ms_rho * HIPR_RECIP_PI) * fabsf(1.0f - EF_o);
+    t.recip_den = 1.0f / fmaxf(1.0e-7f, 1.0f - avg_EF);
+    t.up = oren_nayar::uniform_probability(roughness, wo.z);
+    t.cp = 1.0f - t.up;
+    f2 X, Y;
+    cltc::tangents(wo, X, Y);
+    t.Xx = X.x; t.Xy = X.y;
+    cltc::coefficients(wo.z, roughness, t.a, t.b, t.c, t.d);
+    t.amb = t.a - t.b * t.d;
+    t.det = t.c * t.amb;
+    const float vz = 1.0f / sqrtf(t.d * t.d + 1.0f);
+    t.s = 0.5f * (1.0f + vz);
+    return t;
+}
+namespace oren_nayar {
+HD float evaluate(const OrenNayarTerms& t, f3 wo, f3 wi) {
+    const float ci = wi.z, co = wo.z;
+    const float s = dot(wi, wo) - ci * co;
+    const float s_over_t = s > 0.0f ? s / fmaxf(ci, co) : s;
+    const float single = t.pi_A * (1.0f + t.roughness * s_over_t);
+    const float EF_i = E_FON_approx(ci, t.A, t.B);
+    const float multi = t.m_o * fabsf(1.0f - EF_i) * t.recip_den;
+    return single + multi;
+}
+HD float cltc_pdf(const OrenNayarTerms& t, f3 wi_shading) {       // cltc::pdf
+    const f3 wi = {t.Xx * wi_shading.x + t.Xy * wi_shading.y, -t.Xy * wi_shading.x + t.Xx * wi_shading.y, wi_shading.z};
+    const f3 wh = {t.c * (wi.x - t.b * wi.z), t.amb * wi.y, -t.c * (t.d * wi.x - t.a * wi.z)};
+    const float wh2 = dot(wh, wh);
+    return t.det * t.det / pow2(wh2) * fmaxf(wh.z, 0.0f) / (HIPR_PI * t.s);
+}
+HD Response evaluate_with_PDF(f3 albedo, const OrenNayarTerms& t, f3 wo, f3 wi) {
+    return {albedo * evaluate(t, wo, wi), t.up * (0.5f * HIPR_RECIP_PI) + t.cp * cltc_pdf(t, wi)};
+}
+// The direction oren_nayar::sample draws and the CLTC density sample() reports for it (the uniform branch evaluates cltc::pdf, the CLTC branch its own expression).
+HD f3 sample_direction(const OrenNayarTerms& t, f3 wo, f2 u, float& cltc_density) {
+    if (u.x <= t.up) {
+        u.x = u.x / t.up;
+        const float z = u.x;
+        const float r = sqrtf(fmaxf(0.0f, 1.0f - z * z));
+        float s, c;
+        sincos_(HIPR_TWO_PI * u.y, s, c);
+        const f3 dir = {r * c, r * s, z};
+        cltc_density = cltc_pdf(t, dir);
+        return dir;
+    }
+    u.x = (u.x - t.up) / t.cp;
+    const float radius = sqrtf(u.x);
+    float sp, cp;
+    sincos_(2.0f * HIPR_PI * u.y, sp, cp);
+    float x = radius * cp;
+    const float y = radius * sp;
+    x = -lerp(sqrtf(1.0f - y * y), x, t.s);
+    const f3 wh = {x, y, sqrtf(fmaxf(1.0f - (x * x + y * y), 0.0f))};
+    const float pdf_wh = wh.z / (HIPR_PI * t.s);
+    const f3 wi = {t.a * wh.x + t.b * wh.z, t.c * wh.y, t.d * wh.x + wh.z};
+    const float m = length(wi);
+    cltc_density = pdf_wh * m * m * m / t.det;
+    const f3 local = {t.Xx * wi.x - t.Xy * wi.y, t.Xy * wi.x + t.Xx * wi.y, wi.z};
+    return normalize(local);
+}
+} // namespace oren_nayar
+
+struct GGXTerms { float alpha, recip_G1, pdf_scale; };     // recip_G1 = 1 + lambda(alpha, wo); bounded_reflection_pdf = D(h) * pdf_scale
+HD GGXTerms ggx_terms(float alpha, f3 wo) {
+    GGXTerms t;
+    t.alpha = alpha;
+    t.recip_G1 = 1.0f + vndf::lambda(alpha, wo);
+    const f2 ao = alpha * mk2(wo.x, wo.y);
+    const float len2 = dot(ao, ao);
+    const float tt = sqrtf(len2 + wo.z * wo.z);
+    if (wo.z >= 0.0f) {
+        const float s = 1.0f + length(mk2(wo.x, wo.y));
+        const float a2 = alpha * alpha, s2 = s * s;
+        const float k = (1.0f - a2) * s2 / (s2 + a2 * wo.z * wo.z);
+        t.pdf_scale = 1.0f / (2.0f * (k * wo.z + tt));
+    } else
+        t.pdf_scale = (tt - wo.z) / (2.0f * len2);
+    return t;
+}
+namespace ggx_r {
+HD Response evaluate_with_PDF(const GGXTerms& t, f3 specularity, f3 wo, f3 wi) {
+    if (ggx_smooth(t.alpha)) return {mk3(0.0f), pdf_invalid()};
+    const f3 h = normalize(wo + wi);
+    const float D = vndf::D(t.alpha, h);
+    Response r;
+    r.pdf = D * t.pdf_scale;
+    if (wo.z * wi.z <= 0.0f) r.f = mk3(0.0f);
+    else {
+        const float G = 1.0f / (t.recip_G1 + vndf::lambda(t.alpha, wi));
+        const f3 F = schlick_fresnel3(specularity, dot(wo, h));
+        r.f = F * (D * G / (4.0f * wo.z * wi.z));
+    }
+    return r;
+}
+} // namespace ggx_r
+
 // MODELS: bit i set = shading model i occurs in the scene. Kernels are instantiated per mask so a scene that only
 // uses one model (the common case) carries neither the registers nor the branches of the others.
 #define HIPR_HAS_DEFAULT(M) (((M) & 1) != 0)
@@ -653,6 +773,103 @@ HD Sample shading_sample(const Shading& s, f3 wo, f3 u) {
         Response c = ggx_r::evaluate_with_PDF(s.s3, mk3(HIPR_COAT_SPECULARITY), wo, r.dir);
         if (pdf_valid_not_delta(c.pdf)) { r.f += s.s2 * c.f; r.pdf += c.pdf * cp; }
     }
+    return r;
+}
+
+// The outgoing-direction terms of a hit's shading (Diffuse: the Oren-Nayar ones; Default: those and the two GGX lobes'; Transmissive: none).
+struct ShadingTerms { OrenNayarTerms diffuse; GGXTerms specular, coat; };
+template <int MODELS>
+HD ShadingTerms shading_terms(const Shading& s, f3 wo) {
+    ShadingTerms t = {};
+    const bool transmissive = HIPR_HAS_TRANSMISSIVE(MODELS) && (MODELS == 4 || s.model == HIPR_SHADING_TRANSMISSIVE);
+    if (MODELS == 4 || transmissive) return t;
+    t.diffuse = oren_nayar_terms(s.s0, wo);
+    if (HIPR_HAS_DEFAULT(MODELS) && (MODELS == 1 || s.model == HIPR_SHADING_DEFAULT)) {
+        t.specular = ggx_terms(ggx_alpha_from_roughness(s.s0), wo);
+        t.coat = ggx_terms(s.s3, wo);
+    }
+    return t;
+}
+
+template <int MODELS>
+HD Response shading_evaluate_with_PDF(const Shading& s, const ShadingTerms& t, f3 wo, f3 wi) {
+    if (HIPR_HAS_DIFFUSE(MODELS) && (MODELS == 2 || s.model == HIPR_SHADING_DIFFUSE)) {
+        if (wo.z < 0.000001f || wi.z < 0.000001f) return response_none();
+        return oren_nayar::evaluate_with_PDF(s.a, t.diffuse, wo, wi);
+    }
+    if (HIPR_HAS_TRANSMISSIVE(MODELS) && (MODELS == 4 || s.model == HIPR_SHADING_TRANSMISSIVE)) return shading_evaluate_with_PDF<MODELS>(s, wo, wi);
+    if (!HIPR_HAS_DEFAULT(MODELS)) return response_none();
+    if (wo.z < 0.000001f || wi.z < 0.000001f) return response_none();
+    float sp = s.p0 / 65535.0f, cp = s.p1 / 65535.0f;
+    float dp = 1.0f - (s.p0 + s.p1) / 65535.0f;
+    Response d = oren_nayar::evaluate_with_PDF(s.a, t.diffuse, wo, wi);
+    Response g = ggx_r::evaluate_with_PDF(t.specular, s.b, wo, wi);
+    g.f *= s.s1;
+    Response r;
+    r.f = d.f + g.f;
+    r.pdf = d.pdf * dp + g.pdf * sp;
+    if (s.s2 > 0) {
+        Response c = ggx_r::evaluate_with_PDF(t.coat, mk3(HIPR_COAT_SPECULARITY), wo, wi);
+        r.f += s.s2 * c.f;
+        r.pdf += c.pdf * cp;
+    }
+    return r;
+}
+
+// shading_sample with the lobes' evaluations written once: the chosen lobe only draws the DIRECTION (the two GGX lobes through one call), then every lobe is
+// evaluated for it by the code the light candidates use, and the sum is formed in the order the reference forms it (DefaultShading.h sample: the sampled
+// lobe's own response first, then diffuse, specular, coat as far as they were not the one sampled). A wave whose lanes picked different lobes used to run
+// each lobe's evaluation twice.
+template <int MODELS>
+HD Sample shading_sample(const Shading& s, const ShadingTerms& t, f3 wo, f3 u) {
+    if (wo.z < 0.000001f) return sample_none();
+    if (HIPR_HAS_DIFFUSE(MODELS) && (MODELS == 2 || s.model == HIPR_SHADING_DIFFUSE)) {
+        Sample r;
+        float cltc_density;
+        r.dir = oren_nayar::sample_direction(t.diffuse, wo, mk2(u.x, u.y), cltc_density);
+        r.pdf = t.diffuse.up * (0.5f * HIPR_RECIP_PI) + t.diffuse.cp * cltc_density;
+        r.f = s.a * oren_nayar::evaluate(t.diffuse, wo, r.dir);
+        return r;
+    }
+    if (HIPR_HAS_TRANSMISSIVE(MODELS) && (MODELS == 4 || s.model == HIPR_SHADING_TRANSMISSIVE)) return shading_sample<MODELS>(s, wo, u);
+    if (!HIPR_HAS_DEFAULT(MODELS)) return sample_none();
+    float sp = s.p0 / 65535.0f, cp = s.p1 / 65535.0f;
+    float dp = 1 - cp - sp;
+    bool sample_coat = u.z < cp;
+    bool sample_specular = !sample_coat && u.z < (cp + sp);
+    bool sample_diffuse = !sample_coat && !sample_specular;
+    f2 u2 = {u.x, u.y};
+    Sample r;
+    float cltc_density = 0.0f;
+    if (sample_diffuse) r.dir = oren_nayar::sample_direction(t.diffuse, wo, u2, cltc_density);
+    else {
+        const float alpha = sample_specular ? t.specular.alpha : t.coat.alpha;
+        const float scale = sample_specular ? s.s1 : s.s2, probability = sample_specular ? sp : cp;
+        if (ggx_smooth(alpha)) {        // ggx_r::sample's mirror reflection: a delta PDF, returned as it is
+            r.dir = {-wo.x, -wo.y, wo.z};
+            r.pdf = -1.0f * probability;
+            r.f = schlick_fresnel3(sample_specular ? s.b : mk3(HIPR_COAT_SPECULARITY), fabsf(wo.z)) / fabsf(r.dir.z) * scale;
+            return r;
+        }
+        r.dir = vndf::bounded_sample_reflection(alpha, wo, u2);
+        if (r.dir.z < 0.0f) return sample_none();
+    }
+    Response d = oren_nayar::evaluate_with_PDF(s.a, t.diffuse, wo, r.dir);
+    if (sample_diffuse) d.pdf = t.diffuse.up * (0.5f * HIPR_RECIP_PI) + t.diffuse.cp * cltc_density;
+    Response g = ggx_r::evaluate_with_PDF(t.specular, s.b, wo, r.dir);
+    g.f *= s.s1;
+    Response c = response_none();
+    if (s.s2 > 0) {
+        c = ggx_r::evaluate_with_PDF(t.coat, mk3(HIPR_COAT_SPECULARITY), wo, r.dir);
+        c.f *= s.s2;
+    }
+    r.f = sample_diffuse ? d.f : (sample_specular ? g.f : c.f);
+    r.pdf = sample_diffuse ? d.pdf * dp : (sample_specular ? g.pdf * sp : c.pdf * cp);
+    if (!pdf_valid_not_delta(r.pdf))
+        return r;
+    if (!sample_diffuse && pdf_valid_not_delta(d.pdf)) { r.f += d.f; r.pdf += d.pdf * dp; }
+    if (!sample_specular && pdf_valid_not_delta(g.pdf)) { r.f += g.f; r.pdf += g.pdf * sp; }
+    if (!sample_coat && s.s2 > 0 && pdf_valid_not_delta(c.pdf)) { r.f += c.f; r.pdf += c.pdf * cp; }
     return r;
 }
 

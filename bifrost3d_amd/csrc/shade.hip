@@ -60,11 +60,12 @@ __global__ void k_debug_shading(DeviceTables tables, int model, const float* par
     else if (model == HIPR_SHADING_TRANSMISSIVE) s = make_transmissive(tables, m, cos_theta, hint);
     else s = make_default(tables, m, cos_theta, hint);
     float* o = out_n7 + 7 * i;
+    const ShadingTerms terms = shading_terms<7>(s, wo);     // the forms the shade kernel calls
     if (mode == 0) {
-        const Sample r = shading_sample<7>(s, wo, in);
+        const Sample r = shading_sample<7>(s, terms, wo, in);
         o[0] = r.f.x; o[1] = r.f.y; o[2] = r.f.z; o[3] = r.pdf; o[4] = r.dir.x; o[5] = r.dir.y; o[6] = r.dir.z;
     } else {
-        const Response r = shading_evaluate_with_PDF<7>(s, wo, in);
+        const Response r = shading_evaluate_with_PDF<7>(s, terms, wo, in);
         o[0] = r.f.x; o[1] = r.f.y; o[2] = r.f.z; o[3] = r.pdf; o[4] = o[5] = o[6] = 0.0f;
     }
 }

@@ -218,6 +218,12 @@ HD void shade_path(const DeviceScene& sc, const HiprCameraState& cam, int entry,
     }
 
     if (PART != SHADE_PART_NEE) out.add_radiance = throughput * emission * mk3(mp.emission[0], mp.emission[1], mp.emission[2]);
+#ifndef HIPR_SHADE_TERMS
+#define HIPR_SHADE_TERMS 1      // 0: round 3's evaluation and sampling functions (A/B: profiles/r04_ab_shade_terms.txt)
+#endif
+#if HIPR_SHADE_TERMS
+    const ShadingTerms terms = shading_terms<MODELS>(shading, wo);      // what the evaluations below share: the part that depends on wo only
+#endif
 
     // --- next event estimation: streaming RIS over the light candidates (MonteCarlo.cu:91-123) ------
     LightSample kept = light_sample_none();
@@ -241,7 +247,11 @@ HD void shade_path(const DeviceScene& sc, const HiprCameraState& cam, int entry,
                 c = light_sample_radiance(sc.lights[li], position, mk2(r.x, r.y));
             c.radiance *= float(light_count);
             c.radiance *= fabsf(dot(tbn.n, c.dir)) / pdf_value(c.pdf);
+#if HIPR_SHADE_TERMS
+            Response f = shading_evaluate_with_PDF<MODELS>(shading, terms, wo, to_local(tbn, c.dir));
+#else
             Response f = shading_evaluate_with_PDF<MODELS>(shading, wo, to_local(tbn, c.dir));
+#endif
             if (!pdf_is_delta(c.pdf)) c.radiance *= balance_heuristic(pdf_value(c.pdf), pdf_value(f.pdf));
             else f.f = min3(f.f, mk3(32.0f));
             c.radiance *= f.f;
@@ -265,7 +275,11 @@ HD void shade_path(const DeviceScene& sc, const HiprCameraState& cam, int entry,
     const bool light_sample_kept = PART == SHADE_PART_BSDF ? nee_kept_a_sample : pdf_is_valid(kept.pdf);
 
     // --- BSDF sampling (MonteCarlo.cu:204-232) ---------------------------------------------------
+#if HIPR_SHADE_TERMS
+    const Sample bs = shading_sample<MODELS>(shading, terms, wo, mk3(bsdf_u.x, bsdf_u.y, bsdf_u.z));
+#else
     const Sample bs = shading_sample<MODELS>(shading, wo, mk3(bsdf_u.x, bsdf_u.y, bsdf_u.z));
+#endif
     const bool is_reflection = bs.dir.z >= 0;
     f3 direction = to_world(tbn, bs.dir);
     float new_pdf = bs.pdf;
