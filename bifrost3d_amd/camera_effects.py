@@ -124,7 +124,14 @@ class CameraEffects:
 
     def upload(self, half_pixels: np.ndarray):
         assert half_pixels.dtype == np.float16 and half_pixels.ndim == 3 and half_pixels.shape[2] == 4
-        return self.torch.from_numpy(np.ascontiguousarray(half_pixels)).to(self.device)
+        frame = self.torch.from_numpy(np.ascontiguousarray(half_pixels)).to(self.device)
+        self._torch_stream_done()
+        return frame
+
+    def _torch_stream_done(self):
+        """The effects run on a stream of their own (hipStreamNonBlocking): what torch queued on ITS stream -- an upload, the fill of a fresh target -- has to be
+        complete before a kernel of that stream reads or overwrites the memory."""
+        self.torch.cuda.current_stream(self.device).synchronize()
 
     def view(self, frame, viewport=None) -> FrameView:
         rows, pitch = frame.shape[0], frame.shape[1]
@@ -175,8 +182,10 @@ class CameraEffects:
         dtype = {TARGET_RGBA16F: self.torch.float16, TARGET_RGBA32F: self.torch.float32, TARGET_RGBA8_SRGB: self.torch.uint8}[target_format]
         if target is None:
             target = self.torch.zeros((view.viewport.height + target_offset[1], view.viewport.width + target_offset[0], 4), dtype=dtype, device=self.device)
+        self._torch_stream_done()       # the zero fill above must not land on top of the result
         self._check(self.lib.hipr_camera_effects_process(self.handle, C.byref(settings), delta_time, C.byref(view), target.data_ptr(), target_format,
                                                          target.shape[1], target.shape[0], target_offset[0], target_offset[1]), "process")
+        self._check(self.lib.hipr_camera_effects_synchronize(self.handle), "synchronize")       # the caller goes on with the tensor on torch's stream
         return target
 
     def synchronize(self):

@@ -85,6 +85,7 @@ class Denoiser:
     def process(self, noisy, albedo, out, width: int, height: int, settings: Settings | None = None, update_filtered: bool = True, show: int = SHOW_FILTERED):
         """One frame of the backend: torch half4 frames (rows, pitch, 4) on the device; writes `out` in place."""
         settings = settings or default_settings(self.lib)
+        self.torch.cuda.current_stream(self.device).synchronize()      # the frames were filled on torch's stream; the backend runs on its own (hipStreamNonBlocking)
         self._check(self.lib.hipr_denoiser_process(self.handle, C.byref(settings), noisy.data_ptr(), noisy.shape[1], albedo.data_ptr(), albedo.shape[1], width, height,
                                                    int(update_filtered), show, out.data_ptr(), out.shape[1]), "hipr_denoiser_process")
         self._check(self.lib.hipr_denoiser_synchronize(self.handle), "hipr_denoiser_synchronize")
