@@ -83,7 +83,7 @@ struct Wavefront {
     uint32_t first_slot = 0, n_slots = 0;      // first_slot: the wavefront's phase in the round-robin deal of 64-slot groups (partition_path_slots)
 
     PathState path_state(int which) const {
-        return {path[which][0].as<float4>(), path[which][1].as<float4>(), path[which][2].as<float4>(), path[which][3].as<uint4>()};
+        return {path[which][0].as<float4>(), path[which][1].as<float4>(), path[which][2].as<float4>(), path[which][3].as<uint2>()};
     }
     ShadowQueue shadow_queue() const { return {shadow[0].as<float4>(), shadow[1].as<float4>(), shadow[2].as<float4>()}; }
     void release() {
@@ -495,7 +495,7 @@ void launch_shade(HiprContext* c, const Wavefront& w, const HiprCameraState& cam
     // kernel loses (Cornell 18 390 -> 17 194 Mrays/s)
     const bool split = c->shade_split && c->entry == HIPR_ENTRY_PATH_TRACING && c->scene.light_count != 0 && w.nee_flags.ptr;
     const uint32_t blocks_per_cu = c->shade_blocks_per_cu > 0 ? uint32_t(c->shade_blocks_per_cu) : (split ? uint32_t(HIPR_SHADE_SPLIT_WAVES) : (c->shading_models == 2 ? 2u : 3u));
-    ShadeLaunch a = {grid_for(alive, SHADE_BLOCK, uint32_t(c->cu_count) * blocks_per_cu), w.stream, c->scene, camera, c->entry, w.path_state(cur), w.hits.as<float4>(), order, w.order_coat.as<uint32_t>(), listed, w.path_state(1 - cur),
+    ShadeLaunch a = {grid_for(alive, SHADE_BLOCK, uint32_t(c->cu_count) * blocks_per_cu), w.stream, c->scene, camera, c->frame, c->entry, w.path_state(cur), w.hits.as<float4>(), order, w.order_coat.as<uint32_t>(), listed, w.path_state(1 - cur),
                      w.shadow_queue(), c->radiance.as<float4>(), in_count, reinterpret_cast<unsigned long long*>(out_counts), reinterpret_cast<unsigned long long*>(zero_pair),
                      reinterpret_cast<unsigned long long*>(taken_words + COUNT_PAIR_STRIDE * (1 - cur)), split ? w.nee_flags.as<unsigned char>() : nullptr,
                      c->counters.as<DeviceCounters>(), c->scene_has_textures || !c->lean_shade};
@@ -530,7 +530,7 @@ int partition_path_slots(HiprContext* c) {
             for (DeviceBuffer& b : w.shadow) b.release();
             continue;
         }
-        for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) r |= w.path[i][j].resize(bytes);
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) r |= w.path[i][j].resize(j == 3 ? bytes / 2 : bytes);      // [3]: the 8-byte meta records
         r |= w.hits.resize(bytes);
         r |= w.order.resize(bytes / 4);
         r |= w.order_coat.resize(bytes / 4);
@@ -552,6 +552,8 @@ int partition_path_slots(HiprContext* c) {
     if (two_slots) r |= c->radiance_other.resize(slots * 16);
     return r;
 }
+
+void set_frame_divisors(FrameInfo& f) { f.by_samples_per_pass = make_divisor(f.samples_per_pass); f.by_tiles_x = make_divisor(f.tiles_x); }
 
 int check_context(HiprContext* c) {
     if (!c) return fail(HIPR_ERROR_INVALID_ARGUMENT, "null context");
@@ -1209,6 +1211,7 @@ int hipr_set_frame(HiprContext* c, const HiprFrameDesc* f) {
     fi.tile_phase = f->tile_phase; fi.tile_stride = f->tile_stride;
     fi.owned_tiles = (fi.tiles_total + f->tile_stride - 1 - f->tile_phase) / f->tile_stride;
     fi.samples_per_pass = f->samples_per_pass;
+    set_frame_divisors(fi);
     const uint64_t slots = uint64_t(fi.owned_tiles) * 64u * fi.samples_per_pass;
     if (slots == 0 || slots > 0x7FFFFFFFull) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_set_frame: %llu path slots per pass", (unsigned long long)slots);
     c->frame = fi;
@@ -1271,6 +1274,7 @@ int hipr_set_samples_per_pass(HiprContext* c, uint32_t samples_per_pass) {
     if (int finish_status = finish_all(c)) return finish_status;      // the queues may move
     c->collect_times();
     c->frame.samples_per_pass = samples_per_pass;
+    set_frame_divisors(c->frame);
     if (partition_path_slots(c)) return HIPR_ERROR_OUT_OF_MEMORY;
     return HIPR_OK;
 }
@@ -1619,12 +1623,13 @@ int hipr_debug_generate(HiprContext* c, const HiprCameraState* camera, uint32_t 
     if (!camera || !c->frame_ready) return fail(HIPR_ERROR_NOT_READY, "hipr_debug_generate needs a camera and a frame");
     FrameInfo f = c->frame;
     f.samples_per_pass = 1;
+    set_frame_divisors(f);
     const uint32_t n = f.owned_tiles * 64;
     HiprCameraState cam = *camera;
     cam.accumulations = accumulation;
     DeviceBuffer bo, bd, bt, bm, br;
     if (bo.resize(size_t(n) * 16) | bd.resize(size_t(n) * 16) | bt.resize(size_t(n) * 16) | bm.resize(size_t(n) * 16) | br.resize(size_t(n) * 16)) return HIPR_ERROR_OUT_OF_MEMORY;
-    const PathState out = {bo.as<float4>(), bd.as<float4>(), bt.as<float4>(), bm.as<uint4>()};
+    const PathState out = {bo.as<float4>(), bd.as<float4>(), bt.as<float4>(), bm.as<uint2>()};
     hipLaunchKernelGGL(k_generate, dim3((n + 255) / 256), dim3(256), 0, c->stream, f, cam, out, br.as<float4>(), 0u, 1u, n);
     if (int finish_status = finish_all(c)) return finish_status;
     if (out_origin_tmin) HIP_TRY(hipMemcpy(out_origin_tmin, bo.ptr, size_t(n) * 16, hipMemcpyDeviceToHost));
@@ -1758,14 +1763,14 @@ int hipr_debug_trace_closest(HiprContext* c, const float* rays, const uint32_t* 
     if (n == 0) return HIPR_OK;
     std::vector<float> o, d;
     debug_prepare_rays(c, rays, n, o, d);
-    std::vector<uint32_t> meta(size_t(n) * 4);
-    for (uint32_t i = 0; i < n; ++i) { meta[4 * i] = i; meta[4 * i + 1] = skip ? skip[i] : HIPR_NO_TRIANGLE; meta[4 * i + 2] = 0; meta[4 * i + 3] = 0; }
+    std::vector<uint32_t> meta(size_t(n) * 2);
+    for (uint32_t i = 0; i < n; ++i) { meta[2 * i] = i; meta[2 * i + 1] = skip ? skip[i] : HIPR_NO_TRIANGLE; }
     DeviceBuffer bo, bd, bm, bh, bc;
     int r = bo.upload(o.data(), o.size() * 4, c->stream) | bd.upload(d.data(), d.size() * 4, c->stream) | bm.upload(meta.data(), meta.size() * 4, c->stream) |
             bh.resize(size_t(n) * 16) | bc.upload(&n, 4, c->stream);
     if (r) return HIPR_ERROR_OUT_OF_MEMORY;
     HIP_TRY(hipMemsetAsync(c->counters.ptr, 0, sizeof(DeviceCounters), c->stream));
-    PathState in = {bo.as<float4>(), bd.as<float4>(), nullptr, bm.as<uint4>()};
+    PathState in = {bo.as<float4>(), bd.as<float4>(), nullptr, bm.as<uint2>()};
     Wavefront w;   // borrows the buffers above; never released
     w.stream = c->stream;
     w.hits = bh;

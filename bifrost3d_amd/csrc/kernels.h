@@ -17,6 +17,7 @@
 #pragma once
 
 #include "device_shading.h"
+#include "fast_divide.h"
 
 namespace hipr {
 
@@ -83,7 +84,7 @@ struct PathState {
     float4* o_tmin;       // origin.xyz, tmin
     float4* d_pdf;        // direction.xyz, bsdf pdf
     float4* thr_bounces;  // throughput.xyz, bits(bounces)
-    uint4* meta;          // slot, last accepted triangle, pixel hash, accumulation
+    uint2* meta;          // slot, last accepted triangle (the pixel's hash and the accumulation follow from the slot: path_sample_of_slot)
 };
 
 struct ShadowQueue {
@@ -97,6 +98,7 @@ struct ShadowQueue {
 #endif
 struct FrameInfo {
     uint32_t width, height, tiles_x, tiles_total, tile_phase, tile_stride, owned_tiles, samples_per_pass;
+    Divisor by_samples_per_pass, by_tiles_x;     // fast_divide.h; set with the fields they divide by (hiprenderer.hip set_frame_divisors)
 };
 
 struct DeviceCounters {
@@ -119,9 +121,25 @@ HD uint32_t xcd_chunk(uint32_t block, uint32_t grid) {
 HD bool owned_pixel(const FrameInfo& f, uint32_t k, uint32_t& x, uint32_t& y) {
     uint32_t tile = (k >> 6) * f.tile_stride + f.tile_phase;
     uint32_t lane = k & 63u;
-    x = (tile % f.tiles_x) * 8u + (lane & 7u);
-    y = (tile / f.tiles_x) * 8u + (lane >> 3);
+    const uint32_t row = divide(tile, f.by_tiles_x);
+    x = (tile - row * f.tiles_x) * 8u + (lane & 7u);
+    y = row * 8u + (lane >> 3);
     return tile < f.tiles_total && x < f.width && y < f.height;
+}
+
+// Path slot p <-> (owned pixel k, sample s of the pass), and what the samplers need of it: the pixel's hash and the accumulation the sample belongs to. The queue
+// entries carried both until round 4 (16 B more read and written per entry and bounce); they cost ~25 integer instructions to state again.
+HD void path_sample_of_slot(const FrameInfo& f, const HiprCameraState& cam, uint32_t slot, uint32_t& pixel_hash, uint32_t& accumulation) {
+#if HIPR_PIXEL_MAJOR_SLOTS
+    const uint32_t k = divide(slot, f.by_samples_per_pass), s = slot - k * f.samples_per_pass;
+#else
+    const uint32_t per_sample = f.owned_tiles * 64u;
+    const uint32_t s = slot / per_sample, k = slot - s * per_sample;
+#endif
+    uint32_t x, y;
+    (void)owned_pixel(f, k, x, y);
+    pixel_hash = pcg2d_x(x, y);
+    accumulation = cam.accumulations + s;
 }
 
 HD void camera_ray(const HiprCameraState& cam, uint32_t x, uint32_t y, uint32_t width, uint32_t height, uint32_t accumulation,
@@ -158,7 +176,7 @@ __global__ __launch_bounds__(256) void k_generate(FrameInfo frame, HiprCameraSta
     // the other kind of item), fetch the same nodes, and shade one material -- and the radiance slots of a pixel are one contiguous run for k_accumulate.
     // Round 3's sample-major order (p = s * owned pixels + k) put 64 neighbouring PIXELS of one sample in a wave. profiles/r04_ab_slot_order.txt.
 #if HIPR_PIXEL_MAJOR_SLOTS
-    uint32_t k = p / frame.samples_per_pass, s = p - k * frame.samples_per_pass;
+    uint32_t k = divide(p, frame.by_samples_per_pass), s = p - k * frame.samples_per_pass;
 #else
     uint32_t per_sample = frame.owned_tiles * 64u;
     uint32_t s = p / per_sample, k = p - s * per_sample;
@@ -172,7 +190,7 @@ __global__ __launch_bounds__(256) void k_generate(FrameInfo frame, HiprCameraSta
     out.o_tmin[i] = make_float4(o.x, o.y, o.z, 0.0f);
     out.d_pdf[i] = make_float4(d.x, d.y, d.z, -1.0f);           // bsdf_PDF = delta_dirac(1)
     out.thr_bounces[i] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(0u));
-    out.meta[i] = make_uint4(valid ? p : HIPR_DEAD_SLOT, HIPR_NO_TRIANGLE, pixel_hash, accumulation);
+    out.meta[i] = make_uint2(valid ? p : HIPR_DEAD_SLOT, HIPR_NO_TRIANGLE);
     radiance[p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
@@ -355,7 +373,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(DeviceScene sc, P
     for (uint32_t c = xcd_chunk(blockIdx.x, gridDim.x); c < chunks; c += ((gridDim.x + 7u) >> 3) * 8u) {
         uint32_t i = c * TRACE_BLOCK + threadIdx.x;
         if (i >= n) continue;
-        uint4 meta = in.meta[i];
+        uint2 meta = in.meta[i];
         if (meta.x == HIPR_DEAD_SLOT) { hits[i] = make_float4(0, 0, 0, __uint_as_float(HIPR_HIT_MISS)); continue; }
         float4 o = in.o_tmin[i], d = in.d_pdf[i];
         hits[i] = closest_hit(sc, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), o.w, meta.y, s_stack + threadIdx.x, nodes, tris);
@@ -533,7 +551,7 @@ __global__ __launch_bounds__(256) void k_trace_closest_small(DeviceScene sc, Pat
     const uint32_t n = *count_ptr;
     uint32_t tris = 0;
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-        const uint4 meta = in.meta[i];
+        const uint2 meta = in.meta[i];
         if (meta.x == HIPR_DEAD_SLOT) { hits[i] = make_float4(0, 0, 0, __uint_as_float(HIPR_HIT_MISS)); continue; }
         const float4 ro = in.o_tmin[i], rd = in.d_pdf[i];
         const f3 o = mk3(ro.x, ro.y, ro.z), d = mk3(rd.x, rd.y, rd.z);
@@ -769,7 +787,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(tra
                         }
                     } else if constexpr (MODE != TRACE_SHADOW) {
                         ray_index = idx;
-                        const uint4 meta = in.meta[idx];
+                        const uint2 meta = in.meta[idx];
                         dead = meta.x == HIPR_DEAD_SLOT;
                         pay_k = meta.y;
                         ro = in.o_tmin[idx]; rdv = in.d_pdf[idx];

@@ -10,6 +10,7 @@ struct ShadeLaunch {
     hipStream_t stream;
     DeviceScene scene;
     HiprCameraState camera;
+    FrameInfo frame;           // path slot -> pixel and sample (path_sample_of_slot)
     int entry;                 // HIPR_ENTRY_*
     PathState in;
     const float4* hits;

@@ -11,13 +11,13 @@ namespace hipr {
 template <int MODELS, bool AOV, bool TEXTURES>
 static void launch_models_with(const ShadeLaunch& a) {
     if (!AOV && a.nee_flags) {     // the two halves, one after the other (shade_kernel.h SHADE_PART_*)
-        hipLaunchKernelGGL((k_shade<MODELS, AOV, SHADE_PART_NEE, TEXTURES>), dim3(a.grid), dim3(SHADE_BLOCK), 0, a.stream, a.scene, a.camera, a.entry, a.in, a.hits, a.order, a.order_coat, a.listed, a.out,
+        hipLaunchKernelGGL((k_shade<MODELS, AOV, SHADE_PART_NEE, TEXTURES>), dim3(a.grid), dim3(SHADE_BLOCK), 0, a.stream, a.scene, a.camera, a.frame, a.entry, a.in, a.hits, a.order, a.order_coat, a.listed, a.out,
                            a.shadows, a.radiance, a.in_count, a.out_counts, nullptr, nullptr, a.nee_flags, a.counters);
-        hipLaunchKernelGGL((k_shade<MODELS, AOV, SHADE_PART_BSDF, TEXTURES>), dim3(a.grid), dim3(SHADE_BLOCK), 0, a.stream, a.scene, a.camera, a.entry, a.in, a.hits, a.order, a.order_coat, a.listed, a.out,
+        hipLaunchKernelGGL((k_shade<MODELS, AOV, SHADE_PART_BSDF, TEXTURES>), dim3(a.grid), dim3(SHADE_BLOCK), 0, a.stream, a.scene, a.camera, a.frame, a.entry, a.in, a.hits, a.order, a.order_coat, a.listed, a.out,
                            a.shadows, a.radiance, a.in_count, a.out_counts, a.zero_a, a.zero_b, a.nee_flags, a.counters);
         return;
     }
-    hipLaunchKernelGGL((k_shade<MODELS, AOV, SHADE_PART_ALL, TEXTURES>), dim3(a.grid), dim3(SHADE_BLOCK), 0, a.stream, a.scene, a.camera, a.entry, a.in, a.hits, a.order, a.order_coat, a.listed, a.out, a.shadows,
+    hipLaunchKernelGGL((k_shade<MODELS, AOV, SHADE_PART_ALL, TEXTURES>), dim3(a.grid), dim3(SHADE_BLOCK), 0, a.stream, a.scene, a.camera, a.frame, a.entry, a.in, a.hits, a.order, a.order_coat, a.listed, a.out, a.shadows,
                        a.radiance, a.in_count, a.out_counts, a.zero_a, a.zero_b, nullptr, a.counters);
 }
 

@@ -55,9 +55,11 @@ struct ShadeGeometry {
 // sample_texture, the environment lookups -- which are never executed there but cost the kernel 43 spilled scalar registers (round 4, profiles/r04_ab_shade_without_textures.txt:
 // atrium shade 32.9 -> 31.6 ms per 64 accumulations, Cornell all-Diffuse step -2.8 %).
 template <int MODELS, bool AOV, int PART = SHADE_PART_ALL, bool TEXTURES = true>
-HD void shade_path(const DeviceScene& sc, const HiprCameraState& cam, int entry, const uint32_t* sobol_lds, f3 ro, f3 rd, float bsdf_pdf, f3 throughput, uint32_t bounces,
+HD void shade_path(const DeviceScene& sc, const HiprCameraState& cam, int entry, const uint32_t* sobol_lds, f3 ro, const float4* origin_of_entry, f3 rd, float bsdf_pdf, f3 throughput, uint32_t bounces,
                    uint32_t last_triangle, uint32_t pixel_hash, uint32_t accumulation, float4 hit, const ShadeGeometry& geo, const HiprMaterial& mp, bool nee_kept_a_sample,
                    ShadeOutput& out) {
+    // `ro`: the ray's origin where k_shade fetched it -- rays that did not hit a triangle, and every ray of the AOV entries. A surface hit is shaded from its
+    // barycentrics and never reads it, except the rare rejected hit that sends the same ray on: that one loads it here (origin_of_entry).
     out.continues = out.shadow = out.shaded = out.nee_reached = out.nee_valid = false;
     out.add_radiance = mk3(0.0f);
     const uint32_t id = __float_as_uint(hit.w);
@@ -113,6 +115,7 @@ HD void shade_path(const DeviceScene& sc, const HiprCameraState& cam, int entry,
         // rejected hit: same ray, tmin bumped past it, counters untouched (MonteCarlo.cu:159-164)
         if (PART == SHADE_PART_NEE) return;
         out.continues = true;
+        if (!AOV) { const float4 o4 = *origin_of_entry; ro = mk3(o4.x, o4.y, o4.z); }
         out.o = ro; out.d = rd; out.tmin = nextafterf(hit.x, __builtin_inff()); out.bsdf_pdf = bsdf_pdf;
         out.throughput = throughput; out.bounces = bounces; out.last_triangle = last_triangle;
         return;
@@ -306,18 +309,18 @@ HD void shade_path(const DeviceScene& sc, const HiprCameraState& cam, int entry,
 // dependent gathers of a hit (path state -> hit -> triangle / record -> material) are thereby off the critical path.
 struct ShadeInputs {
     uint32_t entry;        // the queue entry (HIPR_DEAD_SLOT: none)
-    uint4 meta;            // slot, last accepted triangle, pixel hash, accumulation
-    float4 o, d, t, hit;   // origin + tmin, direction + pdf, throughput + bounces, (t, u, v, id)
+    uint2 meta;            // slot, last accepted triangle
+    float4 o, d, t, hit;   // origin + tmin (fetched with the geometry, and only where it is used: shade_fetch_origin), direction + pdf, throughput + bounces, (t, u, v, id)
 };
 
 // `i`: the queue entry, or HIPR_DEAD_SLOT for none (past the end of the queue).
 HD ShadeInputs shade_fetch_inputs(const PathState& in, const float4* hits, uint32_t i) {
     ShadeInputs r;
     r.entry = i;
-    r.meta = make_uint4(HIPR_DEAD_SLOT, 0u, 0u, 0u);
+    r.meta = make_uint2(HIPR_DEAD_SLOT, 0u);
     r.o = r.d = r.t = make_float4(0, 0, 0, 0);
     r.hit = make_float4(0, 0, 0, __uint_as_float(HIPR_HIT_MISS));
-    if (i != HIPR_DEAD_SLOT) { r.meta = in.meta[i]; r.o = in.o_tmin[i]; r.d = in.d_pdf[i]; r.t = in.thr_bounces[i]; r.hit = hits[i]; }
+    if (i != HIPR_DEAD_SLOT) { r.meta = in.meta[i]; r.d = in.d_pdf[i]; r.t = in.thr_bounces[i]; r.hit = hits[i]; }
     return r;
 }
 // The queue entry that place j of the shading order holds (k_classify_hits; the queue's own order without it).
@@ -331,6 +334,12 @@ HD uint32_t shade_entry(const ShadeOrder& o, uint32_t j, uint32_t n) {
 HD bool shade_hits_triangle(const ShadeInputs& in) {
     const uint32_t id = __float_as_uint(in.hit.w);
     return in.meta.x != HIPR_DEAD_SLOT && id != HIPR_HIT_MISS && !(id & HIPR_HIT_LIGHT);
+}
+// The ray's origin, one stage behind the other inputs: known to be needed once the hit id is there. Misses and light hits use it (environment lookup, light
+// evaluation), surface hits do not -- in the listing's order whole batches skip the 16 B (profiles/r04_ab_shade_queue_bytes.txt).
+template <bool AOV>
+HD void shade_fetch_origin(const PathState& in, ShadeInputs& r) {
+    if (r.entry != HIPR_DEAD_SLOT && r.meta.x != HIPR_DEAD_SLOT && (AOV || !shade_hits_triangle(r))) r.o = in.o_tmin[r.entry];
 }
 HD ShadeGeometry shade_fetch_geometry(const DeviceScene& sc, const ShadeInputs& in) {
     ShadeGeometry g;
@@ -365,7 +374,7 @@ HD HiprMaterial shade_fetch_material(const DeviceScene& sc, const ShadeInputs& i
 constexpr uint32_t SHADE_LDS_LIGHTS = 32;   // light arrays up to this size are copied to LDS (1.5 KB); larger ones are read from global memory
 constexpr int shade_waves_per_simd(int part) { return part == SHADE_PART_ALL ? HIPR_SHADE_WAVES : HIPR_SHADE_SPLIT_WAVES; }
 template <int MODELS, bool AOV, int PART, bool TEXTURES = true>
-__global__ __launch_bounds__(SHADE_BLOCK, shade_waves_per_simd(PART)) void k_shade(DeviceScene sc, HiprCameraState cam, int entry, PathState in, const float4* hits, const uint32_t* order_list, const uint32_t* order_coat, const unsigned long long* listed, PathState out,
+__global__ __launch_bounds__(SHADE_BLOCK, shade_waves_per_simd(PART)) void k_shade(DeviceScene sc, HiprCameraState cam, FrameInfo frame, int entry, PathState in, const float4* hits, const uint32_t* order_list, const uint32_t* order_coat, const unsigned long long* listed, PathState out,
                                                         ShadowQueue shadows, float4* radiance, const uint32_t* count_ptr, unsigned long long* out_counts,
                                                         unsigned long long* zero_a, unsigned long long* zero_b, unsigned char* nee_flags, DeviceCounters* counters) {
 #if HIPR_SHADE_ONE_BARRIER
@@ -408,6 +417,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_waves_per_simd(PART)) void k_sha
     if (lights_in_lds) sc.lights = s_lights;
 #endif
     ShadeGeometry geo = shade_fetch_geometry(sc, cur);
+    shade_fetch_origin<AOV>(in, cur);
     HiprMaterial mat = shade_fetch_material(sc, cur, geo);
 #if HIPR_SHADE_ONE_BARRIER
     if (threadIdx.x < 2) s_arrivals[threadIdx.x] = 0ull;
@@ -422,16 +432,28 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_waves_per_simd(PART)) void k_sha
 #endif
     for (; base < n; base += stride) {
         // inputs of the next batch: issued now, first used after this batch has been shaded
-        const ShadeInputs next = shade_fetch_inputs(in, hits, next_entry);
+        ShadeInputs next = shade_fetch_inputs(in, hits, next_entry);
         next_entry = shade_entry(order, base + 2u * stride + threadIdx.x, n);
 
         ShadeOutput so;
         so.continues = so.shadow = so.shaded = false;
-        const uint32_t slot = cur.meta.x, pixel_hash = cur.meta.z, accumulation = cur.meta.w;
+#ifdef HIPR_SHADE_EXTRA_READ      // experiment: 16 (or 32) more bytes read per queue entry, coalesced -- what does a byte of queue traffic cost this kernel?
+        {
+            const float4 extra = shadows.radiance[base + threadIdx.x];
+            if (extra.w == 12345.678f) radiance[base + threadIdx.x] = extra;
+#if HIPR_SHADE_EXTRA_READ > 1
+            const float4 extra2 = shadows.d_slot[base + threadIdx.x];
+            if (extra2.w == 12345.678f) radiance[base + threadIdx.x] = extra2;
+#endif
+        }
+#endif
+        const uint32_t slot = cur.meta.x;
         if (slot != HIPR_DEAD_SLOT) {
+            uint32_t pixel_hash, accumulation;
+            path_sample_of_slot(frame, cam, slot, pixel_hash, accumulation);
             bool nee_kept_a_sample = false;
             if (PART == SHADE_PART_BSDF && shade_hits_triangle(cur)) nee_kept_a_sample = nee_flags[cur.entry] != 0;   // written for every accepted hit; read by those only
-            shade_path<MODELS, AOV, PART, TEXTURES>(sc, cam, entry, s_sobol, mk3(cur.o.x, cur.o.y, cur.o.z), mk3(cur.d.x, cur.d.y, cur.d.z), cur.d.w, mk3(cur.t.x, cur.t.y, cur.t.z),
+            shade_path<MODELS, AOV, PART, TEXTURES>(sc, cam, entry, s_sobol, mk3(cur.o.x, cur.o.y, cur.o.z), in.o_tmin + cur.entry, mk3(cur.d.x, cur.d.y, cur.d.z), cur.d.w, mk3(cur.t.x, cur.t.y, cur.t.z),
                                           __float_as_uint(cur.t.w), cur.meta.y, pixel_hash, accumulation, cur.hit, geo, mat, nee_kept_a_sample, so);
             if (PART == SHADE_PART_NEE && so.nee_reached) nee_flags[cur.entry] = so.nee_valid ? 1 : 0;
             if (so.add_radiance.x != 0.0f || so.add_radiance.y != 0.0f || so.add_radiance.z != 0.0f) {
@@ -442,6 +464,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_waves_per_simd(PART)) void k_sha
         }
         // the hit id of the next batch has arrived by now: request its triangle and shading record
         geo = shade_fetch_geometry(sc, next);
+        shade_fetch_origin<AOV>(in, next);
 
 #if HIPR_SHADE_ONE_BARRIER
         // ---- compaction: ballot + prefix popcount in the wave; the waves of the block take their places in the block's stretch of both queues in the
@@ -496,7 +519,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_waves_per_simd(PART)) void k_sha
             out.o_tmin[j] = make_float4(so.o.x, so.o.y, so.o.z, so.tmin);
             out.d_pdf[j] = make_float4(so.d.x, so.d.y, so.d.z, so.bsdf_pdf);
             out.thr_bounces[j] = make_float4(so.throughput.x, so.throughput.y, so.throughput.z, __uint_as_float(so.bounces));
-            out.meta[j] = make_uint4(slot, so.last_triangle, pixel_hash, accumulation);
+            out.meta[j] = make_uint2(slot, so.last_triangle);
         }
         if (so.shadow) {
             const uint32_t j = shad_base + __popcll(shad_mask & lt);

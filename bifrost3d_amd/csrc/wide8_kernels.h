@@ -157,7 +157,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(wid
                         }
                     } else if constexpr (MODE != TRACE_SHADOW) {
                         ray_index = entry;
-                        const uint4 meta = in.meta[entry];
+                        const uint2 meta = in.meta[entry];
                         dead = meta.x == HIPR_DEAD_SLOT;
                         pay_k = meta.y;
                         ro = in.o_tmin[entry]; rdv = in.d_pdf[entry];
