@@ -224,3 +224,31 @@ CPU_TEST_F(MathFixture, a_mirroring_instance_keeps_its_front_side) {
     }
     EXPECT_TRUE(scene.update_model_transforms({{2u, Transform(Vector3f(5, 1, 0), turned, -3.0f)}}));
 }
+
+// csrc/fast_divide.h: the multiply-high division the kernels use to turn a path slot into (pixel, sample) and a tile into (column, row) must be exact for
+// every 32-bit dividend -- the slot of a path decides its sample sequence. Checked against the operator on the divisors a frame can bring (samples per pass,
+// tiles per row), on the awkward ones (2^k - 1, 2^k, 2^k + 1, the largest), at multiples of the divisor and their neighbours, and on random pairs.
+#include "../../bifrost3d_amd/csrc/fast_divide.h"
+
+CPU_TEST_F(MathFixture, multiply_high_division_is_exact) {
+    uint64_t state = 0x9E3779B97F4A7C15ull;
+    auto next = [&]() { state = state * 6364136223846793005ull + 1442695040888963407ull; return uint32_t(state >> 32); };
+    unsigned long long mismatches = 0;
+    auto check = [&](uint32_t n, uint32_t d, const hipr::Divisor& divisor) { if (hipr::divide(n, divisor) != n / d) ++mismatches; };
+    const uint32_t divisors[] = {1, 2, 3, 5, 6, 7, 9, 10, 12, 15, 17, 24, 31, 32, 33, 60, 63, 64, 100, 120, 135, 160, 240, 255, 256, 257, 480, 641, 1000, 4096, 65535, 65536, 65537,
+                                 1000003, 0x7FFFFFFFu, 0x80000000u, 0x80000001u, 0xFFFFFFFEu, 0xFFFFFFFFu};
+    for (uint32_t d : divisors) {
+        const hipr::Divisor divisor = hipr::make_divisor(d);
+        for (int i = 0; i < 20000; ++i) check(next(), d, divisor);
+        for (uint32_t n : {0u, 1u, d - 1u, d, d + 1u, 2u * d - 1u, 2u * d, 0xFFFFFFFFu, 0xFFFFFFFEu, 0x80000000u, 0x7FFFFFFFu}) check(n, d, divisor);
+        for (uint64_t q = 1; q < 300 && q * d <= 0xFFFFFFFFull; ++q) { check(uint32_t(q * d), d, divisor); check(uint32_t(q * d - 1u), d, divisor); }
+    }
+    for (int i = 0; i < 20000; ++i) {
+        uint32_t d = next() >> (next() % 32u);
+        if (d == 0) d = 1;
+        const hipr::Divisor divisor = hipr::make_divisor(d);
+        for (int j = 0; j < 8; ++j) check(next(), d, divisor);
+        check(0xFFFFFFFFu, d, divisor);
+    }
+    EXPECT_EQ(0ull, mismatches);
+}
