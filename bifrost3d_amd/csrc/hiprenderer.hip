@@ -471,7 +471,7 @@ void launch_trace_fused(HiprContext* c, const Wavefront& w, const PathState& in,
     launch_persistent_for_stack<TRACE_FUSED, INSTRUMENT>(c, w, in, closest_count, shadow_count, upper_bound, sorted);
 }
 
-void launch_shade(HiprContext* c, const Wavefront& w, const HiprCameraState& camera, int cur, uint32_t alive, const uint32_t* in_count, uint32_t* out_counts, uint32_t* zero_pair) {
+void launch_shade(HiprContext* c, const Wavefront& w, const HiprCameraState& camera, int cur, uint32_t alive, const uint32_t* in_count, uint32_t* out_counts, uint32_t* zero_pair, bool camera_rays) {
     // The rays of the bounce listed by kind (kernels.h k_classify_hits): the shade kernel's batches then hold surface hits only, or none.
     const uint32_t* order = nullptr;
     const unsigned long long* listed = nullptr;
@@ -495,7 +495,9 @@ void launch_shade(HiprContext* c, const Wavefront& w, const HiprCameraState& cam
     // kernel loses (Cornell 18 390 -> 17 194 Mrays/s)
     const bool split = c->shade_split && c->entry == HIPR_ENTRY_PATH_TRACING && c->scene.light_count != 0 && w.nee_flags.ptr;
     const uint32_t blocks_per_cu = c->shade_blocks_per_cu > 0 ? uint32_t(c->shade_blocks_per_cu) : (split ? uint32_t(HIPR_SHADE_SPLIT_WAVES) : (c->shading_models == 2 ? 2u : 3u));
-    ShadeLaunch a = {grid_for(alive, SHADE_BLOCK, uint32_t(c->cu_count) * blocks_per_cu), w.stream, c->scene, camera, c->frame, c->entry, w.path_state(cur), w.hits.as<float4>(), order, w.order_coat.as<uint32_t>(), listed, w.path_state(1 - cur),
+    PathState shaded = w.path_state(cur);
+    if (camera_rays) shaded.thr_bounces = nullptr;      // k_generate's queue: throughput 1, no bounce yet -- not stored
+    ShadeLaunch a = {grid_for(alive, SHADE_BLOCK, uint32_t(c->cu_count) * blocks_per_cu), w.stream, c->scene, camera, c->frame, c->entry, shaded, w.hits.as<float4>(), order, w.order_coat.as<uint32_t>(), listed, w.path_state(1 - cur),
                      w.shadow_queue(), c->radiance.as<float4>(), in_count, reinterpret_cast<unsigned long long*>(out_counts), reinterpret_cast<unsigned long long*>(zero_pair),
                      reinterpret_cast<unsigned long long*>(taken_words + COUNT_PAIR_STRIDE * (1 - cur)), split ? w.nee_flags.as<unsigned char>() : nullptr,
                      c->counters.as<DeviceCounters>(), c->scene_has_textures || !c->lean_shade};
@@ -602,7 +604,7 @@ int enqueue_bounce(HiprContext* c, Wavefront& w, const HiprCameraState& camera, 
     }
 
     c->begin_timed(HIPR_KERNEL_SHADE, w.stream);
-    launch_shade(c, w, camera, parity, bound, in_count, out_count, zero_pair);
+    launch_shade(c, w, camera, parity, bound, in_count, out_count, zero_pair, k == 0);
     hipEvent_t shaded = c->end_timed(w.stream);
     if (!shaded) {
         shaded = w.shade_done[parity];

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void k_generate(FrameInfo frame, HiprCameraSta
     if (valid) camera_ray(cam, x, y, frame.width, frame.height, accumulation, pixel_hash, o, d);
     out.o_tmin[i] = make_float4(o.x, o.y, o.z, 0.0f);
     out.d_pdf[i] = make_float4(d.x, d.y, d.z, -1.0f);           // bsdf_PDF = delta_dirac(1)
-    out.thr_bounces[i] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(0u));
+    // throughput (1, 1, 1) and bounce count 0 are not written: shade(0) is launched without the array and fills them in (shade_fetch_inputs)
     out.meta[i] = make_uint2(valid ? p : HIPR_DEAD_SLOT, HIPR_NO_TRIANGLE);
     radiance[p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }

@@ -320,7 +320,10 @@ HD ShadeInputs shade_fetch_inputs(const PathState& in, const float4* hits, uint3
     r.meta = make_uint2(HIPR_DEAD_SLOT, 0u);
     r.o = r.d = r.t = make_float4(0, 0, 0, 0);
     r.hit = make_float4(0, 0, 0, __uint_as_float(HIPR_HIT_MISS));
-    if (i != HIPR_DEAD_SLOT) { r.meta = in.meta[i]; r.d = in.d_pdf[i]; r.t = in.thr_bounces[i]; r.hit = hits[i]; }
+    if (i != HIPR_DEAD_SLOT) {
+        r.meta = in.meta[i]; r.d = in.d_pdf[i]; r.hit = hits[i];
+        r.t = in.thr_bounces ? in.thr_bounces[i] : make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(0u));      // camera rays (bounce 0): k_generate leaves these 16 B unwritten
+    }
     return r;
 }
 // The queue entry that place j of the shading order holds (k_classify_hits; the queue's own order without it).
