@@ -10,7 +10,7 @@ tmp=$(mktemp -d)
 HIPFLAGS="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -fPIC -Wall -Wno-unused-function -Wno-pass-failed"
 SHADEFLAGS="$HIPFLAGS -fno-hip-fp32-correctly-rounded-divide-sqrt -fgpu-flush-denormals-to-zero -ffp-contract=fast ${SHADE_MATH--freciprocal-math -fapprox-func} -DHIPR_FAST_MATH=1"     # SHADE_MATH="" builds the shade kernel with round 3's division
 hipcc $HIPFLAGS $extra -c -o $tmp/hiprenderer.o csrc/hiprenderer.hip &
-hipcc $SHADEFLAGS $extra -c -o $tmp/shade.o csrc/shade.hip &
+hipcc ${SHADE_ALL_FLAGS:-$SHADEFLAGS} $extra -c -o $tmp/shade.o csrc/shade.hip &      # SHADE_ALL_FLAGS: the whole flag set of the shade unit (e.g. "$HIPFLAGS -DHIPR_FAST_MATH=0" for correctly rounded shading)
 wait
 hipcc --offload-arch=gfx950 -shared -fPIC -o csrc/libhiprenderer_$suffix.so $tmp/hiprenderer.o $tmp/shade.o csrc/ray_sort.o csrc/camera_effects.o csrc/denoiser.o csrc/group.o -ldl -lpthread
 rm -rf $tmp
