@@ -77,28 +77,30 @@ def main():
     out["oracle_seconds_equal_seed"] = seconds
     out["equal_seed"] = dict(rms_pair(gpu, cpu), mean_radiance=float(cpu.mean()))
 
-    # ---- the converged leg
+    # ---- the converged leg (--factor 0: none -- the full-size frame, where the oracle's equal-seed image alone takes minutes)
     first, last = spp, spp + args.factor * spp
-    stem = ROOT / "profiles" / "converged" / f"{args.scene}_{w}x{h}_acc{first}_{last}"
-    meta_ok = False
-    if Path(str(stem) + ".npy").exists() and Path(str(stem) + ".json").exists():
-        meta = json.loads(Path(str(stem) + ".json").read_text())
-        meta_ok = meta.get("triangles") == int(scene.desc.triangle_count) and meta.get("bounces") == bounces      # any of the oracle's searches converges to the same image
-    if meta_ok:
-        converged = np.load(str(stem) + ".npy").astype(np.float64)
-        out["converged_source"] = f"profiles/converged/{stem.name}.npy (tools/converged_reference.py, {meta['seconds']:.0f} s on {meta['threads']} host threads)"
-    else:
-        t0 = time.time()
-        accum = cpu_accum.copy()
-        for a in range(first, last, 256):
-            accum, _ = oracle_image(a, min(256, last - a), accum=accum)
-        converged = (accum[..., :3] * last - cpu * first) / (last - first)
-        out["converged_source"] = f"computed here by the oracle in {time.time() - t0:.0f} s"
-    # an independent device image of the same disjoint accumulations: the two converged images should agree far better than either 256 spp image does
-    gpu_converged = (device_image(0, last) * last - gpu * first) / (last - first)
-    out["converged"] = {"accumulations": [first, last], "device_vs_converged_oracle": rms_pair(gpu, converged), "oracle_vs_converged_oracle": rms_pair(cpu, converged),
-                        "device_vs_converged_device": rms_pair(gpu, gpu_converged), "oracle_vs_converged_device": rms_pair(cpu, gpu_converged),
-                        "converged_device_vs_converged_oracle": rms_pair(gpu_converged, converged)}
+    converged = None
+    if args.factor > 0:
+        stem = ROOT / "profiles" / "converged" / f"{args.scene}_{w}x{h}_acc{first}_{last}"
+        meta_ok = False
+        if Path(str(stem) + ".npy").exists() and Path(str(stem) + ".json").exists():
+            meta = json.loads(Path(str(stem) + ".json").read_text())
+            meta_ok = meta.get("triangles") == int(scene.desc.triangle_count) and meta.get("bounces") == bounces      # any of the oracle's searches converges to the same image
+        if meta_ok:
+            converged = np.load(str(stem) + ".npy").astype(np.float64)
+            out["converged_source"] = f"profiles/converged/{stem.name}.npy (tools/converged_reference.py, {meta['seconds']:.0f} s on {meta['threads']} host threads)"
+        else:
+            t0 = time.time()
+            accum = cpu_accum.copy()
+            for a in range(first, last, 256):
+                accum, _ = oracle_image(a, min(256, last - a), accum=accum)
+            converged = (accum[..., :3] * last - cpu * first) / (last - first)
+            out["converged_source"] = f"computed here by the oracle in {time.time() - t0:.0f} s"
+        # an independent device image of the same disjoint accumulations: the two converged images should agree far better than either 256 spp image does
+        gpu_converged = (device_image(0, last) * last - gpu * first) / (last - first)
+        out["converged"] = {"accumulations": [first, last], "device_vs_converged_oracle": rms_pair(gpu, converged), "oracle_vs_converged_oracle": rms_pair(cpu, converged),
+                            "device_vs_converged_device": rms_pair(gpu, gpu_converged), "oracle_vs_converged_device": rms_pair(cpu, gpu_converged),
+                            "converged_device_vs_converged_oracle": rms_pair(gpu_converged, converged)}
 
     # ---- bias statistics
     d = gpu - cpu
@@ -160,7 +162,7 @@ def main():
         delta = per_sample_gpu[:, k] - per_sample_cpu[:, k]
         magnitude = np.abs(delta).max(axis=-1)
         differing = [int(a) for a in np.argsort(magnitude)[::-1][:4] if magnitude[a] > 1e-3 * (np.abs(per_sample_cpu[a, k]).max() + 1e-3)]
-        entry = {"pixel": [int(x), int(y)], "device_mean": [float(v) for v in gpu[y, x]], "oracle_mean": [float(v) for v in cpu[y, x]], "converged_oracle": [float(v) for v in converged[y, x]],
+        entry = {"pixel": [int(x), int(y)], "device_mean": [float(v) for v in gpu[y, x]], "oracle_mean": [float(v) for v in cpu[y, x]], "converged_oracle": [float(v) for v in converged[y, x]] if converged is not None else None,
                  "samples_that_differ": int((magnitude > 1e-3 * (np.abs(per_sample_cpu[:, k]).max(axis=-1) + 1e-3)).sum()),
                  "largest": [{"accumulation": a, "device": [float(v) for v in per_sample_gpu[a, k]], "oracle": [float(v) for v in per_sample_cpu[a, k]]} for a in differing]}
         if differing:    # where along the path do the two sides part: radiance of the worst sample with the path cut after 0, 1, ... bounces
