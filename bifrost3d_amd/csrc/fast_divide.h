@@ -20,8 +20,9 @@ struct Divisor {
     uint32_t add;           // the multiplier has 33 bits: q = (((n - t) >> 1) + t) >> shift with t = mulhi(n, multiplier)
 };
 
-inline Divisor make_divisor(uint32_t d) {       // d > 0
+inline Divisor make_divisor(uint32_t d) {       // d > 0 (0 is taken as 1: the callers validate their frames before they get here)
     Divisor r = {0u, 0u, 0u};
+    if (d == 0u) return r;
     uint32_t log2_floor = 31u;
     while (!((d >> log2_floor) & 1u)) --log2_floor;
     if ((d & (d - 1u)) == 0u) { r.shift = log2_floor; return r; }
