@@ -1062,6 +1062,8 @@ __global__ __launch_bounds__(256) void k_classify_hits(const float4* __restrict_
                                                        unsigned long long* taken /* [0] low word: plain surface hits listed, high word: others listed; [1]: coated surface hits listed */,
                                                        const unsigned char* __restrict__ triangle_class, uint32_t* __restrict__ order_coat) {
     __shared__ uint32_t s_surface[4], s_other[4], s_coat[4];
+    static_assert(CLASSIFY_ROUNDS * 4u == 64u, "the prefix of the (round, wave) table is one wave-wide scan");
+    __shared__ uint32_t s_table[3][CLASSIFY_ROUNDS * 4];      // per class: a wave's rays of each round, then their exclusive prefix in (round, wave) order
     __shared__ unsigned long long s_base;
     __shared__ uint32_t s_coat_base;
     const uint32_t n = *count_ptr;
@@ -1091,26 +1093,41 @@ __global__ __launch_bounds__(256) void k_classify_hits(const float4* __restrict_
             s_coat_base = block_coats ? uint32_t(atomicAdd(taken + 1, (unsigned long long)block_coats)) : 0u;
         }
         __syncthreads();
-        // pass 2: places inside the block's ranges, rays in (round, thread) order
-        uint32_t front = uint32_t(s_base), back = uint32_t(s_base >> 32), coat_front = s_coat_base;
+        // pass 2: places inside the block's ranges, rays in (round, thread) order. Every wave leaves its count of each class for each round in a table, the first wave
+        // turns the table into exclusive prefixes in (round, wave) order -- one barrier on either side of that instead of the two per ROUND of a running sum (round 4:
+        // the pass was the latency of its 34 barriers per chunk, profiles/r04_ab_knobs.txt) -- then every thread places its rays.
+        const uint32_t front = uint32_t(s_base), back = uint32_t(s_base >> 32), coat_front = s_coat_base;
+        unsigned long long surface_masks[CLASSIFY_ROUNDS], other_masks[CLASSIFY_ROUNDS], coat_masks[CLASSES ? CLASSIFY_ROUNDS : 1];
 #pragma unroll
         for (uint32_t r = 0; r < CLASSIFY_ROUNDS; ++r) {
             const bool surface = (surface_bits >> r) & 1u, coated = (coat_bits >> r) & 1u, other = ((valid_bits & ~(surface_bits | coat_bits)) >> r) & 1u;
-            const unsigned long long surface_mask = wave_ballot(surface), other_mask = wave_ballot(other), coat_mask = CLASSES ? wave_ballot(coated) : 0ull;
-            if (lane == 0) { s_surface[wave] = uint32_t(__popcll(surface_mask)); s_other[wave] = uint32_t(__popcll(other_mask)); s_coat[wave] = uint32_t(__popcll(coat_mask)); }
-            __syncthreads();
-            uint32_t before_surface = 0, before_other = 0, before_coat = 0, round_surface = 0, round_other = 0, round_coat = 0;
-            for (uint32_t w = 0; w < 4; ++w) {
-                before_surface += w < wave ? s_surface[w] : 0u; before_other += w < wave ? s_other[w] : 0u; before_coat += w < wave ? s_coat[w] : 0u;
-                round_surface += s_surface[w]; round_other += s_other[w]; round_coat += s_coat[w];
+            surface_masks[r] = wave_ballot(surface); other_masks[r] = wave_ballot(other);
+            if (CLASSES) coat_masks[r] = wave_ballot(coated);
+            if (lane == 0) {
+                s_table[0][r * 4u + wave] = uint32_t(__popcll(surface_masks[r])); s_table[1][r * 4u + wave] = uint32_t(__popcll(other_masks[r]));
+                if (CLASSES) s_table[2][r * 4u + wave] = uint32_t(__popcll(coat_masks[r]));
             }
-            const uint32_t i = chunk + r * 256u + threadIdx.x;
-            if (surface) order[front + before_surface + uint32_t(__popcll(surface_mask & lt))] = i;
-            if (CLASSES && coated) order_coat[coat_front + before_coat + uint32_t(__popcll(coat_mask & lt))] = i;
-            if (other) order[n - 1u - (back + before_other + uint32_t(__popcll(other_mask & lt)))] = i;
-            front += round_surface; back += round_other; coat_front += round_coat;
-            __syncthreads();
         }
+        __syncthreads();
+        if (wave == 0) {        // 16 rounds x 4 waves = 64 entries: one wave-wide exclusive scan per class
+#pragma unroll
+            for (int c = 0; c < (CLASSES ? 3 : 2); ++c) {
+                const uint32_t mine = s_table[c][lane];
+                uint32_t inclusive = mine;
+                for (int off = 1; off < 64; off <<= 1) { const uint32_t up = __shfl_up(inclusive, off); inclusive += lane >= uint32_t(off) ? up : 0u; }
+                s_table[c][lane] = inclusive - mine;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t r = 0; r < CLASSIFY_ROUNDS; ++r) {
+            const bool surface = (surface_bits >> r) & 1u, coated = (coat_bits >> r) & 1u, other = ((valid_bits & ~(surface_bits | coat_bits)) >> r) & 1u;
+            const uint32_t i = chunk + r * 256u + threadIdx.x;
+            if (surface) order[front + s_table[0][r * 4u + wave] + uint32_t(__popcll(surface_masks[r] & lt))] = i;
+            if (CLASSES && coated) order_coat[coat_front + s_table[2][r * 4u + wave] + uint32_t(__popcll(coat_masks[r] & lt))] = i;
+            if (other) order[n - 1u - (back + s_table[1][r * 4u + wave] + uint32_t(__popcll(other_masks[r] & lt)))] = i;
+        }
+        __syncthreads();        // the table is written again by the next chunk
     }
 }
 
