@@ -212,6 +212,7 @@ struct HiprContext {
     bool cull_backfaces = true;         // hipr_set_backface_culling / HIPR_BACKFACE_CULLING=0
     bool shade_split = false;           // HIPR_SHADE_SPLIT=1: the shade kernel as two, next event estimation and the rest (shade_kernel.h; measured)
     bool shade_ordered = true;          // k_classify_hits before k_shade (HIPR_SHADE_ORDERED=0: shade in queue order)
+    bool shade_ordered_camera = false;  // ... also before shade(0) (HIPR_SHADE_ORDERED_CAMERA=1; measured: profiles/r04_ab_knobs.txt)
     int persistent_blocks_per_cu[3][3] = {{0, 0, 0}, {0, 0, 0}};   // [shadow][stack bucket]
     int wide8_blocks_per_cu[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};   // [mode][stack bucket]
 
@@ -479,7 +480,8 @@ void launch_shade(HiprContext* c, const Wavefront& w, const HiprCameraState& cam
     // where nearly all did (the closed Cornell box: +7 %): on for the scenes of the persistent kernels, which are the large ones.
     // A bounce of a few thousand paths runs one wave per SIMD at most: the order they are taken in changes nothing, the listing pass would cost a launch.
     uint32_t* taken_words = w.queue_counts.as<uint32_t>() + COUNT_PAIR_STRIDE * COUNT_PAIRS;
-    if (c->shade_ordered && c->use_persistent() && c->entry == HIPR_ENTRY_PATH_TRACING && alive >= c->shade_ordered_from) {
+    // Camera rays need no listing: a wave of them is one pixel's samples (or an 8 x 8 tile's pixels) -- they hit a surface, or miss, together (HIPR_SHADE_ORDERED_CAMERA=1 lists them anyway).
+    if (c->shade_ordered && c->use_persistent() && c->entry == HIPR_ENTRY_PATH_TRACING && alive >= c->shade_ordered_from && (!camera_rays || c->shade_ordered_camera)) {
         unsigned long long* taken = reinterpret_cast<unsigned long long*>(taken_words + COUNT_PAIR_STRIDE * cur);
         if (c->shade_classes && c->any_coated_triangle)
             hipLaunchKernelGGL(k_classify_hits<true>, dim3(grid_for(alive, 256u * CLASSIFY_ROUNDS, uint32_t(c->cu_count) * 8u)), dim3(256), 0, w.stream, w.hits.as<float4>(), in_count, w.order.as<uint32_t>(), taken,
@@ -971,6 +973,7 @@ int hipr_create(int device_id, HiprContext** out_context) {
     if (const char* v = getenv("HIPR_LEAN_TRACE")) c->lean_trace = atoi(v) != 0;
     if (const char* v = getenv("HIPR_LEAN_SHADE")) c->lean_shade = atoi(v) != 0;
     if (const char* v = getenv("HIPR_SHADE_ORDERED")) c->shade_ordered = atoi(v) != 0;
+    if (const char* v = getenv("HIPR_SHADE_ORDERED_CAMERA")) c->shade_ordered_camera = atoi(v) != 0;
     if (const char* v = getenv("HIPR_SHADE_SPLIT")) c->shade_split = atoi(v) != 0;
     if (const char* v = getenv("HIPR_BACKFACE_CULLING")) c->cull_backfaces = atoi(v) != 0;
     if (const char* v = getenv("HIPR_PIPELINE_PASSES")) c->pipeline_passes = atoi(v) != 0;
