@@ -515,10 +515,11 @@ def denoiser_figures(args, device):
 
 # --------------------------------------------------------------------------------------------------------------------------------
 # Rooflines. Algorithmic HBM bytes per unit of work, DESIGN.md "Kernels" / SURVEY.md 8d:
-#   generate       80 B per path        (64 B path state + 16 B radiance slot written)
-#   trace_closest  48 B path state read + 16 B hit written per ray, + 64 B per BVH node visited + 48 B per triangle tested (8-wide tree: 32 B, two triangles share a 64 B leaf record)
-#   shade          80 B per queued ray (hit + path state) + 352 B per shaded hit (triangle 48, shading record 96, material 64,
-#                  3 RIS light candidates 144) + 64 B per continued path + 48 B per shadow ray queued + 32 B radiance read-modify-write per queued ray
+#   generate       56 B per path        (origin 16 + direction 16 + meta 8 written + the 16 B radiance slot zeroed; rounds 1-3: 80 B, with the throughput word and a 16-byte meta)
+#   trace_closest  40 B path state read (origin, direction, 8-byte meta) + 16 B hit written per ray, + 64 B per BVH node visited + 48 B per triangle tested (8-wide tree: 32 B, two triangles share a 64 B leaf record)
+#   shade          60 B per queued ray (hit 16, direction 16, throughput 16 -- not for camera rays --, meta 8, listing index 4) + 16 B origin per ray that did not hit a triangle
+#                  + 352 B per shaded hit (triangle 48, shading record 96, material 64, 3 RIS light candidates 144) + 56 B per continued path + 48 B per shadow ray queued
+#                  + 32 B radiance read-modify-write per queued ray
 #   trace_shadow   48 B record + 32 B radiance rmw per shadow ray, + 64 B per node + 48 B per triangle
 #   accumulate     16 B radiance per sample + 64 B f64 accumulation rmw + 8 B half4 per owned pixel
 # --------------------------------------------------------------------------------------------------------------------------------
@@ -526,9 +527,9 @@ def rooflines_of(counters, times, per_ray, small, fused, samples_per_step, traff
     n_closest, n_shadow, n_camera, n_hits = (counters[k] for k in ("closest_rays", "shadow_rays", "camera_rays", "shaded_hits"))
     tri_share = 1.0 / 64.0 if small else 1.0   # exhaustive search: the triangle array is read once per 64-ray wave through the scalar cache
     kernel_bytes = {
-        "generate": 80.0 * n_camera,
-        "trace_closest": n_closest * (48 + 16 + 64 * per_ray["nodes"] + triangle_bytes * per_ray["triangles"] * tri_share),
-        "shade": 80.0 * n_closest + 352.0 * n_hits + 64.0 * max(0, n_closest - n_camera) + 48.0 * n_shadow + 32.0 * n_closest,
+        "generate": 56.0 * n_camera,
+        "trace_closest": n_closest * (40 + 16 + 64 * per_ray["nodes"] + triangle_bytes * per_ray["triangles"] * tri_share),
+        "shade": 60.0 * n_closest - 16.0 * n_camera + 16.0 * max(0, n_closest - n_hits) + 352.0 * n_hits + 56.0 * max(0, n_closest - n_camera) + 48.0 * n_shadow + 32.0 * n_closest,
         "trace_shadow": n_shadow * (48 + 32 + 64 * per_ray["shadow_nodes"] + triangle_bytes * per_ray["shadow_triangles"] * tri_share),
         "accumulate": 16.0 * n_camera + (64.0 + 8.0) * n_camera / max(1, samples_per_step),
     }
@@ -601,9 +602,9 @@ def useful_traffic(name, counters, launches, samples_per_step):
         closest = n_closest if name != "trace_shadow" else 0
         shadow = n_shadow if name != "trace_closest" else 0
         writes = 16.0 * closest + 16.0 * shadow                 # a hit record per closest-hit ray; the radiance slot of a shadow ray's path
-        reads = 48.0 * closest + (48.0 + 16.0) * shadow        # ray records (origin, direction, slot / id) + the radiance slot read for the add
+        reads = 40.0 * closest + (48.0 + 16.0) * shadow        # ray records (origin, direction, 8-byte slot / id; shadow rays: + radiance carried) + the radiance slot read for the add
         return {"writes": writes / launches, "reads": reads / launches, "bytes": (writes + reads) / launches,
-                "what": "per launch: 16 B hit per closest-hit ray + 16 B radiance per shadow ray written; 48 B ray record per ray + 16 B radiance per shadow ray read; the tree itself "
+                "what": "per launch: 16 B hit per closest-hit ray + 16 B radiance per shadow ray written; 40 B ray record per closest-hit ray, 48 B per shadow ray + its 16 B radiance slot read; the tree itself "
                         "(10 MB at 251 k triangles) is compulsory once per launch at most and left out"}
     return None
 
