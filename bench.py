@@ -64,7 +64,7 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 METRIC = "Mrays/sec + ms/frame at 1080p/256spp; per-pixel RMSE vs OptiXRenderer"
-SCENES = ["atrium", "cornell_diffuse", "cornell", "material", "material_coat", "opacity"]
+SCENES = ["atrium", "atrium_textured", "cornell_diffuse", "cornell", "material", "material_coat", "opacity"]
 
 
 def parse_args(argv=None):
@@ -177,6 +177,10 @@ def make_scene(name, args):
                 + (", coat 1 / coat roughness 0.7" if name == "material_coat" else "") + ", checkered textured floor, directional light", 32)
     if name == "opacity":
         return Scene("opacity"), "SimpleViewer opacity scene (cut-out box, coverage 0.75 planes, 24 triangles)", 32
+    if name == "atrium_textured":     # the stand-in with what the real Sponza brings and the plain one does not: a texture on every material, cut-out banners (host/AtriumScene.h)
+        scene = Scene("atrium", param0=args.atrium_triangles, param1=1, textured=True)
+        return scene, (f"procedural atrium, {scene.desc.triangle_count} triangles, every material textured (8 tint / roughness textures), cut-out cloth banners "
+                       f"(30 % of the triangles): the full kernels with texture samplers and coverage lookups"), 4
     scene = Scene("atrium", param0=args.atrium_triangles, param1=1)
     return scene, f"procedural atrium, {scene.desc.triangle_count} triangles (Sponza-class stand-in, BASELINE configs[3]), DefaultShading", 4
 

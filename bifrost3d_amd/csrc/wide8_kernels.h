@@ -239,9 +239,15 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(wid
                                 if (is_shadow && hit && t > tmin && t < tmax) {
                                     float coverage = 1.0f;
                                     if (COVERAGE && !(flags >> which & 1u)) {
-                                        const float4 tc = sc.triangles[3 * size_t(id) + 2];       // instance and primitive of the scene triangle
-                                        const HiprInstance& inst = sc.instances[__float_as_uint(tc.y)];
-                                        coverage = material_coverage(sc, sc.materials[inst.material_index], triangle_texcoord(sc, inst, __float_as_uint(tc.z), u, v));
+                                        // The triangle's texture coordinates and material index from its SHADING record (k_build_shade_triangles: the same floats the
+                                        // vertex arrays hold, zero without texture coordinates): three loads side by side where triangle -> instance -> indices -> texture
+                                        // coordinates were four one after the other (round 4: a wave waits on this chain for every lane that meets a cut-out;
+                                        // profiles/r04_ab_coverage_chain.txt). triangle_texcoord's expression, term for term.
+                                        const float4* record = sc.shade_triangles + SHADE_TRIANGLE_QUADS * size_t(id);
+                                        const float4 r3 = record[3], r6 = record[6], r7 = record[7];
+                                        const float w = 1.0f - u - v;
+                                        const f2 uv = mk2(r6.z, r6.w) * u + mk2(r7.x, r7.y) * v + mk2(r6.x, r6.y) * w;
+                                        coverage = material_coverage(sc, sc.materials[__float_as_uint(r3.w)], uv);
                                     }
                                     pay_x *= 1.0f - coverage; pay_y *= 1.0f - coverage; pay_z *= 1.0f - coverage;
                                     if (pay_x < 0.0000001f && pay_y < 0.0000001f && pay_z < 0.0000001f) {   // fully shadowed: the ray is done

@@ -76,14 +76,14 @@ def make_camera(width: int, height: int, position=(0.0, 0.0, 0.0), rotation=(0.0
 class Scene:
     """A flattened scene owned by the C++ host library (what handle_updates() would hand to hipr_upload_scene)."""
 
-    def __init__(self, name: str, diffuse_only: bool = False, param0: int = 0, param1: int = 0, environment: bool = False, coat: bool = False, spot: bool = False):
+    def __init__(self, name: str, diffuse_only: bool = False, param0: int = 0, param1: int = 0, environment: bool = False, coat: bool = False, spot: bool = False, textured: bool = False):
         self.lib = load_host_library()
         if name.startswith("file:"):    # a model file set up the way SimpleViewer sets up its command-line scene
             self.handle = self.lib.hiprh_scene_load(name[5:].encode(), 1 if diffuse_only else 0)
             if not self.handle:
                 raise capi.HiprError(f"could not load '{name[5:]}'")
         else:
-            self.handle = self.lib.hiprh_scene_create(name.encode(), (1 if diffuse_only else 0) | (2 if environment else 0) | (4 if coat else 0) | (8 if spot else 0), param0, param1)
+            self.handle = self.lib.hiprh_scene_create(name.encode(), (1 if diffuse_only else 0) | (2 if environment else 0) | (4 if coat else 0) | (8 if spot else 0) | (16 if textured else 0), param0, param1)
             if not self.handle:
                 raise capi.HiprError(f"unknown scene '{name}'")
         self.name = name

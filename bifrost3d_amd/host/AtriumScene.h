@@ -45,10 +45,47 @@ MeshData grid_surface(unsigned nu, unsigned nv, F f, bool texcoords) {
 
 // `Builder`: SceneBuilder (flat scene, directly) or ViewerScenes::BifrostSceneSink (the same calls recorded as Bifrost meshes, materials,
 // models and lights, i.e. the route a host application takes through HIPRenderer::Renderer).
+// `textured` (builders that take textures: SceneBuilder): every material gets one of eight tileable tint / roughness textures and the cloth banners become cut-outs with
+// a lace pattern -- what the real Sponza brings (a texture on every material, alpha-masked plants and chains) and the plain stand-in does not. With it the scene is
+// rendered by the FULL kernels: texture samplers in the shade kernel, coverage lookups for shadow rays in the traversal.
 template <typename Builder>
-void build_atrium(Builder& sb, unsigned target_triangles, unsigned seed) {
+void build_atrium(Builder& sb, unsigned target_triangles, unsigned seed, bool textured = false) {
     using namespace atrium_detail;
     Lcg rng = {seed * 747796405u + 2891336453u};
+    uint32_t tint_textures[8] = {}, lace_texture = 0;
+    if constexpr (Builder::takes_textures) if (textured) {
+        Lcg texture_rng = {seed * 2654435761u + 12345u};
+        for (uint32_t t = 0; t < 8; ++t) {       // value noise over an 8 x 8 lattice, wrapped: tint scale 0.55 .. 1 per channel, roughness scale 0.7 .. 1 in alpha
+            const uint32_t size = 128, cells = 8;
+            float lattice[4][cells * cells];
+            for (auto& channel : lattice) for (float& v : channel) v = texture_rng.next();
+            ImageData image;
+            image.width = image.height = size; image.format = HIPR_TEXEL_RGBA8; image.is_sRGB = false;
+            image.pixels.resize(size_t(size) * size * 4);
+            for (uint32_t y = 0; y < size; ++y)
+                for (uint32_t x = 0; x < size; ++x) {
+                    const float fx = float(x) * cells / size, fy = float(y) * cells / size;
+                    const uint32_t x0 = uint32_t(fx) % cells, y0 = uint32_t(fy) % cells, x1 = (x0 + 1) % cells, y1 = (y0 + 1) % cells;
+                    const float tx = fx - std::floor(fx), ty = fy - std::floor(fy);
+                    for (int c = 0; c < 4; ++c) {
+                        const float* l = lattice[c];
+                        const float v = (l[x0 + y0 * cells] * (1 - tx) + l[x1 + y0 * cells] * tx) * (1 - ty) + (l[x0 + y1 * cells] * (1 - tx) + l[x1 + y1 * cells] * tx) * ty;
+                        const float lo = c == 3 ? 0.7f : 0.55f;
+                        image.pixels[(size_t(y) * size + x) * 4 + size_t(c)] = uint8_t(255.0f * (lo + (1.0f - lo) * v) + 0.5f);
+                    }
+                }
+            tint_textures[t] = sb.add_texture(image, true, true, true, true);
+        }
+        ImageData lace;                           // 64 x 64 coverage: a lattice of round holes, a quarter of the area open
+        lace.width = lace.height = 64; lace.format = HIPR_TEXEL_R8; lace.is_sRGB = false;
+        lace.pixels.resize(64 * 64);
+        for (uint32_t y = 0; y < 64; ++y)
+            for (uint32_t x = 0; x < 64; ++x) {
+                const float dx = float(x % 16) - 7.5f, dy = float(y % 16) - 7.5f;
+                lace.pixels[y * 64 + x] = dx * dx + dy * dy < 4.6f * 4.6f ? 0 : 255;
+            }
+        lace_texture = sb.add_texture(lace, true, true, false, false);
+    }
     // 25 metal-rough materials: a spread of dielectrics, metals and coated plastics.
     std::vector<uint32_t> materials;
     for (int i = 0; i < 25; ++i) {
@@ -57,6 +94,7 @@ void build_atrium(Builder& sb, unsigned target_triangles, unsigned seed) {
         bool metal = (i % 5) == 0;
         HiprMaterial m = SceneBuilder::make_material(tint, roughness, metal ? 1.0f : 0.04f, metal ? 1.0f : 0.0f);
         if ((i % 7) == 3) { m.coat = SceneBuilder::unorm16(1.0f); m.coat_roughness = SceneBuilder::unorm16(0.1f + 0.5f * rng.next()); }
+        m.tint_roughness_texture_ID = int32_t(tint_textures[i % 8]);      // 0: none
         materials.push_back(sb.add_material(m));
     }
     auto material = [&](int i) { return materials[size_t(i) % materials.size()]; };
@@ -127,6 +165,8 @@ void build_atrium(Builder& sb, unsigned target_triangles, unsigned seed) {
             float sag = 0.6f * std::sin(v * PI<float>());
             return Vector3f((u - 0.5f) * 2.4f, 8.5f - v * 5.0f - 0.15f * sag, 0.25f * std::sin(u * folds + phase) * (0.3f + v) + sag * 0.4f); }, true));
         HiprMaterial m = SceneBuilder::make_material(RGB(0.3f + 0.6f * rng.next(), 0.15f + 0.3f * rng.next(), 0.15f + 0.5f * rng.next()), 0.85f, 0.04f, 0.0f, HIPR_MATERIAL_THIN_WALLED);
+        m.tint_roughness_texture_ID = int32_t(tint_textures[(cidx + 3) % 8]);
+        if (lace_texture) { m.flags |= HIPR_MATERIAL_CUTOUT; m.coverage = 0.5f; m.coverage_texture_ID = int32_t(lace_texture); }      // cut-out threshold 0.5 (upload_material, OR/Renderer.cpp:754-812)
         float x = (float(cidx) + 0.5f) / cloth_count * (W - 8.0f) - 0.5f * (W - 8.0f);
         sb.add_model(mesh, sb.add_material(m), Transform(Vector3f(x, 0.0f, (cidx & 1) ? 1.2f : -1.2f), Quaternionf::from_angle_axis(0.5f * PI<float>(), Vector3f::up())));
     }

@@ -455,6 +455,7 @@ void create_opacity_scene(CameraID camera_ID, SceneNode root_node, unsigned quad
 // ---- the atrium through the Bifrost managers --------------------------------------------------------------------------------------------
 namespace {
 struct BifrostSceneSink {
+    static constexpr bool takes_textures = false;       // the textured atrium is built in the flat builder only
     SceneNode root;
     SceneRootID scene_root;
     std::vector<Mesh> meshes;

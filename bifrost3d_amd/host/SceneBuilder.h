@@ -45,6 +45,7 @@ struct CameraDescription {
 class SceneBuilder {
 public:
     SceneBuilder();
+    static constexpr bool takes_textures = true;        // Scenes::build_atrium's textured variant
 
     uint32_t add_mesh(MeshData mesh);                                   // returns mesh index
     uint32_t add_material(const HiprMaterial& material);                // returns material index (0 is the invalid material)

@@ -131,7 +131,7 @@ void create_cornell_box(SceneBuilder& sb, unsigned wall_quads_per_edge) {
     sb.set_environment_tint(RGB(0.68f, 0.92f, 1.0f));   // SimpleViewer default g_environment_color, main.cpp:58
 }
 
-void create_atrium(SceneBuilder& sb, unsigned target_triangles, unsigned seed) { build_atrium(sb, target_triangles, seed); }
+void create_atrium(SceneBuilder& sb, unsigned target_triangles, unsigned seed, bool textured) { build_atrium(sb, target_triangles, seed, textured); }
 
 void create_quad_scene(SceneBuilder& sb, unsigned width, unsigned height) {
     // create_ortho_camera_with_quad_scene, tests/OptiXRendererTests/RendererTest.h:67-117: a quad covering the

@@ -77,7 +77,7 @@ static void* scene_create(const char* name, unsigned variant, unsigned param0, u
     SceneBuilder* sb = new SceneBuilder();
     std::string n = name;
     if (n == "cornell") Scenes::create_cornell_box(*sb, param0 ? param0 : 1u);   // param0: quads per wall edge
-    else if (n == "atrium") Scenes::create_atrium(*sb, param0 ? param0 : 260000u, param1 ? param1 : 1u);
+    else if (n == "atrium") Scenes::create_atrium(*sb, param0 ? param0 : 260000u, param1 ? param1 : 1u, (variant & 16u) != 0);      // variant bit 4: textured, with cut-out banners
     else if (n == "quad") Scenes::create_quad_scene(*sb, param0, param1);
     else if (n == "empty_ortho") Scenes::create_empty_ortho_scene(*sb, param0, param1, RGB(0.1f, 0.5f, 2.0f));
     else { delete sb; return nullptr; }

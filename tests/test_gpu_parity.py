@@ -256,6 +256,25 @@ def test_atrium_image_matches_oracle(ctx, oracle_q, atrium):
     image_bar("atrium_20k", gpu, cpu, 0.995, 2e-4, band=2e-3, outliers=2)      # measured: 0.9992, 5e-5 without the outliers (at most one so far)
 
 
+def test_textured_atrium_image_matches_oracle(ctx, oracle_q):
+    """Round 4: the stand-in with what the real Sponza brings and the plain one does not -- a tint / roughness texture on every material, cut-out cloth banners
+    (30 % of the triangles are not statically opaque) -- so the FULL kernels render it: texture samplers in k_shade, coverage lookups for shadow rays and
+    k_trace_wide8<..., COVERAGE = true>. Image against the oracle under the usual statistical bar; the ray counters agree; and the scene is not the plain one
+    (its image differs, and rays pass through the banners' holes: more shadow rays reach their light)."""
+    textured = Scene("atrium", param0=20000, param1=3, textured=True)
+    plain = Scene("atrium", param0=20000, param1=3)
+    assert textured.desc.texture_count == 10 and textured.desc.triangle_count == plain.desc.triangle_count
+    w, h, spp = 64, 36, 8
+    ctx.upload_scene(textured)
+    gpu, counters = render_gpu(ctx, textured, w, h, spp, 4)
+    cpu, cpu_counters, _ = oracle_q.render(textured.desc, textured.state, textured.camera(w, h, max_bounce_count=4), w, h, spp, use_bvh=ctx.oracle_search())
+    image_bar("atrium_20k_textured", gpu, cpu, 0.99, 3e-4, band=2e-3, outliers=2)
+    for key in ("camera_rays", "closest_rays", "shadow_rays", "shaded_hits"):
+        assert abs(counters[key] - cpu_counters[key]) <= max(4, 0.002 * cpu_counters[key]), (key, counters[key], cpu_counters[key])
+    reference, _ = render_gpu(ctx, plain, w, h, spp, 4)
+    assert rmse(gpu, reference) > 1e-2
+
+
 def test_tiling_and_batching_are_bit_invariant(ctx, cornell):
     """The image must not depend on how pixels are split over GPUs (tile_stride) or on samples_per_pass:
     the RNG is a pure function of (pixel, accumulation, bounce) and every path owns its radiance slot."""

@@ -22,7 +22,7 @@ def one_line(source, target):
 
 lines = {}
 for source, target in (("bench_default.json", TAG + "_bench_final.json"), ("bench_under_rocprof.json", TAG + "_atrium_bench_under_rocprof.json"), ("bench_material.json", TAG + "_bench_material.json"),
-                       ("bench_cornell_diffuse.json", TAG + "_bench_cornell_diffuse.json"), ("bench_atrium10M_4k.json", TAG + "_bench_atrium10M_4k.json"),
+                       ("bench_cornell_diffuse.json", TAG + "_bench_cornell_diffuse.json"), ("bench_atrium_textured.json", TAG + "_bench_atrium_textured.json"), ("bench_atrium10M_4k.json", TAG + "_bench_atrium10M_4k.json"),
                        ("bench_atrium_1spp.json", TAG + "_bench_atrium_1spp.json"), ("bench_2rank_gloo_shared_device.json", TAG + "_bench_2rank_gloo_shared_device.json")):
     if (src / source).exists() and (src / source).stat().st_size:
         lines[target] = one_line(source, target)

@@ -5,7 +5,7 @@
 #   bench     the default `python bench.py` line (what the driver runs)
 #   stats     rocprofv3 --kernel-trace --stats of the same workload with ONE wavefront (every kernel alone on the device: the durations the bench line's
 #             rooflines are priced on; the timed region of the default line runs two co-running wavefronts whose launches overlap)
-#   workloads the other BASELINE configurations (material, cornell_diffuse, 10 M triangles at 4K, 1 spp per pass, two ranks on one device)
+#   workloads the other BASELINE configurations (material, cornell_diffuse, the textured atrium, 10 M triangles at 4K, 1 spp per pass, two ranks on one device)
 #   rmse      tools/rmse_protocol.py at 480x270 and 160x90
 #   tests     the GPU suite with image metrics, then smoke()
 #   tracelog  lanes / iterations / refills of the traversal kernel (HIPR_TRACE_LOG)
@@ -29,7 +29,7 @@ for part in $parts; do
         cd $root
         find $out/trace -name "*kernel_trace.csv" -size +8M -delete ;;
     workloads)
-        for scene in material cornell_diffuse; do
+        for scene in material cornell_diffuse atrium_textured; do
             python bench.py --scene $scene --steps 4 --warmup 1 $quiet > $out/bench_$scene.json 2> $out/bench_$scene.err
         done
         python bench.py --atrium-triangles 10000000 --width 3840 --height 2160 --spp-per-pass 8 --steps 4 --warmup 1 $quiet > $out/bench_atrium10M_4k.json 2> $out/bench_atrium10M_4k.err
