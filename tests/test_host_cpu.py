@@ -109,6 +109,32 @@ def test_bvh_structure_cornell_and_atrium():
         assert deepest <= d.bvh_max_depth <= 64
 
 
+def test_textured_atrium_brings_textures_and_cut_outs():
+    """Scene("atrium", textured=True): the same geometry as the plain stand-in, with one of eight tileable tint / roughness textures on every material and the cloth
+    banners as cut-outs behind a lace coverage texture (host/AtriumScene.h) -- the triangles of those models are the ones not flagged statically opaque, every texture ID
+    points at an uploaded texture, and the oracle sees the difference (hits rejected by the cut-outs, a darker image)."""
+    import oracle_bindings
+    TEXEL_R8, TEXEL_RGBA8, MATERIAL_CUTOUT, TRIANGLE_OPAQUE = 1, 4, 2, 1          # include/hiprenderer_c.h: HIPR_TEXEL_*, HIPR_MATERIAL_CUTOUT, HIPR_TRIANGLE_OPAQUE
+    plain, textured = Scene("atrium", param0=20000, param1=3), Scene("atrium", param0=20000, param1=3, textured=True)
+    p, t = plain.desc, textured.desc
+    assert t.triangle_count == p.triangle_count and t.material_count == p.material_count and p.texture_count == 1 and t.texture_count == 10     # slot 0 = no texture
+    textures = [t.textures[i] for i in range(t.texture_count)]
+    assert all(x.width == 128 and x.height == 128 and x.format == TEXEL_RGBA8 for x in textures[1:9]) and textures[9].width == 64 and textures[9].format == TEXEL_R8
+    materials = [t.materials[i] for i in range(1, t.material_count)]
+    assert all(0 < m.tint_roughness_texture_ID < 9 for m in materials)
+    cut_outs = [m for m in materials if m.flags & MATERIAL_CUTOUT]
+    assert len(cut_outs) == 6 and all(m.coverage_texture_ID == 9 and m.coverage == 0.5 for m in cut_outs)
+    opaque = sum(1 for i in range(t.triangle_count) if t.triangles[i].flags & TRIANGLE_OPAQUE)
+    assert all(plain.desc.triangles[i].flags & TRIANGLE_OPAQUE for i in range(0, p.triangle_count, 97))
+    assert 0.6 * t.triangle_count < opaque < 0.8 * t.triangle_count          # the banners hold 30 % of the triangle budget
+    oracle = oracle_bindings.get_oracle(True)
+    w, h, spp = 48, 27, 2
+    image_p, counters_p, _ = oracle.render(p, plain.state, plain.camera(w, h, max_bounce_count=4), w, h, spp, use_bvh=3)
+    image_t, counters_t, _ = oracle.render(t, textured.state, textured.camera(w, h, max_bounce_count=4), w, h, spp, use_bvh=3)
+    assert counters_p["rejected_hits"] == 0 and counters_t["rejected_hits"] > 0
+    assert float(image_t[..., :3].mean()) < 0.9 * float(image_p[..., :3].mean())
+
+
 def test_bvh_depth_cap_holds_for_adversarial_input():
     # exponentially spaced slivers drive SAH towards a degenerate chain; the builder must cap the depth
     n = 3000
