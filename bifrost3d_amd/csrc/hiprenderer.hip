@@ -125,6 +125,7 @@ struct HiprContext {
     DeviceBuffer nodes, triangles, instances, indices, geometry, texcoords, tints, emissions, materials, lights, textures, texels;
     bool all_triangles_opaque = false;  // no triangle of the uploaded scene needs its material's coverage sampled (HIPR_TRIANGLE_OPAQUE on all): k_trace_wide8<..., COVERAGE = false>
     bool lean_trace = true;             // HIPR_LEAN_TRACE=0: always the full kernel
+    bool scene_has_environment = true;  // ... an environment map or a presampled environment light: k_shade<..., TEXTURES = 2>; textures without one: TEXTURES = 1
     bool scene_has_textures = true;     // a material references a texture, or the scene brings an environment map / presampled environment light: k_shade<..., TEXTURES = true>
     bool lean_shade = true;             // HIPR_LEAN_SHADE=0: always the full kernel
     DeviceBuffer triangle_class;        // one byte per triangle for the listing pass (k_classify_hits): bit 0 = its material is coated
@@ -502,7 +503,7 @@ void launch_shade(HiprContext* c, const Wavefront& w, const HiprCameraState& cam
     ShadeLaunch a = {grid_for(alive, SHADE_BLOCK, uint32_t(c->cu_count) * blocks_per_cu), w.stream, c->scene, camera, c->frame, c->entry, shaded, w.hits.as<float4>(), order, w.order_coat.as<uint32_t>(), listed, w.path_state(1 - cur),
                      w.shadow_queue(), c->radiance.as<float4>(), in_count, reinterpret_cast<unsigned long long*>(out_counts), reinterpret_cast<unsigned long long*>(zero_pair),
                      reinterpret_cast<unsigned long long*>(taken_words + COUNT_PAIR_STRIDE * (1 - cur)), split ? w.nee_flags.as<unsigned char>() : nullptr,
-                     c->counters.as<DeviceCounters>(), c->scene_has_textures || !c->lean_shade};
+                     c->counters.as<DeviceCounters>(), c->scene_has_textures || !c->lean_shade, c->scene_has_environment || !c->lean_shade};
     hipr::launch_shade(c->shading_models, a);
 }
 
@@ -883,11 +884,13 @@ int build_derived_geometry(HiprContext* c, const HiprSceneDesc* s) {
     }
     // the listing pass's class of every triangle (k_classify_hits): bit 0 = the material of its instance carries a coat
     c->scene_has_textures = s->environment != nullptr;
+    c->scene_has_environment = s->environment != nullptr;
     for (uint32_t m = 0; m < s->material_count; ++m) {
         const HiprMaterial& material = s->materials[m];
         c->scene_has_textures = c->scene_has_textures || material.tint_roughness_texture_ID || material.roughness_texture_ID || material.metallic_texture_ID || material.coverage_texture_ID;
     }
-    for (uint32_t l = 0; l < s->light_count; ++l) c->scene_has_textures = c->scene_has_textures || (s->lights[l].flags & HIPR_LIGHT_TYPE_MASK) == HIPR_LIGHT_PRESAMPLED_ENVIRONMENT;
+    for (uint32_t l = 0; l < s->light_count; ++l) c->scene_has_environment = c->scene_has_environment || (s->lights[l].flags & HIPR_LIGHT_TYPE_MASK) == HIPR_LIGHT_PRESAMPLED_ENVIRONMENT;
+    c->scene_has_textures = c->scene_has_textures || c->scene_has_environment;
     c->any_coated_triangle = false;
     c->all_triangles_opaque = true;
     for (uint32_t t = 0; t < s->triangle_count; ++t) c->all_triangles_opaque = c->all_triangles_opaque && (s->triangles[t].flags & HIPR_TRIANGLE_OPAQUE) != 0;

@@ -26,7 +26,8 @@ struct ShadeLaunch {
     unsigned long long* zero_b;
     unsigned char* nee_flags;         // one byte per queue entry: non-null runs the kernel as its two halves (shade_kernel.h SHADE_PART_*)
     DeviceCounters* counters;
-    bool textures;                    // the scene holds textures or an environment map (false: k_shade<..., TEXTURES = false>)
+    bool textures;                    // the scene holds textures or an environment map (false: k_shade<..., TEXTURES = 0>)
+    bool environment;                 // ... an environment map or a presampled environment light (false with textures: TEXTURES = 1)
 };
 
 void launch_shade(int shading_models, const ShadeLaunch& args);

@@ -8,7 +8,7 @@
 
 namespace hipr {
 
-template <int MODELS, bool AOV, bool TEXTURES>
+template <int MODELS, bool AOV, int TEXTURES>
 static void launch_models_with(const ShadeLaunch& a) {
     if (!AOV && a.nee_flags) {     // the two halves, one after the other (shade_kernel.h SHADE_PART_*)
         hipLaunchKernelGGL((k_shade<MODELS, AOV, SHADE_PART_NEE, TEXTURES>), dim3(a.grid), dim3(SHADE_BLOCK), 0, a.stream, a.scene, a.camera, a.frame, a.entry, a.in, a.hits, a.order, a.order_coat, a.listed, a.out,
@@ -24,8 +24,9 @@ static void launch_models_with(const ShadeLaunch& a) {
 // Scenes without a texture or an environment map run the instantiation without the samplers (shade_kernel.h TEXTURES); the AOV entries keep the one generic kernel.
 template <int MODELS, bool AOV>
 static void launch_models(const ShadeLaunch& a) {
-    if (!AOV && !a.textures) launch_models_with<MODELS, AOV, false>(a);
-    else launch_models_with<MODELS, AOV, true>(a);
+    if (!AOV && !a.textures) launch_models_with<MODELS, AOV, 0>(a);
+    else if (!AOV && !a.environment) launch_models_with<MODELS, AOV, 1>(a);      // material textures under a plain sky (the two-kernel form too: its frames are compared bit for bit)
+    else launch_models_with<MODELS, AOV, 2>(a);
 }
 
 // The kernel is instantiated per set of shading models the uploaded scene uses (bit 0 Default, 1 Diffuse, 2 Transmissive).

@@ -51,10 +51,11 @@ struct ShadeGeometry {
     float4 s0, s1, s2, s3, s4, s5;     // shading record (k_build_shade_triangles)
 };
 
-// TEXTURES: the scene holds textures or an environment map. Scenes with neither (decided at upload) run the instantiation without the samplers -- four inlined copies of
+// TEXTURES: 0 = the scene holds neither textures nor an environment map, 1 = material textures only (round 4: the environment lookups -- atan2 / asin, the PDF image, the presampled
+// light -- are dead code for a textured scene under a plain sky, profiles/r04_ab_coverage_chain.txt), 2 = everything. Scenes with neither (decided at upload) run the instantiation without the samplers -- four inlined copies of
 // sample_texture, the environment lookups -- which are never executed there but cost the kernel 43 spilled scalar registers (round 4, profiles/r04_ab_shade_without_textures.txt:
 // atrium shade 32.9 -> 31.6 ms per 64 accumulations, Cornell all-Diffuse step -2.8 %).
-template <int MODELS, bool AOV, int PART = SHADE_PART_ALL, bool TEXTURES = true>
+template <int MODELS, bool AOV, int PART = SHADE_PART_ALL, int TEXTURES = 2>
 HD void shade_path(const DeviceScene& sc, const HiprCameraState& cam, int entry, const uint32_t* sobol_lds, f3 ro, const float4* origin_of_entry, f3 rd, float bsdf_pdf, f3 throughput, uint32_t bounces,
                    uint32_t last_triangle, uint32_t pixel_hash, uint32_t accumulation, float4 hit, const ShadeGeometry& geo, const HiprMaterial& mp, bool nee_kept_a_sample,
                    ShadeOutput& out) {
@@ -71,7 +72,7 @@ HD void shade_path(const DeviceScene& sc, const HiprCameraState& cam, int entry,
         }
         // miss program (SimpleRGPs.cu:349-362): the tint, or the environment map weighted against the BSDF sample that got here
         f3 environment = mk3(sc.env_tint[0], sc.env_tint[1], sc.env_tint[2]);
-        if (TEXTURES && sc.env_map_ID) {
+        if (TEXTURES >= 2 && sc.env_map_ID) {
             environment = environment_evaluate(sc, rd);
             if (pdf_valid_not_delta(bsdf_pdf)) environment *= balance_heuristic(pdf_value(bsdf_pdf), pdf_value(environment_pdf(sc, rd)));
         }
@@ -241,7 +242,7 @@ HD void shade_path(const DeviceScene& sc, const HiprCameraState& cam, int entry,
             int li = int(r.z * light_count);
             li = li > light_count - 1 ? light_count - 1 : li;
             LightSample c;
-            if (TEXTURES && (sc.lights[li].flags & HIPR_LIGHT_TYPE_MASK) == HIPR_LIGHT_PRESAMPLED_ENVIRONMENT) {   // table lookup, PresampledEnvironmentLightImpl.h:22-27
+            if (TEXTURES >= 2 && (sc.lights[li].flags & HIPR_LIGHT_TYPE_MASK) == HIPR_LIGHT_PRESAMPLED_ENVIRONMENT) {   // table lookup, PresampledEnvironmentLightImpl.h:22-27
                 int index = int(r.x * float(sc.env_sample_count));
                 index = index > int(sc.env_sample_count) - 1 ? int(sc.env_sample_count) - 1 : index;
                 const float4 a = sc.env_samples[2 * index], b = sc.env_samples[2 * index + 1];
@@ -376,7 +377,7 @@ HD HiprMaterial shade_fetch_material(const DeviceScene& sc, const ShadeInputs& i
 #endif
 constexpr uint32_t SHADE_LDS_LIGHTS = 32;   // light arrays up to this size are copied to LDS (1.5 KB); larger ones are read from global memory
 constexpr int shade_waves_per_simd(int part) { return part == SHADE_PART_ALL ? HIPR_SHADE_WAVES : HIPR_SHADE_SPLIT_WAVES; }
-template <int MODELS, bool AOV, int PART, bool TEXTURES = true>
+template <int MODELS, bool AOV, int PART, int TEXTURES = 2>
 __global__ __launch_bounds__(SHADE_BLOCK, shade_waves_per_simd(PART)) void k_shade(DeviceScene sc, HiprCameraState cam, FrameInfo frame, int entry, PathState in, const float4* hits, const uint32_t* order_list, const uint32_t* order_coat, const unsigned long long* listed, PathState out,
                                                         ShadowQueue shadows, float4* radiance, const uint32_t* count_ptr, unsigned long long* out_counts,
                                                         unsigned long long* zero_a, unsigned long long* zero_b, unsigned char* nee_flags, DeviceCounters* counters) {
