@@ -123,6 +123,7 @@ struct HiprContext {
     Wide8Scene wide8 = {};              // the 8-wide tree with leaf records: what the persistent kernels walk when the scene brings one
     uint32_t wide8_height = 0;
     DeviceBuffer nodes, triangles, instances, indices, geometry, texcoords, tints, emissions, materials, lights, textures, texels;
+    bool coverage_textures_r8 = false;  // every coverage texture of the uploaded scene is HIPR_TEXEL_R8 and linear: k_trace_wide8<..., COVERAGE_R8 = true>
     bool all_triangles_opaque = false;  // no triangle of the uploaded scene needs its material's coverage sampled (HIPR_TRIANGLE_OPAQUE on all): k_trace_wide8<..., COVERAGE = false>
     bool lean_trace = true;             // HIPR_LEAN_TRACE=0: always the full kernel
     bool scene_has_environment = true;  // ... an environment map or a presampled environment light: k_shade<..., TEXTURES = 2>; textures without one: TEXTURES = 1
@@ -387,6 +388,11 @@ void launch_wide8(HiprContext* c, const Wavefront& w, const PathState& in, const
         else
             hipLaunchKernelGGL((k_trace_wide8<STACK, MODE, INSTRUMENT, true, true>), dim3(grid), dim3(TRACE_BLOCK), 0, w.stream, c->scene, c->wide8, in, w.hits.as<float4>(), w.shadow_queue(),
                                c->radiance.as<float4>(), closest_count, shadow_count, next_work_counter(c), c->refill_below, c->counters.as<DeviceCounters>(), sorted);
+        return;
+    }
+    if constexpr (!INSTRUMENT && MODE != TRACE_CLOSEST) if (!sorted && !c->all_triangles_opaque && c->coverage_textures_r8 && c->lean_trace) {     // the coverage sampler for 8-bit single-channel textures only
+        hipLaunchKernelGGL((k_trace_wide8<STACK, MODE, INSTRUMENT, true, false, true>), dim3(grid), dim3(TRACE_BLOCK), 0, w.stream, c->scene, c->wide8, in, w.hits.as<float4>(), w.shadow_queue(),
+                           c->radiance.as<float4>(), closest_count, shadow_count, next_work_counter(c), c->refill_below, c->counters.as<DeviceCounters>());
         return;
     }
     // scenes whose triangles are all statically opaque run the kernel without the coverage code (closest-only launches never reach it anyway)
@@ -891,6 +897,10 @@ int build_derived_geometry(HiprContext* c, const HiprSceneDesc* s) {
     }
     for (uint32_t l = 0; l < s->light_count; ++l) c->scene_has_environment = c->scene_has_environment || (s->lights[l].flags & HIPR_LIGHT_TYPE_MASK) == HIPR_LIGHT_PRESAMPLED_ENVIRONMENT;
     c->scene_has_textures = c->scene_has_textures || c->scene_has_environment;
+    c->coverage_textures_r8 = true;
+    for (uint32_t m = 0; m < s->material_count; ++m)
+        if (const int32_t id = s->materials[m].coverage_texture_ID)
+            c->coverage_textures_r8 = c->coverage_textures_r8 && uint32_t(id) < s->texture_count && s->textures[id].format == HIPR_TEXEL_R8 && !s->textures[id].is_sRGB;
     c->any_coated_triangle = false;
     c->all_triangles_opaque = true;
     for (uint32_t t = 0; t < s->triangle_count; ++t) c->all_triangles_opaque = c->all_triangles_opaque && (s->triangles[t].flags & HIPR_TRIANGLE_OPAQUE) != 0;

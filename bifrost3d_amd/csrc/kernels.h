@@ -434,6 +434,33 @@ HD float material_coverage(const DeviceScene& sc, const HiprMaterial& m, f2 uv) 
     return m.coverage * tex;
 }
 
+// The same for scenes whose coverage textures are all single-channel 8-bit and linear (what the loaders make of an alpha channel; decided at upload): the sampler
+// without its other three formats and the sRGB decode -- code a shadow ray never reaches there, and registers the traversal loop gets back
+// (k_trace_wide8<..., COVERAGE_R8 = true>, profiles/r04_ab_coverage_chain.txt). Term for term what sample_texture / fetch_texel compute for such a texture.
+HD float sample_texture_r8(const DeviceScene& sc, int id, f2 uv) {
+    const HiprTexture tex = sc.textures[id];
+    const uint8_t* base = sc.texels + tex.texel_offset;
+    const int w = int(tex.width), h = int(tex.height);
+    auto texel = [&](int x, int y) { return base[size_t(y) * tex.width + size_t(x)] / 255.0f; };
+    if (tex.filter & 1) {
+        const float xb = uv.x * w - 0.5f, yb = uv.y * h - 0.5f;
+        const float xf = floorf(xb), yf = floorf(yb);
+        const float fx = xb - xf, fy = yb - yf;
+        const int x0 = wrap_coord(int(xf), w, tex.wrap_u), x1 = wrap_coord(int(xf) + 1, w, tex.wrap_u);
+        const int y0 = wrap_coord(int(yf), h, tex.wrap_v), y1 = wrap_coord(int(yf) + 1, h, tex.wrap_v);
+        const float a = texel(x0, y0), b = texel(x1, y0), c = texel(x0, y1), d = texel(x1, y1);
+        const float lo = a + (b - a) * fx, hi = c + (d - c) * fx;
+        return lo + (hi - lo) * fy;
+    }
+    return texel(wrap_coord(int(floorf(uv.x * w)), w, tex.wrap_u), wrap_coord(int(floorf(uv.y * h)), h, tex.wrap_v));
+}
+HD float material_coverage_r8(const DeviceScene& sc, const HiprMaterial& m, f2 uv) {
+    float tex = 1.0f;
+    if (m.coverage_texture_ID) tex = sample_texture_r8(sc, m.coverage_texture_ID, uv);
+    if (m.flags & HIPR_MATERIAL_CUTOUT) return tex < m.coverage ? 0.0f : 1.0f;
+    return m.coverage * tex;
+}
+
 // the same for a material known to carry no coverage texture (the shade kernel's instantiation for scenes without textures)
 HD float material_coverage_untextured(const HiprMaterial& m) {
     if (m.flags & HIPR_MATERIAL_CUTOUT) return 1.0f < m.coverage ? 0.0f : 1.0f;

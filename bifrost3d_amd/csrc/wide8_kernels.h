@@ -54,12 +54,13 @@ constexpr int WIDE8_STACK_SHALLOW = 12;      // 12 KB per block of two waves: tw
 #endif
 HD constexpr int wide8_waves_per_simd(int stack_entries) { return stack_entries <= 8 ? HIPR_WIDE8_WAVES_LOW : (stack_entries <= 12 ? HIPR_WIDE8_WAVES : (stack_entries <= 16 ? 5 : 4)); }
 
+// COVERAGE_R8: ... and every coverage texture is single-channel 8-bit, linear (kernels.h material_coverage_r8).
 // COVERAGE: the scene holds triangles that are not statically opaque (coverage textures, cut-outs, partial coverage): a shadow ray that hits one samples its material's
 // coverage. Scenes without any (the common case; decided at upload) run the instantiation without that code: it is a fifth of the kernel's instructions and, though never
 // executed there, it weighs on the register allocation of the loop around it (profiles/r04_ab_trace_without_coverage.txt).
 // SORTED: the rays are taken in the order of `sorted` (ray_sort.hip: closest-hit rays first, each kind by origin cell and direction octant) instead of queue order;
 // every result is stored where it is in queue order, so nothing downstream sees the difference.
-template <int STACK, int MODE, bool INSTRUMENT, bool COVERAGE = true, bool SORTED = false>
+template <int STACK, int MODE, bool INSTRUMENT, bool COVERAGE = true, bool SORTED = false, bool COVERAGE_R8 = false>
 __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(wide8_waves_per_simd(STACK)))) void k_trace_wide8(DeviceScene sc, Wide8Scene tree, PathState in, float4* hits, ShadowQueue q,
         float4* radiance, const uint32_t* closest_count_ptr, const uint32_t* shadow_count_ptr, uint32_t* work_counter, int refill_below, DeviceCounters* counters,
         const uint32_t* sorted = nullptr) {
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(wid
                                         const float4 r3 = record[3], r6 = record[6], r7 = record[7];
                                         const float w = 1.0f - u - v;
                                         const f2 uv = mk2(r6.z, r6.w) * u + mk2(r7.x, r7.y) * v + mk2(r6.x, r6.y) * w;
-                                        coverage = material_coverage(sc, sc.materials[__float_as_uint(r3.w)], uv);
+                                        coverage = COVERAGE_R8 ? material_coverage_r8(sc, sc.materials[__float_as_uint(r3.w)], uv) : material_coverage(sc, sc.materials[__float_as_uint(r3.w)], uv);
                                     }
                                     pay_x *= 1.0f - coverage; pay_y *= 1.0f - coverage; pay_z *= 1.0f - coverage;
                                     if (pay_x < 0.0000001f && pay_y < 0.0000001f && pay_z < 0.0000001f) {   // fully shadowed: the ray is done
