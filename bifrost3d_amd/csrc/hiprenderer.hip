@@ -126,7 +126,7 @@ struct HiprContext {
     bool coverage_textures_r8 = false;  // every coverage texture of the uploaded scene is HIPR_TEXEL_R8 and linear: k_trace_wide8<..., COVERAGE_R8 = true>
     bool all_triangles_opaque = false;  // no triangle of the uploaded scene needs its material's coverage sampled (HIPR_TRIANGLE_OPAQUE on all): k_trace_wide8<..., COVERAGE = false>
     bool lean_trace = true;             // HIPR_LEAN_TRACE=0: always the full kernel
-    bool scene_has_environment = true;  // ... an environment map or a presampled environment light: k_shade<..., TEXTURES = 2>; textures without one: TEXTURES = 1
+    bool scene_has_environment = true;  // ... an environment map, a presampled environment light or a float texture: k_shade<..., TEXTURES = 2>; 8-bit textures without those: TEXTURES = 1
     bool scene_has_textures = true;     // a material references a texture, or the scene brings an environment map / presampled environment light: k_shade<..., TEXTURES = true>
     bool lean_shade = true;             // HIPR_LEAN_SHADE=0: always the full kernel
     DeviceBuffer triangle_class;        // one byte per triangle for the listing pass (k_classify_hits): bit 0 = its material is coated
@@ -896,6 +896,8 @@ int build_derived_geometry(HiprContext* c, const HiprSceneDesc* s) {
         c->scene_has_textures = c->scene_has_textures || material.tint_roughness_texture_ID || material.roughness_texture_ID || material.metallic_texture_ID || material.coverage_texture_ID;
     }
     for (uint32_t l = 0; l < s->light_count; ++l) c->scene_has_environment = c->scene_has_environment || (s->lights[l].flags & HIPR_LIGHT_TYPE_MASK) == HIPR_LIGHT_PRESAMPLED_ENVIRONMENT;
+    for (uint32_t t = 1; t < s->texture_count; ++t)       // float textures take the generic samplers: TEXTURES = 2 as well
+        c->scene_has_environment = c->scene_has_environment || s->textures[t].format == HIPR_TEXEL_R32F || s->textures[t].format == HIPR_TEXEL_RGBA32F;
     c->scene_has_textures = c->scene_has_textures || c->scene_has_environment;
     c->coverage_textures_r8 = true;
     for (uint32_t m = 0; m < s->material_count; ++m)

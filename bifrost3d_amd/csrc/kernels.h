@@ -389,19 +389,21 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(DeviceScene sc, P
 // ---------------------------------------------------------------------------------------------
 HD float srgb_to_linear(float c) { return c <= 0.04045f ? c / 12.92f : pow_((c + 0.055f) / 1.055f, 2.4f); }
 
+// FLOAT_FORMATS = false: the caller knows the scene holds 8-bit textures only (k_shade<..., TEXTURES = 1>)
+template <bool FLOAT_FORMATS = true>
 HD f4 fetch_texel(const DeviceScene& sc, const HiprTexture& tex, int x, int y) {
     const uint8_t* base = sc.texels + tex.texel_offset;
     size_t i = size_t(y) * tex.width + size_t(x);
     f4 r;
     if (tex.format == HIPR_TEXEL_R8) { r = {base[i] / 255.0f, 0, 0, 1}; }
-    else if (tex.format == HIPR_TEXEL_RGBA8) {
+    else if (!FLOAT_FORMATS || tex.format == HIPR_TEXEL_RGBA8) {
         uint32_t p = reinterpret_cast<const uint32_t*>(base)[i];
         r = {(p & 0xFFu) / 255.0f, ((p >> 8) & 0xFFu) / 255.0f, ((p >> 16) & 0xFFu) / 255.0f, (p >> 24) / 255.0f};
     } else if (tex.format == HIPR_TEXEL_R32F) { r = {reinterpret_cast<const float*>(base)[i], 0, 0, 1}; }
     else { float4 v = reinterpret_cast<const float4*>(base)[i]; r = {v.x, v.y, v.z, v.w}; }
     if (tex.is_sRGB) {
         r.x = srgb_to_linear(r.x);
-        if (tex.format == HIPR_TEXEL_RGBA8 || tex.format == HIPR_TEXEL_RGBA32F) { r.y = srgb_to_linear(r.y); r.z = srgb_to_linear(r.z); }
+        if (tex.format == HIPR_TEXEL_RGBA8 || (FLOAT_FORMATS && tex.format == HIPR_TEXEL_RGBA32F)) { r.y = srgb_to_linear(r.y); r.z = srgb_to_linear(r.z); }
     }
     return r;
 }
@@ -409,6 +411,7 @@ HD int wrap_coord(int i, int n, int repeat) {
     if (repeat) { i %= n; return i < 0 ? i + n : i; }
     return i < 0 ? 0 : (i >= n ? n - 1 : i);
 }
+template <bool FLOAT_FORMATS = true>
 HD f4 sample_texture(const DeviceScene& sc, int id, f2 uv) {
     const HiprTexture tex = sc.textures[id];
     int w = int(tex.width), h = int(tex.height);
@@ -418,18 +421,19 @@ HD f4 sample_texture(const DeviceScene& sc, int id, f2 uv) {
         float fx = xb - xf, fy = yb - yf;
         int x0 = wrap_coord(int(xf), w, tex.wrap_u), x1 = wrap_coord(int(xf) + 1, w, tex.wrap_u);
         int y0 = wrap_coord(int(yf), h, tex.wrap_v), y1 = wrap_coord(int(yf) + 1, h, tex.wrap_v);
-        f4 a = fetch_texel(sc, tex, x0, y0), b = fetch_texel(sc, tex, x1, y0);
-        f4 c = fetch_texel(sc, tex, x0, y1), d = fetch_texel(sc, tex, x1, y1);
+        f4 a = fetch_texel<FLOAT_FORMATS>(sc, tex, x0, y0), b = fetch_texel<FLOAT_FORMATS>(sc, tex, x1, y0);
+        f4 c = fetch_texel<FLOAT_FORMATS>(sc, tex, x0, y1), d = fetch_texel<FLOAT_FORMATS>(sc, tex, x1, y1);
         f4 lo = a + (b - a) * fx, hi = c + (d - c) * fx;
         return lo + (hi - lo) * fy;
     }
     int x = wrap_coord(int(floorf(uv.x * w)), w, tex.wrap_u);
     int y = wrap_coord(int(floorf(uv.y * h)), h, tex.wrap_v);
-    return fetch_texel(sc, tex, x, y);
+    return fetch_texel<FLOAT_FORMATS>(sc, tex, x, y);
 }
+template <bool FLOAT_FORMATS = true>
 HD float material_coverage(const DeviceScene& sc, const HiprMaterial& m, f2 uv) {
     float tex = 1.0f;
-    if (m.coverage_texture_ID) tex = sample_texture(sc, m.coverage_texture_ID, uv).x;
+    if (m.coverage_texture_ID) tex = sample_texture<FLOAT_FORMATS>(sc, m.coverage_texture_ID, uv).x;
     if (m.flags & HIPR_MATERIAL_CUTOUT) return tex < m.coverage ? 0.0f : 1.0f;
     return m.coverage * tex;
 }

@@ -51,7 +51,7 @@ struct ShadeGeometry {
     float4 s0, s1, s2, s3, s4, s5;     // shading record (k_build_shade_triangles)
 };
 
-// TEXTURES: 0 = the scene holds neither textures nor an environment map, 1 = material textures only (round 4: the environment lookups -- atan2 / asin, the PDF image, the presampled
+// TEXTURES: 0 = the scene holds neither textures nor an environment map, 1 = 8-bit material textures only (round 4: the samplers lose their float formats, and the environment lookups -- atan2 / asin, the PDF image, the presampled
 // light -- are dead code for a textured scene under a plain sky, profiles/r04_ab_coverage_chain.txt), 2 = everything. Scenes with neither (decided at upload) run the instantiation without the samplers -- four inlined copies of
 // sample_texture, the environment lookups -- which are never executed there but cost the kernel 43 spilled scalar registers (round 4, profiles/r04_ab_shade_without_textures.txt:
 // atrium shade 32.9 -> 31.6 ms per 64 accumulations, Cornell all-Diffuse step -2.8 %).
@@ -111,7 +111,7 @@ HD void shade_path(const DeviceScene& sc, const HiprCameraState& cam, int entry,
     const bool backside_cull = !hit_from_front && !thin_walled && !transmissive;
 
     const f4 bsdf_u = sobol4f_tables(accumulation, pixel_hash, 8u * bounces + 2u, sobol_lds);   // BSDF dimension, always drawn
-    const float coverage = TEXTURES ? material_coverage(sc, mp, texcoord) : material_coverage_untextured(mp);
+    const float coverage = TEXTURES ? material_coverage<TEXTURES >= 2>(sc, mp, texcoord) : material_coverage_untextured(mp);
     if (backside_cull || coverage < bsdf_u.w) {
         // rejected hit: same ray, tmin bumped past it, counters untouched (MonteCarlo.cu:159-164)
         if (PART == SHADE_PART_NEE) return;
@@ -154,14 +154,14 @@ HD void shade_path(const DeviceScene& sc, const HiprCameraState& cam, int entry,
 
     // --- material ---------------------------------------------------------------------------------
     f4 tr = {mp.tint[0], mp.tint[1], mp.tint[2], mp.roughness};
-    if (TEXTURES && mp.tint_roughness_texture_ID) tr = tr * sample_texture(sc, mp.tint_roughness_texture_ID, texcoord);
-    if (TEXTURES && mp.roughness_texture_ID) tr.w *= sample_texture(sc, mp.roughness_texture_ID, texcoord).x;
+    if (TEXTURES && mp.tint_roughness_texture_ID) tr = tr * sample_texture<TEXTURES >= 2>(sc, mp.tint_roughness_texture_ID, texcoord);
+    if (TEXTURES && mp.roughness_texture_ID) tr.w *= sample_texture<TEXTURES >= 2>(sc, mp.roughness_texture_ID, texcoord).x;
     tr = tr * tint_scale;
     MaterialInputs in;
     in.tint = {tr.x, tr.y, tr.z};
     in.roughness = tr.w;
     in.specularity = mp.specularity;
-    in.metallic = (TEXTURES && mp.metallic_texture_ID) ? mp.metallic * sample_texture(sc, mp.metallic_texture_ID, texcoord).x : mp.metallic;
+    in.metallic = (TEXTURES && mp.metallic_texture_ID) ? mp.metallic * sample_texture<TEXTURES >= 2>(sc, mp.metallic_texture_ID, texcoord).x : mp.metallic;
     in.coat = mp.coat / 65535.0f;
     in.coat_roughness = mp.coat_roughness / 65535.0f;
     // PathRegularizationSettings::PDF_scale_at_accumulation (OR/PublicTypes.h:44), per path: a pass may carry several accumulations
