@@ -176,6 +176,39 @@ static bool statically_opaque(const HiprMaterial& m) {
     return m.coverage >= 1.0f;
 }
 
+// A triangle of a material that is NOT statically opaque can still be: where its coverage texture covers it everywhere -- a finely tessellated cut-out surface
+// (a fence, a lace banner) has many triangles that lie wholly on solid texels. Those get HIPR_TRIANGLE_OPAQUE too, and a shadow ray that hits one ends without
+// the material -> texture -> texel lookups; get_coverage (OptiXRenderer/Types.h:405-414) would have returned 1 for every point of the triangle, so nothing changes
+// for the reference's any-hit program, the oracle's or the kernels'. Decided conservatively from the texels the sampler can touch for ANY point of the triangle:
+// the texture coordinates of its points lie in the bounding box of its corners' (the interpolation's rounding is covered by a texel of slack on every side), so
+// every texel under that box, plus the bilinear neighbour, must pass. 8-bit linear textures only; boxes of more than 64 x 64 texels are left to the sampler.
+static bool covered_everywhere(const HiprMaterial& m, const HiprTexture& t, const uint8_t* texels, const float (&uv)[3][2]) {
+    if ((t.format != HIPR_TEXEL_R8 && t.format != HIPR_TEXEL_RGBA8) || t.is_sRGB || t.width == 0 || t.height == 0) return false;
+    const bool cutout = (m.flags & HIPR_MATERIAL_CUTOUT) != 0;
+    if (!cutout && !(m.coverage >= 1.0f)) return false;
+    const bool linear = (t.filter & 1) != 0;
+    const int size[2] = {int(t.width), int(t.height)};
+    int first[2], last[2];
+    for (int a = 0; a < 2; ++a) {
+        const float lo = std::min(uv[0][a], std::min(uv[1][a], uv[2][a])) * float(size[a]), hi = std::max(uv[0][a], std::max(uv[1][a], uv[2][a])) * float(size[a]);
+        if (!(std::fabs(lo) < 1048576.0f) || !(std::fabs(hi) < 1048576.0f)) return false;      // also NaN
+        first[a] = int(std::floor(lo - (linear ? 0.5f : 0.0f))) - 1;
+        last[a] = int(std::floor(hi - (linear ? 0.5f : 0.0f))) + (linear ? 1 : 0) + 1;
+        if (last[a] - first[a] + 1 > 64) return false;
+    }
+    const int channels = t.format == HIPR_TEXEL_RGBA8 ? 4 : 1;
+    const uint8_t* base = texels + t.texel_offset;
+    auto wrap = [](int i, int n, bool repeat) { if (repeat) { i %= n; return i < 0 ? i + n : i; } return i < 0 ? 0 : (i >= n ? n - 1 : i); };
+    for (int y = first[1]; y <= last[1]; ++y)
+        for (int x = first[0]; x <= last[0]; ++x) {
+            const uint8_t value = base[(size_t(wrap(y, size[1], t.wrap_v != 0)) * t.width + size_t(wrap(x, size[0], t.wrap_u != 0))) * size_t(channels)];      // the sampler's .x
+            // cut-out: the sampled value must not fall below the threshold -- with a margin that a bilinear blend of passing texels cannot round through;
+            // plain coverage: coverage * texture must be 1, i.e. every texel exactly 1
+            if (cutout ? !(float(value) / 255.0f > m.coverage + 1e-5f) : value != 255) return false;
+        }
+    return true;
+}
+
 // backside_cull of the hit program (OptiXRenderer/Shading/MonteCarlo.cu:147-164): !hit_from_front && !thin_walled && !transmissive, thin_walled = cut-out or thin-walled.
 static bool refuses_hits_from_behind(const HiprMaterial& m) {
     return !(m.flags & (HIPR_MATERIAL_CUTOUT | HIPR_MATERIAL_THIN_WALLED)) && m.shading_model != HIPR_SHADING_TRANSMISSIVE;
@@ -188,7 +221,8 @@ void SceneBuilder::finalize(uint32_t bvh_max_depth) {
         const HiprInstance& inst = m_instances[i];
         const MeshRecord& mesh = m_meshes[m_instance_mesh[i]];
         const float* M = inst.object_to_world;
-        const bool opaque = statically_opaque(m_materials[inst.material_index]);
+        const HiprMaterial& material = m_materials[inst.material_index];
+        const bool opaque = statically_opaque(material);
         const bool one_sided = refuses_hits_from_behind(m_materials[inst.material_index]);
         auto to_world = [&](uint32_t v, float* out) {
             const float* p = m_geometry[mesh.vertex_offset + v].position;
@@ -201,7 +235,14 @@ void SceneBuilder::finalize(uint32_t bvh_max_depth) {
             to_world(idx[0], t.v0); to_world(idx[1], t.v1); to_world(idx[2], t.v2);
             t.instance_index = i;
             t.primitive_index = p;
-            t.flags = (opaque ? HIPR_TRIANGLE_OPAQUE : 0) | (one_sided ? HIPR_TRIANGLE_ONE_SIDED : 0);
+            bool triangle_opaque = opaque;
+            if (!opaque && material.coverage_texture_ID > 0 && size_t(material.coverage_texture_ID) < m_textures.size()) {      // covered_everywhere: this triangle may still be
+                float uv[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+                if (inst.mesh_flags & HIPR_MESH_TEXCOORDS)
+                    for (int k = 0; k < 3; ++k) { uv[k][0] = m_texcoords[2 * size_t(mesh.vertex_offset + idx[k])]; uv[k][1] = m_texcoords[2 * size_t(mesh.vertex_offset + idx[k]) + 1]; }
+                triangle_opaque = covered_everywhere(material, m_textures[size_t(material.coverage_texture_ID)], m_texels.data(), uv);
+            }
+            t.flags = (triangle_opaque ? HIPR_TRIANGLE_OPAQUE : 0) | (one_sided ? HIPR_TRIANGLE_ONE_SIDED : 0);
             world.push_back(t);
         }
     }

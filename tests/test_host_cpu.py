@@ -135,6 +135,48 @@ def test_textured_atrium_brings_textures_and_cut_outs():
     assert float(image_t[..., :3].mean()) < 0.9 * float(image_p[..., :3].mean())
 
 
+def test_triangles_wholly_on_solid_texels_are_flagged_opaque_and_nothing_changes():
+    """SceneBuilder::finalize flags a triangle of a cut-out material HIPR_TRIANGLE_OPAQUE when its coverage texture covers it everywhere (covered_everywhere: every texel
+    the sampler can touch for any point of the triangle passes) -- a shadow ray then ends on it without the material / texture lookups. The claim under test: get_coverage
+    would have returned 1 at EVERY point of such a triangle. With the flags of those triangles cleared again (a copy of the scene), the oracle's brute-force any-hit
+    evaluates the texture instead -- and must return the same transmittance, bit for bit, for rays aimed at random points of the newly flagged triangles and for random
+    rays through the hall."""
+    import ctypes as C
+    import oracle_bindings
+    scene = Scene("atrium", param0=120000, param1=2, textured=True)
+    d = scene.desc
+    cut_out_instances = {i for i in range(d.instance_count) if d.materials[d.instances[i].material_index].coverage_texture_ID}
+    flagged = [i for i in range(d.triangle_count) if d.triangles[i].instance_index in cut_out_instances and d.triangles[i].flags & 1]
+    mixed = [i for i in range(d.triangle_count) if d.triangles[i].instance_index in cut_out_instances and not d.triangles[i].flags & 1]
+    assert len(flagged) > 1000 and len(mixed) > len(flagged)                 # a lace with a quarter of its area open: most triangles straddle a hole
+    rng = np.random.default_rng(11)
+    chosen = rng.choice(flagged, 4000)
+    corners = np.array([[list(d.triangles[i].v0), list(d.triangles[i].v1), list(d.triangles[i].v2)] for i in chosen], np.float64)
+    weights = rng.dirichlet((1.0, 1.0, 1.0), len(chosen))
+    points = np.einsum("nk,nkc->nc", weights, corners)
+    normals = np.cross(corners[:, 1] - corners[:, 0], corners[:, 2] - corners[:, 0])
+    normals /= np.linalg.norm(normals, axis=1, keepdims=True)
+    aimed = np.zeros((len(chosen), 8), np.float32)
+    aimed[:, 0:3] = points + 0.01 * normals; aimed[:, 4:7] = -normals; aimed[:, 7] = 0.02
+    through = np.zeros((6000, 8), np.float32)
+    through[:, 0:3] = rng.uniform([-14, 0.2, -6], [14, 9.5, 6], (6000, 3))
+    direction = rng.normal(size=(6000, 3)); direction /= np.linalg.norm(direction, axis=1, keepdims=True)
+    through[:, 4:7] = direction; through[:, 7] = 40.0
+    rays = np.concatenate([aimed, through])
+    oracle = oracle_bindings.get_oracle(True)
+    with_flags, _ = oracle.trace_shadow(d, rays, use_bvh=0)
+    triangles = (capi.HiprTriangle * d.triangle_count)()
+    C.memmove(triangles, d.triangles, C.sizeof(triangles))
+    for i in flagged: triangles[i].flags &= ~1
+    unflagged = capi.HiprSceneDesc()
+    C.memmove(C.byref(unflagged), C.byref(d), C.sizeof(unflagged))
+    unflagged.triangles = triangles
+    without_flags, _ = oracle.trace_shadow(unflagged, rays, use_bvh=0)
+    assert np.array_equal(with_flags, without_flags)
+    assert (with_flags[:len(chosen)] == 0.0).all()                          # the aimed rays end on their triangle
+    assert 0.05 < float((with_flags[len(chosen):] == 0.0).mean()) < 0.95    # the others: some blocked, some not
+
+
 def test_bvh_depth_cap_holds_for_adversarial_input():
     # exponentially spaced slivers drive SAH towards a degenerate chain; the builder must cap the depth
     n = 3000
