@@ -34,7 +34,7 @@ def test_the_deadline_ends_ranks_that_never_finish():
 
 def test_bench_host_logic_without_a_gpu():
     """The parts of bench.py that decide what is measured, importable and checkable on the host: the kernel names the counter passes are summed under
-    (instrumented launches are NOT the timed kernel), the --fixed-frame batching (exactly `steps` steps timed after exactly `warmup`), the VALU roofline's
+    (instrumented launches are NOT the timed kernel), the fixed-frame batching (exactly `steps` steps timed), the VALU roofline's
     arithmetic on counters calibrated by the rate kernel, the unavoidable bytes of a trace launch."""
     sys.path.insert(0, str(ROOT))
     import bench
@@ -44,9 +44,10 @@ def test_bench_host_logic_without_a_gpu():
     assert bench.kernel_bench_name("void hipr::k_trace_wide8<12, 2, true>(...)") is None              # the counting build of the kernel
     assert bench.kernel_bench_name("void hipr::k_trace_persistent<16, 2, true, false>(...)") is None
     assert bench.kernel_bench_name("void hipr::k_shade<1, false, 0>(...)") == "shade" and bench.kernel_bench_name("k_classify_hits") is None
-    for steps, warmup, world, expected in ((8, 2, 8, 2), (8, 8, 8, 8), (8, 0, 8, 8), (8, 2, 1, 1), (6, 3, 4, 3), (5, 1, 8, 1), (20, 4, 8, 4), (16, 8, 8, 8)):
-        g = bench.fixed_frame_batch(steps, warmup, world)
-        assert g == expected and steps % g == 0 and warmup % g == 0 and 1 <= g <= max(1, world), (steps, warmup, world, g)
+    # exactly `steps` steps are timed: the batch divides the step count (the warm-up's remainder runs as one shorter pass); the driver's 20 steps on 8 GPUs: 5
+    for steps, world, expected in ((8, 8, 8), (8, 1, 1), (6, 4, 3), (5, 8, 5), (20, 8, 5), (20, 4, 4), (20, 2, 2), (16, 8, 8), (7, 4, 1)):
+        g = bench.fixed_frame_batch(steps, world)
+        assert g == expected and steps % g == 0 and 1 <= g <= max(1, world), (steps, world, g)
     # a rate kernel counted at half its instructions (a counter that saw half the SIMDs) doubles the kernel's figure; 32 of 64 lanes stay 32
     cus = 256
     expected = cus * 8 * 4 * bench.RATE_KERNEL_ITERATIONS * 8.0
@@ -59,3 +60,60 @@ def test_bench_host_logic_without_a_gpu():
     u = bench.useful_traffic("trace", {"closest_rays": 100, "shadow_rays": 50, "camera_rays": 10}, 5, 64)
     assert u["writes"] == (16 * 100 + 16 * 50) / 5 and u["reads"] == (40 * 100 + 64 * 50) / 5 and u["bytes"] == u["writes"] + u["reads"]
     assert bench.useful_traffic("shade", {"closest_rays": 1, "shadow_rays": 1, "camera_rays": 1}, 1, 1) is None
+
+
+def test_the_line_the_driver_parses_is_small_and_round_trips():
+    """round 4's single line had grown to 25 KB and the driver's record of it was unparseable. `compact_line` on that very record (canned:
+    profiles/r04_bench_final.json) and on records with NaNs, huge texts and missing parts: under 4 KB, strict JSON, the contract keys and the two extra objects."""
+    import json
+    import math
+    sys.path.insert(0, str(ROOT))
+    import bench
+    full = json.loads((ROOT / "profiles" / "r04_bench_final.json").read_text())
+    assert len(json.dumps(full)) > 20000
+    cases = [full]
+    noisy = json.loads(json.dumps(full))
+    noisy["config"]["workload"] = "w" * 5000
+    noisy["roofline"]["kernel"] = "k" * 3000
+    noisy["roofline"]["frac_model"] = float("nan")
+    noisy["roofline_valu"] = {"bound": "valu", "error": "e" * 4000}
+    noisy["cpu_baseline"]["sample"] = "s" * 4000
+    noisy["config"]["workload_textured"] = {"value": 4899.0, "ms_per_step": float("inf")}
+    noisy["ranks"] = {"ms_per_step": [1.0] * 8, "gather_ms": 0.1, "passes": 4, "steps_per_pass": 5, "paths_per_gpu_per_step": 1}
+    cases.append(noisy)
+    bare = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    bare["config"] = {"workload": "x"}
+    cases.append(bare)
+    for record in cases:
+        line = bench.compact_line(record, "bench_details.json")
+        text = json.dumps(line, allow_nan=False)
+        assert len(text) < bench.LINE_LIMIT == 4096, len(text)
+        assert "\n" not in text and json.loads(text) == line
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+            assert key in line, key
+        assert line["metric"] == json.loads((ROOT / "BASELINE.json").read_text())["metric"] and "workload" in line["config"] and "model" not in line["config"]
+    line = bench.compact_line(full)
+    assert line["value"] == float(f"{full['value']:.6g}") and line["config"]["ms_per_256spp_frame"] == float(f"{full['config']['ms_per_256spp_frame']:.6g}")
+    roofline = line["roofline"]
+    assert roofline["bound"] == "hbm" and roofline["unit"] == "GB/s" and roofline["peak"] == 8000.0 and math.isclose(roofline["frac"], roofline["achieved"] / roofline["peak"], rel_tol=1e-4)
+    for key in ("kernel", "avg_launch_ms", "launches", "traffic", "algorithmic_bytes_per_launch", "frac_model", "frac_basis", "traffic_over_useful"):
+        assert key in roofline, key
+    assert set(line["roofline_valu"]) >= {"frac", "lanes_per_instruction"} and set(line["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample", "c2"}
+    assert set(line["config"]["rmse_vs_oracle"]["spp256"]) == {"rmse_rgb", "rmse_reference_compare_rms"}
+    # what does not fit goes, the contract stays
+    assert "roofline" in bench.compact_line(noisy) and bench.compact_line(noisy)["roofline"]["frac_model"] is None
+
+
+def test_emit_writes_the_details_and_one_line(tmp_path):
+    import json
+    sys.path.insert(0, str(ROOT))
+    import bench
+    full = json.loads((ROOT / "profiles" / "r04_bench_final.json").read_text())
+    read_fd, write_fd = os.pipe()
+    line = bench.emit(full, write_fd, str(tmp_path / "details.json"))
+    os.close(write_fd)
+    with os.fdopen(read_fd) as fh:
+        printed = fh.read()
+    assert printed.count("\n") == 1 and json.loads(printed) == line and len(printed) < 4096
+    details = json.loads((tmp_path / "details.json").read_text())
+    assert details["scaling_proxy"] and details["other_workloads"] and details["roofline_by_kernel"]

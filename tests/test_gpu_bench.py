@@ -14,17 +14,25 @@ SMALL = ["--width", "640", "--height", "360", "--atrium-triangles", "20000", "--
          "--no-other-workloads", "--no-rmse", "--no-plugin", "--no-cpu-baseline"]
 
 
-def run_bench(extra):
+def run_bench(extra, tmp_path=None):
+    """Returns (the one line of stdout, the full record of --details)."""
+    import tempfile
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    done = subprocess.run([sys.executable, str(ROOT / "bench.py")] + SMALL + extra, capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
+    details = Path(tempfile.mkdtemp(prefix="hipr_bench_")) / "details.json"
+    done = subprocess.run([sys.executable, str(ROOT / "bench.py")] + SMALL + extra + ["--details", str(details)], capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
     assert done.returncode == 0, done.stderr[-2000:]
     lines = [text for text in done.stdout.splitlines() if text.strip()]
     assert len(lines) == 1, lines          # ONE JSON line on stdout, everything else on stderr
-    return json.loads(lines[0])
+    assert len(lines[0]) < 4096            # and one the driver can hold (round 4's 25 KB line could not be parsed)
+    return json.loads(lines[0]), json.loads(details.read_text())
 
 
 def test_bench_line_contract_single_gpu():
-    line = run_bench([])
+    compact, line = run_bench([])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "roofline_valu"):
+        assert key in compact, key
+    assert compact["scaling"] == "strong" and compact["value"] == pytest.approx(line["value"], rel=1e-5) and compact["roofline"]["frac"] == pytest.approx(line["roofline"]["frac"], rel=1e-5)
+    assert compact["config"]["workload_textured"]["value"] > 0 and compact["roofline"]["traffic"] and "lanes_per_instruction" in compact["roofline_valu"]
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
         assert key in line, key
     assert line["n_gpus"] == 1 and line["steps"] == 2 and line["warmup"] == 1 and line["unit"] == "Mrays/s" and line["value"] > 0
@@ -57,15 +65,17 @@ def test_bench_line_contract_single_gpu():
 
 
 def test_bench_two_ranks_on_one_device():
-    one = run_bench([])
-    two = run_bench(["--gpus", "2", "--share-device", "--dist-backend", "gloo"])
-    assert two["n_gpus"] == 2 and two["config"]["frame_finite_and_lit"]
-    assert two["config"]["parallelism"].endswith("x2")
-    # weak scaling: each rank traces the per-GPU share of one rank alone, on its half of the tiles -> twice the paths, and (same scene, same camera,
-    # deterministic sampling) about twice the rays of the single-rank step
-    assert two["config"]["rays_per_step"] == pytest.approx(2.0 * one["config"]["rays_per_step"], rel=0.02)
-    assert two["scaling"] == "weak" and len(two["ranks"]["ms_per_step"]) == 2 and two["ranks"]["gather_ms"] >= 0.0
-    # the same job split over the ranks: the rays of one rank alone, half of the paths per GPU
-    fixed = run_bench(["--gpus", "2", "--share-device", "--dist-backend", "gloo", "--fixed-frame"])
-    assert fixed["scaling"] == "strong" and fixed["config"]["rays_per_step"] == pytest.approx(one["config"]["rays_per_step"], rel=0.02)
+    _, one = run_bench(["--no-textured", "--no-scaling-proxy", "--pmc-traffic", "off"])
+    # the default at N > 1 (round 5): the SAME job split over the ranks -- the rays of one rank alone, half of the paths per GPU, the same workload named
+    compact, fixed = run_bench(["--gpus", "2", "--share-device", "--dist-backend", "gloo"])
+    assert fixed["n_gpus"] == 2 and fixed["config"]["frame_finite_and_lit"] and fixed["config"]["parallelism"].endswith("x2")
+    assert fixed["scaling"] == "strong" and compact["scaling"] == "strong" and fixed["config"]["rays_per_step"] == pytest.approx(one["config"]["rays_per_step"], rel=0.02)
     assert fixed["ranks"]["paths_per_gpu_per_step"] * 2 == pytest.approx(one["config"]["pixel_samples"] / one["steps"], rel=0.01)
+    assert fixed["config"]["workload"] == one["config"]["workload"] and compact["config"]["workload"] == one["config"]["workload"][:420]
+    assert len(fixed["ranks"]["ms_per_step"]) == 2 and fixed["ranks"]["gather_ms"] >= 0.0 and fixed["ranks"]["steps_per_pass"] == 2 and compact["ranks"]["passes"] == 1
+    # a warm-up that does not fill a pass (3 timed steps: batch 1; 4 timed + 1 warm-up: batch 2 with a remainder pass)
+    _, odd = run_bench(["--gpus", "2", "--share-device", "--dist-backend", "gloo", "--steps", "4", "--warmup", "1"])
+    assert odd["steps"] == 4 and odd["ranks"]["steps_per_pass"] == 2 and odd["config"]["rays_per_step"] == pytest.approx(one["config"]["rays_per_step"], rel=0.02)
+    # weak scaling, the opt-in: each rank traces the per-GPU share of one rank alone, on its half of the tiles -> twice the paths and about twice the rays per step
+    _, two = run_bench(["--gpus", "2", "--share-device", "--dist-backend", "gloo", "--weak"])
+    assert two["config"]["rays_per_step"] == pytest.approx(2.0 * one["config"]["rays_per_step"], rel=0.02) and two["scaling"] == "weak"
