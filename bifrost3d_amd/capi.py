@@ -12,6 +12,8 @@ from pathlib import Path
 
 PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("HIPR_LIBRARY", PKG_DIR / "csrc" / "libhiprenderer.so"))   # HIPR_LIBRARY: A/B builds of the kernels
+# The verification build (Makefile VERIFYFLAGS: exact division / sqrt, no contraction, transcendentals in f64 rounded once): loaded by tests and bench.py's parity legs only
+VERIFY_LIB_PATH = PKG_DIR / "csrc" / "libhiprenderer_verify.so"
 HOST_LIB_PATH = Path(os.environ.get("HIPR_HOST_LIBRARY", PKG_DIR / "host" / "libhiprenderer_host.so"))   # HIPR_HOST_LIBRARY: A/B builds of the host side (BVH builder)
 TABLES_PATH = PKG_DIR / "data" / "HIPRenderer" / "shading_tables.bin"
 
@@ -142,7 +144,7 @@ C_ABI_SYMBOLS = (
     "hipr_group_create", "hipr_group_destroy", "hipr_group_size", "hipr_group_context", "hipr_group_gather_description", "hipr_group_upload_tables", "hipr_group_upload_scene",
     "hipr_group_set_scene_state", "hipr_group_set_entry_point", "hipr_group_use_scratch_accumulation", "hipr_group_set_frame", "hipr_group_set_samples_per_pass",
     "hipr_group_trace_pass", "hipr_group_accumulate_samples", "hipr_group_read_accumulation", "hipr_group_get_counters",
-    "hipr_debug_shading", "hipr_debug_light", "hipr_debug_generate", "hipr_debug_sobol", "hipr_debug_valu_issue_rates", "hipr_debug_sample_offsets", "hipr_debug_trace_closest", "hipr_debug_trace_shadow",
+    "hipr_debug_shading", "hipr_debug_shade", "hipr_debug_light", "hipr_debug_generate", "hipr_debug_sobol", "hipr_debug_valu_issue_rates", "hipr_debug_sample_offsets", "hipr_debug_trace_closest", "hipr_debug_trace_shadow",
 )
 
 

@@ -9,10 +9,36 @@
 // Reference: extensions/OptiXRenderer/OptiXRenderer/RNG.h:39-75,127-157,238-293, Utils.h:331-342.
 #pragma once
 
+// HIPR_HOST_DEVICE (tests/native/DeviceShadeHost.hip only): HD = __host__ __device__, so that hipcc's host pass compiles the shared code -- the BSDFs, shading models and
+// lights of device_shading.h, shade_path of shade_kernel.h with the samplers and scene structures of kernels.h -- for x86 as well, statement for statement, and the
+// CPU test suite can set the device's K3 against the oracle BIT for bit (tests/test_device_code_on_host_cpu.py). With HIPR_VERIFY_MATH and -ffp-contract=off the host
+// build evaluates what libhiprenderer_verify.so evaluates on the GPU: IEEE f32 operations in the same order. Test infrastructure: the product libraries are never
+// built this way and have no CPU path.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifdef HIPR_HOST_DEVICE
+// host overloads of the bit-cast and bit-reversal device functions the shared code uses (clang overloads on the target attribute)
+#include <cstring>
+__host__ static inline unsigned int __float_as_uint(float f) { unsigned int u; std::memcpy(&u, &f, 4); return u; }
+__host__ static inline float __uint_as_float(unsigned int u) { float f; std::memcpy(&f, &u, 4); return f; }
+__host__ static inline int __float_as_int(float f) { int u; std::memcpy(&u, &f, 4); return u; }
+__host__ static inline float __int_as_float(int u) { float f; std::memcpy(&f, &u, 4); return f; }
+__host__ static inline unsigned int __brev(unsigned int v) {
+    v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+    v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+    v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
+    v = ((v >> 8) & 0x00FF00FFu) | ((v & 0x00FF00FFu) << 8);
+    return (v >> 16) | (v << 16);
+}
+#endif
+#ifndef HD
+#ifdef HIPR_HOST_DEVICE
+#define HD __host__ __device__ __forceinline__
+#else
 #define HD __device__ __forceinline__
+#endif
+#endif
 
 namespace hipr {
 

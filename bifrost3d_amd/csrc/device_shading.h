@@ -38,21 +38,65 @@ HD Sample sample_none() { return {{0, 0, 0}, 0.0f, {0, 0, 0}}; }
 
 // HIPR_FAST_MATH (set for the shade translation unit): hardware sin / cos / exp2 / log2 like the reference's
 // --use_fast_math PTX (extensions/OptiXRenderer/CMakeLists.txt:82-83); otherwise the correctly rounded-ish ocml versions.
-#if HIPR_FAST_MATH
-HD void sincos_(float a, float& s, float& c) { s = __sinf(a); c = __cosf(a); }
+// HIPR_VERIFY_MATH (libhiprenderer_verify.so, the VERIFICATION build of round 5): every transcendental of the path -- sin, cos, pow, atan2, asin -- is
+// evaluated in f64 and rounded ONCE to f32, and the oracle does the same with glibc's f64 functions (oracle/vecmath.h exact_*). Two independent f64 results
+// that are each within a few f64 ulp of the true value round to the same f32 except where the true value lies within ~2^-50 relative of a rounding boundary
+// (probability ~2^-26 per call), so device and oracle stay independent implementations AND agree bit for bit on all but a handful of paths per frame;
+// with correctly rounded division and square root and no contraction (the traversal unit's flags) K3 is then checked exactly, not statistically
+// (tests/test_gpu_verify_build.py). FP64 is half rate on CDNA4; the build is for tests, never for the product path.
+#ifndef HIPR_VERIFY_MATH
+#define HIPR_VERIFY_MATH 0
+#endif
+// How each transcendental is evaluated: 1 = the hardware's approximation (product shade unit), 2 = in f64, rounded once (verification build), 0 = ocml's f32 function
+// (the traversal unit, where none of them is on a hot path). Separately settable for the attribution experiment of round 5 (tools/fast_math_attribution.sh: which
+// approximation moves how many paths).
+#ifndef HIPR_SINCOS_KIND
+#define HIPR_SINCOS_KIND (HIPR_VERIFY_MATH ? 2 : (HIPR_FAST_MATH ? 1 : 0))
+#endif
+#ifndef HIPR_POW_KIND
+#define HIPR_POW_KIND (HIPR_VERIFY_MATH ? 2 : (HIPR_FAST_MATH ? 1 : 0))
+#endif
+#ifndef HIPR_ATAN_ASIN_KIND
+#define HIPR_ATAN_ASIN_KIND (HIPR_VERIFY_MATH ? 2 : 0)
+#endif
 #ifndef HIPR_NATIVE_POW
 #define HIPR_NATIVE_POW 1
 #endif
-#if HIPR_NATIVE_POW
-// x^y as exp2(y * log2(x)) on the hardware's v_log_f32 / v_exp_f32, what --use_fast_math makes of powf in the reference's PTX (HIP's __powf is the full ocml pow).
-HD float pow_(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
+HD void sincos_(float a, float& s, float& c) {
+#if HIPR_SINCOS_KIND == 2
+    s = float(sin(double(a))); c = float(cos(double(a)));
+#elif HIPR_SINCOS_KIND == 1
+    s = __sinf(a); c = __cosf(a);
 #else
-HD float pow_(float x, float y) { return __powf(x, y); }
+    s = sinf(a); c = cosf(a);
 #endif
+}
+HD float pow_(float x, float y) {
+#if HIPR_POW_KIND == 2
+    return float(pow(double(x), double(y)));
+#elif HIPR_POW_KIND == 1 && HIPR_NATIVE_POW
+    // x^y as exp2(y * log2(x)) on the hardware's v_log_f32 / v_exp_f32, what --use_fast_math makes of powf in the reference's PTX (HIP's __powf is the full ocml pow).
+    return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
+#elif HIPR_POW_KIND == 1
+    return __powf(x, y);
 #else
-HD void sincos_(float a, float& s, float& c) { s = sinf(a); c = cosf(a); }
-HD float pow_(float x, float y) { return powf(x, y); }
+    return powf(x, y);
 #endif
+}
+HD float atan2_(float y, float x) {
+#if HIPR_ATAN_ASIN_KIND == 2
+    return float(atan2(double(y), double(x)));
+#else
+    return atan2f(y, x);
+#endif
+}
+HD float asin_(float x) {
+#if HIPR_ATAN_ASIN_KIND == 2
+    return float(asin(double(x)));
+#else
+    return asinf(x);
+#endif
+}
 
 HD float sgn(float v) { return v >= 0.0f ? 1.0f : -1.0f; }
 HD float pow2(float x) { return x * x; }
@@ -575,11 +619,42 @@ HD Shading make_transmissive(const DeviceTables& t, const MaterialInputs& m, flo
 // The terms of the BSDFs above that depend on the outgoing direction and the material only. A hit evaluates its shading four times -- three light
 // candidates and the BSDF sample's other lobes -- with the same wo: the terms are computed once per hit (round 4; the compiler hoisted them out of the
 // candidate loop by itself but computed them again, up to three times, in the sampling code behind it). Same expressions in the same order as the
-// functions they are taken from.
+// functions they are taken from -- to the operation: a quotient stays a quotient by the same divisor (round 4 had multiplied by a stored reciprocal in two places,
+// which the verification build of round 5 showed as last-ulp differences from the plain functions in 3-60 % of the evaluations; in the product's fast arithmetic
+// x / d is x * v_rcp_f32(d) either way and the reciprocal of a per-hit divisor is hoisted by the compiler). tests/test_device_code_on_host_cpu.py holds both
+// forms to the oracle bit for bit.
 // ---------------------------------------------------------------------------------------------
+// A divisor that is the same for every evaluation of a hit. In the product's arithmetic x / d IS x * v_rcp_f32(d) (-freciprocal-math), so the reciprocal is taken once
+// per hit and the evaluations multiply -- instruction for instruction what the division compiles to there, minus the v_rcp_f32; in the correctly rounded builds
+// (verification build, host build of the tests) the quotient stays a quotient by d, as the plain functions and the oracle write it.
+#ifndef HIPR_RECIPROCAL_DIVISION
+#define HIPR_RECIPROCAL_DIVISION HIPR_FAST_MATH      // the unit is built with -freciprocal-math: x / d is x * v_rcp_f32(d)
+#endif
+struct HitDivisor {
+#if HIPR_RECIPROCAL_DIVISION
+    float reciprocal;
+#else
+    float d;
+#endif
+};
+HD HitDivisor hit_divisor(float d) {
+#if HIPR_RECIPROCAL_DIVISION
+    return {1.0f / d};
+#else
+    return {d};
+#endif
+}
+HD float operator/(float x, HitDivisor h) {
+#if HIPR_RECIPROCAL_DIVISION
+    return x * h.reciprocal;
+#else
+    return x / h.d;
+#endif
+}
+
 struct OrenNayarTerms {
     float roughness, B, pi_A;        // evaluate: single = pi_A * (1 + roughness * s_over_t)
-    float m_o, recip_den;            //           multi = m_o * |1 - EF_i| * recip_den, m_o = (ms_rho / pi) * |1 - EF_o|
+    float m_o; HitDivisor den;       //           multi = m_o * |1 - EF_i| / den, m_o = (ms_rho / pi) * |1 - EF_o|, den = max(1e-7, 1 - avg_EF)
     float A;
     float up, cp;                    // uniform / CLTC mixture
     float Xx, Xy;                    // cltc::tangents: X; Y = (-X.y, X.x)
@@ -596,7 +671,7 @@ HD OrenNayarTerms oren_nayar_terms(float roughness, f3 wo) {
     const float avg_EF = t.A * (1.0f + c2 * roughness);
     const float ms_rho = avg_EF / (1.0f - (1.0f - avg_EF));
     t.m_o = (ms_rho * HIPR_RECIP_PI) * fabsf(1.0f - EF_o);
-    t.recip_den = 1.0f / fmaxf(1.0e-7f, 1.0f - avg_EF);
+    t.den = hit_divisor(fmaxf(1.0e-7f, 1.0f - avg_EF));
     t.up = oren_nayar::uniform_probability(roughness, wo.z);
     t.cp = 1.0f - t.up;
     f2 X, Y;
@@ -616,7 +691,7 @@ HD float evaluate(const OrenNayarTerms& t, f3 wo, f3 wi) {
     const float s_over_t = s > 0.0f ? s / fmaxf(ci, co) : s;
     const float single = t.pi_A * (1.0f + t.roughness * s_over_t);
     const float EF_i = E_FON_approx(ci, t.A, t.B);
-    const float multi = t.m_o * fabsf(1.0f - EF_i) * t.recip_den;
+    const float multi = t.m_o * fabsf(1.0f - EF_i) / t.den;
     return single + multi;
 }
 HD float cltc_pdf(const OrenNayarTerms& t, f3 wi_shading) {       // cltc::pdf
@@ -657,7 +732,7 @@ HD f3 sample_direction(const OrenNayarTerms& t, f3 wo, f2 u, float& cltc_density
 }
 } // namespace oren_nayar
 
-struct GGXTerms { float alpha, recip_G1, pdf_scale; };     // recip_G1 = 1 + lambda(alpha, wo); bounded_reflection_pdf = D(h) * pdf_scale
+struct GGXTerms { float alpha, recip_G1, pdf_numerator; HitDivisor pdf_divisor; };     // recip_G1 = 1 + lambda(alpha, wo); bounded_reflection_pdf = D(h) * pdf_numerator / pdf_divisor
 HD GGXTerms ggx_terms(float alpha, f3 wo) {
     GGXTerms t;
     t.alpha = alpha;
@@ -669,9 +744,12 @@ HD GGXTerms ggx_terms(float alpha, f3 wo) {
         const float s = 1.0f + length(mk2(wo.x, wo.y));
         const float a2 = alpha * alpha, s2 = s * s;
         const float k = (1.0f - a2) * s2 / (s2 + a2 * wo.z * wo.z);
-        t.pdf_scale = 1.0f / (2.0f * (k * wo.z + tt));
-    } else
-        t.pdf_scale = (tt - wo.z) / (2.0f * len2);
+        t.pdf_numerator = 1.0f;      // ndf / (2 (k wo.z + t)); ndf * 1 is ndf
+        t.pdf_divisor = hit_divisor(2.0f * (k * wo.z + tt));
+    } else {
+        t.pdf_numerator = tt - wo.z; // ndf * (t - wo.z) / (2 len2)
+        t.pdf_divisor = hit_divisor(2.0f * len2);
+    }
     return t;
 }
 namespace ggx_r {
@@ -680,7 +758,7 @@ HD Response evaluate_with_PDF(const GGXTerms& t, f3 specularity, f3 wo, f3 wi) {
     const f3 h = normalize(wo + wi);
     const float D = vndf::D(t.alpha, h);
     Response r;
-    r.pdf = D * t.pdf_scale;
+    r.pdf = D * t.pdf_numerator / t.pdf_divisor;
     if (wo.z * wi.z <= 0.0f) r.f = mk3(0.0f);
     else {
         const float G = 1.0f / (t.recip_G1 + vndf::lambda(t.alpha, wi));
@@ -889,7 +967,7 @@ HD f3 to_world(const Frame& f, f3 v) { return v.x * f.t + v.y * f.b + v.z * f.n;
 HD float balance_heuristic(float p1, float p2) {
     float divisor = p1 + p2;
     float result = p1 / divisor;
-    bool invalid = isinf(divisor) || (result != result);
+    bool invalid = __builtin_isinf(divisor) || (result != result);
     return invalid ? (p1 <= p2 ? 0.0f : 1.0f) : result;
 }
 

@@ -184,11 +184,15 @@ struct HiprContext {
     // per step, material 37.0 -> 35.7, 10 M triangles at 4K 91.8 -> 87.9: where one wavefront's launch drains, the other's blocks move in -- three and four do not
     // (62.0, 64.9), and a pass of 2 M paths (one accumulation per pass) loses 8 % to the halved launches: two from 2^24 path slots per pass on, else one.
     static constexpr uint64_t TWO_WAVEFRONTS_FROM_SLOTS = 1ull << 24;
-    int wavefronts_wanted() const {
+    // `frame_is_set`: `frame` holds a valid description. hipr_set_frame partitions BEFORE it sets frame_ready (the first partition after an upload was
+    // therefore always one wavefront with full-size queues, the first pass re-partitioned into two, and -- buffers never shrink -- wavefront 0 kept its full-size
+    // queues next to wavefront 1's half: about 1.5x the queue memory of a 64-accumulation 1080p pass, plus a redundant allocation and synchronisation).
+    int wavefronts_wanted(bool frame_is_set) const {
         if (wavefront_limit > 0) return wavefront_limit;
-        if (scene_ready && use_persistent()) return frame_ready && uint64_t(frame.owned_tiles) * 64u * frame.samples_per_pass >= TWO_WAVEFRONTS_FROM_SLOTS ? 2 : 1;
+        if (scene_ready && use_persistent()) return frame_is_set && uint64_t(frame.owned_tiles) * 64u * frame.samples_per_pass >= TWO_WAVEFRONTS_FROM_SLOTS ? 2 : 1;
         return 2;
     }
+    int wavefronts_wanted() const { return wavefronts_wanted(frame_ready); }
     // The search of the uploaded scene, fixed when it is uploaded (hipr_set_trace_variant / HIPR_TRACE_VARIANT name a request for the NEXT upload).
     int chosen_variant = HIPR_TRACE_BVH2;
     void choose_variant() {
@@ -521,7 +525,7 @@ int partition_path_slots(HiprContext* c) {
     c->n_slots = uint32_t(slots);
     c->traced_samples = 0;   // the radiance buffer may move and its sample layout changes: nothing traced before can be folded any more
     int r = 0;
-    c->partitioned_for = c->wavefronts_wanted();
+    c->partitioned_for = c->wavefronts_wanted(true);      // every caller has put a valid description into c->frame
     c->wavefront_count = int(std::max<uint64_t>(1, std::min<uint64_t>(uint64_t(c->partitioned_for), slots / 65536u)));
     // The slots are dealt to the wavefronts in groups of 64 (one wave of camera rays), round robin: with the pixel-major slot order every wavefront then
     // covers the whole frame evenly -- contiguous halves would be the top and the bottom of the image, one of them done with its deep bounces long before
@@ -875,7 +879,10 @@ float reverse_halton(int prime, int i) {
 
 // What the kernels read per triangle is derived on the device from the uploaded pools: the shading records (k_build_shade_triangles), the
 // vertex + edges form the trace kernels test (k_build_trace_triangles) and, for scenes searched exhaustively, the items (build_trace_items).
-int build_derived_geometry(HiprContext* c, const HiprSceneDesc* s) {
+// `pools_uploaded`: the call follows an upload of materials, textures and texels (hipr_upload_scene). hipr_update_scene_geometry leaves those pools on the device as they are,
+// so the kernel instantiations chosen from them (textures or not, environment code, 8-bit coverage sampler) must keep what the UPLOAD decided (a refit
+// description with other materials or texture formats would otherwise switch the kernels over pools that still hold the old data).
+int build_derived_geometry(HiprContext* c, const HiprSceneDesc* s, bool pools_uploaded) {
     DeviceScene& d = c->scene;
     hipStream_t st = c->stream;
     if (s->triangle_count) {   // flatten the per-hit attribute chain into one record per triangle
@@ -889,6 +896,7 @@ int build_derived_geometry(HiprContext* c, const HiprSceneDesc* s) {
         HIP_TRY(hipStreamSynchronize(st));
     }
     // the listing pass's class of every triangle (k_classify_hits): bit 0 = the material of its instance carries a coat
+    if (pools_uploaded) {
     c->scene_has_textures = s->environment != nullptr;
     c->scene_has_environment = s->environment != nullptr;
     for (uint32_t m = 0; m < s->material_count; ++m) {
@@ -903,6 +911,7 @@ int build_derived_geometry(HiprContext* c, const HiprSceneDesc* s) {
     for (uint32_t m = 0; m < s->material_count; ++m)
         if (const int32_t id = s->materials[m].coverage_texture_ID)
             c->coverage_textures_r8 = c->coverage_textures_r8 && uint32_t(id) < s->texture_count && s->textures[id].format == HIPR_TEXEL_R8 && !s->textures[id].is_sRGB;
+    }
     c->any_coated_triangle = false;
     c->all_triangles_opaque = true;
     for (uint32_t t = 0; t < s->triangle_count; ++t) c->all_triangles_opaque = c->all_triangles_opaque && (s->triangles[t].flags & HIPR_TRIANGLE_OPAQUE) != 0;
@@ -1152,7 +1161,7 @@ int hipr_upload_scene(HiprContext* c, const HiprSceneDesc* s) {
     d.node_count = s->node_count;
     d.triangle_count = s->triangle_count;
     d.light_count = s->light_count;
-    if (int status = build_derived_geometry(c, s)) return status;
+    if (int status = build_derived_geometry(c, s, true)) return status;
     if (int status = upload_wide8(c, s, wide8_height)) return status;
     c->choose_variant();
     c->stack_size = s->bvh_max_depth <= 16 ? 16 : (s->bvh_max_depth <= 32 ? 32 : 64);
@@ -1208,7 +1217,7 @@ int hipr_update_scene_geometry(HiprContext* c, const HiprSceneDesc* s) {
     int models = 0;   // the instances were re-uploaded: a changed material_index may reference another shading model
     for (uint32_t i = 0; i < s->instance_count; ++i) models |= 1 << std::min<int>(s->materials[s->instances[i].material_index].shading_model, 2);
     c->shading_models = models ? models : 7;
-    return build_derived_geometry(c, s);
+    return build_derived_geometry(c, s, false);
 }
 
 int hipr_set_scene_state(HiprContext* c, const HiprSceneState* state) {
@@ -1678,6 +1687,30 @@ int hipr_debug_shading(HiprContext* c, int shading_model, const float* params10,
     if (int finish_status = finish_all(c)) return finish_status;
     HIP_TRY(hipMemcpy(out_n7, bo.ptr, size_t(n) * 28, hipMemcpyDeviceToHost));
     bp.release(); bw.release(); bi.release(); bo.release();
+    return HIPR_OK;
+}
+
+int hipr_debug_shade(HiprContext* c, const HiprCameraState* camera, uint32_t n, const float* rays_n8, const float* throughput_bounces_n4, const float* hits_n4, const uint32_t* last_triangle,
+                     const uint32_t* pixel_hash, const uint32_t* accumulation, float* out_n32) {
+    if (int s = check_context(c)) return s;
+    if (!c->tables_ready || !c->scene_ready) return fail(HIPR_ERROR_NOT_READY, "hipr_debug_shade needs the tables and a scene");
+    if (!camera || !rays_n8 || !throughput_bounces_n4 || !hits_n4 || !last_triangle || !pixel_hash || !accumulation || !out_n32) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_debug_shade: null argument");
+    if (n == 0) return HIPR_OK;
+    for (uint32_t i = 0; i < n; ++i) {      // the entries name triangles and lights of the uploaded scene
+        uint32_t id;
+        std::memcpy(&id, hits_n4 + 4 * size_t(i) + 3, 4);
+        if (id == HIPR_HIT_MISS) continue;
+        if ((id & HIPR_HIT_LIGHT) ? (id & ~HIPR_HIT_LIGHT) >= c->scene.light_count : id >= c->scene.triangle_count) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_debug_shade: entry %u names hit %u outside the scene", i, id);
+    }
+    DeviceBuffer br, bt, bh, bl, bp, ba, bo;
+    if (br.upload(rays_n8, size_t(n) * 32, c->stream) | bt.upload(throughput_bounces_n4, size_t(n) * 16, c->stream) | bh.upload(hits_n4, size_t(n) * 16, c->stream) |
+        bl.upload(last_triangle, size_t(n) * 4, c->stream) | bp.upload(pixel_hash, size_t(n) * 4, c->stream) | ba.upload(accumulation, size_t(n) * 4, c->stream) | bo.resize(size_t(n) * 128))
+        return HIPR_ERROR_OUT_OF_MEMORY;
+    hipr::launch_debug_shade(c->stream, c->scene, *camera, n, br.as<float4>(), bt.as<float4>(), bh.as<float4>(), bl.as<uint32_t>(), bp.as<uint32_t>(), ba.as<uint32_t>(), bo.as<float>());
+    HIP_TRY(hipGetLastError());
+    if (int finish_status = finish_all(c)) return finish_status;
+    HIP_TRY(hipMemcpy(out_n32, bo.ptr, size_t(n) * 128, hipMemcpyDeviceToHost));
+    br.release(); bt.release(); bh.release(); bl.release(); bp.release(); ba.release(); bo.release();
     return HIPR_OK;
 }
 

@@ -475,8 +475,8 @@ HD float material_coverage_untextured(const HiprMaterial& m) {
 // Presampled environment light (ORS/LightSources/PresampledEnvironmentLightImpl.h:18-41, OR/Utils.h:288-292)
 // ---------------------------------------------------------------------------------------------
 HD f2 direction_to_latlong_texcoord(f3 direction) {
-    const float u = (atan2f(direction.z, direction.x) + HIPR_PI) * 0.5f / HIPR_PI;
-    const float v = (asinf(direction.y) + HIPR_PI * 0.5f) / HIPR_PI;
+    const float u = (atan2_(direction.z, direction.x) + HIPR_PI) * 0.5f / HIPR_PI;
+    const float v = (asin_(direction.y) + HIPR_PI * 0.5f) / HIPR_PI;
     return {u, v};
 }
 // Solid angle PDF of sampling `direction` from the environment: nearest, clamped lookup of the per-texel PDF over sin(theta).
@@ -1017,6 +1017,36 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(tra
     }
 }
 
+// The 128-byte shading record of triangle t (what k_shade fetches per hit; layout below): the body of k_build_shade_triangles, also run by the host build of the
+// shade stage (tests/native/DeviceShadeHost.hip).
+HD void build_shade_triangle_record(const DeviceScene& sc, uint32_t t, float4* out) {
+    const float4 tc = sc.triangles[3 * size_t(t) + 2];
+    const HiprInstance inst = sc.instances[__float_as_uint(tc.y)];
+    const uint32_t prim = __float_as_uint(tc.z);
+    const uint32_t* idx = sc.indices + 3 * size_t(inst.index_offset + prim);
+    const uint32_t i[3] = {idx[0], idx[1], idx[2]};
+    const float* M = inst.object_to_world;
+    const uint32_t words[3] = {uint32_t(inst.material_index), uint32_t(inst.instance_id), inst.mesh_flags};
+    float4* q = out + SHADE_TRIANGLE_QUADS * size_t(t) + 3;
+    for (int k = 0; k < 3; ++k) {
+        f3 n = {0, 0, 0};
+        if (inst.mesh_flags & HIPR_MESH_NORMALS) {
+            const f3 o = decode_octahedral(sc.geometry[inst.vertex_offset + i[k]].w);
+            n = mk3(M[0] * o.x + M[1] * o.y + M[2] * o.z, M[4] * o.x + M[5] * o.y + M[6] * o.z, M[8] * o.x + M[9] * o.y + M[10] * o.z);
+        }
+        q[k] = make_float4(n.x, n.y, n.z, __uint_as_float(words[k]));
+    }
+    float2 uv[3] = {{0, 0}, {0, 0}, {0, 0}};
+    if (inst.mesh_flags & HIPR_MESH_TEXCOORDS) for (int k = 0; k < 3; ++k) uv[k] = sc.texcoords[inst.vertex_offset + i[k]];
+    uint32_t tint[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    if (inst.mesh_flags & HIPR_MESH_TINTS) for (int k = 0; k < 3; ++k) tint[k] = sc.tints[inst.vertex_offset + i[k]];
+    q[3] = make_float4(uv[0].x, uv[0].y, uv[1].x, uv[1].y);
+    q[4] = make_float4(uv[2].x, uv[2].y, __uint_as_float(tint[0]), __uint_as_float(tint[1]));
+    q[-3] = sc.triangles[3 * size_t(t)];
+    q[-2] = sc.triangles[3 * size_t(t) + 1];
+    q[-1] = make_float4(tc.x, tc.y, tc.z, __uint_as_float(tint[2]));
+}
+
 #ifndef HIPR_SHADE_TU
 // ---------------------------------------------------------------------------------------------
 // Shading records. The reference resolves a hit through instance -> mesh buffers -> index -> vertex (TriangleAttributes.cu:35-84,
@@ -1044,31 +1074,7 @@ __global__ __launch_bounds__(256) void k_build_trace_triangles(const float4* __r
 __global__ __launch_bounds__(256) void k_build_shade_triangles(DeviceScene sc, float4* out) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= sc.triangle_count) return;
-    const float4 tc = sc.triangles[3 * size_t(t) + 2];
-    const HiprInstance inst = sc.instances[__float_as_uint(tc.y)];
-    const uint32_t prim = __float_as_uint(tc.z);
-    const uint32_t* idx = sc.indices + 3 * size_t(inst.index_offset + prim);
-    const uint32_t i[3] = {idx[0], idx[1], idx[2]};
-    const float* M = inst.object_to_world;
-    const uint32_t words[3] = {uint32_t(inst.material_index), uint32_t(inst.instance_id), inst.mesh_flags};
-    float4* q = out + SHADE_TRIANGLE_QUADS * size_t(t) + 3;
-    for (int k = 0; k < 3; ++k) {
-        f3 n = {0, 0, 0};
-        if (inst.mesh_flags & HIPR_MESH_NORMALS) {
-            const f3 o = decode_octahedral(sc.geometry[inst.vertex_offset + i[k]].w);
-            n = mk3(M[0] * o.x + M[1] * o.y + M[2] * o.z, M[4] * o.x + M[5] * o.y + M[6] * o.z, M[8] * o.x + M[9] * o.y + M[10] * o.z);
-        }
-        q[k] = make_float4(n.x, n.y, n.z, __uint_as_float(words[k]));
-    }
-    float2 uv[3] = {{0, 0}, {0, 0}, {0, 0}};
-    if (inst.mesh_flags & HIPR_MESH_TEXCOORDS) for (int k = 0; k < 3; ++k) uv[k] = sc.texcoords[inst.vertex_offset + i[k]];
-    uint32_t tint[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-    if (inst.mesh_flags & HIPR_MESH_TINTS) for (int k = 0; k < 3; ++k) tint[k] = sc.tints[inst.vertex_offset + i[k]];
-    q[3] = make_float4(uv[0].x, uv[0].y, uv[1].x, uv[1].y);
-    q[4] = make_float4(uv[2].x, uv[2].y, __uint_as_float(tint[0]), __uint_as_float(tint[1]));
-    q[-3] = sc.triangles[3 * size_t(t)];
-    q[-2] = sc.triangles[3 * size_t(t) + 1];
-    q[-1] = make_float4(tc.x, tc.y, tc.z, __uint_as_float(tint[2]));
+    build_shade_triangle_record(sc, t, out);
 }
 
 // ---------------------------------------------------------------------------------------------

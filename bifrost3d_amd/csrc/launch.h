@@ -48,6 +48,8 @@ size_t ray_sort_temp_bytes(uint32_t capacity);
 int launch_ray_sort(const RaySortLaunch& args);      // 0, or the hipError_t of the sort
 
 // All pointers are device pointers; see k_debug_shading (shade.hip).
+void launch_debug_shade(hipStream_t stream, const DeviceScene& scene, const HiprCameraState& camera, uint32_t n, const float4* rays, const float4* throughput_bounces, const float4* hits,
+                        const uint32_t* last_triangle, const uint32_t* pixel_hash, const uint32_t* accumulation, float* out);
 void launch_debug_light(hipStream_t stream, const HiprLight& light, const float* position3, const float* in_n3, int n, int mode, float* out_n8);
 void launch_debug_shading(hipStream_t stream, const DeviceTables& tables, int model, const float* params10, const float* wo_n3, const float* in_n3, int n, int mode,
                           float* out_n7);

@@ -87,6 +87,45 @@ __global__ void k_debug_light(HiprLight light, const float* position3, const flo
     }
 }
 
+// hipr_debug_shade: shade_path for n given queue entries, one record of 32 words each (tests/native/DeviceShadeHost.hip writes the same record from the host
+// build of this code, oracle/integrator.cpp shade_hit_for_test from the oracle's hit programs): 0 flags (1 continues, 2 shadow ray, 4 shaded), 1-3 radiance added,
+// 4-7 next origin + tmin, 8-11 next direction + BSDF PDF, 12-15 throughput + bits(bounces), 16 bits(last triangle), 17-20 shadow origin + tmax, 21-23 direction to
+// the light, 24-26 radiance the shadow ray carries. The generic instantiation (all models, all samplers): the template arguments of k_shade only remove code.
+__global__ __launch_bounds__(64) void k_debug_shade(DeviceScene sc, HiprCameraState cam, uint32_t n, const float4* rays, const float4* throughput_bounces, const float4* hits,
+                                                    const uint32_t* last_triangle, const uint32_t* pixel_hash, const uint32_t* accumulation, float* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    ShadeInputs in;
+    in.entry = i;
+    in.meta = make_uint2(0u, last_triangle[i]);
+    in.o = rays[2 * i]; in.d = rays[2 * i + 1]; in.t = throughput_bounces[i]; in.hit = hits[i];
+    const ShadeGeometry geo = shade_fetch_geometry(sc, in);
+    const HiprMaterial mat = shade_fetch_material(sc, in, geo);
+    ShadeOutput so = {};
+    shade_path<7, false, SHADE_PART_ALL, 2>(sc, cam, HIPR_ENTRY_PATH_TRACING, sc.sobol_tables, mk3(in.o.x, in.o.y, in.o.z), rays + 2 * i, mk3(in.d.x, in.d.y, in.d.z), in.d.w, mk3(in.t.x, in.t.y, in.t.z),
+                                            __float_as_uint(in.t.w), in.meta.y, pixel_hash[i], accumulation[i], in.hit, geo, mat, false, so);
+    float* o = out + 32 * size_t(i);
+    for (int k = 0; k < 32; ++k) o[k] = 0.0f;
+    o[0] = __uint_as_float((so.continues ? 1u : 0u) | (so.shadow ? 2u : 0u) | (so.shaded ? 4u : 0u));
+    o[1] = so.add_radiance.x; o[2] = so.add_radiance.y; o[3] = so.add_radiance.z;
+    if (so.continues) {
+        o[4] = so.o.x; o[5] = so.o.y; o[6] = so.o.z; o[7] = so.tmin;
+        o[8] = so.d.x; o[9] = so.d.y; o[10] = so.d.z; o[11] = so.bsdf_pdf;
+        o[12] = so.throughput.x; o[13] = so.throughput.y; o[14] = so.throughput.z; o[15] = __uint_as_float(so.bounces);
+        o[16] = __uint_as_float(so.last_triangle);
+    }
+    if (so.shadow) {
+        o[17] = so.so.x; o[18] = so.so.y; o[19] = so.so.z; o[20] = so.stmax;
+        o[21] = so.sd.x; o[22] = so.sd.y; o[23] = so.sd.z;
+        o[24] = so.sradiance.x; o[25] = so.sradiance.y; o[26] = so.sradiance.z;
+    }
+}
+
+void launch_debug_shade(hipStream_t stream, const DeviceScene& scene, const HiprCameraState& camera, uint32_t n, const float4* rays, const float4* throughput_bounces, const float4* hits,
+                        const uint32_t* last_triangle, const uint32_t* pixel_hash, const uint32_t* accumulation, float* out) {
+    hipLaunchKernelGGL(k_debug_shade, dim3((n + 63) / 64), dim3(64), 0, stream, scene, camera, n, rays, throughput_bounces, hits, last_triangle, pixel_hash, accumulation, out);
+}
+
 void launch_debug_light(hipStream_t stream, const HiprLight& light, const float* position3, const float* in_n3, int n, int mode, float* out_n8) {
     hipLaunchKernelGGL(k_debug_light, dim3((n + 63) / 64), dim3(64), 0, stream, light, position3, in_n3, n, mode, out_n8);
 }

@@ -9,8 +9,9 @@ from . import capi
 
 
 class Context:
-    def __init__(self, device_id: int = 0):
-        self.lib = capi.load_library()
+    def __init__(self, device_id: int = 0, library=None):
+        """`library`: another build of libhiprenderer.so (capi.VERIFY_LIB_PATH for the verification build); the product library by default."""
+        self.lib = capi.load_library(library)
         self.handle = C.c_void_p()
         capi.check(self.lib, self.lib.hipr_create(device_id, C.byref(self.handle)), "hipr_create")
         self._tables = capi.load_tables()
@@ -168,6 +169,19 @@ class Context:
         fp = C.POINTER(C.c_float)
         self._check(self.lib.hipr_debug_shading(self.handle, int(shading_model), params.ctypes.data_as(fp), wo.ctypes.data_as(fp), inputs.ctypes.data_as(fp), len(inputs),
                                                 int(mode), out.ctypes.data_as(fp)), "hipr_debug_shading")
+        return out
+
+    def debug_shade(self, camera, rays, throughput_bounces, hits, last_triangle, pixel_hash, accumulation):
+        """hipr_debug_shade: shade_path for n queue entries of the uploaded scene -> (n, 32) records (include/hiprenderer_c.h)."""
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        n = len(rays)
+        throughput_bounces = np.ascontiguousarray(throughput_bounces, np.float32).reshape(n, 4)
+        hits = np.ascontiguousarray(hits, np.float32).reshape(n, 4)
+        words = [np.ascontiguousarray(a, np.uint32).reshape(n) for a in (last_triangle, pixel_hash, accumulation)]
+        out = np.zeros((n, 32), np.float32)
+        fp, up = C.POINTER(C.c_float), C.POINTER(C.c_uint32)
+        self._check(self.lib.hipr_debug_shade(self.handle, C.byref(camera), n, rays.ctypes.data_as(fp), throughput_bounces.ctypes.data_as(fp), hits.ctypes.data_as(fp),
+                                              *[a.ctypes.data_as(up) for a in words], out.ctypes.data_as(fp)), "hipr_debug_shade")
         return out
 
     def debug_light(self, light: capi.HiprLight, position, inputs, mode=0):

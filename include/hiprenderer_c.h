@@ -509,6 +509,15 @@ int hipr_debug_generate(HiprContext* context, const HiprCameraState* camera, uin
  * direction[3]; mode 1: evaluate_with_PDF(wo, wi = in) -> out7 = f[3], pdf, 0, 0, 0. Host pointers. */
 int hipr_debug_shading(HiprContext* context, int shading_model, const float* params10, const float* wo_n3, const float* in_n3, uint32_t n, int mode,
                        float* out_n7);
+/* K3 at stage level: shade_path -- the closest-hit / miss / light-hit programs of ORS/MonteCarlo.cu:129-302 and ORS/SimpleRGPs.cu:349-362 as the shade kernel runs
+ * them -- for n given queue entries of the uploaded scene: rays_n8 = origin, tmin, direction, BSDF PDF of the ray (raw: negative = delta dirac); throughput_bounces_n4 =
+ * throughput, bits(bounces); hits_n4 = t, u, v, bits(triangle | 0x80000000 + light | 0xFFFFFFFF miss) as hipr_debug_trace_closest returns them; the triangle the ray
+ * left from, the pixel's hash (pcg2d(x, y).x) and the accumulation of the sample. out_n32: per entry 0 flags (1 the path continues, 2 a shadow ray was emitted, 4 the hit
+ * was shaded), 1-3 radiance added, 4-7 next origin + tmin, 8-11 next direction + BSDF PDF, 12-15 throughput + bits(bounces), 16 bits(last accepted triangle), 17-20
+ * shadow origin + tmax, 21-23 direction to the light, 24-26 radiance the shadow ray carries; words of parts that do not apply are zero. Host pointers. The oracle's
+ * hit programs write the same record (tests: bit-identical for the verification build, decision by decision statistics for the product). */
+int hipr_debug_shade(HiprContext* context, const HiprCameraState* camera, uint32_t n, const float* rays_n8, const float* throughput_bounces_n4, const float* hits_n4,
+                     const uint32_t* last_triangle, const uint32_t* pixel_hash, const uint32_t* accumulation, float* out_n32);
 /* The light sources as the shade kernel evaluates them, for the reference's light tests (ORT/LightSources/SphereLightTest.h,
  * SpotLightTest.h). mode 0: LightSources::sample_radiance(light, position, u = in.xy) -> out8 = radiance[3], PDF,
  * direction_to_light[3], distance. mode 1 (spot lights only): out8 = evaluate(light, position, direction = in)[3],

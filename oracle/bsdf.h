@@ -61,7 +61,7 @@ inline float3 pow2(float3 x) { return x * x; }
 inline float pow4(float x) { float xx = x * x; return xx * xx; }
 inline float pow5(float x) { float xx = x * x; return xx * xx * x; }
 inline bool same_hemisphere(float3 wo, float3 wi) { return wo.z * wi.z >= 0.0f; }
-inline void sincos(float theta, float& s, float& c) { s = sinf(theta); c = cosf(theta); }
+inline void sincos(float theta, float& s, float& c) { s = exact_sinf(theta); c = exact_cosf(theta); }
 
 inline float dielectric_specularity(float ior_o, float ior_i) { return pow2((ior_o - ior_i) / (ior_o + ior_i)); }
 inline float3 conductor_specularity(float3 ior_o, float3 ior_i, float3 ext_i) {
@@ -98,7 +98,7 @@ inline float dielectric_schlick_fresnel(float f0, float abs_cos_theta, float ior
 inline float modulate_roughness_under_coat(float base_roughness, float coat_roughness) {
     float x_coat = 1 - AIR_IOR / COAT_IOR;
     float r4 = fminf(1, pow4(base_roughness) + 2.0f * x_coat * pow4(coat_roughness));
-    return powf(r4, 0.25f);
+    return exact_powf(r4, 0.25f);
 }
 // refract against the normal (0,0,1), OR/Utils.h:242-272.
 inline bool refract_z(float3& out, float3 wi, float ior_i_over_o) {
@@ -228,7 +228,7 @@ inline float PDF(float radius) { return 1.0f / (PIf * pow2(radius)); }
 inline float2 sample(float radius, float2 u) {
     float r = sqrtf(u.x) * radius;
     float phi = 2.0f * PIf * u.y;
-    return {r * cosf(phi), r * sinf(phi)};
+    return {r * exact_cosf(phi), r * exact_sinf(phi)};
 }
 }
 
@@ -405,7 +405,7 @@ static const float constant1_FON = 0.5f - 2.0f / (3.0f * PIf);
 
 inline float E_FON_exact(float cos_theta, float, float A, float B) {
     float Si = sqrtf(1.0f - (cos_theta * cos_theta));
-    float G = Si * (acosf(cos_theta) - Si * cos_theta) + (2.0f / 3.0f) * ((Si / cos_theta) * (1.0f - (Si * Si * Si)) - Si);
+    float G = Si * (exact_acosf(cos_theta) - Si * cos_theta) + (2.0f / 3.0f) * ((Si / cos_theta) * (1.0f - (Si * Si * Si)) - Si);
     return A + B * G * RECIP_PIf;
 }
 inline float E_FON_approx(float cos_theta, float, float A, float B) {
@@ -445,7 +445,7 @@ inline float3 evaluate(float3 albedo, float roughness, float3 wo, float3 wi, boo
     return albedo * evaluate(roughness, wo, wi, exact);
 }
 inline float uniform_probability(float roughness, float cos_theta) {
-    return powf(roughness, 0.1f) * (0.162925f + cos_theta * (-0.372058f + (0.538233f - 0.290822f * cos_theta) * cos_theta));
+    return exact_powf(roughness, 0.1f) * (0.162925f + cos_theta * (-0.372058f + (0.538233f - 0.290822f * cos_theta) * cos_theta));
 }
 inline PDF pdf(float roughness, float3 wo, float3 wi) {
     float up = uniform_probability(roughness, wo.z);

@@ -516,7 +516,7 @@ void intersect_lights(const HiprSceneDesc& scene, const Ray& ray, Hit& hit) {
 // Textures: software replacement of the samplers configured at OR/Renderer.cpp:703-751.
 // ---------------------------------------------------------------------------------------------
 static inline float srgb_to_linear(float c) {
-    return c <= 0.04045f ? c / 12.92f : powf((c + 0.055f) / 1.055f, 2.4f);
+    return c <= 0.04045f ? c / 12.92f : exact_powf((c + 0.055f) / 1.055f, 2.4f);
 }
 
 static inline float4 fetch_texel(const HiprSceneDesc& scene, const HiprTexture& tex, int x, int y) {
@@ -621,13 +621,18 @@ static SurfaceAttributes interpolate_attributes(const HiprSceneDesc& scene, cons
     a.position = p1 * u + p2 * v + p0 * w;
 
     if (inst.mesh_flags & HIPR_MESH_NORMALS) {
+        // The reference interpolates the decoded vertex normals in object space (TriangleAttributes.cu:58-61) and carries the result to world space with
+        // rtTransformNormal(RT_OBJECT_TO_WORLD) + normalize (MonteCarlo.cu:176). Instance transforms are rotation + uniform scale + translation
+        // (BF/Math/Transform.h:28-34), for which M (sum w_i n_i) = sum w_i (M n_i): the specification shared with the device is the
+        // right-hand side -- every vertex normal taken to world space first (what the device's per-triangle shading record holds, k_build_shade_triangles),
+        // interpolated there, normalised once. The two orders differ in the last bits only; stating one of them is what lets K3 be compared bit for bit.
         const HiprVertexGeometry* g = scene.geometry + inst.vertex_offset;
-        float3 n = decode_octahedral(g[idx[1]].oct_normal) * u + decode_octahedral(g[idx[2]].oct_normal) * v + decode_octahedral(g[idx[0]].oct_normal) * w;
-        n = normalize(n);
-        // rtTransformNormal(RT_OBJECT_TO_WORLD) for rotation + uniform scale, then normalize (MonteCarlo.cu:176).
         const float* M = inst.object_to_world;
-        float3 wn = {M[0] * n.x + M[1] * n.y + M[2] * n.z, M[4] * n.x + M[5] * n.y + M[6] * n.z, M[8] * n.x + M[9] * n.y + M[10] * n.z};
-        a.shading_normal = normalize(wn);
+        auto world_normal = [&](uint32_t i) {
+            const float3 o = decode_octahedral(g[i].oct_normal);
+            return make_float3(M[0] * o.x + M[1] * o.y + M[2] * o.z, M[4] * o.x + M[5] * o.y + M[6] * o.z, M[8] * o.x + M[9] * o.y + M[10] * o.z);
+        };
+        a.shading_normal = normalize(world_normal(idx[1]) * u + world_normal(idx[2]) * v + world_normal(idx[0]) * w);
     } else
         a.shading_normal = a.geometric_normal;
 
@@ -808,8 +813,8 @@ struct Payload {
 // ---------------------------------------------------------------------------------------------
 static inline float2 direction_to_latlong_texcoord(float3 direction) {
     const float PI = 3.14159265358979323846f;
-    float u = (atan2f(direction.z, direction.x) + PI) * 0.5f / PI;
-    float v = (asinf(direction.y) + PI * 0.5f) / PI;
+    float u = (exact_atan2f(direction.z, direction.x) + PI) * 0.5f / PI;
+    float v = (exact_asinf(direction.y) + PI * 0.5f) / PI;
     return {u, v};
 }
 
@@ -982,6 +987,70 @@ static bool closest_hit_program(const HiprSceneDesc& scene, const HiprSceneState
     return true;
 }
 
+// What runs for a traced ray once its closest hit is known: the miss program, light_closest_hit or path_tracing_closest_hit<> -- path_trace_pixel's loop body
+// between the closest-hit query and the shadow query. Its own function so that shade_hit_for_test below can run exactly this for a given ray and hit.
+static void hit_programs(const HiprSceneDesc& scene, const HiprSceneState& state, const HiprCameraState& cam, const float4* offsets, Payload& payload, const Ray& ray,
+                         const Hit& hit, RenderCounters* counters) {
+    if (hit.id == HIT_MISS) {
+        // miss program (SimpleRGPs.cu:349-362) + evaluate_intersection (LightImpl.h:86-97) for an environment map
+        float3 env = {state.environment_tint[0], state.environment_tint[1], state.environment_tint[2]};
+        if (scene.environment && scene.environment->environment_map_ID) {
+            env = environment_evaluate(scene, state, ray.direction);
+            if (payload.bsdf_PDF.use_for_MIS()) env *= MIS_weight(payload.bsdf_PDF, environment_pdf(*scene.environment, ray.direction));
+        }
+        payload.radiance += payload.throughput * env;
+        payload.throughput = {0, 0, 0};
+    } else if (hit.id & HIT_LIGHT_BIT) {
+        // light_closest_hit (MonteCarlo.cu:291-302)
+        const HiprLight& light = scene.lights[hit.id & ~HIT_LIGHT_BIT];
+        float3 L = Lights::evaluate_intersection(light, ray.origin, ray.direction, payload.bsdf_PDF);
+        payload.throughput = fminf3(payload.throughput, make_float3(4));
+        payload.radiance += payload.throughput * L;
+        payload.throughput = {0, 0, 0};
+    } else {
+        bool accepted = closest_hit_program(scene, state, cam, offsets, payload, hit, ray.direction);
+        if (accepted && counters) counters->shaded_hits++;
+        if (!accepted && counters) counters->rejected_hits++;
+    }
+}
+
+// Stage-level checker of K3 (tests/test_device_code_on_host_cpu.py, tests/test_gpu_verify_build.py): one trip through the hit programs for a ray whose closest hit is
+// given, with everything the device's shade stage reports for it -- radiance added, the continuing ray and path state, the shadow ray. Same record as
+// tests/native/DeviceShadeHost.hip writes for the device code (32 words per entry, the words of parts that do not apply left zero).
+void shade_hit_for_test(const HiprSceneDesc& scene, const HiprSceneState& state, const HiprCameraState& cam, const float4* offsets, const float* ray8, const float* thr_bounces4,
+                        const float* hit4, uint32_t last_triangle, uint32_t pixel_hash, uint32_t accumulation, float* out32) {
+    auto bits = [](uint32_t v) { float f; std::memcpy(&f, &v, 4); return f; };
+    auto word = [](float f) { uint32_t v; std::memcpy(&v, &f, 4); return v; };
+    Payload payload;
+    payload.position = {ray8[0], ray8[1], ray8[2]}; payload.ray_min_t = ray8[3];
+    payload.direction = {ray8[4], ray8[5], ray8[6]}; payload.bsdf_PDF = PDF(ray8[7]);
+    payload.throughput = {thr_bounces4[0], thr_bounces4[1], thr_bounces4[2]}; payload.bounces = word(thr_bounces4[3]);
+    payload.last_triangle = last_triangle; payload.pixel_hash = pixel_hash; payload.accumulation = accumulation;
+    const Ray ray = {payload.position, payload.ray_min_t, payload.direction, INFINITY};
+    const Hit hit = {hit4[0], hit4[1], hit4[2], word(hit4[3])};
+    const uint32_t bounces_before = payload.bounces;
+    hit_programs(scene, state, cam, offsets, payload, ray, hit, nullptr);
+    for (int k = 0; k < 32; ++k) out32[k] = 0.0f;
+    const bool surface = hit.id != HIT_MISS && !(hit.id & HIT_LIGHT_BIT);
+    const bool rejected = surface && payload.bounces == bounces_before;      // a refused hit sends the same ray on (ray_min_t bumped), nothing else changes
+    const bool continues = surface && (rejected || (payload.bounces <= cam.max_bounce_count && !is_black(payload.throughput)));
+    const LightSample& ls = payload.light_sample;
+    const bool shadow = surface && !rejected && (ls.radiance.x > 0 || ls.radiance.y > 0 || ls.radiance.z > 0);
+    out32[0] = bits((continues ? 1u : 0u) | (shadow ? 2u : 0u) | (surface && !rejected ? 4u : 0u));
+    out32[1] = payload.radiance.x; out32[2] = payload.radiance.y; out32[3] = payload.radiance.z;
+    if (continues) {
+        out32[4] = payload.position.x; out32[5] = payload.position.y; out32[6] = payload.position.z; out32[7] = payload.ray_min_t;
+        out32[8] = payload.direction.x; out32[9] = payload.direction.y; out32[10] = payload.direction.z; out32[11] = payload.bsdf_PDF.v;
+        out32[12] = payload.throughput.x; out32[13] = payload.throughput.y; out32[14] = payload.throughput.z; out32[15] = bits(payload.bounces);
+        out32[16] = bits(payload.last_triangle);
+    }
+    if (shadow) {
+        out32[17] = payload.light_sample_origin.x; out32[18] = payload.light_sample_origin.y; out32[19] = payload.light_sample_origin.z; out32[20] = ls.distance;
+        out32[21] = ls.direction_to_light.x; out32[22] = ls.direction_to_light.y; out32[23] = ls.direction_to_light.z;
+        out32[24] = ls.radiance.x; out32[25] = ls.radiance.y; out32[26] = ls.radiance.z;
+    }
+}
+
 float3 path_trace_pixel(const HiprSceneDesc& scene, const HiprSceneState& state, const HiprCameraState& cam,
                         const float4* offsets, int x, int y, int width, int height, uint32_t accumulation,
                         const RenderSettings& settings, RenderCounters* counters) {
@@ -1000,27 +1069,7 @@ float3 path_trace_pixel(const HiprSceneDesc& scene, const HiprSceneState& state,
         intersect_lights(scene, ray, hit);
         if (counters) counters->closest_rays++;
 
-        if (hit.id == HIT_MISS) {
-            // miss program (SimpleRGPs.cu:349-362) + evaluate_intersection (LightImpl.h:86-97) for an environment map
-            float3 env = {state.environment_tint[0], state.environment_tint[1], state.environment_tint[2]};
-            if (scene.environment && scene.environment->environment_map_ID) {
-                env = environment_evaluate(scene, state, ray.direction);
-                if (payload.bsdf_PDF.use_for_MIS()) env *= MIS_weight(payload.bsdf_PDF, environment_pdf(*scene.environment, ray.direction));
-            }
-            payload.radiance += payload.throughput * env;
-            payload.throughput = {0, 0, 0};
-        } else if (hit.id & HIT_LIGHT_BIT) {
-            // light_closest_hit (MonteCarlo.cu:291-302)
-            const HiprLight& light = scene.lights[hit.id & ~HIT_LIGHT_BIT];
-            float3 L = Lights::evaluate_intersection(light, ray.origin, ray.direction, payload.bsdf_PDF);
-            payload.throughput = fminf3(payload.throughput, make_float3(4));
-            payload.radiance += payload.throughput * L;
-            payload.throughput = {0, 0, 0};
-        } else {
-            bool accepted = closest_hit_program(scene, state, cam, offsets, payload, hit, ray.direction);
-            if (accepted && counters) counters->shaded_hits++;
-            if (!accepted && counters) counters->rejected_hits++;
-        }
+        hit_programs(scene, state, cam, offsets, payload, ray, hit, counters);
 
         const LightSample& ls = payload.light_sample;
         if (ls.radiance.x > 0 || ls.radiance.y > 0 || ls.radiance.z > 0) {

@@ -77,6 +77,10 @@ float3 path_trace_pixel(const HiprSceneDesc& scene, const HiprSceneState& state,
                         const float4* sample_offsets, int x, int y, int width, int height, uint32_t accumulation,
                         const RenderSettings& settings, RenderCounters* counters);
 
+// The hit programs for one traced ray and its given closest hit (stage-level checker of K3; record layout in integrator.cpp).
+void shade_hit_for_test(const HiprSceneDesc& scene, const HiprSceneState& state, const HiprCameraState& cam, const float4* sample_offsets, const float* ray8,
+                        const float* throughput_bounces4, const float* hit4, uint32_t last_triangle, uint32_t pixel_hash, uint32_t accumulation, float* out32);
+
 // One pixel-sample of an AOV entry point (HIPR_ENTRY_DEPTH ... HIPR_ENTRY_PRIMITIVE_ID), ORS/SimpleRGPs.cu:227-340.
 float3 aov_pixel(const HiprSceneDesc& scene, const HiprSceneState& state, const HiprCameraState& cam, const float4* sample_offsets, int x, int y,
                  int width, int height, uint32_t accumulation, int entry, const RenderSettings& settings);

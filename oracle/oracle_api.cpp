@@ -394,6 +394,24 @@ double oracle_render(const HiprSceneDesc* scene, const HiprSceneState* state, co
     return oracle_render_entry(scene, state, cam, width, height, accumulation_count, use_bvh, HIPR_ENTRY_PATH_TRACING, accum_rgba, counters9);
 }
 
+// K3 at stage level: the hit programs for n traced rays whose closest hits are given (integrator.cpp shade_hit_for_test); 32 words per entry.
+void oracle_debug_shade(const HiprSceneDesc* scene, const HiprSceneState* state, const HiprCameraState* cam, uint32_t n, const float* rays_n8, const float* throughput_bounces_n4,
+                        const float* hits_n4, const uint32_t* last_triangle, const uint32_t* pixel_hash, const uint32_t* accumulation, float* out_n32) {
+    reset_search_items();
+    std::vector<float4> offsets(256);
+    for (int i = 0; i < 256; ++i) offsets[i] = rng::sample_offset(i);
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t i = 0; i < int64_t(n); ++i)
+        shade_hit_for_test(*scene, *state, *cam, offsets.data(), rays_n8 + 8 * i, throughput_bounces_n4 + 4 * i, hits_n4 + 4 * i, last_triangle[i], pixel_hash[i], accumulation[i], out_n32 + 32 * i);
+}
+
+// 1: every transcendental of the path in f64, rounded once to f32 (vecmath.h exact_*): the checker of the verification build. Returns the previous setting.
+int oracle_set_f64_transcendentals(int on) {
+    const int before = oracle::g_f64_transcendentals ? 1 : 0;
+    oracle::g_f64_transcendentals = on != 0;
+    return before;
+}
+
 int oracle_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -16,6 +16,19 @@
 
 namespace oracle {
 
+// The transcendentals of the path (sin, cos, pow, atan2, asin, acos). By default glibc's f32 functions, the independent counterpart of whatever the product's
+// shade kernel uses (hardware approximations). With oracle_set_f64_transcendentals(1) -- the checker of the VERIFICATION build, libhiprenderer_verify.so,
+// csrc/device_shading.h HIPR_VERIFY_MATH -- each is evaluated in f64 and rounded once to f32: two independent f64 implementations (glibc here, ocml on the
+// device), each within a few f64 ulp of the true value, round to the same f32 except with probability ~2^-26 per call, so the two sides agree bit for bit on
+// all but a handful of paths per frame without sharing any code. Set before a render, read by its threads.
+inline bool g_f64_transcendentals = false;
+inline float exact_sinf(float x) { return g_f64_transcendentals ? float(std::sin(double(x))) : sinf(x); }
+inline float exact_cosf(float x) { return g_f64_transcendentals ? float(std::cos(double(x))) : cosf(x); }
+inline float exact_powf(float x, float y) { return g_f64_transcendentals ? float(std::pow(double(x), double(y))) : powf(x, y); }
+inline float exact_atan2f(float y, float x) { return g_f64_transcendentals ? float(std::atan2(double(y), double(x))) : atan2f(y, x); }
+inline float exact_asinf(float x) { return g_f64_transcendentals ? float(std::asin(double(x))) : asinf(x); }
+inline float exact_acosf(float x) { return g_f64_transcendentals ? float(std::acos(double(x))) : acosf(x); }
+
 struct float2 { float x, y; };
 struct float3 { float x, y, z; };
 struct float4 { float x, y, z, w; };
