@@ -10,6 +10,11 @@
 //           peer one ncclSend) over xGMI; RCCL is loaded with dlopen so that the library has no link-time dependency on it. When
 //           it cannot be loaded, when two members share a device (tests on a one-GPU box) or with HIPR_GROUP_GATHER=copy, the
 //           same bytes move by peer-to-peer hipMemcpyAsync (device to device over xGMI as well).
+//   watchdog (round 5): no member ever blocks in the exchange. Every thread brackets its RCCL calls with ncclGroupStart / ncclGroupEnd (the discipline RCCL documents for
+//           several communicators in one process) and then POLLS its stream (hipStreamQuery) against a deadline (HIPR_GROUP_GATHER_TIMEOUT_MS, 10 s by default) instead
+//           of waiting on it. An exchange that does not finish -- a peer that never posted its half -- ends the call with HIPR_ERROR_TIMEOUT naming the member; the
+//           communicators are aborted (ncclCommAbort), the members get fresh streams and the group gathers with peer-to-peer copies for the rest of its life. Nothing
+//           is re-executed and no process is replaced. tests/test_gpu_coverage.py::test_device_group_watchdog_ends_a_stalled_exchange injects the stall.
 // The reference renders on one device (OR/Renderer.cpp:289-291); there is no reference behaviour here beyond "the same image", which
 // holds bit for bit: the RNG is a pure function of (pixel, accumulation, bounce) and every member walks the same BVH.
 #include "../../include/hiprenderer_c.h"
@@ -19,6 +24,8 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -39,6 +46,7 @@ struct Rccl {
     void* library = nullptr;
     int (*CommInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
     int (*CommDestroy)(void* comm) = nullptr;
+    int (*CommAbort)(void* comm) = nullptr;      // optional: frees a communicator whose operations will never complete
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     int (*Send)(const void* sendbuff, size_t count, int datatype, int peer, void* comm, hipStream_t stream) = nullptr;
@@ -51,6 +59,7 @@ struct Rccl {
         if (!library) return false;
         CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(library, "ncclCommInitAll"));
         CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(library, "ncclCommDestroy"));
+        CommAbort = reinterpret_cast<decltype(CommAbort)>(dlsym(library, "ncclCommAbort"));
         GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(library, "ncclGroupStart"));
         GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(library, "ncclGroupEnd"));
         Send = reinterpret_cast<decltype(Send)>(dlsym(library, "ncclSend"));
@@ -93,6 +102,8 @@ struct HiprGroup {
     bool frame_ready = false;
     std::string gather_description;
     Workers workers;
+    int gather_timeout_ms = 10000;  // HIPR_GROUP_GATHER_TIMEOUT_MS
+    int stall_member_once = -1;     // HIPR_GROUP_TEST_STALL_MEMBER: test hook, the member whose half of the NEXT exchange is held back past the deadline
 };
 
 namespace {
@@ -157,6 +168,39 @@ int for_each_member(HiprGroup* g, std::function<int(Member&, uint32_t)> work) {
     return HIPR_OK;
 }
 
+// Waits for `stream` by polling, up to `timeout_ms`: a member's thread must come back from the exchange whatever its peers do.
+bool wait_for_stream(hipStream_t stream, int timeout_ms) {
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms);
+    for (;;) {
+        const hipError_t status = hipStreamQuery(stream);
+        if (status == hipSuccess) return true;
+        if (status != hipErrorNotReady) { (void)hipGetLastError(); return false; }
+        if (std::chrono::steady_clock::now() > deadline) return false;
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+}
+
+// After an exchange that stalled: the communicators are given up (their pending operations would hold the streams for ever), every member gets a fresh stream and the
+// group gathers with peer-to-peer copies from now on.
+void fall_back_to_copies(HiprGroup* g, const char* why) {
+    for (Member& m : g->members) {
+        (void)hipSetDevice(m.device);
+        if (m.comm) {
+            if (g->rccl.CommAbort) g->rccl.CommAbort(m.comm);      // without ncclCommAbort the communicator is left alone: destroying it would wait for the stalled operations
+            m.comm = nullptr;
+        }
+        hipStream_t fresh = nullptr;
+        if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) == hipSuccess) {
+            (void)hipStreamDestroy(m.stream);      // returns at once; the runtime releases the stream when what is queued on it has ended
+            m.stream = fresh;
+        }
+    }
+    (void)hipGetLastError();
+    g->use_rccl = false;
+    g->gather_description = std::string("peer-to-peer hipMemcpyAsync (fallen back: ") + why + ")";
+    fprintf(stderr, "hiprenderer: device group: %s; the group gathers with peer-to-peer copies from now on\n", why);
+}
+
 void stop_workers(HiprGroup* g) {
     Workers& w = g->workers;
     {
@@ -211,6 +255,8 @@ int hipr_group_create(const int* device_ids, uint32_t count, HiprGroup** out_gro
         }
     }
     (void)hipGetLastError();
+    if (const char* v = getenv("HIPR_GROUP_GATHER_TIMEOUT_MS")) g->gather_timeout_ms = std::max(1, atoi(v));
+    if (const char* v = getenv("HIPR_GROUP_TEST_STALL_MEMBER")) g->stall_member_once = atoi(v);
     const char* mode = getenv("HIPR_GROUP_GATHER");
     g->gather_description = "peer-to-peer hipMemcpyAsync";
     if (count > 1 && distinct && !(mode && !strcmp(mode, "copy")) && g->rccl.load()) {
@@ -323,22 +369,47 @@ int hipr_group_accumulate_samples(HiprGroup* g, uint32_t first_sample, uint32_t 
         return hipr_accumulate_samples(m.context, first_sample, sample_count, first_accumulation, out_half4_device ? m.compact : nullptr, 0, 1);
     });
     if (status || !out_half4_device) return status;
+    const int stalled = g->stall_member_once;
+    g->stall_member_once = -1;
+    std::atomic<int> timed_out{-1};
     status = for_each_member(g, [&](Member& m, uint32_t i) -> int {
         auto hip_failed = [&](const char* what) { hipr_internal_set_last_error(what); return HIPR_ERROR_HIP; };
         if (hipSetDevice(m.device) != hipSuccess) return hip_failed("hipSetDevice failed in the tile gather");
+        if (int(i) == stalled) {      // test hook: this member's half of the exchange is held back past the deadline (a host function that sleeps on its stream)
+            static int sleep_ms;
+            sleep_ms = g->gather_timeout_ms + 500;
+            (void)hipLaunchHostFunc(m.stream, [](void* ms) { std::this_thread::sleep_for(std::chrono::milliseconds(*static_cast<int*>(ms))); }, &sleep_ms);
+        }
         if (g->use_rccl) {
+            // one communicator per thread, every thread's calls inside its own group call (RCCL: several communicators driven from one process)
+            int r = 0;
             if (i == 0) {
                 if (hipMemcpyAsync(gathered, m.compact, bytes, hipMemcpyDeviceToDevice, m.stream) != hipSuccess) return hip_failed("copy of member 0's own tiles failed");
-                int r = g->rccl.GroupStart();
+                r = g->rccl.GroupStart();
                 for (uint32_t peer = 1; peer < n && r == 0; ++peer) r = g->rccl.Recv(gathered + size_t(peer) * bytes, bytes, NCCL_UINT8, int(peer), m.comm, m.stream);
                 r = g->rccl.GroupEnd() | r;
                 if (r != 0) return hip_failed("ncclRecv of the members' tiles failed");
-            } else if (g->rccl.Send(m.compact, bytes, NCCL_UINT8, 0, m.comm, m.stream) != 0)
-                return hip_failed("ncclSend of a member's tiles failed");
+            } else {
+                r = g->rccl.GroupStart();
+                if (r == 0) r = g->rccl.Send(m.compact, bytes, NCCL_UINT8, 0, m.comm, m.stream);
+                r = g->rccl.GroupEnd() | r;
+                if (r != 0) return hip_failed("ncclSend of a member's tiles failed");
+            }
         } else if (hipMemcpyAsync(gathered + size_t(i) * bytes, m.compact, bytes, hipMemcpyDeviceToDevice, m.stream) != hipSuccess)
             return hip_failed("peer-to-peer copy of a member's tiles failed");
-        return hipStreamSynchronize(m.stream) == hipSuccess ? HIPR_OK : hip_failed("the gather stream failed");
+        if (wait_for_stream(m.stream, g->gather_timeout_ms)) return HIPR_OK;
+        int none = -1;
+        timed_out.compare_exchange_strong(none, int(i));
+        const std::string text = "the tile exchange (" + g->gather_description + ") did not finish within " + std::to_string(g->gather_timeout_ms) + " ms on this member's stream";
+        hipr_internal_set_last_error(text.c_str());
+        return HIPR_ERROR_TIMEOUT;
     });
+    if (timed_out.load() >= 0 || (status && g->use_rccl)) {
+        // the frame of this call is not delivered; the next call finds a group that copies
+        const std::string message = hipr_last_error();
+        fall_back_to_copies(g, status == HIPR_ERROR_TIMEOUT ? "an exchange did not finish within its deadline" : "an RCCL call failed");
+        hipr_internal_set_last_error(message.c_str());
+    }
     if (status) return status;
     if (int s = hipr_scatter_tiles(g->members[0].context, g->gathered, g->compact_pixels, n, g->width, g->height, out_half4_device, out_pitch_pixels)) return s;
     return synchronize ? hipr_synchronize(g->members[0].context) : HIPR_OK;

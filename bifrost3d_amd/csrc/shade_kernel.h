@@ -34,6 +34,7 @@ struct ShadeOutput {
     bool shaded;         // an accepted surface hit
     f3 o, d; float tmin, bsdf_pdf; f3 throughput; uint32_t bounces, last_triangle;
     f3 so, sd; float stmax; f3 sradiance;
+    uint32_t shadow_class;   // the light the shadow ray goes to, min(light index, SHADOW_CLASSES - 1): the block lists its shadow rays by it (k_shade)
     f3 add_radiance;
     bool nee_reached;    // SHADE_PART_NEE: the hit was accepted and next event estimation ran ...
     bool nee_valid;      // ... and kept a light sample with a valid PDF
@@ -44,6 +45,16 @@ struct ShadeOutput {
 // rest (emission, miss and light hits, rejected hits, BSDF sampling; queues the paths that continue). Both halves redo the hit's attributes, textures
 // and shading setup; each needs fewer registers than the whole.
 constexpr int SHADE_PART_ALL = 0, SHADE_PART_NEE = 1, SHADE_PART_BSDF = 2;
+// HIPR_SHADOW_CLASSES > 1 (opt-in A/B of round 5): shadow rays listed BY LIGHT inside every block's stretch of the shadow queue -- the rays toward
+// light 0, then light 1, then all others -- so that the trace waves, which take them 64 at a time, hold rays toward ONE light from a few neighbouring pixels
+// (near-parallel for a directional light, converging on one small sphere): coherent by construction, no extra pass, no extra atomics, no gathered reads; frames and
+// counters bit-identical. Measured on the atrium (directional + sphere light; profiles/r05_ab_shadow_by_light.txt): trace 79.9 -> 80.0 ms per step -- nothing --
+// and the three ballots cost the shade kernel 1.6 ms (24.0 -> 25.6). The lanes the fused launches lack are those of the BSDF-sampled closest-hit rays, whose
+// directions no listing makes alike; the shadow rays were not what held the waves back. Off (1 class: the code reduces to the single list).
+#ifndef HIPR_SHADOW_CLASSES
+#define HIPR_SHADOW_CLASSES 1
+#endif
+constexpr uint32_t SHADOW_CLASSES = HIPR_SHADOW_CLASSES;
 
 // What shade_path reads of the hit triangle, fetched one loop iteration ahead by k_shade.
 struct ShadeGeometry {
@@ -231,6 +242,7 @@ HD void shade_path(const DeviceScene& sc, const HiprCameraState& cam, int entry,
 
     // --- next event estimation: streaming RIS over the light candidates (MonteCarlo.cu:91-123) ------
     LightSample kept = light_sample_none();
+    uint32_t kept_light = 0;
     if (PART != SHADE_PART_BSDF && sc.light_count != 0) {
         const f4 base = sobol4f_tables(accumulation, pixel_hash, 8u * bounces + 1u, sobol_lds);
         const int n = sc.next_event_sample_count;
@@ -261,7 +273,7 @@ HD void shade_path(const DeviceScene& sc, const HiprCameraState& cam, int entry,
             c.radiance *= f.f;
             const float w_old = sum(kept.radiance), w_new = sum(c.radiance);
             const float p_new = w_new / (w_old + w_new);
-            if (r.w < p_new) { kept = c; kept.radiance /= p_new; }
+            if (r.w < p_new) { kept = c; kept.radiance /= p_new; kept_light = uint32_t(li); }
             else kept.radiance /= 1.0f - p_new;
         }
         kept.radiance /= float(n);
@@ -272,6 +284,7 @@ HD void shade_path(const DeviceScene& sc, const HiprCameraState& cam, int entry,
         if (kept.radiance.x > 0 || kept.radiance.y > 0 || kept.radiance.z > 0) {
             out.shadow = true;
             out.so = light_origin; out.sd = kept.dir; out.stmax = kept.distance; out.sradiance = kept.radiance;
+            out.shadow_class = min(kept_light, SHADOW_CLASSES - 1u);
         }
         out.nee_valid = pdf_is_valid(kept.pdf);
         if (PART == SHADE_PART_NEE) return;
@@ -382,7 +395,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_waves_per_simd(PART)) void k_sha
                                                         ShadowQueue shadows, float4* radiance, const uint32_t* count_ptr, unsigned long long* out_counts,
                                                         unsigned long long* zero_a, unsigned long long* zero_b, unsigned char* nee_flags, DeviceCounters* counters) {
 #if HIPR_SHADE_ONE_BARRIER
-    __shared__ unsigned long long s_arrivals[2];
+    __shared__ unsigned long long s_arrivals[2], s_totals[2];
     __shared__ uint32_t s_base[4];
 #else
     __shared__ uint32_t s_cont[SHADE_BLOCK / 64], s_shad[SHADE_BLOCK / 64], s_base[2];
@@ -480,24 +493,45 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_waves_per_simd(PART)) void k_sha
         const unsigned long long lt = (1ull << lane) - 1ull;
         shaded_total += so.shaded ? 1u : 0u;
         const uint32_t parity = batch & 1u;
+        // shadow rays by light: class masks of this wave (the last class takes every light from index SHADOW_CLASSES - 1 on)
+        unsigned long long class_mask[SHADOW_CLASSES];
+#pragma unroll
+        for (uint32_t k = 0; k < SHADOW_CLASSES; ++k) class_mask[k] = SHADOW_CLASSES == 1 ? shad_mask : wave_ballot(so.shadow && so.shadow_class == k);
+        // packed per-wave counts: paths that continue (bits 0-9), shadow rays of class k (bits 10 + 10 k ...), arrivals (bits 50-52); a block holds at most 256 of each
         unsigned long long before_me = 0ull;
         if (lane == 0) {
-            const unsigned long long mine = (unsigned long long)__popcll(cont_mask) | ((unsigned long long)__popcll(shad_mask) << 24) | (1ull << 48);
+            unsigned long long mine = (unsigned long long)__popcll(cont_mask) | (1ull << 50);
+#pragma unroll
+            for (uint32_t k = 0; k < SHADOW_CLASSES; ++k) mine |= (unsigned long long)__popcll(class_mask[k]) << (10u + 10u * k);
             before_me = atomicAdd(&s_arrivals[parity], mine);
-            if ((before_me >> 48) == SHADE_BLOCK / 64 - 1) {   // the last wave of the batch
+            if ((before_me >> 50) == SHADE_BLOCK / 64 - 1) {   // the last wave of the batch
                 const unsigned long long total = before_me + mine;
-                const unsigned long long c = total & 0xFFFFFFull, sh = (total >> 24) & 0xFFFFFFull;
+                const unsigned long long c = total & 0x3FFull;
+                unsigned long long sh = 0ull;
+#pragma unroll
+                for (uint32_t k = 0; k < SHADOW_CLASSES; ++k) sh += (total >> (10u + 10u * k)) & 0x3FFull;
                 const unsigned long long base = (c | sh) ? atomicAdd(out_counts, (sh << 32) | c) : 0ull;
                 s_base[2 * parity] = uint32_t(base);
                 s_base[2 * parity + 1] = uint32_t(base >> 32);
+                s_totals[parity] = total;
                 s_arrivals[1u - parity] = 0ull;
             }
         }
         before_me = __shfl(before_me, 0);
         mat = shade_fetch_material(sc, next, geo);
         __syncthreads();
-        const uint32_t cont_slot = s_base[2 * parity] + uint32_t(before_me & 0xFFFFFFull) + __popcll(cont_mask & lt);
-        const uint32_t shad_base = s_base[2 * parity + 1] + uint32_t((before_me >> 24) & 0xFFFFFFull);
+        const uint32_t cont_slot = s_base[2 * parity] + uint32_t(before_me & 0x3FFull) + __popcll(cont_mask & lt);
+        // this lane's shadow ray: after the block's rays of lower classes, after the rays of its class from the waves that arrived earlier, after the lanes below it
+        uint32_t shad_slot = s_base[2 * parity + 1];
+        {
+            const unsigned long long total = s_totals[parity];
+            const uint32_t mine = so.shadow ? so.shadow_class : 0u;
+#pragma unroll
+            for (uint32_t k = 0; k < SHADOW_CLASSES; ++k) {
+                if (k < mine) shad_slot += uint32_t((total >> (10u + 10u * k)) & 0x3FFull);
+                if (k == mine) shad_slot += uint32_t((before_me >> (10u + 10u * k)) & 0x3FFull) + __popcll(class_mask[k] & lt);
+            }
+        }
         ++batch;
 #else
         // ---- compaction: ballot + prefix popcount in the wave, LDS scan over the block's waves, one atomic for both queues
@@ -516,7 +550,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_waves_per_simd(PART)) void k_sha
         }
         mat = shade_fetch_material(sc, next, geo);
         __syncthreads();
-        const uint32_t cont_slot = s_base[0] + s_cont[wave] + __popcll(cont_mask & lt), shad_base = s_base[1] + s_shad[wave];
+        const uint32_t cont_slot = s_base[0] + s_cont[wave] + __popcll(cont_mask & lt), shad_slot = s_base[1] + s_shad[wave] + __popcll(shad_mask & lt);
 #endif
         if (so.continues) {
             const uint32_t j = cont_slot;
@@ -526,7 +560,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, shade_waves_per_simd(PART)) void k_sha
             out.meta[j] = make_uint2(slot, so.last_triangle);
         }
         if (so.shadow) {
-            const uint32_t j = shad_base + __popcll(shad_mask & lt);
+            const uint32_t j = shad_slot;
             shadows.o_tmax[j] = make_float4(so.so.x, so.so.y, so.so.z, so.stmax);
             shadows.d_slot[j] = make_float4(so.sd.x, so.sd.y, so.sd.z, __uint_as_float(slot));
             shadows.radiance[j] = make_float4(so.sradiance.x, so.sradiance.y, so.sradiance.z, 0.0f);

@@ -33,7 +33,8 @@ typedef enum HiprStatus {
     HIPR_ERROR_OUT_OF_MEMORY = -3,
     HIPR_ERROR_HIP = -4,            /* a HIP runtime call failed, see hipr_last_error() */
     HIPR_ERROR_NOT_READY = -5,      /* render before tables/scene/frame were set */
-    HIPR_ERROR_UNSUPPORTED = -6
+    HIPR_ERROR_UNSUPPORTED = -6,
+    HIPR_ERROR_TIMEOUT = -7         /* a device group's tile exchange did not finish within its deadline (hipr_group_accumulate_samples); hipr_last_error() names the member */
 } HiprStatus;
 
 /* ------------------------------------------------------------------------------------------- */
@@ -412,7 +413,7 @@ int hipr_group_create(const int* device_ids, uint32_t count, HiprGroup** out_gro
 int hipr_group_destroy(HiprGroup* group);
 uint32_t hipr_group_size(HiprGroup* group);
 HiprContext* hipr_group_context(HiprGroup* group, uint32_t member);
-const char* hipr_group_gather_description(HiprGroup* group);   /* which transport the gather uses */
+const char* hipr_group_gather_description(HiprGroup* group);   /* which transport the gather uses (and that it fell back, after an exchange that stalled) */
 int hipr_group_upload_tables(HiprGroup* group, const HiprTables* tables);
 int hipr_group_upload_scene(HiprGroup* group, const HiprSceneDesc* scene);
 int hipr_group_update_scene_geometry(HiprGroup* group, const HiprSceneDesc* scene);

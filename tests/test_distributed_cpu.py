@@ -1,4 +1,4 @@
-"""world_size-2 gloo test of the N > 1 path: tile partition -> per-rank compact buffers -> gather on rank 0 ->
+"""world_size-2 and -4 gloo tests of the N > 1 path: tile partition -> per-rank compact buffers -> gather on rank 0 ->
 assembly equals the single-process image. The per-rank pixels come from the CPU oracle (no GPU here); on the GPU
 box the same gather feeds hipr_scatter_tiles (covered by tests/test_gpu_parity.py::test_scatter_tiles_roundtrip)."""
 import os
@@ -56,6 +56,28 @@ def test_two_rank_tile_gather_reassembles_the_frame(tmp_path, size):
     import torch.multiprocessing as mp
     out = tmp_path / "frame.npy"
     mp.spawn(_worker, args=(2, _free_port(), size[0], size[1], str(out)), nprocs=2, join=True)
+    assembled, full = np.load(out)
+    assert np.array_equal(assembled, full)
+    assert full[..., :3].max() > 0
+
+
+@pytest.mark.parametrize("size", [(37, 19), (72, 40)])
+def test_four_rank_tile_gather_with_uneven_shares(tmp_path, size):
+    """World size 4: 37 x 19 is 5 x 3 = 15 tiles -- an ODD count over four ranks, shares of 4 / 4 / 4 / 3 tiles with partial tiles on two
+    edges, so the last rank's compact buffer is padded to rank 0's length and its padding must not land in the frame; 72 x 40 is 45 tiles (12 / 11 / 11 / 11)."""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, str(ROOT))
+    from bifrost3d_amd import distributed
+    tiles = [distributed.owned_tile_count(size[0], size[1], r, 4) for r in range(4)]
+    assert sum(tiles) == ((size[0] + 7) // 8) * ((size[1] + 7) // 8) and tiles[0] > tiles[3]
+    covered = np.zeros((size[1], size[0]), int)
+    for r in range(4):
+        coords = distributed.compact_pixel_coords(size[0], size[1], r, 4)
+        valid = coords[:, 0] >= 0
+        np.add.at(covered, (coords[valid, 1], coords[valid, 0]), 1)
+    assert (covered == 1).all()      # every pixel owned by exactly one rank
+    out = tmp_path / "frame.npy"
+    mp.spawn(_worker, args=(4, _free_port(), size[0], size[1], str(out)), nprocs=4, join=True)
     assembled, full = np.load(out)
     assert np.array_equal(assembled, full)
     assert full[..., :3].max() > 0

@@ -54,7 +54,7 @@ CASES = [(20000, "atrium17502_160x90_acc256_4352", 7.4e-4), (260000, "atrium_160
 
 
 @pytest.mark.parametrize("target, stem, measured", CASES, ids=["atrium17k", "atrium251k"])
-def test_equal_seed_difference_is_unbiased_noise(ctx, oracle_q, target, stem, measured):
+def test_equal_seed_difference_is_unbiased_noise(ctx, oracle_q, verify_ctx, target, stem, measured):
     meta = json.loads((ROOT / "profiles" / "converged" / (stem + ".json")).read_text())
     converged = np.load(ROOT / "profiles" / "converged" / (stem + ".npy")).astype(np.float64)
     scene = Scene("atrium", param0=target, param1=1)
@@ -80,5 +80,13 @@ def test_equal_seed_difference_is_unbiased_noise(ctx, oracle_q, target, stem, me
     assert abs(to_truth_device - to_truth_oracle) <= 0.01 * to_truth_oracle, (to_truth_device, to_truth_oracle)
     # two estimators of one integral at 64 spp: their distance to the truth is the Monte Carlo noise, an order of magnitude above their mutual difference
     assert equal_seed <= 0.25 * to_truth_oracle, (equal_seed, to_truth_oracle)
-    if measured is not None:
-        assert equal_seed <= 2.0 * measured, (equal_seed, measured)
+    # Round 5: the bar is no longer "twice what was measured when the test was written". Leg A: the verification build of the same source renders this frame
+    # bit-identical to the oracle (f64 transcendentals), so the code is exact. Leg B: the product's equal-seed distance to the oracle is its distance to the
+    # verification build ON THE DEVICE -- the divergence of paths under the shade unit's fast arithmetic and nothing else -- and that stays a small fraction of the
+    # frame's Monte Carlo noise (measured: 2 %; `measured` is kept in the table for the record: 7.4e-4 / 2.4e-3 in round 4, 7.5e-4 / 2.4e-3 in round 5).
+    from conftest import verification_build_equals_oracle
+    exact_image = verification_build_equals_oracle(verify_ctx, oracle_q, scene, W, H, SPP, BOUNCES, stem).astype(np.float64)
+    on_device = rmse(gpu, exact_image)
+    print(f"STATISTICS {stem}: product vs verification build on the device {on_device:.3e}")
+    assert abs(on_device - equal_seed) <= 0.1 * on_device + 1e-7, (on_device, equal_seed)
+    assert equal_seed <= 0.05 * to_truth_oracle, (equal_seed, to_truth_oracle)
