@@ -9,6 +9,7 @@
 #   rmse      tools/rmse_protocol.py at 480x270 and 160x90
 #   tests     the GPU suite with image metrics, then smoke()
 #   tracelog  lanes / iterations / refills of the traversal kernel (HIPR_TRACE_LOG)
+#   verify    tools/verify_probe.py: verification build vs oracle (bit-identical pixels) and product vs verification build, 1920x1080x256 spp and 160x90x64 spp
 #   counters  FETCH_SIZE / WRITE_SIZE passes of three workloads and the SQ / TCC / TCP passes of the atrium
 # Results under gpurun_out/<tag>/; `python tools/collect_evidence.py gpurun_out/<tag> <tag>` copies the summaries into profiles/<tag>_*.
 set -u
@@ -22,19 +23,20 @@ quiet="--no-cpu-baseline --no-other-workloads --no-plugin --no-scaling-proxy"
 for part in $parts; do
     case $part in
     bench)
-        python bench.py > $out/bench_default.json 2> $out/bench_default.err; tail -c 600 $out/bench_default.json ;;
+        python bench.py --details $out/bench_details.json > $out/bench_default.json 2> $out/bench_default.err; wc -c $out/bench_default.json; tail -c 600 $out/bench_default.json
+        python3 bench.py --gpus 1 --steps 20 --warmup 5 --details $out/bench_driver_command_details.json > $out/bench_driver_command.json 2> $out/bench_driver_command.err ;;
     stats)
         cd /tmp
-        timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $root/bench.py $quiet --no-rmse --pmc-traffic off --wavefronts 1 > $out/bench_under_rocprof.json 2> $out/bench_under_rocprof.err
+        timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $root/bench.py $quiet --no-rmse --no-textured --pmc-traffic off --wavefronts 1 --details $out/bench_under_rocprof_details.json > $out/bench_under_rocprof.json 2> $out/bench_under_rocprof.err
         cd $root
         find $out/trace -name "*kernel_trace.csv" -size +8M -delete ;;
     workloads)
         for scene in material cornell_diffuse atrium_textured; do
-            python bench.py --scene $scene --steps 4 --warmup 1 $quiet > $out/bench_$scene.json 2> $out/bench_$scene.err
+            python bench.py --scene $scene --steps 4 --warmup 1 $quiet --details $out/bench_${scene}_details.json > $out/bench_$scene.json 2> $out/bench_$scene.err
         done
-        python bench.py --atrium-triangles 10000000 --width 3840 --height 2160 --spp-per-pass 8 --steps 4 --warmup 1 $quiet > $out/bench_atrium10M_4k.json 2> $out/bench_atrium10M_4k.err
-        python bench.py --spp-per-pass 1 --steps 64 --warmup 8 $quiet --no-rmse > $out/bench_atrium_1spp.json 2> $out/bench_atrium_1spp.err
-        python bench.py --gpus 2 --share-device --dist-backend gloo --steps 4 --warmup 1 --no-rmse > $out/bench_2rank_gloo_shared_device.json 2> $out/bench_2rank.err ;;
+        python bench.py --atrium-triangles 10000000 --width 3840 --height 2160 --spp-per-pass 8 --steps 4 --warmup 1 $quiet --details $out/bench_atrium10M_4k_details.json > $out/bench_atrium10M_4k.json 2> $out/bench_atrium10M_4k.err
+        python bench.py --spp-per-pass 1 --steps 64 --warmup 8 $quiet --no-rmse --details $out/bench_atrium_1spp_details.json > $out/bench_atrium_1spp.json 2> $out/bench_atrium_1spp.err
+        python bench.py --gpus 2 --share-device --dist-backend gloo --steps 4 --warmup 1 --no-rmse --details $out/bench_2rank_gloo_shared_device_details.json > $out/bench_2rank_gloo_shared_device.json 2> $out/bench_2rank.err ;;
     rmse)
         timeout 1800 python tools/rmse_protocol.py --size 480x270 --decay-to 1024 --out $out/rmse_protocol_480x270.json > $out/rmse_480.log 2>&1
         timeout 900 python tools/rmse_protocol.py --size 160x90 --decay-to 4096 --out $out/rmse_protocol_160x90.json > $out/rmse_160.log 2>&1 ;;
@@ -51,6 +53,10 @@ for part in $parts; do
         for d in sq1 sq2 tcc tcp; do python tools/pmc_summary.py $out/sq_atrium/$d k_shade k_trace_wide8 k_generate k_accumulate k_classify_hits > $out/sq_atrium_$d.txt; done
         find $out -name "*.csv" -size +3M -delete
         find $out -name "*agent_info.csv" -delete ;;
+    verify)
+        # the verification build against the oracle at the metric's own size (the oracle's 1080p x 256 spp image takes minutes of the box's host cores), then stage level
+        timeout 3000 python tools/verify_probe.py --no-stages --no-libm --scenes atrium --size 1920x1080 --spp 256 --out $out/verify_probe_1920x1080.json > $out/verify_probe_1920x1080.log 2>&1
+        timeout 900 python tools/verify_probe.py --out $out/verify_probe_160x90.json > $out/verify_probe_160x90.log 2>&1 ;;
     *) echo "unknown part $part" ;;
     esac
 done
