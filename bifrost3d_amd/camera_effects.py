@@ -109,6 +109,10 @@ class CameraEffects:
         import torch
         self.torch = torch
         self.device = torch.device("cuda", device_index)
+        # The effects run on torch's current stream (hipr_camera_effects_set_stream): what torch queued before a call -- an upload, the fill of a fresh target -- and what it
+        # queues after it are then ordered with the effects' kernels by the stream itself, and no call blocks the host (the hand-over used to be two
+        # blocking synchronisations per processed frame). Should the stream not be taken, the blocking hand-over stays.
+        self.shares_torch_stream = self.lib.hipr_camera_effects_set_stream(self.handle, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)) == 0
 
     def close(self):
         if getattr(self, "handle", None):
@@ -131,7 +135,8 @@ class CameraEffects:
     def _torch_stream_done(self):
         """The effects run on a stream of their own (hipStreamNonBlocking): what torch queued on ITS stream -- an upload, the fill of a fresh target -- has to be
         complete before a kernel of that stream reads or overwrites the memory."""
-        self.torch.cuda.current_stream(self.device).synchronize()
+        if not self.shares_torch_stream:
+            self.torch.cuda.current_stream(self.device).synchronize()
 
     def view(self, frame, viewport=None) -> FrameView:
         rows, pitch = frame.shape[0], frame.shape[1]
@@ -185,7 +190,8 @@ class CameraEffects:
         self._torch_stream_done()       # the zero fill above must not land on top of the result
         self._check(self.lib.hipr_camera_effects_process(self.handle, C.byref(settings), delta_time, C.byref(view), target.data_ptr(), target_format,
                                                          target.shape[1], target.shape[0], target_offset[0], target_offset[1]), "process")
-        self._check(self.lib.hipr_camera_effects_synchronize(self.handle), "synchronize")       # the caller goes on with the tensor on torch's stream
+        if not self.shares_torch_stream:
+            self._check(self.lib.hipr_camera_effects_synchronize(self.handle), "synchronize")       # the caller goes on with the tensor on torch's stream
         return target
 
     def synchronize(self):

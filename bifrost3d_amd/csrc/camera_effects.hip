@@ -748,7 +748,7 @@ void hipr_camera_effects_destroy(HiprCameraEffects* fx) {
 const char* hipr_camera_effects_last_error(const HiprCameraEffects* fx) { return fx ? fx->last_error.c_str() : "null camera effects object"; }
 
 int hipr_camera_effects_set_stream(HiprCameraEffects* fx, void* hip_stream) {
-    if (!fx || !hip_stream) return fail(fx, HIPR_ERROR_INVALID_ARGUMENT, "hipr_camera_effects_set_stream: null argument");
+    if (!fx) return fail(fx, HIPR_ERROR_INVALID_ARGUMENT, "hipr_camera_effects_set_stream: null object");      // a null stream is the device's default stream (what a host framework's "current stream" usually is)
     FX_HIP(hipStreamSynchronize(fx->stream));
     if (fx->owns_stream) (void)hipStreamDestroy(fx->stream);
     fx->stream = static_cast<hipStream_t>(hip_stream);

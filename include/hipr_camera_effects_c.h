@@ -63,7 +63,7 @@ typedef struct HiprCameraEffects HiprCameraEffects;
 int hipr_camera_effects_create(int device_index, HiprCameraEffects** out);      /* CameraEffects::CameraEffects, CameraEffects.cpp:361-398; linear exposure starts at 0 */
 void hipr_camera_effects_destroy(HiprCameraEffects* effects);
 const char* hipr_camera_effects_last_error(const HiprCameraEffects* effects);
-int hipr_camera_effects_set_stream(HiprCameraEffects* effects, void* hip_stream);
+int hipr_camera_effects_set_stream(HiprCameraEffects* effects, void* hip_stream);      /* the stream every stage runs on from now on (caller-owned; null = the default stream) */
 int hipr_camera_effects_synchronize(HiprCameraEffects* effects);
 
 /* CameraEffects::process (CameraEffects.cpp:412-507): exposure by the settings' mode with eye adaptation over `delta_time`
