@@ -1027,10 +1027,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         device_index = 0 if args.share_device else local_rank
         torch.cuda.set_device(device_index)
+        # a collective that does not complete ends the rank after five minutes (the default is ten; the driver's own limit is far above both), which ends the job
+        import datetime
+        limit = datetime.timedelta(seconds=300)
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index), timeout=limit)
         else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=limit)
     else:
         device_index = 0
         torch.cuda.set_device(0)
