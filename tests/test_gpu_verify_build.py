@@ -207,3 +207,33 @@ def test_decisions_of_the_product_under_its_fast_arithmetic(product, verify, ora
     assert totals["shaded"] > 50000
     assert sum(rates.values()) <= 1e-4      # measured: none in 61 293 shaded hits; where the paths do part, and why: profiles/r05_divergence_sites.txt (tools/divergence_sites.py)
     assert np.quantile(relative, 0.99) < 1e-3
+
+
+AOV_ENTRIES = [("depth", capi.ENTRY_DEPTH), ("albedo", capi.ENTRY_ALBEDO), ("tint", capi.ENTRY_TINT), ("roughness", capi.ENTRY_ROUGHNESS),
+               ("shading_normal", capi.ENTRY_SHADING_NORMAL), ("primitive_id", capi.ENTRY_PRIMITIVE_ID), ("denoiser_albedo", capi.ENTRY_DENOISER_ALBEDO)]
+
+
+@pytest.mark.parametrize("name, entry", AOV_ENTRIES)
+@pytest.mark.parametrize("scene_name", ["cornell", "atrium17k", "atrium17k_textured"])
+def test_aov_entry_points_of_the_verification_build_equal_the_oracle(verify, oracle_q, scene_name, name, entry):
+    """The visualisation backends (ORS/SimpleRGPs.cu:227-340) and the denoiser's feature image: first-hit attributes, the rho tables, the primitive-id hash. The
+    product's test holds them to 1e-5 (2e-3 for the albedos); with exact arithmetic on both sides they are equal bit for bit, NaN for NaN (a miss of the depth entry adds
+    |origin - 1e30 direction| = inf, whose running mean is NaN from the second accumulation on -- on both sides in the same pixels)."""
+    scene = {"cornell": lambda: Scene("cornell"), "atrium17k": lambda: Scene("atrium", param0=20000, param1=1),
+             "atrium17k_textured": lambda: Scene("atrium", param0=20000, param1=1, textured=True)}[scene_name]()
+    w, h, spp = 96, 54, 3
+    verify.upload_scene(scene)
+    verify.set_frame(w, h, 0, 1, 1)
+    verify.set_entry_point(entry)
+    try:
+        for a in range(spp):
+            verify.render_pass(scene.camera(w, h, accumulations=a, max_bounce_count=4), synchronize=True)
+        ours = verify.read_accumulation()[..., :3]
+    finally:
+        verify.set_entry_point(capi.ENTRY_PATH_TRACING)
+    with exact_transcendentals(oracle_q) as oracle:
+        theirs, _, _ = oracle.render(scene.desc, scene.state, scene.camera(w, h, max_bounce_count=4), w, h, spp, use_bvh=verify.oracle_search(), entry=entry)
+    theirs = theirs[..., :3]
+    same = (ours == theirs) | (np.isnan(ours) & np.isnan(theirs))
+    assert same.all(), (scene_name, name, int((~same.all(axis=-1)).sum()))
+    assert np.isfinite(theirs).mean() > 0.05 and np.nanmax(np.abs(theirs)) > 0
