@@ -55,6 +55,7 @@ constexpr int SHADE_PART_ALL = 0, SHADE_PART_NEE = 1, SHADE_PART_BSDF = 2;
 #define HIPR_SHADOW_CLASSES 1
 #endif
 constexpr uint32_t SHADOW_CLASSES = HIPR_SHADOW_CLASSES;
+static_assert(SHADE_BLOCK <= 1023 && 10u + 10u * SHADOW_CLASSES <= 50u, "k_shade packs a block's queue counts into 10-bit fields of one LDS word (paths that continue, shadow rays per class, arrivals from bit 50)");
 
 // What shade_path reads of the hit triangle, fetched one loop iteration ahead by k_shade.
 struct ShadeGeometry {
