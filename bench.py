@@ -397,6 +397,55 @@ def rmse_against_oracle(ctx, scene, bounces, spps=(8, 256), width=160, height=90
     return out
 
 
+def verify_build_leg(ctx, scene, bounces, spp=256, width=160, height=90):
+    """Parity of the CODE, exact (round 5): the VERIFICATION build of the same kernels (csrc/libhiprenderer_verify.so: correctly rounded division / square root, no
+    contraction, transcendentals in f64 rounded once) renders the rmse_vs_oracle frame and is compared with the oracle evaluating its transcendentals in f64 (glibc):
+    the share of pixels whose f64 running mean is bit-identical (expected: 1.0) -- and the product against the verification build ON THE DEVICE, which is what the
+    product's fast arithmetic does to the image (tests/test_gpu_verify_build.py). The oracle is the checker here, outside the timed region."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import numpy as np
+    from bifrost3d_amd import capi
+    from bifrost3d_amd.renderer import Context
+    from oracle_bindings import get_oracle
+    if not capi.VERIFY_LIB_PATH.exists():
+        return {"error": "libhiprenderer_verify.so is not built"}
+    oracle = get_oracle(True)
+
+    def render(context):
+        batch = min(spp, 32)
+        context.set_frame(width, height, 0, 1, batch)
+        for a in range(0, spp, batch):
+            context.render_pass(scene.camera(width, height, accumulations=a, max_bounce_count=bounces))
+        context.synchronize()
+        return context.read_accumulation()[..., :3]
+
+    ctx.set_wavefront_count(1)
+    product = render(ctx)
+    verify = Context(ctx_device(ctx), library=capi.VERIFY_LIB_PATH)
+    try:
+        verify.upload_scene(scene)
+        exact = render(verify)
+        search = verify.oracle_search()
+    finally:
+        verify.close()
+    before = oracle.lib.oracle_set_f64_transcendentals(1)
+    try:
+        cpu, _, seconds = oracle.render(scene.desc, scene.state, scene.camera(width, height, max_bounce_count=bounces), width, height, spp, use_bvh=search)
+    finally:
+        oracle.lib.oracle_set_f64_transcendentals(before)
+    cpu = cpu[..., :3]
+    identical = (exact == cpu).all(axis=-1)
+    d = np.abs(product - exact)
+    luminance = 0.2126 * d[..., 0] + 0.7152 * d[..., 1] + 0.0722 * d[..., 2]
+    return {"frame": [width, height], "spp": spp, "pixels_bit_identical_to_oracle": float(identical.mean()), "rmse_vs_oracle": float(np.sqrt(np.mean((exact - cpu) ** 2))),
+            "product_vs_verify_rmse": float(np.sqrt(np.mean(d ** 2))), "product_vs_verify_compare_rms": float(np.sqrt(np.mean(luminance ** 2))), "oracle_seconds": float(seconds),
+            "what": "verification build (exact arithmetic, same source) vs oracle with f64 transcendentals; product vs verification build on the device"}
+
+
+def ctx_device(ctx) -> int:
+    return getattr(ctx, "device_id", 0)
+
+
 def cpu_baseline_smallpt(seconds: float):
     """SmallPT restatement (oracle/smallpt.cpp, follows apps/SmallPT/smallpt.h:22-147) on the host cores: 256x256, as many
     accumulations as fit the time budget (at most 64, BASELINE.json config 1)."""
@@ -909,9 +958,11 @@ def compact_line(full: dict, details_path=None) -> dict:
         for spp in ("spp8", "spp256"):
             if spp in rmse:
                 c["rmse_vs_oracle"][spp] = _pick(rmse[spp], ("rmse_rgb", "rmse_reference_compare_rms"))
-    for key in ("workload_textured", "rmse_full_size", "verify_build"):
+    for key in ("workload_textured", "rmse_full_size"):
         if key in config:
             c[key] = config[key]
+    if isinstance(config.get("verify_build"), dict):
+        c["verify_build"] = _pick(config["verify_build"], ("frame", "spp", "pixels_bit_identical_to_oracle", "rmse_vs_oracle", "product_vs_verify_rmse", "product_vs_verify_compare_rms", "error"))
     line["config"] = c
     roofline = full.get("roofline") or {}
     r = _pick(roofline, ("bound", "peak", "unit", "avg_launch_ms", "launches", "traffic", "achieved", "frac", "algorithmic_bytes_per_launch", "achieved_model", "frac_model",
@@ -1130,6 +1181,10 @@ def main():
                                                           "frac_of_copy": out["roofline"]["achieved"] / copy_gbs if out["roofline"].get("achieved") else None}
             if not args.no_rmse:
                 out["config"]["rmse_vs_oracle"] = rmse_against_oracle(ctx, scene, bounces, converged_name=scene_name if not args.scene_file else None)
+                try:
+                    out["config"]["verify_build"] = verify_build_leg(ctx, scene, bounces)
+                except Exception as e:      # the line stands without it
+                    out["config"]["verify_build"] = {"error": str(e)[:200]}
             if not args.no_other_workloads and not args.scene_file:
                 others = {}
                 for other in ("cornell_diffuse", "material"):

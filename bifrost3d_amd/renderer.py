@@ -12,6 +12,7 @@ class Context:
     def __init__(self, device_id: int = 0, library=None):
         """`library`: another build of libhiprenderer.so (capi.VERIFY_LIB_PATH for the verification build); the product library by default."""
         self.lib = capi.load_library(library)
+        self.device_id = device_id
         self.handle = C.c_void_p()
         capi.check(self.lib, self.lib.hipr_create(device_id, C.byref(self.handle)), "hipr_create")
         self._tables = capi.load_tables()
