@@ -782,9 +782,24 @@ def measure(ctx, scene, scene_name, bounces, args, rank, world, device, steps, w
         if world == 1:
             return
         ctx.synchronize()   # the context renders on its own streams, torch.distributed on torch's: order them explicitly
-        gathered = distributed.gather_to_root(compact.cpu() if on_host else compact, world, rank)
+        if getattr(args, "gather_group", None) is None:
+            injected = os.environ.get("HIPR_BENCH_TEST_FAIL_GATHER") == "1"      # test hook (tests/test_gpu_bench.py): the first gather raises on every rank
+            try:
+                if injected:
+                    raise RuntimeError("injected by HIPR_BENCH_TEST_FAIL_GATHER")
+                gathered = distributed.gather_to_root(compact.cpu() if on_host else compact, world, rank)
+            except Exception as e:      # RCCL refused the gather (on every rank alike; a collective that merely stalls ends the job at the process group's timeout instead)
+                if on_host and not injected:
+                    raise
+                sys.stderr.write(f"bench.py: rank {rank}: the RCCL gather failed ({str(e)[:200]}); the tiles go through the host (gloo) from now on\n")
+                args.gather_group = dist.new_group(backend="gloo")
+        if getattr(args, "gather_group", None) is not None:
+            gathered = distributed.gather_to_root(compact.cpu(), world, rank, group=args.gather_group)
+            on_host_now = True
+        else:
+            on_host_now = on_host
         if rank == 0:
-            if on_host:
+            if on_host_now:
                 gathered = gathered.to(device)
             torch.cuda.current_stream(device).synchronize()
             ctx.scatter_tiles(gathered.data_ptr(), n_compact, world, W, H, frame.data_ptr(), W)
@@ -990,7 +1005,7 @@ def compact_line(full: dict, details_path=None) -> dict:
             b["c2"]["sample"] = text(cpu["c2"].get("sample"), 160)
         line["cpu_baseline"] = b
     if isinstance(full.get("ranks"), dict):
-        line["ranks"] = _pick(full["ranks"], ("ms_per_step", "gather_ms", "passes", "steps_per_pass", "paths_per_gpu_per_step"))
+        line["ranks"] = _pick(full["ranks"], ("ms_per_step", "gather_ms", "gather_transport", "passes", "steps_per_pass", "paths_per_gpu_per_step"))
     if isinstance(full.get("kernel_ms_per_step_alone") or full.get("kernel_ms_per_step"), dict):
         line["kernel_ms_per_step"] = full.get("kernel_ms_per_step_alone") or full.get("kernel_ms_per_step")
     if details_path:
@@ -1045,6 +1060,7 @@ def emit(full: dict, result_fd: int, details_arg=None) -> dict:
 
 def main():
     args = parse_args()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL and device-tensor sharing across processes need it on this pool
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
 
@@ -1150,6 +1166,7 @@ def main():
             out["retrace_mode"] = result["retrace_mode"]
         if world > 1:
             out["ranks"] = {"ms_per_step": [e / args.steps * 1e3 for e in result["rank_elapsed"]], "gather_ms": result["gather_ms"],
+                            "gather_transport": ("gloo through the host (the first gather failed)" if getattr(args, "gather_group", None) is not None else ("gloo through the host" if args.dist_backend == "gloo" else "RCCL (torch.distributed nccl)")),
                             "passes": result["passes"], "steps_per_pass": result["steps_per_pass"], "accumulations_per_pass_per_rank": result["S"],
                             "paths_per_gpu_per_step": int(main_figures["pixel_samples"] / args.steps / world),
                             "note": "ms_per_step per rank = that rank's own clock over the timed region (the line's ms_per_step is the maximum); gather_ms = rank 0's time in the "

@@ -57,15 +57,15 @@ def assemble_numpy(compact: np.ndarray, width: int, height: int, world: int) -> 
     return out
 
 
-def gather_to_root(local, world: int, rank: int):
-    """Gathers equally sized per-rank tensors on rank 0; returns [world, ...] there, None elsewhere."""
+def gather_to_root(local, world: int, rank: int, group=None):
+    """Gathers equally sized per-rank tensors on rank 0; returns [world, ...] there, None elsewhere. `group`: another process group than the default one."""
     import torch
     import torch.distributed as dist
     if world == 1:
         return local.unsqueeze(0)
     if rank == 0:
         gathered = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
-        dist.gather(local, gather_list=list(gathered.unbind(0)), dst=0)      # the ranks' tiles land in place: no stacking copy afterwards
+        dist.gather(local, gather_list=list(gathered.unbind(0)), dst=0, group=group)      # the ranks' tiles land in place: no stacking copy afterwards
         return gathered
-    dist.gather(local, gather_list=None, dst=0)
+    dist.gather(local, gather_list=None, dst=0, group=group)
     return None

@@ -14,10 +14,10 @@ SMALL = ["--width", "640", "--height", "360", "--atrium-triangles", "20000", "--
          "--no-other-workloads", "--no-rmse", "--no-plugin", "--no-cpu-baseline"]
 
 
-def run_bench(extra, tmp_path=None):
+def run_bench(extra, tmp_path=None, extra_env=None):
     """Returns (the one line of stdout, the full record of --details)."""
     import tempfile
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", **(extra_env or {}))
     details = Path(tempfile.mkdtemp(prefix="hipr_bench_")) / "details.json"
     done = subprocess.run([sys.executable, str(ROOT / "bench.py")] + SMALL + extra + ["--details", str(details)], capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
     assert done.returncode == 0, done.stderr[-2000:]
@@ -79,3 +79,12 @@ def test_bench_two_ranks_on_one_device():
     # weak scaling, the opt-in: each rank traces the per-GPU share of one rank alone, on its half of the tiles -> twice the paths and about twice the rays per step
     _, two = run_bench(["--gpus", "2", "--share-device", "--dist-backend", "gloo", "--weak"])
     assert two["config"]["rays_per_step"] == pytest.approx(2.0 * one["config"]["rays_per_step"], rel=0.02) and two["scaling"] == "weak"
+
+
+def test_bench_gathers_through_the_host_when_the_first_gather_fails():
+    """The N > 1 line must not be lost to a transport problem: a gather that raises (injected on every rank) is followed by a gloo group and a host-staged gather for the
+    rest of the run; the line says which transport delivered the frame."""
+    _, one = run_bench(["--no-textured", "--no-scaling-proxy", "--pmc-traffic", "off"])
+    compact, two = run_bench(["--gpus", "2", "--share-device", "--dist-backend", "gloo"], extra_env={"HIPR_BENCH_TEST_FAIL_GATHER": "1"})
+    assert two["config"]["frame_finite_and_lit"] and "the first gather failed" in two["ranks"]["gather_transport"] and "failed" in compact["ranks"]["gather_transport"]
+    assert two["config"]["rays_per_step"] == pytest.approx(one["config"]["rays_per_step"], rel=0.02)
