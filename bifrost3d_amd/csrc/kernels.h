@@ -407,9 +407,22 @@ HD f4 fetch_texel(const DeviceScene& sc, const HiprTexture& tex, int x, int y) {
     }
     return r;
 }
+// The texel index of coordinate i in a texture of n texels. The same integers as `i %= n; i < 0 ? i + n : i` by two exact shortcuts (round 5): for a power-of-two size the
+// mask IS the non-negative remainder, also of a negative i (two's complement), and most textures are powers of two -- the remainder by a per-lane n that the compiler
+// expands into ~35 instructions is then skipped by the whole wave; and the neighbour texel of a bilinear tap follows from the wrapped first one (wrap_next) instead of a
+// second remainder. Measured on the textured atrium (128 x 128 tint textures, 64 x 64 coverage): profiles/r05_ab_texture_wrap.txt.
 HD int wrap_coord(int i, int n, int repeat) {
-    if (repeat) { i %= n; return i < 0 ? i + n : i; }
+    if (repeat) {
+        if ((n & (n - 1)) == 0) return i & (n - 1);
+        i %= n;
+        return i < 0 ? i + n : i;
+    }
     return i < 0 ? 0 : (i >= n ? n - 1 : i);
+}
+// wrap_coord(i + 1, n, repeat), given wrapped = wrap_coord(i, n, repeat): ((i + 1) mod n) = ((i mod n) + 1) mod n
+HD int wrap_next(int wrapped, int i, int n, int repeat) {
+    if (repeat) return wrapped + 1 == n ? 0 : wrapped + 1;
+    return i + 1 < 0 ? 0 : (i + 1 >= n ? n - 1 : i + 1);
 }
 template <bool FLOAT_FORMATS = true>
 HD f4 sample_texture(const DeviceScene& sc, int id, f2 uv) {
@@ -419,8 +432,8 @@ HD f4 sample_texture(const DeviceScene& sc, int id, f2 uv) {
         float xb = uv.x * w - 0.5f, yb = uv.y * h - 0.5f;
         float xf = floorf(xb), yf = floorf(yb);
         float fx = xb - xf, fy = yb - yf;
-        int x0 = wrap_coord(int(xf), w, tex.wrap_u), x1 = wrap_coord(int(xf) + 1, w, tex.wrap_u);
-        int y0 = wrap_coord(int(yf), h, tex.wrap_v), y1 = wrap_coord(int(yf) + 1, h, tex.wrap_v);
+        int x0 = wrap_coord(int(xf), w, tex.wrap_u), x1 = wrap_next(x0, int(xf), w, tex.wrap_u);
+        int y0 = wrap_coord(int(yf), h, tex.wrap_v), y1 = wrap_next(y0, int(yf), h, tex.wrap_v);
         f4 a = fetch_texel<FLOAT_FORMATS>(sc, tex, x0, y0), b = fetch_texel<FLOAT_FORMATS>(sc, tex, x1, y0);
         f4 c = fetch_texel<FLOAT_FORMATS>(sc, tex, x0, y1), d = fetch_texel<FLOAT_FORMATS>(sc, tex, x1, y1);
         f4 lo = a + (b - a) * fx, hi = c + (d - c) * fx;
@@ -450,8 +463,8 @@ HD float sample_texture_r8(const DeviceScene& sc, int id, f2 uv) {
         const float xb = uv.x * w - 0.5f, yb = uv.y * h - 0.5f;
         const float xf = floorf(xb), yf = floorf(yb);
         const float fx = xb - xf, fy = yb - yf;
-        const int x0 = wrap_coord(int(xf), w, tex.wrap_u), x1 = wrap_coord(int(xf) + 1, w, tex.wrap_u);
-        const int y0 = wrap_coord(int(yf), h, tex.wrap_v), y1 = wrap_coord(int(yf) + 1, h, tex.wrap_v);
+        const int x0 = wrap_coord(int(xf), w, tex.wrap_u), x1 = wrap_next(x0, int(xf), w, tex.wrap_u);
+        const int y0 = wrap_coord(int(yf), h, tex.wrap_v), y1 = wrap_next(y0, int(yf), h, tex.wrap_v);
         const float a = texel(x0, y0), b = texel(x1, y0), c = texel(x0, y1), d = texel(x1, y1);
         const float lo = a + (b - a) * fx, hi = c + (d - c) * fx;
         return lo + (hi - lo) * fy;
