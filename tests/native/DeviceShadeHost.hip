@@ -194,6 +194,14 @@ void dsh_shading(void* scene, int model, const float* params, const float* wo_n3
     }
 }
 
+// The samplers' texel index arithmetic (csrc/kernels.h): out[2 k] = wrap_coord(i, n, repeat), out[2 k + 1] = wrap_next(out[2 k], i, n, repeat) = the neighbour texel of a bilinear tap.
+void dsh_wrap(const int* coordinates, int count, int n, int repeat, int* out) {
+    for (int k = 0; k < count; ++k) {
+        out[2 * k] = wrap_coord(coordinates[k], n, repeat);
+        out[2 * k + 1] = wrap_next(out[2 * k], coordinates[k], n, repeat);
+    }
+}
+
 // k_debug_light (csrc/shade.hip: hipr_debug_light).
 void dsh_light(const HiprLight* light, const float* position3, const float* in_n3, int n, int mode, float* out_n8) {
     const f3 position = {position3[0], position3[1], position3[2]};

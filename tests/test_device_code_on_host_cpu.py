@@ -170,3 +170,21 @@ def test_the_comparison_sees_a_last_bit(exact_oracle):
         device.close()
     assert 0 < differing < 0.5 * entries and ("direction.x" in by_word or "throughput.x" in by_word), (differing, entries, by_word)
     assert worst[0] < 1e-3      # and what differs does so at rounding level: no path took another branch in this small frame, or if one did, the test above would have caught it
+
+
+def test_texel_index_arithmetic_of_the_samplers():
+    """wrap_coord / wrap_next of csrc/kernels.h (round 5: a mask for power-of-two sizes, the neighbour texel from the wrapped one) against the definition -- Python's floor
+    modulo for repeat, a clamp otherwise -- for every size 1 ... 130 and coordinates from far below zero to far beyond the size, both texels of a bilinear tap."""
+    import ctypes as C
+    from device_host_bindings import library
+    lib = library()
+    lib.dsh_wrap.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    coordinates = np.concatenate([np.arange(-700, 700), np.array([-2**20, -65537, -65536, 65535, 65536, 2**20, 2**30, -2**30])]).astype(np.int32)
+    out = np.zeros(2 * len(coordinates), np.int32)
+    for n in list(range(1, 131)) + [256, 1000, 1024, 4096, 5000]:
+        for repeat in (1, 0):
+            lib.dsh_wrap(coordinates.ctypes.data_as(C.POINTER(C.c_int)), len(coordinates), n, repeat, out.ctypes.data_as(C.POINTER(C.c_int)))
+            i = coordinates.astype(np.int64)
+            first = i % n if repeat else np.clip(i, 0, n - 1)
+            second = (i + 1) % n if repeat else np.clip(i + 1, 0, n - 1)
+            assert np.array_equal(out[0::2], first) and np.array_equal(out[1::2], second), (n, repeat)
