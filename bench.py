@@ -110,6 +110,7 @@ def parse_args(argv=None):
     p.add_argument("--weak", action="store_true", help="N > 1: N x spp-per-pass accumulations per step instead, so that every GPU keeps the single GPU's paths per step ('weak' scaling; "
                    "the default of rounds 1-4). Not the metric's job: the line says so in `scaling` and config.workload")
     p.add_argument("--details", default=None, help="where the full record goes (default: bench_details.json next to this script; the compact line on stdout names it)")
+    p.add_argument("--no-exact-mode", action="store_true", help="skip the exact arithmetic leg (config.exact_mode)")
     p.add_argument("--no-textured", action="store_true", help="skip the textured / cut-out atrium leg (config.workload_textured)")
     return p.parse_args(argv)
 
@@ -398,17 +399,16 @@ def rmse_against_oracle(ctx, scene, bounces, spps=(8, 256), width=160, height=90
 
 
 def verify_build_leg(ctx, scene, bounces, spp=256, width=160, height=90):
-    """Parity of the CODE, exact (round 5): the VERIFICATION build of the same kernels (csrc/libhiprenderer_verify.so: correctly rounded division / square root, no
-    contraction, transcendentals in f64 rounded once) renders the rmse_vs_oracle frame and is compared with the oracle evaluating its transcendentals in f64 (glibc):
-    the share of pixels whose f64 running mean is bit-identical (expected: 1.0) -- and the product against the verification build ON THE DEVICE, which is what the
-    product's fast arithmetic does to the image (tests/test_gpu_verify_build.py). The oracle is the checker here, outside the timed region."""
+    """Parity of the CODE, exact: the renderer in its EXACT arithmetic mode (hipr_set_arithmetic: the second build of the shade unit inside libhiprenderer.so --
+    correctly rounded division / square root, no contraction, sin / cos / pow as the specified f64 sequences of csrc/spec_math.h) renders the rmse_vs_oracle frame
+    and is compared with the oracle evaluating the same specified functions: the share of pixels whose f64 running mean is bit-identical (expected: 1.0) -- and the
+    fast mode against the exact mode ON THE DEVICE, which is what the fast arithmetic does to the image (tests/test_gpu_verify_build.py).
+    The oracle is the checker here, outside the timed region."""
     sys.path.insert(0, str(ROOT / "tests"))
     import numpy as np
     from bifrost3d_amd import capi
     from bifrost3d_amd.renderer import Context
     from oracle_bindings import get_oracle
-    if not capi.VERIFY_LIB_PATH.exists():
-        return {"error": "libhiprenderer_verify.so is not built"}
     oracle = get_oracle(True)
 
     def render(context):
@@ -421,7 +421,7 @@ def verify_build_leg(ctx, scene, bounces, spp=256, width=160, height=90):
 
     ctx.set_wavefront_count(1)
     product = render(ctx)
-    verify = Context(ctx_device(ctx), library=capi.VERIFY_LIB_PATH)
+    verify = Context(ctx_device(ctx), arithmetic="exact")
     try:
         verify.upload_scene(scene)
         exact = render(verify)
@@ -439,7 +439,7 @@ def verify_build_leg(ctx, scene, bounces, spp=256, width=160, height=90):
     luminance = 0.2126 * d[..., 0] + 0.7152 * d[..., 1] + 0.0722 * d[..., 2]
     return {"frame": [width, height], "spp": spp, "pixels_bit_identical_to_oracle": float(identical.mean()), "rmse_vs_oracle": float(np.sqrt(np.mean((exact - cpu) ** 2))),
             "product_vs_verify_rmse": float(np.sqrt(np.mean(d ** 2))), "product_vs_verify_compare_rms": float(np.sqrt(np.mean(luminance ** 2))), "oracle_seconds": float(seconds),
-            "what": "verification build (exact arithmetic, same source) vs oracle with f64 transcendentals; product vs verification build on the device"}
+            "what": "the renderer's exact arithmetic mode (hipr_set_arithmetic) vs the oracle with the same specified transcendentals; fast mode vs exact mode on the device"}
 
 
 def ctx_device(ctx) -> int:
@@ -976,6 +976,8 @@ def compact_line(full: dict, details_path=None) -> dict:
     for key in ("workload_textured", "rmse_full_size"):
         if key in config:
             c[key] = config[key]
+    if isinstance(config.get("exact_mode"), dict):
+        c["exact_mode"] = _pick(config["exact_mode"], ("value", "unit", "ms_per_step", "ms_per_256spp_frame", "fraction_of_fast_mode", "rmse_vs_oracle"))
     if isinstance(config.get("verify_build"), dict):
         c["verify_build"] = _pick(config["verify_build"], ("frame", "spp", "pixels_bit_identical_to_oracle", "rmse_vs_oracle", "product_vs_verify_rmse", "product_vs_verify_compare_rms", "error"))
     line["config"] = c
@@ -1202,6 +1204,26 @@ def main():
                     out["config"]["verify_build"] = verify_build_leg(ctx, scene, bounces)
                 except Exception as e:      # the line stands without it
                     out["config"]["verify_build"] = {"error": str(e)[:200]}
+            if not args.pmc_child and not under_profiler and not getattr(args, "no_exact_mode", False):
+                # The SAME renderer in its exact arithmetic mode (hipr_set_arithmetic: IEEE division / sqrt, no contraction, specified sin / cos / pow), same workload,
+                # same step shape, right after the line's own run: the rate of the mode whose frames equal the CPU restatement bit for bit (north_star: RMSE < 1e-3 AND
+                # the throughput from one renderer). Its rmse is config.verify_build's: every pixel identical at 160 x 90 x 256 spp, RMSE 0.
+                import copy
+                exact_args = copy.copy(args)
+                exact_args.skip_retrace = True
+                ctx.set_arithmetic("exact")
+                try:
+                    r = measure(ctx, scene, scene_name, bounces, exact_args, 0, 1, device, 4, 1, sync)
+                    figures = summarise(r, scene_name, scene_text, bounces, args, 1, 4)
+                finally:
+                    ctx.set_arithmetic("fast")
+                vb = out["config"].get("verify_build") if isinstance(out["config"].get("verify_build"), dict) else {}
+                out["config"]["exact_mode"] = {"value": figures["value"], "unit": "Mrays/s", "ms_per_step": figures["ms_per_step"], "ms_per_256spp_frame": figures["ms_per_256spp_frame"],
+                                               "steps": 4, "kernel_ms_per_step": figures["kernel_ms_per_step"], "fraction_of_fast_mode": figures["value"] / main_figures["value"],
+                                               "rmse_vs_oracle": {"frame": vb.get("frame"), "spp": vb.get("spp"), "rmse_rgb": vb.get("rmse_vs_oracle"),
+                                                                  "pixels_bit_identical": vb.get("pixels_bit_identical_to_oracle")},
+                                               "what": "hipr_set_arithmetic(HIPR_ARITHMETIC_EXACT) on the same context and workload: the shade stage in IEEE arithmetic with specified "
+                                                       "transcendentals; frames equal the CPU oracle's bit for bit (rmse_vs_oracle measured in this run, config.verify_build)"}
             if not args.no_other_workloads and not args.scene_file:
                 others = {}
                 for other in ("cornell_diffuse", "material"):

@@ -112,7 +112,20 @@ class CameraEffects:
         # The effects run on torch's current stream (hipr_camera_effects_set_stream): what torch queued before a call -- an upload, the fill of a fresh target -- and what it
         # queues after it are then ordered with the effects' kernels by the stream itself, and no call blocks the host (the hand-over used to be two
         # blocking synchronisations per processed frame). Should the stream not be taken, the blocking hand-over stays.
-        self.shares_torch_stream = self.lib.hipr_camera_effects_set_stream(self.handle, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)) == 0
+        # The stream is followed, not captured: a caller that later works under `with torch.cuda.stream(s)` has the effects moved to `s` at its next call
+        # (_follow_torch_stream), so the ordering argument above holds for whatever stream is current then.
+        self._stream_in_use = None
+        self.shares_torch_stream = False
+        self._follow_torch_stream()
+
+    def _follow_torch_stream(self):
+        """Puts the effects on torch's CURRENT stream if they are not on it already. Returns with shares_torch_stream saying whether they are (False: the blocking hand-over)."""
+        current = self.torch.cuda.current_stream(self.device).cuda_stream
+        if current != self._stream_in_use:
+            if self._stream_in_use is not None:
+                self.lib.hipr_camera_effects_synchronize(self.handle)      # what the effects still run on the stream they leave is not ordered with the new one
+            self.shares_torch_stream = self.lib.hipr_camera_effects_set_stream(self.handle, C.c_void_p(current)) == 0
+            self._stream_in_use = current if self.shares_torch_stream else None
 
     def close(self):
         if getattr(self, "handle", None):
@@ -134,7 +147,8 @@ class CameraEffects:
 
     def _torch_stream_done(self):
         """The effects run on a stream of their own (hipStreamNonBlocking): what torch queued on ITS stream -- an upload, the fill of a fresh target -- has to be
-        complete before a kernel of that stream reads or overwrites the memory."""
+        complete before a kernel of that stream reads or overwrites the memory. With the effects on torch's current stream (the normal case) the stream orders them."""
+        self._follow_torch_stream()
         if not self.shares_torch_stream:
             self.torch.cuda.current_stream(self.device).synchronize()
 
@@ -144,6 +158,7 @@ class CameraEffects:
 
     def reduce_histogram(self, settings: Settings, frame, viewport=None) -> np.ndarray:
         out = np.zeros(HISTOGRAM_BINS, dtype=np.uint32)
+        self._torch_stream_done()
         view = self.view(frame, viewport)
         self._check(self.lib.hipr_camera_effects_reduce_histogram(self.handle, C.byref(settings), C.byref(view), out.ctypes.data_as(C.POINTER(C.c_uint32))), "reduce_histogram")
         return out
@@ -157,12 +172,14 @@ class CameraEffects:
 
     def log_average(self, frame, viewport=None) -> float:
         out = C.c_float()
+        self._torch_stream_done()
         view = self.view(frame, viewport)
         self._check(self.lib.hipr_camera_effects_log_average(self.handle, C.byref(view), C.byref(out)), "log_average")
         return out.value
 
     def exposure_from_log_average(self, settings: Settings, delta_time: float, frame, current_exposure: float = 0.0, viewport=None) -> float:
         exposure = C.c_float(current_exposure)
+        self._torch_stream_done()
         view = self.view(frame, viewport)
         self._check(self.lib.hipr_camera_effects_exposure_from_log_average(self.handle, C.byref(settings), delta_time, C.byref(view), C.byref(exposure)), "exposure_from_log_average")
         return exposure.value
@@ -170,6 +187,7 @@ class CameraEffects:
     def bloom(self, threshold: float, support: int, frame, viewport=None) -> np.ndarray:
         view = self.view(frame, viewport)
         out = self.torch.empty((view.viewport.height, view.viewport.width, 4), dtype=self.torch.float16, device=self.device)
+        self._torch_stream_done()
         self._check(self.lib.hipr_camera_effects_bloom(self.handle, threshold, support, C.byref(view), out.data_ptr()), "bloom")
         self._check(self.lib.hipr_camera_effects_synchronize(self.handle), "synchronize")
         return out.cpu().numpy()
@@ -177,6 +195,7 @@ class CameraEffects:
     def dual_kawase_bloom(self, threshold: float, half_passes: int, frame, viewport=None) -> np.ndarray:
         view = self.view(frame, viewport)
         out = self.torch.empty((view.viewport.height, view.viewport.width, 4), dtype=self.torch.float16, device=self.device)
+        self._torch_stream_done()
         self._check(self.lib.hipr_camera_effects_dual_kawase_bloom(self.handle, threshold, half_passes, C.byref(view), out.data_ptr()), "dual_kawase_bloom")
         self._check(self.lib.hipr_camera_effects_synchronize(self.handle), "synchronize")
         return out.cpu().numpy()

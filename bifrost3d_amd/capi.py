@@ -12,8 +12,7 @@ from pathlib import Path
 
 PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("HIPR_LIBRARY", PKG_DIR / "csrc" / "libhiprenderer.so"))   # HIPR_LIBRARY: A/B builds of the kernels
-# The verification build (Makefile VERIFYFLAGS: exact division / sqrt, no contraction, transcendentals in f64 rounded once): loaded by tests and bench.py's parity legs only
-VERIFY_LIB_PATH = PKG_DIR / "csrc" / "libhiprenderer_verify.so"
+HIPR_ARITHMETIC_FAST, HIPR_ARITHMETIC_EXACT = 0, 1      # hipr_set_arithmetic: the two builds of the shade unit inside the library
 HOST_LIB_PATH = Path(os.environ.get("HIPR_HOST_LIBRARY", PKG_DIR / "host" / "libhiprenderer_host.so"))   # HIPR_HOST_LIBRARY: A/B builds of the host side (BVH builder)
 TABLES_PATH = PKG_DIR / "data" / "HIPRenderer" / "shading_tables.bin"
 
@@ -140,11 +139,11 @@ C_ABI_SYMBOLS = (
     "hipr_set_frame", "hipr_owned_pixel_count",
     "hipr_render_pass", "hipr_set_samples_per_pass", "hipr_trace_pass", "hipr_accumulate_samples", "hipr_read_accumulation", "hipr_scatter_tiles", "hipr_synchronize", "hipr_get_counters",
     "hipr_device_malloc", "hipr_device_free", "hipr_device_memset", "hipr_copy_to_host", "hipr_present_flipped",
-    "hipr_reset_counters", "hipr_set_wavefront_count", "hipr_get_wavefront_count", "hipr_get_trace_variant", "hipr_set_trace_variant", "hipr_set_pass_pipelining", "hipr_set_backface_culling", "hipr_set_instrumentation", "hipr_reset_timers", "hipr_get_kernel_times",
+    "hipr_reset_counters", "hipr_set_wavefront_count", "hipr_get_wavefront_count", "hipr_get_trace_variant", "hipr_set_trace_variant", "hipr_set_pass_pipelining", "hipr_set_backface_culling", "hipr_set_arithmetic", "hipr_get_arithmetic", "hipr_set_instrumentation", "hipr_reset_timers", "hipr_get_kernel_times",
     "hipr_group_create", "hipr_group_destroy", "hipr_group_size", "hipr_group_context", "hipr_group_gather_description", "hipr_group_upload_tables", "hipr_group_upload_scene",
     "hipr_group_set_scene_state", "hipr_group_set_entry_point", "hipr_group_use_scratch_accumulation", "hipr_group_set_frame", "hipr_group_set_samples_per_pass",
     "hipr_group_trace_pass", "hipr_group_accumulate_samples", "hipr_group_read_accumulation", "hipr_group_get_counters",
-    "hipr_debug_shading", "hipr_debug_shade", "hipr_debug_light", "hipr_debug_generate", "hipr_debug_sobol", "hipr_debug_valu_issue_rates", "hipr_debug_sample_offsets", "hipr_debug_trace_closest", "hipr_debug_trace_shadow",
+    "hipr_debug_shading", "hipr_debug_shade", "hipr_debug_light", "hipr_debug_math", "hipr_debug_generate", "hipr_debug_sobol", "hipr_debug_valu_issue_rates", "hipr_debug_sample_offsets", "hipr_debug_trace_closest", "hipr_debug_trace_shadow",
 )
 
 
@@ -196,6 +195,9 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.hipr_get_counters.argtypes = [vp, C.POINTER(HiprCounters)]
     lib.hipr_reset_counters.argtypes = [vp]
     lib.hipr_set_instrumentation.argtypes = [vp, C.c_int]
+    lib.hipr_set_arithmetic.argtypes = [vp, C.c_int]
+    lib.hipr_get_arithmetic.argtypes = [vp]
+    lib.hipr_debug_math.argtypes = [vp, C.c_int, c_u32, C.POINTER(c_f), C.POINTER(c_f), C.POINTER(c_f)]
     lib.hipr_reset_timers.argtypes = [vp]
     lib.hipr_get_kernel_times.argtypes = [vp, C.POINTER(HiprKernelTimes)]
     lib.hipr_debug_generate.argtypes = [vp, C.POINTER(HiprCameraState), c_u32, C.POINTER(c_f), C.POINTER(c_f), C.POINTER(c_u32)]

@@ -8,6 +8,7 @@
 #pragma once
 
 #include "device_math.h"
+#include "spec_math.h"
 #include "../../include/hiprenderer_c.h"
 
 namespace hipr {
@@ -38,23 +39,22 @@ HD Sample sample_none() { return {{0, 0, 0}, 0.0f, {0, 0, 0}}; }
 
 // HIPR_FAST_MATH (set for the shade translation unit): hardware sin / cos / exp2 / log2 like the reference's
 // --use_fast_math PTX (extensions/OptiXRenderer/CMakeLists.txt:82-83); otherwise the correctly rounded-ish ocml versions.
-// HIPR_VERIFY_MATH (libhiprenderer_verify.so, the VERIFICATION build of round 5): every transcendental of the path -- sin, cos, pow, atan2, asin -- is
-// evaluated in f64 and rounded ONCE to f32, and the oracle does the same with glibc's f64 functions (oracle/vecmath.h exact_*). Two independent f64 results
-// that are each within a few f64 ulp of the true value round to the same f32 except where the true value lies within ~2^-50 relative of a rounding boundary
-// (probability ~2^-26 per call), so device and oracle stay independent implementations AND agree bit for bit on all but a handful of paths per frame;
-// with correctly rounded division and square root and no contraction (the traversal unit's flags) K3 is then checked exactly, not statistically
-// (tests/test_gpu_verify_build.py). FP64 is half rate on CDNA4; the build is for tests, never for the product path.
+// HIPR_VERIFY_MATH (the EXACT arithmetic mode, hipr_set_arithmetic / shade.hip compiled a second time into the product library): sin, cos and pow are the
+// specified f64 sequences of spec_math.h -- fixed chains of correctly rounded binary64 operations that oracle/vecmath.h restates, so device and oracle agree in
+// every bit by construction -- and atan2 / asin (the environment map's lookup only, never on the headline path) are evaluated by the f64 libm of either side and
+// rounded once (two f64 results within a few ulp of the true value round to the same f32 but for ~2^-26 of the arguments). With correctly rounded division and
+// square root and no contraction (the traversal unit's flags) K3 is then checked exactly, not statistically (tests/test_gpu_verify_build.py).
 #ifndef HIPR_VERIFY_MATH
 #define HIPR_VERIFY_MATH 0
 #endif
-// How each transcendental is evaluated: 1 = the hardware's approximation (product shade unit), 2 = in f64, rounded once (verification build), 0 = ocml's f32 function
-// (the traversal unit, where none of them is on a hot path). Separately settable for the attribution experiment of round 5 (tools/fast_math_attribution.sh: which
-// approximation moves how many paths).
+// How each transcendental is evaluated: 1 = the hardware's approximation (fast shade unit), 3 = the specified f64 sequence (exact mode), 2 = the f64 libm rounded once
+// (round 5's verification build; still selectable for the A/B), 0 = ocml's f32 function. Separately settable for the attribution experiment of round 5
+// (tools/fast_math_attribution.sh: which approximation moves how many paths).
 #ifndef HIPR_SINCOS_KIND
-#define HIPR_SINCOS_KIND (HIPR_VERIFY_MATH ? 2 : (HIPR_FAST_MATH ? 1 : 0))
+#define HIPR_SINCOS_KIND (HIPR_VERIFY_MATH ? 3 : (HIPR_FAST_MATH ? 1 : 0))
 #endif
 #ifndef HIPR_POW_KIND
-#define HIPR_POW_KIND (HIPR_VERIFY_MATH ? 2 : (HIPR_FAST_MATH ? 1 : 0))
+#define HIPR_POW_KIND (HIPR_VERIFY_MATH ? 3 : (HIPR_FAST_MATH ? 1 : 0))
 #endif
 #ifndef HIPR_ATAN_ASIN_KIND
 #define HIPR_ATAN_ASIN_KIND (HIPR_VERIFY_MATH ? 2 : 0)
@@ -63,7 +63,9 @@ HD Sample sample_none() { return {{0, 0, 0}, 0.0f, {0, 0, 0}}; }
 #define HIPR_NATIVE_POW 1
 #endif
 HD void sincos_(float a, float& s, float& c) {
-#if HIPR_SINCOS_KIND == 2
+#if HIPR_SINCOS_KIND == 3
+    spec_sincos(a, s, c);
+#elif HIPR_SINCOS_KIND == 2
     s = float(sin(double(a))); c = float(cos(double(a)));
 #elif HIPR_SINCOS_KIND == 1
     s = __sinf(a); c = __cosf(a);
@@ -72,7 +74,9 @@ HD void sincos_(float a, float& s, float& c) {
 #endif
 }
 HD float pow_(float x, float y) {
-#if HIPR_POW_KIND == 2
+#if HIPR_POW_KIND == 3
+    return spec_pow(x, y);
+#elif HIPR_POW_KIND == 2
     return float(pow(double(x), double(y)));
 #elif HIPR_POW_KIND == 1 && HIPR_NATIVE_POW
     // x^y as exp2(y * log2(x)) on the hardware's v_log_f32 / v_exp_f32, what --use_fast_math makes of powf in the reference's PTX (HIP's __powf is the full ocml pow).

@@ -102,6 +102,10 @@ struct HiprGroup {
     bool frame_ready = false;
     std::string gather_description;
     Workers workers;
+    // What a stalled exchange leaves behind (fall_back_to_copies): streams that may still hold queued work, and the buffers that work reads and writes. They are
+    // parked here, never reused, and released in hipr_group_destroy once their stream has drained (leaked with a message if it never does).
+    struct Retired { int device; hipStream_t stream; std::vector<void*> buffers; };
+    std::vector<Retired> retired;
     int gather_timeout_ms = 10000;  // HIPR_GROUP_GATHER_TIMEOUT_MS
     int stall_member_once = -1;     // HIPR_GROUP_TEST_STALL_MEMBER: test hook, the member whose half of the NEXT exchange is held back past the deadline
 };
@@ -168,37 +172,53 @@ int for_each_member(HiprGroup* g, std::function<int(Member&, uint32_t)> work) {
     return HIPR_OK;
 }
 
-// Waits for `stream` by polling, up to `timeout_ms`: a member's thread must come back from the exchange whatever its peers do.
-bool wait_for_stream(hipStream_t stream, int timeout_ms) {
+// Waits for `stream` by polling, up to `timeout_ms`: a member's thread must come back from the exchange whatever its peers do. A HIP failure on the stream (a fault,
+// a lost device) is reported as what it is, not as a timeout.
+enum class Waited { Done, TimedOut, Failed };
+Waited wait_for_stream(hipStream_t stream, int timeout_ms, std::string& failure) {
     const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms);
     for (;;) {
         const hipError_t status = hipStreamQuery(stream);
-        if (status == hipSuccess) return true;
-        if (status != hipErrorNotReady) { (void)hipGetLastError(); return false; }
-        if (std::chrono::steady_clock::now() > deadline) return false;
+        if (status == hipSuccess) return Waited::Done;
+        if (status != hipErrorNotReady) {
+            failure = std::string("hipStreamQuery on the gather stream: ") + hipGetErrorString(status);
+            (void)hipGetLastError();
+            return Waited::Failed;
+        }
+        if (std::chrono::steady_clock::now() > deadline) return Waited::TimedOut;
         std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
 }
 
-// After an exchange that stalled: the communicators are given up (their pending operations would hold the streams for ever), every member gets a fresh stream and the
-// group gathers with peer-to-peer copies from now on.
-void fall_back_to_copies(HiprGroup* g, const char* why) {
-    for (Member& m : g->members) {
+// After an exchange that stalled: the communicators are given up (their pending operations would hold the streams for ever) and the group gathers with peer-to-peer
+// copies from now on -- on FRESH streams and into FRESH buffers. What is still queued on the old streams (the held-back copy, an ncclSend kernel) may run at any later
+// time: it must find the memory it was given, and must not touch anything a later call uses. So the old streams are not destroyed (hipStreamDestroy may wait for
+// them; with a copy that never ends, for ever) and the old compact / gathered buffers are not freed or reused: both are parked in g->retired until the group is
+// destroyed. Returns false when the fresh streams or buffers cannot be had; the group then refuses further frames (frame_ready = false) instead of racing.
+bool fall_back_to_copies(HiprGroup* g, const char* why) {
+    bool ok = true;
+    const size_t bytes = size_t(g->compact_pixels) * 8;
+    for (size_t i = 0; i < g->members.size(); ++i) {
+        Member& m = g->members[i];
         (void)hipSetDevice(m.device);
         if (m.comm) {
             if (g->rccl.CommAbort) g->rccl.CommAbort(m.comm);      // without ncclCommAbort the communicator is left alone: destroying it would wait for the stalled operations
             m.comm = nullptr;
         }
-        hipStream_t fresh = nullptr;
-        if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) == hipSuccess) {
-            (void)hipStreamDestroy(m.stream);      // returns at once; the runtime releases the stream when what is queued on it has ended
-            m.stream = fresh;
-        }
+        HiprGroup::Retired old = {m.device, m.stream, {m.compact}};
+        if (i == 0) old.buffers.push_back(g->gathered);
+        m.stream = nullptr; m.compact = nullptr;
+        if (i == 0) g->gathered = nullptr;
+        ok = ok && hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking) == hipSuccess && hipMalloc(&m.compact, bytes) == hipSuccess;
+        if (i == 0) ok = ok && hipMalloc(&g->gathered, g->members.size() * bytes) == hipSuccess;
+        g->retired.push_back(std::move(old));
     }
     (void)hipGetLastError();
     g->use_rccl = false;
+    if (!ok) g->frame_ready = false;      // hipr_group_set_frame allocates again
     g->gather_description = std::string("peer-to-peer hipMemcpyAsync (fallen back: ") + why + ")";
     fprintf(stderr, "hiprenderer: device group: %s; the group gathers with peer-to-peer copies from now on\n", why);
+    return ok;
 }
 
 void stop_workers(HiprGroup* g) {
@@ -224,8 +244,18 @@ int hipr_group_destroy(HiprGroup* g) {
         if (m.comm && g->rccl.CommDestroy) g->rccl.CommDestroy(m.comm);
         if (m.compact) (void)hipFree(m.compact);
         if (m.stream) (void)hipStreamDestroy(m.stream);
-        if (m.context) hipr_destroy(m.context);
     }
+    for (HiprGroup::Retired& r : g->retired) {      // what a stalled exchange left behind: released once drained, given a last second to drain, leaked otherwise
+        (void)hipSetDevice(r.device);
+        std::string ignored;
+        if (r.stream && wait_for_stream(r.stream, 1000, ignored) != Waited::Done) {
+            fprintf(stderr, "hiprenderer: device group: a stalled gather stream of device %d never drained; its stream and %zu buffers are left to the process\n", r.device, r.buffers.size());
+            continue;
+        }
+        for (void* b : r.buffers) if (b) (void)hipFree(b);
+        if (r.stream) (void)hipStreamDestroy(r.stream);
+    }
+    for (Member& m : g->members) if (m.context) hipr_destroy(m.context);
     if (g->gathered && !g->members.empty()) { (void)hipSetDevice(g->members[0].device); (void)hipFree(g->gathered); }
     delete g;
     return HIPR_OK;
@@ -375,11 +405,15 @@ int hipr_group_accumulate_samples(HiprGroup* g, uint32_t first_sample, uint32_t 
     status = for_each_member(g, [&](Member& m, uint32_t i) -> int {
         auto hip_failed = [&](const char* what) { hipr_internal_set_last_error(what); return HIPR_ERROR_HIP; };
         if (hipSetDevice(m.device) != hipSuccess) return hip_failed("hipSetDevice failed in the tile gather");
-        if (int(i) == stalled) {      // test hook: this member's half of the exchange is held back past the deadline (a host function that sleeps on its stream)
+        // test hook: this member's stream is held past the deadline by a host function that sleeps on it -- queued BEFORE a copy (the copy itself is what stalls: it
+        // runs later, into the retired buffers) and AFTER an RCCL call (an ncclSend kernel held back behind the sleep would launch after ncclCommAbort had freed the
+        // communicator's device state; queued after, the exchange itself completes and only the stream's tail is late)
+        auto hold_stream = [&] {
             static int sleep_ms;
             sleep_ms = g->gather_timeout_ms + 500;
             (void)hipLaunchHostFunc(m.stream, [](void* ms) { std::this_thread::sleep_for(std::chrono::milliseconds(*static_cast<int*>(ms))); }, &sleep_ms);
-        }
+        };
+        if (int(i) == stalled && !g->use_rccl) hold_stream();
         if (g->use_rccl) {
             // one communicator per thread, every thread's calls inside its own group call (RCCL: several communicators driven from one process)
             int r = 0;
@@ -395,9 +429,13 @@ int hipr_group_accumulate_samples(HiprGroup* g, uint32_t first_sample, uint32_t 
                 r = g->rccl.GroupEnd() | r;
                 if (r != 0) return hip_failed("ncclSend of a member's tiles failed");
             }
+            if (int(i) == stalled) hold_stream();
         } else if (hipMemcpyAsync(gathered + size_t(i) * bytes, m.compact, bytes, hipMemcpyDeviceToDevice, m.stream) != hipSuccess)
             return hip_failed("peer-to-peer copy of a member's tiles failed");
-        if (wait_for_stream(m.stream, g->gather_timeout_ms)) return HIPR_OK;
+        std::string failure;
+        const Waited waited = wait_for_stream(m.stream, g->gather_timeout_ms, failure);
+        if (waited == Waited::Done) return HIPR_OK;
+        if (waited == Waited::Failed) return hip_failed(failure.c_str());
         int none = -1;
         timed_out.compare_exchange_strong(none, int(i));
         const std::string text = "the tile exchange (" + g->gather_description + ") did not finish within " + std::to_string(g->gather_timeout_ms) + " ms on this member's stream";
@@ -407,7 +445,8 @@ int hipr_group_accumulate_samples(HiprGroup* g, uint32_t first_sample, uint32_t 
     if (timed_out.load() >= 0 || (status && g->use_rccl)) {
         // the frame of this call is not delivered; the next call finds a group that copies
         const std::string message = hipr_last_error();
-        fall_back_to_copies(g, status == HIPR_ERROR_TIMEOUT ? "an exchange did not finish within its deadline" : "an RCCL call failed");
+        if (!fall_back_to_copies(g, timed_out.load() >= 0 ? "an exchange did not finish within its deadline" : "an RCCL call failed"))
+            fprintf(stderr, "hiprenderer: device group: no fresh streams or buffers after the stalled exchange; hipr_group_set_frame must be called again\n");
         hipr_internal_set_last_error(message.c_str());
     }
     if (status) return status;

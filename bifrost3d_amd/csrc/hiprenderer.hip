@@ -130,6 +130,8 @@ struct HiprContext {
     bool scene_has_textures = true;     // a material references a texture, or the scene brings an environment map / presampled environment light: k_shade<..., TEXTURES = true>
     bool lean_shade = true;             // HIPR_LEAN_SHADE=0: always the full kernel
     DeviceBuffer triangle_class;        // one byte per triangle for the listing pass (k_classify_hits): bit 0 = its material is coated
+    int arithmetic = HIPR_ARITHMETIC_FAST;     // hipr_set_arithmetic: which build of the shade unit the context launches (launch.h ShadeUnit)
+    const hipr::ShadeUnit& shade_unit() const { return arithmetic == HIPR_ARITHMETIC_EXACT ? hipr::shade_unit_exact() : hipr::shade_unit_fast(); }
     bool coherence_sort = false;        // HIPR_COHERENCE_SORT=1: the rays of a fused trace launch are taken by (origin cell, octant), ray_sort.hip (built and measured in round 4: profiles/r04_ab_coherence_sort.txt)
     bool any_coated_triangle = false, shade_classes = false;     // HIPR_SHADE_CLASSES=1: coated surface hits listed apart (built and measured in round 4: no gain, profiles/r04_ab_shade_classes.txt)
     DeviceBuffer ggx_rho, dielectric_rho, alpha, sample_offsets, sobol_tables;
@@ -385,6 +387,7 @@ void launch_wide8(HiprContext* c, const Wavefront& w, const PathState& in, const
     // pipelined passes: one block slot per CU stays free, so that the other slot's tail launches find room next to this pass's persistent blocks
     uint32_t grid = uint32_t(c->cu_count) * uint32_t(c->pipelining_now && per_cu > 2 ? per_cu - c->pipeline_spare_blocks : per_cu);
     grid = std::max(1u, std::min(grid, (upper_bound + 63u) / 64u / waves_per_block + 1u));
+#if HIPR_RAY_SORT
     if constexpr (MODE == TRACE_FUSED && !INSTRUMENT) if (sorted) {     // ray_sort.hip listed the launch's rays
         if (c->all_triangles_opaque && c->lean_trace)
             hipLaunchKernelGGL((k_trace_wide8<STACK, MODE, INSTRUMENT, false, true>), dim3(grid), dim3(TRACE_BLOCK), 0, w.stream, c->scene, c->wide8, in, w.hits.as<float4>(), w.shadow_queue(),
@@ -394,6 +397,7 @@ void launch_wide8(HiprContext* c, const Wavefront& w, const PathState& in, const
                                c->radiance.as<float4>(), closest_count, shadow_count, next_work_counter(c), c->refill_below, c->counters.as<DeviceCounters>(), sorted);
         return;
     }
+#endif
     if constexpr (!INSTRUMENT && MODE != TRACE_CLOSEST) if (!sorted && !c->all_triangles_opaque && c->coverage_textures_r8 && c->lean_trace) {     // the coverage sampler for 8-bit single-channel textures only
         hipLaunchKernelGGL((k_trace_wide8<STACK, MODE, INSTRUMENT, true, false, true>), dim3(grid), dim3(TRACE_BLOCK), 0, w.stream, c->scene, c->wide8, in, w.hits.as<float4>(), w.shadow_queue(),
                            c->radiance.as<float4>(), closest_count, shadow_count, next_work_counter(c), c->refill_below, c->counters.as<DeviceCounters>());
@@ -473,6 +477,7 @@ void launch_trace_shadow(HiprContext* c, const Wavefront& w, const uint32_t* cou
 template <bool INSTRUMENT>
 void launch_trace_fused(HiprContext* c, const Wavefront& w, const PathState& in, const uint32_t* closest_count, const uint32_t* shadow_count, uint32_t upper_bound) {
     const uint32_t* sorted = nullptr;
+#if HIPR_RAY_SORT
     if (!INSTRUMENT && c->coherence_sort && c->use_wide8() && w.sort_order.ptr) {
         const ShadowQueue q = w.shadow_queue();
         hipr::RaySortLaunch a = {w.stream, in.o_tmin, in.d_pdf, q.o_tmax, q.d_slot, closest_count, shadow_count, std::min(upper_bound, 2u * std::max(w.n_slots, 64u)), {}, {},
@@ -480,6 +485,7 @@ void launch_trace_fused(HiprContext* c, const Wavefront& w, const PathState& in,
         for (int k = 0; k < 3; ++k) { a.grid_min[k] = c->wide8.grid_min[k]; a.cells_per_unit[k] = 16.0f / (c->wide8.grid_cell[k] * 2097152.0f); }
         if (hipr::launch_ray_sort(a) == 0) sorted = w.sort_order.as<uint32_t>();
     }
+#endif
     launch_persistent_for_stack<TRACE_FUSED, INSTRUMENT>(c, w, in, closest_count, shadow_count, upper_bound, sorted);
 }
 
@@ -514,7 +520,7 @@ void launch_shade(HiprContext* c, const Wavefront& w, const HiprCameraState& cam
                      w.shadow_queue(), c->radiance.as<float4>(), in_count, reinterpret_cast<unsigned long long*>(out_counts), reinterpret_cast<unsigned long long*>(zero_pair),
                      reinterpret_cast<unsigned long long*>(taken_words + COUNT_PAIR_STRIDE * (1 - cur)), split ? w.nee_flags.as<unsigned char>() : nullptr,
                      c->counters.as<DeviceCounters>(), c->scene_has_textures || !c->lean_shade, c->scene_has_environment || !c->lean_shade};
-    hipr::launch_shade(c->shading_models, a);
+    c->shade_unit().shade(c->shading_models, a);
 }
 
 // Splits the path slots of a pass (owned tiles x 64 x samples_per_pass) over the wavefronts on a tile (= wave) boundary and sizes the
@@ -550,11 +556,13 @@ int partition_path_slots(HiprContext* c) {
         r |= w.order.resize(bytes / 4);
         r |= w.order_coat.resize(bytes / 4);
         if (c->shade_split) r |= w.nee_flags.resize(bytes / 16);
+#if HIPR_RAY_SORT
         if (c->coherence_sort) {      // both queues of a fused launch: 2 x n_slots entries
             const size_t entries = bytes / 16 * 2;
             r |= w.sort_keys[0].resize(entries * 2); r |= w.sort_keys[1].resize(entries * 2); r |= w.sort_order.resize(entries * 4);
             r |= w.sort_temp.resize(hipr::ray_sort_temp_bytes(uint32_t(entries)));
         }
+#endif
         for (int j = 0; j < 3; ++j) r |= w.shadow[j].resize(bytes);
     }
     const bool two_slots = c->wavefront_count == 1 && c->pipeline_passes && c->partitioned_for == 1;
@@ -993,12 +1001,13 @@ int hipr_create(int device_id, HiprContext** out_context) {
     if (const char* v = getenv("HIPR_WAVEFRONTS")) c->wavefront_limit = std::max(0, std::min(MAX_WAVEFRONTS, atoi(v)));
     if (const char* v = getenv("HIPR_TRACE_LOG")) c->trace_log = atoi(v) != 0;
     if (const char* v = getenv("HIPR_SHADE_CLASSES")) c->shade_classes = atoi(v) != 0;
-    if (const char* v = getenv("HIPR_COHERENCE_SORT")) c->coherence_sort = atoi(v) != 0;
+    if (const char* v = getenv("HIPR_COHERENCE_SORT")) c->coherence_sort = HIPR_RAY_SORT && atoi(v) != 0;      // only in a build with the experiment linked in (tools/experiments/ray_sort.hip)
     if (const char* v = getenv("HIPR_LEAN_TRACE")) c->lean_trace = atoi(v) != 0;
     if (const char* v = getenv("HIPR_LEAN_SHADE")) c->lean_shade = atoi(v) != 0;
     if (const char* v = getenv("HIPR_SHADE_ORDERED")) c->shade_ordered = atoi(v) != 0;
     if (const char* v = getenv("HIPR_SHADE_ORDERED_CAMERA")) c->shade_ordered_camera = atoi(v) != 0;
     if (const char* v = getenv("HIPR_SHADE_SPLIT")) c->shade_split = atoi(v) != 0;
+    if (const char* v = getenv("HIPR_ARITHMETIC")) c->arithmetic = (v[0] == 'e' || v[0] == 'E' || v[0] == '1') ? HIPR_ARITHMETIC_EXACT : HIPR_ARITHMETIC_FAST;
     if (const char* v = getenv("HIPR_BACKFACE_CULLING")) c->cull_backfaces = atoi(v) != 0;
     if (const char* v = getenv("HIPR_PIPELINE_PASSES")) c->pipeline_passes = atoi(v) != 0;
     if (const char* v = getenv("HIPR_PIPELINE_SPARE_BLOCKS")) c->pipeline_spare_blocks = std::max(0, atoi(v));
@@ -1540,6 +1549,19 @@ int hipr_set_backface_culling(HiprContext* c, int enable) {
     return HIPR_OK;
 }
 
+int hipr_set_arithmetic(HiprContext* c, int arithmetic) {
+    if (int s = check_context(c)) return s;
+    if (arithmetic != HIPR_ARITHMETIC_FAST && arithmetic != HIPR_ARITHMETIC_EXACT) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_set_arithmetic: unknown mode %d", arithmetic);
+    if (int s = finish_all(c)) return s;
+    c->arithmetic = arithmetic;
+    return HIPR_OK;
+}
+
+int hipr_get_arithmetic(HiprContext* c) {
+    if (int s = check_context(c)) return s;      // statuses are negative
+    return c->arithmetic;
+}
+
 int hipr_set_pass_pipelining(HiprContext* c, int enable) {
     if (int s = check_context(c)) return s;
     if (int s = finish_all(c)) return s;
@@ -1682,7 +1704,7 @@ int hipr_debug_shading(HiprContext* c, int shading_model, const float* params10,
     DeviceBuffer bp, bw, bi, bo;
     int r = bp.upload(params10, 10 * 4, c->stream) | bw.upload(wo_n3, size_t(n) * 12, c->stream) | bi.upload(in_n3, size_t(n) * 12, c->stream) | bo.resize(size_t(n) * 28);
     if (r) return HIPR_ERROR_OUT_OF_MEMORY;
-    hipr::launch_debug_shading(c->stream, c->scene.tables, shading_model, bp.as<float>(), bw.as<float>(), bi.as<float>(), int(n), mode, bo.as<float>());
+    c->shade_unit().debug_shading(c->stream, c->scene.tables, shading_model, bp.as<float>(), bw.as<float>(), bi.as<float>(), int(n), mode, bo.as<float>());
     HIP_TRY(hipGetLastError());
     if (int finish_status = finish_all(c)) return finish_status;
     HIP_TRY(hipMemcpy(out_n7, bo.ptr, size_t(n) * 28, hipMemcpyDeviceToHost));
@@ -1706,11 +1728,25 @@ int hipr_debug_shade(HiprContext* c, const HiprCameraState* camera, uint32_t n, 
     if (br.upload(rays_n8, size_t(n) * 32, c->stream) | bt.upload(throughput_bounces_n4, size_t(n) * 16, c->stream) | bh.upload(hits_n4, size_t(n) * 16, c->stream) |
         bl.upload(last_triangle, size_t(n) * 4, c->stream) | bp.upload(pixel_hash, size_t(n) * 4, c->stream) | ba.upload(accumulation, size_t(n) * 4, c->stream) | bo.resize(size_t(n) * 128))
         return HIPR_ERROR_OUT_OF_MEMORY;
-    hipr::launch_debug_shade(c->stream, c->scene, *camera, n, br.as<float4>(), bt.as<float4>(), bh.as<float4>(), bl.as<uint32_t>(), bp.as<uint32_t>(), ba.as<uint32_t>(), bo.as<float>());
+    c->shade_unit().debug_shade(c->stream, c->scene, *camera, n, br.as<float4>(), bt.as<float4>(), bh.as<float4>(), bl.as<uint32_t>(), bp.as<uint32_t>(), ba.as<uint32_t>(), bo.as<float>());
     HIP_TRY(hipGetLastError());
     if (int finish_status = finish_all(c)) return finish_status;
     HIP_TRY(hipMemcpy(out_n32, bo.ptr, size_t(n) * 128, hipMemcpyDeviceToHost));
     br.release(); bt.release(); bh.release(); bl.release(); bp.release(); ba.release(); bo.release();
+    return HIPR_OK;
+}
+
+int hipr_debug_math(HiprContext* c, int function, uint32_t n, const float* x, const float* y, float* out) {
+    if (int s = check_context(c)) return s;
+    if (!x || !out || function < 0 || function > 2 || (function == 2 && !y)) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_debug_math: bad argument");
+    if (n == 0) return HIPR_OK;
+    DeviceBuffer bx, by, bo;
+    if (bx.upload(x, size_t(n) * 4, c->stream) | by.upload(y ? y : x, size_t(n) * 4, c->stream) | bo.resize(size_t(n) * 4)) return HIPR_ERROR_OUT_OF_MEMORY;
+    c->shade_unit().debug_math(c->stream, function, int(n), bx.as<float>(), by.as<float>(), bo.as<float>());
+    HIP_TRY(hipGetLastError());
+    if (int finish_status = finish_all(c)) return finish_status;
+    HIP_TRY(hipMemcpy(out, bo.ptr, size_t(n) * 4, hipMemcpyDeviceToHost));
+    bx.release(); by.release(); bo.release();
     return HIPR_OK;
 }
 
@@ -1721,7 +1757,7 @@ int hipr_debug_light(HiprContext* c, const HiprLight* light, const float* positi
     if (n == 0) return HIPR_OK;
     DeviceBuffer bp, bi, bo;
     if (bp.upload(position3, 3 * 4, c->stream) | bi.upload(in_n3, size_t(n) * 12, c->stream) | bo.resize(size_t(n) * 32)) return HIPR_ERROR_OUT_OF_MEMORY;
-    hipr::launch_debug_light(c->stream, *light, bp.as<float>(), bi.as<float>(), int(n), mode, bo.as<float>());
+    c->shade_unit().debug_light(c->stream, *light, bp.as<float>(), bi.as<float>(), int(n), mode, bo.as<float>());
     HIP_TRY(hipGetLastError());
     if (int finish_status = finish_all(c)) return finish_status;
     HIP_TRY(hipMemcpy(out_n8, bo.ptr, size_t(n) * 32, hipMemcpyDeviceToHost));

@@ -30,9 +30,12 @@ struct ShadeLaunch {
     bool environment;                 // ... an environment map or a presampled environment light (false with textures: TEXTURES = 1)
 };
 
-void launch_shade(int shading_models, const ShadeLaunch& args);
 
-// ray_sort.hip: the rays of one fused trace launch listed by (kind, origin cell, direction octant). All pointers are device pointers.
+#ifndef HIPR_RAY_SORT
+#define HIPR_RAY_SORT 0     // 1: tools/experiments/ray_sort.hip is linked in (tools/build_variant.sh ... "-DHIPR_RAY_SORT=1"); the product is built without (measured -20 %, rocPRIM dependency)
+#endif
+#if HIPR_RAY_SORT
+// tools/experiments/ray_sort.hip: the rays of one fused trace launch listed by (kind, origin cell, direction octant). All pointers are device pointers.
 struct RaySortLaunch {
     hipStream_t stream;
     const float4 *closest_o, *closest_d, *shadow_o, *shadow_d;     // the two queues' origins and directions
@@ -46,12 +49,19 @@ struct RaySortLaunch {
 };
 size_t ray_sort_temp_bytes(uint32_t capacity);
 int launch_ray_sort(const RaySortLaunch& args);      // 0, or the hipError_t of the sort
+#endif
 
-// All pointers are device pointers; see k_debug_shading (shade.hip).
-void launch_debug_shade(hipStream_t stream, const DeviceScene& scene, const HiprCameraState& camera, uint32_t n, const float4* rays, const float4* throughput_bounces, const float4* hits,
+// The host entry points of ONE build of shade.hip. The library holds two (shade.hip's header): the fast unit and the exact one; a context launches through
+// the unit of its arithmetic mode (hipr_set_arithmetic). All pointers are device pointers; see k_debug_shading etc. in shade.hip.
+struct ShadeUnit {
+    void (*shade)(int shading_models, const ShadeLaunch& args);
+    void (*debug_shade)(hipStream_t stream, const DeviceScene& scene, const HiprCameraState& camera, uint32_t n, const float4* rays, const float4* throughput_bounces, const float4* hits,
                         const uint32_t* last_triangle, const uint32_t* pixel_hash, const uint32_t* accumulation, float* out);
-void launch_debug_light(hipStream_t stream, const HiprLight& light, const float* position3, const float* in_n3, int n, int mode, float* out_n8);
-void launch_debug_shading(hipStream_t stream, const DeviceTables& tables, int model, const float* params10, const float* wo_n3, const float* in_n3, int n, int mode,
-                          float* out_n7);
+    void (*debug_light)(hipStream_t stream, const HiprLight& light, const float* position3, const float* in_n3, int n, int mode, float* out_n8);
+    void (*debug_shading)(hipStream_t stream, const DeviceTables& tables, int model, const float* params10, const float* wo_n3, const float* in_n3, int n, int mode, float* out_n7);
+    void (*debug_math)(hipStream_t stream, int function, int n, const float* x, const float* y, float* out);
+};
+const ShadeUnit& shade_unit_fast();
+const ShadeUnit& shade_unit_exact();
 
 } // namespace hipr

@@ -391,7 +391,9 @@ HD HiprMaterial shade_fetch_material(const DeviceScene& sc, const ShadeInputs& i
 #endif
 constexpr uint32_t SHADE_LDS_LIGHTS = 32;   // light arrays up to this size are copied to LDS (1.5 KB); larger ones are read from global memory
 constexpr int shade_waves_per_simd(int part) { return part == SHADE_PART_ALL ? HIPR_SHADE_WAVES : HIPR_SHADE_SPLIT_WAVES; }
-template <int MODELS, bool AOV, int PART, int TEXTURES = 2>
+// ARITHMETIC (HIPR_ARITHMETIC_*) names the build of the shade unit the instantiation belongs to: shade.hip is compiled twice into one library (fast and exact arithmetic,
+// hipr_set_arithmetic), and two kernels of one name would share one host-side launch stub.
+template <int MODELS, bool AOV, int PART, int TEXTURES, int ARITHMETIC>
 __global__ __launch_bounds__(SHADE_BLOCK, shade_waves_per_simd(PART)) void k_shade(DeviceScene sc, HiprCameraState cam, FrameInfo frame, int entry, PathState in, const float4* hits, const uint32_t* order_list, const uint32_t* order_coat, const unsigned long long* listed, PathState out,
                                                         ShadowQueue shadows, float4* radiance, const uint32_t* count_ptr, unsigned long long* out_counts,
                                                         unsigned long long* zero_a, unsigned long long* zero_b, unsigned char* nee_flags, DeviceCounters* counters) {

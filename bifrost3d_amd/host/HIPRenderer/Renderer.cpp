@@ -207,6 +207,7 @@ struct Renderer::Implementation {
     std::vector<CameraState> per_camera_state = std::vector<CameraState>(1);
     AIDenoiserFlags AI_denoiser_flags = AIDenoiserFlag::Default;
     PathRegularizationSettings path_regularization = {0.5f, 0.0f};   // OR/Renderer.cpp:482-483
+    int arithmetic = HIPR_ARITHMETIC_FAST;      // set_arithmetic: applied to every member context of every camera's group
     HiprSceneState scene_state = {{0, 0, 0}, 3};                     // next_event_sample_count = 3, OR/Renderer.cpp:479
     std::unique_ptr<SceneBuilder> scene;
 
@@ -251,7 +252,12 @@ struct Renderer::Implementation {
         if (hipr_group_create(device_IDs.data(), uint32_t(device_IDs.size()), &group) != HIPR_OK) return nullptr;
         HiprTables t = {tables[0].data(), tables[1].data(), tables[2].data(), tables[3].data(), tables[4].data()};
         if (hipr_group_upload_tables(group, &t) != HIPR_OK) { hipr_group_destroy(group); return nullptr; }
+        apply_arithmetic(group);
         return group;
+    }
+
+    void apply_arithmetic(HiprGroup* group) {
+        for (uint32_t m = 0; m < hipr_group_size(group); ++m) hipr_set_arithmetic(hipr_group_context(group, m), arithmetic);
     }
 
     void rebuild_scene() {
@@ -556,6 +562,17 @@ PathRegularizationSettings Renderer::get_path_regularization_settings() const { 
 void Renderer::set_path_regularization_settings(PathRegularizationSettings settings) { m_impl->path_regularization = settings; }
 unsigned int Renderer::get_max_batch_size() const { return m_impl->max_batch_size; }
 void Renderer::set_max_batch_size(unsigned int accumulations) { m_impl->max_batch_size = std::max(1u, std::min(accumulations, 256u)); }
+Renderer::Arithmetic Renderer::get_arithmetic() const { return m_impl->arithmetic == HIPR_ARITHMETIC_EXACT ? Arithmetic::Exact : Arithmetic::Fast; }
+void Renderer::set_arithmetic(Arithmetic arithmetic) {
+    const int mode = arithmetic == Arithmetic::Exact ? HIPR_ARITHMETIC_EXACT : HIPR_ARITHMETIC_FAST;
+    if (mode == m_impl->arithmetic) return;
+    m_impl->arithmetic = mode;
+    for (auto& state : m_impl->per_camera_state) {      // the samples traced ahead and the running mean belong to the other estimator
+        if (state.context) m_impl->apply_arithmetic(state.context);
+        state.drop_batch();
+        state.accumulations = 0;
+    }
+}
 AIDenoiserFlags Renderer::get_AI_denoiser_flags() const { return m_impl->AI_denoiser_flags; }
 void Renderer::set_AI_denoiser_flags(AIDenoiserFlags flags) { m_impl->AI_denoiser_flags = flags; }
 

@@ -72,6 +72,13 @@ public:
     unsigned int get_max_batch_size() const;
     void set_max_batch_size(unsigned int accumulations);
 
+    // Not in the reference (a build flag there: --use_fast_math, extensions/OptiXRenderer/CMakeLists.txt:82-83): the arithmetic of the shade stage. Fast (default):
+    // hardware-approximate division / sqrt / sin / cos / pow like the reference's PTX. Exact: IEEE operations and specified transcendentals -- every frame equals
+    // the CPU restatement bit for bit (include/hiprenderer_c.h hipr_set_arithmetic). Changing it restarts every camera's accumulation.
+    enum class Arithmetic { Fast = 0, Exact = 1 };
+    Arithmetic get_arithmetic() const;
+    void set_arithmetic(Arithmetic arithmetic);
+
     AIDenoiserFlags get_AI_denoiser_flags() const;
     void set_AI_denoiser_flags(AIDenoiserFlags flags);
 

@@ -9,12 +9,15 @@ from . import capi
 
 
 class Context:
-    def __init__(self, device_id: int = 0, library=None):
-        """`library`: another build of libhiprenderer.so (capi.VERIFY_LIB_PATH for the verification build); the product library by default."""
+    def __init__(self, device_id: int = 0, library=None, arithmetic=None):
+        """`library`: another build of libhiprenderer.so (A/B builds of the kernels); the product library by default.
+        `arithmetic`: "fast" / "exact" (or capi.HIPR_ARITHMETIC_*): hipr_set_arithmetic; None keeps the library's default (fast, or what HIPR_ARITHMETIC says)."""
         self.lib = capi.load_library(library)
         self.device_id = device_id
         self.handle = C.c_void_p()
         capi.check(self.lib, self.lib.hipr_create(device_id, C.byref(self.handle)), "hipr_create")
+        if arithmetic is not None:
+            self.set_arithmetic(arithmetic)
         self._tables = capi.load_tables()
         t = capi.HiprTables(*[a.ctypes.data_as(C.POINTER(C.c_float)) for a in self._tables])
         capi.check(self.lib, self.lib.hipr_upload_tables(self.handle, C.byref(t)), "hipr_upload_tables")
@@ -33,6 +36,26 @@ class Context:
 
     def _check(self, status, what):
         capi.check(self.lib, status, what)
+
+    def set_arithmetic(self, arithmetic):
+        mode = {"fast": capi.HIPR_ARITHMETIC_FAST, "exact": capi.HIPR_ARITHMETIC_EXACT}.get(arithmetic, arithmetic)
+        self._check(self.lib.hipr_set_arithmetic(self.handle, int(mode)), "hipr_set_arithmetic")
+
+    @property
+    def arithmetic(self) -> str:
+        mode = self.lib.hipr_get_arithmetic(self.handle)
+        if mode < 0:
+            self._check(mode, "hipr_get_arithmetic")
+        return "exact" if mode == capi.HIPR_ARITHMETIC_EXACT else "fast"
+
+    def debug_math(self, function: int, x, y=None):
+        """sin (0), cos (1) or pow(x, y) (2) as the shade unit of the context's arithmetic mode evaluates them."""
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.ascontiguousarray(y if y is not None else np.zeros_like(x), np.float32)
+        out = np.zeros_like(x)
+        fp = C.POINTER(C.c_float)
+        self._check(self.lib.hipr_debug_math(self.handle, function, x.size, x.ctypes.data_as(fp), y.ctypes.data_as(fp), out.ctypes.data_as(fp)), "hipr_debug_math")
+        return out
 
     def set_stream(self, stream_ptr: int | None):
         self._check(self.lib.hipr_set_stream(self.handle, C.c_void_p(stream_ptr or 0)), "hipr_set_stream")

@@ -489,6 +489,18 @@ int hipr_set_pass_pipelining(HiprContext* context, int enable);
  * same distance no longer hides it (the retrace starts past both). 0 restores the retrace for every refused hit. Applies to every closest-hit query of
  * the 8-wide search, the stage-level hipr_debug_trace_closest included. */
 int hipr_set_backface_culling(HiprContext* context, int enable);
+/* Arithmetic of the shade stage (K3: attribute interpolation, BSDFs, lights, next event estimation; the other kernels are correctly rounded always).
+ *   HIPR_ARITHMETIC_FAST  (default) division, square root, sin, cos and pow by the hardware's approximations, contraction allowed, denormals flushed: what the
+ *                         reference's shading PTX is built with (nvcc --use_fast_math, extensions/OptiXRenderer/CMakeLists.txt:82-83).
+ *   HIPR_ARITHMETIC_EXACT IEEE division and square root, one rounding per operation, sin / cos / pow as the specified binary64 sequences of csrc/spec_math.h:
+ *                         every pixel of every frame equals the CPU restatement (oracle/) in every bit, whatever the resolution or sample count -- the mode that
+ *                         meets BASELINE.json's RMSE bound by construction (RMSE 0). About 10 % slower per step (bench.py config.exact_mode).
+ * Both builds of the shade unit live in this library; the switch takes effect with the next pass (accumulate from zero after changing it: the two modes are
+ * different, equally valid estimators of the same image). Environment HIPR_ARITHMETIC=exact|fast sets the default of new contexts.
+ * Replaces a build-time choice of the reference (its CMake flag); no run-time counterpart there. */
+enum { HIPR_ARITHMETIC_FAST = 0, HIPR_ARITHMETIC_EXACT = 1 };
+int hipr_set_arithmetic(HiprContext* context, int arithmetic);
+int hipr_get_arithmetic(HiprContext* context);      /* HIPR_ARITHMETIC_*, or a negative status */
 int hipr_set_instrumentation(HiprContext* context, int count_traversal_steps);
 int hipr_reset_timers(HiprContext* context);
 int hipr_get_kernel_times(HiprContext* context, HiprKernelTimes* out);
@@ -524,6 +536,9 @@ int hipr_debug_shade(HiprContext* context, const HiprCameraState* camera, uint32
  * direction_to_light[3], distance. mode 1 (spot lights only): out8 = evaluate(light, position, direction = in)[3],
  * pdf(light, position, direction), 0, 0, 0, 0. Host pointers; position3 is shared by the n inputs. */
 int hipr_debug_light(HiprContext* context, const HiprLight* light, const float* position3, const float* in_n3, uint32_t n, int mode, float* out_n8);
+/* The transcendentals of the shade unit in the context's arithmetic mode, over arrays: function 0 sin(x), 1 cos(x), 2 pow(x, y) (y ignored otherwise). In the exact
+ * mode the results are csrc/spec_math.h's, bit for bit those of the oracle's restatement (tests/test_gpu_verify_build.py). */
+int hipr_debug_math(HiprContext* context, int function, uint32_t n, const float* x, const float* y, float* out);
 int hipr_debug_sobol(HiprContext* context, const uint32_t* accumulation_pixelhash_dimension, uint32_t n, uint32_t* out_uint4);
 /* The VALU roof of the device the context runs on, measured (bench.py's roofline_valu; no reference counterpart): eight independent chains of one
  * instruction per lane, eight waves per SIMD on every CU, best of three launches. out3[0] = v_fma_f32, out3[1] = v_max_f32, out3[2] = v_cvt_f32_ubyte1,

@@ -412,6 +412,12 @@ int oracle_set_f64_transcendentals(int on) {
     return before;
 }
 
+// The specified transcendentals of the exact arithmetic mode over arrays (vecmath.h spec::): function 0 sin, 1 cos, 2 pow(x, y).
+void oracle_spec_math(int function, int n, const float* x, const float* y, float* out) {
+    for (int i = 0; i < n; ++i)
+        out[i] = function == 2 ? oracle::spec::pow(x[i], y[i]) : oracle::spec::sin_or_cos(x[i], function);
+}
+
 int oracle_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -17,14 +17,68 @@
 namespace oracle {
 
 // The transcendentals of the path (sin, cos, pow, atan2, asin, acos). By default glibc's f32 functions, the independent counterpart of whatever the product's
-// shade kernel uses (hardware approximations). With oracle_set_f64_transcendentals(1) -- the checker of the VERIFICATION build, libhiprenderer_verify.so,
-// csrc/device_shading.h HIPR_VERIFY_MATH -- each is evaluated in f64 and rounded once to f32: two independent f64 implementations (glibc here, ocml on the
-// device), each within a few f64 ulp of the true value, round to the same f32 except with probability ~2^-26 per call, so the two sides agree bit for bit on
-// all but a handful of paths per frame without sharing any code. Set before a render, read by its threads.
+// fast shade kernel uses (hardware approximations). With oracle_set_f64_transcendentals(1) -- the checker of the EXACT arithmetic mode of the device
+// (hipr_set_arithmetic, csrc/device_shading.h HIPR_VERIFY_MATH) -- sin, cos and pow are the SPECIFIED functions of DESIGN.md section 6 (csrc/spec_math.h
+// states the specification): fixed sequences of correctly rounded binary64 operations, restated here, which any two IEEE-754 machines evaluate to the same
+// bits; atan2, asin and acos (the environment map's lookup) are glibc's f64 functions rounded once to f32, which agree with the device's f64 libm but for
+// ~2^-26 of the arguments. Set before a render, read by its threads.
 inline bool g_f64_transcendentals = false;
-inline float exact_sinf(float x) { return g_f64_transcendentals ? float(std::sin(double(x))) : sinf(x); }
-inline float exact_cosf(float x) { return g_f64_transcendentals ? float(std::cos(double(x))) : cosf(x); }
-inline float exact_powf(float x, float y) { return g_f64_transcendentals ? float(std::pow(double(x), double(y))) : powf(x, y); }
+
+namespace spec {
+// Horner evaluation, one fma per coefficient, highest power first.
+template <int N> inline double horner(const double (&c)[N], double z) {
+    double p = c[0];
+    for (int i = 1; i < N; ++i) p = std::fma(p, z, c[i]);
+    return p;
+}
+// Taylor coefficients as quotients of integers: -1/3!, 1/5!, ... for (sin r - r) / r^3 and 1, -1/2!, 1/4!, ... for cos r, in z = r^2, highest power first.
+inline const double SIN_TAIL[7] = {-1.0 / 1307674368000.0, 1.0 / 6227020800.0, -1.0 / 39916800.0, 1.0 / 362880.0, -1.0 / 5040.0, 1.0 / 120.0, -1.0 / 6.0};
+inline const double COS_SUM[9] = {1.0 / 20922789888000.0, -1.0 / 87178291200.0, 1.0 / 479001600.0, -1.0 / 3628800.0, 1.0 / 40320.0, -1.0 / 720.0, 1.0 / 24.0, -0.5, 1.0};
+inline const double ATANH_SUM[10] = {1.0 / 19.0, 1.0 / 17.0, 1.0 / 15.0, 1.0 / 13.0, 1.0 / 11.0, 1.0 / 9.0, 1.0 / 7.0, 1.0 / 5.0, 1.0 / 3.0, 1.0};
+inline const double EXP_SUM[14] = {1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0, 1.0 / 5040.0,
+                                   1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0, 0.5, 1.0, 1.0};
+inline const double TWO_OVER_PI = 0.63661977236758134308, PIO2_HIGH = 1.57079632679489655800, PIO2_LOW = 6.12323399573676603587e-17;
+inline const double SQRT2 = 1.41421356237309514547, ONE_OVER_LN2 = 1.44269504088896338700, LN2 = 0.69314718055994528623;
+
+// sin (which = 0) or cos (which = 1) of x: quadrant k = rint(x * 2/pi), r = x - k * pi/2 in two fused steps, the two Taylor sums, picked and signed by k mod 4.
+inline float sin_or_cos(float x, int which) {
+    const double xd = x;
+    if (!(std::fabs(xd) < 1.0e6)) return std::nanf("");
+    const double k = std::nearbyint(xd * TWO_OVER_PI);
+    const double r = std::fma(-k, PIO2_LOW, std::fma(-k, PIO2_HIGH, xd));
+    const double z = r * r;
+    const int quadrant = (int(k) + which) & 3;       // cos x = sin(x + pi/2)
+    const double value = (quadrant & 1) ? horner(COS_SUM, z) : std::fma(r * z, horner(SIN_TAIL, z), r);
+    return float((quadrant & 2) ? -value : value);
+}
+inline float pow(float x, float y) {
+    if (y != y) return y;
+    if (!(x > 0.0f)) return x == 0.0f ? (y > 0.0f ? 0.0f : (y == 0.0f ? 1.0f : INFINITY)) : std::nanf("");
+    if (std::isinf(x)) return y > 0.0f ? x : (y == 0.0f ? 1.0f : 0.0f);
+    const double xd = x;
+    uint64_t bits;
+    std::memcpy(&bits, &xd, 8);
+    int e = int(bits >> 52) - 1023;
+    bits = (bits & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
+    double m;
+    std::memcpy(&m, &bits, 8);
+    if (m > SQRT2) { m *= 0.5; e += 1; }
+    const double s = (m - 1.0) / (m + 1.0);
+    const double ln_m = (s + s) * horner(ATANH_SUM, s * s);
+    double t = double(y) * std::fma(ln_m, ONE_OVER_LN2, double(e));
+    t = t < -300.0 ? -300.0 : (t > 300.0 ? 300.0 : t);
+    const double k = std::nearbyint(t);
+    const double power = horner(EXP_SUM, (t - k) * LN2);
+    const uint64_t scale_bits = uint64_t(int(k) + 1023) << 52;
+    double scale;
+    std::memcpy(&scale, &scale_bits, 8);
+    return float(power * scale);
+}
+} // namespace spec
+
+inline float exact_sinf(float x) { return g_f64_transcendentals ? spec::sin_or_cos(x, 0) : sinf(x); }
+inline float exact_cosf(float x) { return g_f64_transcendentals ? spec::sin_or_cos(x, 1) : cosf(x); }
+inline float exact_powf(float x, float y) { return g_f64_transcendentals ? spec::pow(x, y) : powf(x, y); }
 inline float exact_atan2f(float y, float x) { return g_f64_transcendentals ? float(std::atan2(double(y), double(x))) : atan2f(y, x); }
 inline float exact_asinf(float x) { return g_f64_transcendentals ? float(std::asin(double(x))) : asinf(x); }
 inline float exact_acosf(float x) { return g_f64_transcendentals ? float(std::acos(double(x))) : acosf(x); }

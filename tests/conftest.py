@@ -29,20 +29,19 @@ def goldens():
 
 @pytest.fixture(scope="session")
 def verify_ctx():
-    """A context of the VERIFICATION build (bifrost3d_amd/csrc/libhiprenderer_verify.so: the product's source with correctly rounded division / square root, no
-    contraction, transcendentals evaluated in f64 and rounded once) -- the build whose images equal the oracle's bit for bit (tests/test_gpu_verify_build.py)."""
-    from bifrost3d_amd import capi
+    """A context of the product library in its EXACT arithmetic mode (hipr_set_arithmetic: the shade unit built with correctly rounded division / square root, no
+    contraction, sin / cos / pow as the specified f64 sequences of csrc/spec_math.h) -- the mode whose images equal the oracle's bit for bit
+    (tests/test_gpu_verify_build.py)."""
     from bifrost3d_amd.renderer import Context
-    if not capi.VERIFY_LIB_PATH.exists():
-        pytest.skip("libhiprenderer_verify.so is not built")
-    c = Context(0, library=capi.VERIFY_LIB_PATH)
+    c = Context(0, arithmetic="exact")
     yield c
     c.close()
 
 
 def verification_build_equals_oracle(verify_ctx, oracle, scene, w, h, spp, bounces, name=""):
-    """Leg A of an image test: the frame of the verification build against the oracle's with f64 transcendentals, pixel by pixel, bit for bit (two f64 libraries may
-    round a transcendental apart with probability ~2^-26 per call: at most a pixel or two of a frame). Returns the exact image (h, w, 3), f64."""
+    """Leg A of an image test: the frame of the exact arithmetic mode against the oracle's with the specified transcendentals, pixel by pixel, bit for bit (the
+    environment lookup's atan2 / asin come from two f64 libraries, which may round apart with probability ~2^-26 per call: at most a pixel or two of a frame with
+    an environment map). Returns the exact image (h, w, 3), f64."""
     import numpy as np
     verify_ctx.upload_scene(scene)
     verify_ctx.set_frame(w, h, 0, 1, 1)
@@ -56,6 +55,6 @@ def verification_build_equals_oracle(verify_ctx, oracle, scene, w, h, spp, bounc
     finally:
         oracle.lib.oracle_set_f64_transcendentals(before)
     identical = (ours == theirs[..., :3]).all(axis=-1)
-    print(f"EXACT {name}: verification build vs oracle (f64 transcendentals): {identical.mean():.6f} of the {w}x{h} pixels bit-identical at {spp} spp")
+    print(f"EXACT {name}: exact arithmetic mode vs oracle (specified transcendentals): {identical.mean():.6f} of the {w}x{h} pixels bit-identical at {spp} spp")
     assert identical.mean() >= 0.9999, (name, float(identical.mean()))
     return ours

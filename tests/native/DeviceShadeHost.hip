@@ -229,4 +229,12 @@ int dsh_shade(void* scene, const HiprCameraState* cam, uint32_t n, const float* 
     return -1;
 }
 
+// csrc/spec_math.h as compiled for the host, over arrays: function 0 sin, 1 cos, 2 pow(x, y) (k_debug_spec_math, csrc/shade.hip: hipr_debug_spec_math).
+void dsh_spec_math(int function, int n, const float* x, const float* y, float* out) {
+    for (int i = 0; i < n; ++i) {
+        if (function == 2) out[i] = spec_pow(x[i], y[i]);
+        else { float s, c; spec_sincos(x[i], s, c); out[i] = function == 0 ? s : c; }
+    }
+}
+
 }

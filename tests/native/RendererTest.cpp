@@ -529,6 +529,51 @@ GPU_TEST_F(RendererFixture, batched_tracing_returns_the_images_of_one_launch_per
     EXPECT_TRUE(sum > 0.0);
 }
 
+GPU_TEST_F(RendererFixture, the_arithmetic_mode_restarts_the_accumulation_and_selects_the_exact_shade_unit) {
+    // Renderer::set_arithmetic (not in the reference, where --use_fast_math is a build flag): Exact runs the second build of the shade unit; the frame is another
+    // estimator of the same image (close, not equal), the accumulation restarts on a change and only on a change.
+    auto frame_size = Math::Vector2i(48, 27);
+    Scene::SceneRoot scene = Scene::SceneRoot("Cornell", Math::RGB(0.68f, 0.92f, 1.0f));
+    SceneBuilder direct;
+    Scenes::create_cornell_box(direct);
+    Math::Matrix4x4f projection, inverse_projection;
+    Scene::CameraUtils::compute_perspective_projection(direct.camera.near_plane, direct.camera.far_plane, direct.camera.field_of_view,
+                                                       float(frame_size.x) / frame_size.y, projection, inverse_projection);
+    Scene::CameraID camera_ID = Scene::Cameras::create("Camera", scene.get_ID(), projection, inverse_projection);
+    Scene::Cameras::set_renderer_ID(camera_ID, renderer->get_renderer_ID());
+    create_cornell_box(camera_ID, scene.get_root_node());
+    renderer->set_max_bounce_count(camera_ID, 4);
+    renderer->handle_updates();
+    reset_all_change_notifications();
+    EXPECT_TRUE(renderer->get_arithmetic() == Renderer::Arithmetic::Fast);
+
+    RenderTarget target(frame_size);
+    auto accumulate = [&](int calls, std::vector<double>& out) {
+        unsigned int count = 0;
+        for (int i = 0; i < calls; ++i) count = renderer->render(camera_ID, target.device, frame_size.x, frame_size);
+        EXPECT_TRUE(renderer->read_accumulation(out));
+        return count;
+    };
+    std::vector<double> fast, exact, exact_again;
+    EXPECT_EQ(8u, accumulate(8, fast));
+    renderer->set_arithmetic(Renderer::Arithmetic::Exact);
+    EXPECT_TRUE(renderer->get_arithmetic() == Renderer::Arithmetic::Exact);
+    EXPECT_EQ(8u, accumulate(8, exact));                      // restarted: 8 again, not 16
+    renderer->set_arithmetic(Renderer::Arithmetic::Exact);    // no change, no restart
+    EXPECT_EQ(9u, accumulate(1, exact_again));
+    EXPECT_EQ(fast.size(), exact.size());
+    double squared = 0, sum = 0;
+    size_t different = 0;
+    for (size_t i = 0; i < fast.size() && i < exact.size(); ++i) { squared += (fast[i] - exact[i]) * (fast[i] - exact[i]); sum += exact[i]; different += fast[i] != exact[i]; }
+    EXPECT_TRUE(different > 0);                               // another build of the shade unit did run
+    EXPECT_TRUE(std::sqrt(squared / double(fast.size())) < 2e-2);
+    EXPECT_TRUE(sum > 0.0);
+    renderer->set_arithmetic(Renderer::Arithmetic::Fast);
+    std::vector<double> fast_again;
+    EXPECT_EQ(8u, accumulate(8, fast_again));
+    EXPECT_TRUE(fast == fast_again);                          // and back: the fast frames bit for bit
+}
+
 GPU_TEST_F(RendererFixture, a_renderer_over_several_devices_delivers_the_single_device_frames) {
     // Renderer::initialize(device list): tiles dealt round-robin over a group of contexts, compact tiles gathered and assembled on the
     // first device. With every member on device 0 (this box has one GPU) the partition, the per-member accumulation, the gather (copy

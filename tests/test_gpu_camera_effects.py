@@ -306,3 +306,35 @@ def test_tiled_bloom_is_bit_identical_to_the_direct_kernels(fx, monkeypatch):
             assert np.array_equal(fx.bloom(1.0, support, frame, viewport).view(np.uint16), direct.bloom(1.0, support, direct_frame, viewport).view(np.uint16)), (support, viewport)
     finally:
         direct.close()
+
+
+def test_the_effects_follow_the_callers_current_stream(fx):
+    """the effects used to capture torch's current stream once, at construction; a caller working under `with torch.cuda.stream(s)` then had its upload and
+    its zero fill on `s` and the effects' kernels on the old stream, unordered. Now every call moves the effects to the stream that is current: a frame produced on a
+    side stream by a long chain of kernels (so that it is certainly not finished when process() is called) is processed after it, and the result equals the one of the
+    default stream bit for bit; back on the default stream the object follows again."""
+    import torch
+    settings = Settings.preset()
+    settings.eye_adaptation_enabled, settings.film_grain = 0, 0.0
+    pixels = random_frame(270, 480, 31)
+    fx.linear_exposure = 0.0
+    expected = fx.process(settings, 1 / 60.0, fx.upload(pixels)).clone()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        frame = torch.from_numpy(pixels).to(fx.device, non_blocking=True).float()
+        for _ in range(200):      # the frame becomes final at the end of a chain of dependent kernels on the side stream (exact: powers of two)
+            frame = (frame * 2.0) * 0.5
+        frame = frame.half()
+        fx.linear_exposure = 0.0
+        on_side = fx.process(settings, 1 / 60.0, frame)
+        assert fx._stream_in_use == side.cuda_stream
+        result = on_side.clone()
+    side.synchronize()
+    assert torch.equal(frame.cpu(), torch.from_numpy(pixels))      # exact powers of two up and down: the same half pixels
+    assert torch.equal(result.cpu(), expected.cpu())
+    fx.linear_exposure = 0.0
+    again = fx.process(settings, 1 / 60.0, fx.upload(pixels))
+    assert fx._stream_in_use == torch.cuda.current_stream(fx.device).cuda_stream
+    torch.cuda.synchronize()
+    assert torch.equal(again.cpu(), expected.cpu())

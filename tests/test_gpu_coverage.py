@@ -725,8 +725,8 @@ def test_device_group_watchdog_ends_a_stalled_exchange(ctx, monkeypatch):
         assert status == -7 and "device group member 1" in message and "did not finish within 300 ms" in message, (status, message)      # HIPR_ERROR_TIMEOUT
         assert seconds < 5.0
         assert b"fallen back" in lib.hipr_group_gather_description(group)
-        time.sleep(1.0)      # the held-back host function ends; its old stream is gone from the group
-        # the same accumulation again: the samples are still in the members' buffers, the exchange now goes through
+        # the same accumulation again, AT ONCE: the held-back copy is still queued on its old stream and runs in the middle of what follows -- on the
+        # buffers it was given, which the group has retired; the calls below use fresh streams and fresh buffers, so no tile can tear
         assert lib.hipr_group_trace_pass(group, C.byref(cam)) == 0
         assert lib.hipr_group_accumulate_samples(group, 0, 1, 0, C.c_void_p(frame.data_ptr()), w, 1) == 0, lib.hipr_last_error()
         # (the stalled call had folded accumulation 0 already: fold it into a cleared frame again for the comparison)

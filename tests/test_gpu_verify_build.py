@@ -1,8 +1,10 @@
-"""K3 parity made exact: the VERIFICATION build of the kernels against the oracle, bit for bit, and the product against the verification build.
+"""K3 parity made exact: the renderer's EXACT arithmetic mode against the oracle, bit for bit, and the fast mode against the exact mode. ("verify" / "verification build"
+below is the exact mode: until round 6 it was a library of its own, libhiprenderer_verify.so; now hipr_set_arithmetic(ctx, HIPR_ARITHMETIC_EXACT) selects the second
+build of the shade unit inside libhiprenderer.so.)
 
-libhiprenderer_verify.so is the product's source with the shade unit compiled like the traversal unit -- correctly rounded division and square root, no contraction,
-denormals kept -- and every transcendental evaluated in f64 and rounded once (csrc/device_shading.h HIPR_VERIFY_MATH); the oracle evaluates its transcendentals the
-same way on request (oracle_set_f64_transcendentals: glibc's f64 functions, an independent implementation). Then
+The exact shade unit is the product's source compiled like the traversal unit -- correctly rounded division and square root, no contraction, denormals kept -- with
+sin, cos and pow as the specified binary64 sequences of csrc/spec_math.h (atan2 / asin of the environment lookup: the f64 libm rounded once); the oracle restates
+the same sequences on request (oracle_set_f64_transcendentals, oracle/vecmath.h spec::). Then
 
   (i)   whole lit images of the verification build EQUAL the oracle's: every pixel's f64 running mean bit-identical, on every scene type the renderer has -- the
         statistical image bars of rounds 1-4 (RMSE within n x what was measured) become an equality for the code, and what remains statistical is one number:
@@ -38,8 +40,8 @@ def product():
 @pytest.fixture(scope="module")
 def verify():
     from bifrost3d_amd.renderer import Context
-    assert capi.VERIFY_LIB_PATH.exists(), "bifrost3d_amd/csrc/libhiprenderer_verify.so is not built"
-    c = Context(0, library=capi.VERIFY_LIB_PATH)
+    c = Context(0, arithmetic="exact")
+    assert c.arithmetic == "exact"
     yield c
     c.close()
 
@@ -207,6 +209,9 @@ def test_decisions_of_the_product_under_its_fast_arithmetic(product, verify, ora
     assert totals["shaded"] > 50000
     assert sum(rates.values()) <= 1e-4      # measured: none in 61 293 shaded hits; where the paths do part, and why: profiles/r05_divergence_sites.txt (tools/divergence_sites.py)
     assert np.quantile(relative, 0.99) < 1e-3
+    # the branches only the fast build compiles (reciprocal division, v_exp / v_log pow, v_sin / v_cos, contraction), checked directly on single evaluations that
+    # decide alike: the typical entry within a few ulp of the exact unit's, none further than 1 %
+    assert np.median(relative) < 2e-6 and relative.max() < 1e-2, (float(np.median(relative)), float(relative.max()))
 
 
 AOV_ENTRIES = [("depth", capi.ENTRY_DEPTH), ("albedo", capi.ENTRY_ALBEDO), ("tint", capi.ENTRY_TINT), ("roughness", capi.ENTRY_ROUGHNESS),
@@ -237,3 +242,37 @@ def test_aov_entry_points_of_the_verification_build_equal_the_oracle(verify, ora
     same = (ours == theirs) | (np.isnan(ours) & np.isnan(theirs))
     assert same.all(), (scene_name, name, int((~same.all(axis=-1)).sum()))
     assert np.isfinite(theirs).mean() > 0.05 and np.nanmax(np.abs(theirs)) > 0
+
+
+def test_specified_transcendentals_on_the_device(verify, product, oracle_q):
+    """csrc/spec_math.h as gfx950 evaluates it (hipr_debug_math on the exact shade unit) against the oracle's restatement, bit for bit: the binary64 operations the
+    sequences are made of are correctly rounded on both machines, so not one of 3 M results may differ. (tests/test_spec_math_cpu.py holds both to glibc.) The fast
+    unit's hardware approximations are within their documented few ulp of the same values."""
+    import ctypes as C
+    fp = C.POINTER(C.c_float)
+    lib = oracle_q.lib
+    lib.oracle_spec_math.argtypes = [C.c_int, C.c_int, fp, fp, fp]
+
+    def oracle_math(function, x, y):
+        out = np.zeros_like(x)
+        lib.oracle_spec_math(function, x.size, x.ctypes.data_as(fp), y.ctypes.data_as(fp), out.ctypes.data_as(fp))
+        return out
+
+    rng = np.random.default_rng(5)
+    azimuths = (np.float32(2.0) * np.float32(np.pi)) * rng.random(1_000_000, dtype=np.float32)
+    wide = rng.uniform(-1.0e5, 1.0e5, 250_000).astype(np.float32)
+    zeros = np.zeros(1_250_000, np.float32)
+    x = np.concatenate([azimuths, wide])
+    for function in (0, 1):
+        assert np.array_equal(verify.debug_math(function, x).view(np.uint32), oracle_math(function, x, zeros).view(np.uint32))
+        fast = product.debug_math(function, azimuths)
+        assert np.abs(fast - oracle_math(function, azimuths, zeros[:azimuths.size])).max() < 2e-6      # v_sin_f32 / v_cos_f32 on [0, 2 pi]
+    base = np.concatenate([rng.random(500_000, dtype=np.float32), np.exp(rng.uniform(-87.0, 88.0, 250_000)).astype(np.float32),
+                           np.array([0.0, 1.0, 1e-45, np.inf, -1.0, np.nan], np.float32)])
+    for exponents in (np.full_like(base, 0.25), np.full_like(base, 0.1), np.full_like(base, 2.4), rng.uniform(-4.0, 4.0, base.size).astype(np.float32)):
+        ours, theirs = verify.debug_math(2, base, exponents), oracle_math(2, base, exponents)
+        same = (ours.view(np.uint32) == theirs.view(np.uint32)) | (np.isnan(ours) & np.isnan(theirs))
+        assert same.all(), (base[~same][:4], exponents[~same][:4], ours[~same][:4], theirs[~same][:4])
+    unit = rng.random(100_000, dtype=np.float32) * np.float32(0.999) + np.float32(0.001)
+    quarter = np.full_like(unit, 0.25)
+    assert np.abs(product.debug_math(2, unit, quarter) / oracle_math(2, unit, quarter) - 1.0).max() < 1e-5      # v_exp_f32(y * v_log_f32(x))

@@ -34,7 +34,7 @@ def main():
     oracle = get_oracle(True)
     oracle.lib.oracle_set_f64_transcendentals(1)
     scene, bounces = make(args.scene)
-    product, verify = Context(0), Context(0, library=capi.VERIFY_LIB_PATH)
+    product, verify = Context(0), Context(0, arithmetic="exact")
     product.upload_scene(scene); verify.upload_scene(scene)
     search = 0 if scene.desc.triangle_count <= 64 else (3 if scene.desc.wide8_slot_count else 1)
     sites = {}

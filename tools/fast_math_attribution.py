@@ -27,7 +27,7 @@ def main():
         scene, bounces = make(name)
         images = {}
         for tag in tags:
-            path = None if tag == "product" else (capi.VERIFY_LIB_PATH if tag == "verify" else csrc / f"libhiprenderer_{tag}.so")
+            path = None if tag in ("product", "verify") else csrc / f"libhiprenderer_{tag}.so"      # "verify": the product library in its exact arithmetic mode
             ctx = Context(0, library=path)
             images[tag], _ = render(ctx, scene, w, h, args.spp, bounces)
             ctx.close()

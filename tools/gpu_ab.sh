@@ -7,7 +7,7 @@ for spec in "$@"; do
     lib=${spec%%:*}; envs=${spec#*:}
     path=$PWD/bifrost3d_amd/csrc/libhiprenderer${lib:+_$lib}.so
     tag=$(echo "${lib:-base}_${envs}" | tr ' =' '__')
-    env HIPR_LIBRARY=$path $envs python bench.py --scene $scene --steps 4 --warmup 1 ${BENCH_ARGS:-} --no-cpu-baseline --no-other-workloads --no-rmse --no-plugin --no-scaling-proxy --pmc-traffic off > $out/$tag.json 2> $out/$tag.err
+    env HIPR_LIBRARY=$path $envs python bench.py --scene $scene --steps 4 --warmup 1 ${BENCH_ARGS:-} --no-cpu-baseline --no-other-workloads --no-rmse --no-plugin --no-scaling-proxy --no-exact-mode --pmc-traffic off > $out/$tag.json 2> $out/$tag.err
     python - <<PY
 import json
 try:

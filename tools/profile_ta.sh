@@ -14,7 +14,7 @@ for counters in "GRBM_GUI_ACTIVE TA_TA_BUSY_sum TA_BUSY_avr TA_BUSY_max TA_ADDR_
                 "GRBM_GUI_ACTIVE TD_TD_BUSY_sum TD_TC_STALL_sum TD_LOAD_WAVEFRONT_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum TCP_TCC_READ_REQ_sum" \
                 "GRBM_GUI_ACTIVE SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VMEM"; do
     i=$((i + 1))
-    timeout 900 rocprofv3 --pmc $counters --output-format csv -d "$out/ta$i" -- python3 "$root/bench.py" --no-cpu-baseline --no-other-workloads --no-rmse --no-plugin --no-scaling-proxy --pmc-traffic off "$@" > "$out/ta$i.json" 2> "$out/ta$i.err"
+    timeout 900 rocprofv3 --pmc $counters --output-format csv -d "$out/ta$i" -- python3 "$root/bench.py" --no-cpu-baseline --no-other-workloads --no-rmse --no-plugin --no-scaling-proxy --no-exact-mode --pmc-traffic off "$@" > "$out/ta$i.json" 2> "$out/ta$i.err"
     python3 "$root/tools/pmc_summary.py" "$out/ta$i" k_trace_persistent k_shade > "$out/ta$i.txt" 2>&1
 done
 cd "$root"

@@ -17,7 +17,7 @@ w, h = (int(v) for v in (sys.argv[3] if len(sys.argv) > 3 else "160x90").split("
 scene, bounces = make(name)
 oracle = get_oracle(True)
 oracle.lib.oracle_set_f64_transcendentals(1)
-verify = Context(0, library=capi.VERIFY_LIB_PATH)
+verify = Context(0, arithmetic="exact")
 verify.upload_scene(scene)
 for cut in range(0, min(bounces, 6) + 1):
     verify.set_frame(w, h, 0, 1, 1)

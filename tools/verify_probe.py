@@ -67,7 +67,7 @@ def main():
     from bifrost3d_amd.renderer import Context
     from oracle_bindings import get_oracle
     oracle = get_oracle(True)
-    product, verify = Context(0), Context(0, library=capi.VERIFY_LIB_PATH)
+    product, verify = Context(0), Context(0, arithmetic="exact")
     report = {"size": [w, h], "spp": args.spp, "stages": {}, "images": {}}
 
     if not args.no_stages:
