@@ -142,6 +142,8 @@ struct HiprContext {
     uint64_t uploaded_texel_bytes = 0;
     int stack_size = 16;
     int shading_models = 7;             // bit mask of the shading models the scene's instances reference
+    std::vector<HiprMaterial> uploaded_materials;      // host copies of what hipr_upload_scene put on the device: a refit (hipr_update_scene_geometry) leaves the material pool
+    std::vector<uint32_t> uploaded_light_types;        // and the environment data as they are, so what is derived from them must come from THESE, not from the refit's description
 
     // frame
     FrameInfo frame = {};
@@ -513,7 +515,7 @@ void launch_shade(HiprContext* c, const Wavefront& w, const HiprCameraState& cam
     // measured: the Default / Transmissive kernels gain from a third wave per SIMD (atrium 29.4 -> 25.9 ms of shading per step), the lighter all-Diffuse
     // kernel loses (Cornell 18 390 -> 17 194 Mrays/s)
     const bool split = c->shade_split && c->entry == HIPR_ENTRY_PATH_TRACING && c->scene.light_count != 0 && w.nee_flags.ptr;
-    const uint32_t blocks_per_cu = c->shade_blocks_per_cu > 0 ? uint32_t(c->shade_blocks_per_cu) : (split ? uint32_t(HIPR_SHADE_SPLIT_WAVES) : (c->shading_models == 2 ? 2u : 3u));
+    const uint32_t blocks_per_cu = c->shade_blocks_per_cu > 0 ? uint32_t(c->shade_blocks_per_cu) : (split ? uint32_t(HIPR_SHADE_SPLIT_WAVES) : (c->shading_models == 2 ? 2u : uint32_t(c->shade_unit().waves_per_simd)));
     PathState shaded = w.path_state(cur);
     if (camera_rays) shaded.thr_bounces = nullptr;      // k_generate's queue: throughput 1, no bounce yet -- not stored
     ShadeLaunch a = {grid_for(alive, SHADE_BLOCK, uint32_t(c->cu_count) * blocks_per_cu), w.stream, c->scene, camera, c->frame, c->entry, shaded, w.hits.as<float4>(), order, w.order_coat.as<uint32_t>(), listed, w.path_state(1 - cur),
@@ -892,6 +894,11 @@ float reverse_halton(int prime, int i) {
 // description with other materials or texture formats would otherwise switch the kernels over pools that still hold the old data).
 int build_derived_geometry(HiprContext* c, const HiprSceneDesc* s, bool pools_uploaded) {
     DeviceScene& d = c->scene;
+    if (pools_uploaded) {
+        c->uploaded_materials.assign(s->materials, s->materials + s->material_count);
+        c->uploaded_light_types.resize(s->light_count);
+        for (uint32_t l = 0; l < s->light_count; ++l) c->uploaded_light_types[l] = s->lights[l].flags & HIPR_LIGHT_TYPE_MASK;
+    }
     hipStream_t st = c->stream;
     if (s->triangle_count) {   // flatten the per-hit attribute chain into one record per triangle
         if (c->shade_triangles.resize(size_t(s->triangle_count) * SHADE_TRIANGLE_QUADS * sizeof(float4))) return HIPR_ERROR_OUT_OF_MEMORY;
@@ -926,7 +933,7 @@ int build_derived_geometry(HiprContext* c, const HiprSceneDesc* s, bool pools_up
     if (s->triangle_count) {
         std::vector<unsigned char> classes(s->triangle_count, 0);
         for (uint32_t t = 0; t < s->triangle_count; ++t) {
-            const HiprMaterial& m = s->materials[s->instances[s->triangles[t].instance_index].material_index];
+            const HiprMaterial& m = c->uploaded_materials[s->instances[s->triangles[t].instance_index].material_index];      // the pool on the device (see uploaded_materials)
             classes[t] = m.coat != 0 ? 1 : 0;
             c->any_coated_triangle = c->any_coated_triangle || classes[t] != 0;
         }
@@ -1211,6 +1218,11 @@ int hipr_update_scene_geometry(HiprContext* c, const HiprSceneDesc* s) {
     if (validate_wide8(s, wide8_height, invalid, sizeof(invalid))) return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_update_scene_geometry: %s", invalid);
     if (c->wide8.slot_count && (s->wide8_slot_count != c->wide8.slot_count || wide8_height != c->wide8_height))
         return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_update_scene_geometry: the 8-wide tree's topology changed");
+    // The lights ARE uploaded again (they move), but the kernels were instantiated for the kinds of light the upload brought -- environment code or not -- and the
+    // environment's own data is not part of a refit: a light may move, not change its type.
+    for (uint32_t l = 0; l < s->light_count; ++l)
+        if ((s->lights[l].flags & HIPR_LIGHT_TYPE_MASK) != c->uploaded_light_types[l])
+            return fail(HIPR_ERROR_INVALID_ARGUMENT, "hipr_update_scene_geometry: light %u changes its type (%u -> %u); upload the scene instead", l, c->uploaded_light_types[l], s->lights[l].flags & HIPR_LIGHT_TYPE_MASK);
     if (int finish_status = finish_all(c)) return finish_status;      // pipelined passes included: no pending pass may go on over the new geometry
     hipStream_t st = c->stream;
     int r = 0;
@@ -1223,8 +1235,8 @@ int hipr_update_scene_geometry(HiprContext* c, const HiprSceneDesc* s) {
     HIP_TRY(hipStreamSynchronize(st));
     if (c->wide8.slot_count)
         if (int status = upload_wide8(c, s, wide8_height)) return status;
-    int models = 0;   // the instances were re-uploaded: a changed material_index may reference another shading model
-    for (uint32_t i = 0; i < s->instance_count; ++i) models |= 1 << std::min<int>(s->materials[s->instances[i].material_index].shading_model, 2);
+    int models = 0;   // the instances were re-uploaded: a changed material_index may reference another shading model -- of the material pool the DEVICE holds
+    for (uint32_t i = 0; i < s->instance_count; ++i) models |= 1 << std::min<int>(c->uploaded_materials[s->instances[i].material_index].shading_model, 2);
     c->shading_models = models ? models : 7;
     return build_derived_geometry(c, s, false);
 }

@@ -60,6 +60,7 @@ struct ShadeUnit {
     void (*debug_light)(hipStream_t stream, const HiprLight& light, const float* position3, const float* in_n3, int n, int mode, float* out_n8);
     void (*debug_shading)(hipStream_t stream, const DeviceTables& tables, int model, const float* params10, const float* wo_n3, const float* in_n3, int n, int mode, float* out_n7);
     void (*debug_math)(hipStream_t stream, int function, int n, const float* x, const float* y, float* out);
+    int waves_per_simd;     // what this build's k_shade is compiled for (HIPR_SHADE_WAVES): the persistent grid is that many blocks of 256 threads per CU, all resident
 };
 const ShadeUnit& shade_unit_fast();
 const ShadeUnit& shade_unit_exact();

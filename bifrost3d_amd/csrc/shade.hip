@@ -165,7 +165,7 @@ static void launch_debug_math(hipStream_t stream, int function, int n, const flo
 
 // (a function: a namespace-scope constant would be emitted for the device as well, where the launchers do not exist)
 const ShadeUnit& HIPR_UNIT(shade_unit)() {
-    static const ShadeUnit unit = {launch_shade, launch_debug_shade, launch_debug_light, launch_debug_shading, launch_debug_math};
+    static const ShadeUnit unit = {launch_shade, launch_debug_shade, launch_debug_light, launch_debug_shading, launch_debug_math, HIPR_SHADE_WAVES};
     return unit;
 }
 

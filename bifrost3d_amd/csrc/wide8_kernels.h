@@ -49,6 +49,11 @@ constexpr int WIDE8_STACK_SHALLOW = 12;      // 12 KB per block of two waves: tw
 #ifndef HIPR_WIDE8_SIGN_HITS
 #define HIPR_WIDE8_SIGN_HITS 1      // the hit children of a node from the sign bits of fma(tfar, slack, -tnear): the specification since round 4 (0: round 3's multiply + compare)
 #endif
+// The wave runs the leaf block when leaf lanes x DEN > node lanes x NUM (1 / 1: the kind more lanes wait for; an A/B knob of round 6, profiles/r06_ab_leaf_vote.txt).
+#ifndef HIPR_WIDE8_LEAF_VOTE_NUM
+#define HIPR_WIDE8_LEAF_VOTE_NUM 1
+#define HIPR_WIDE8_LEAF_VOTE_DEN 1
+#endif
 #ifndef HIPR_WIDE8_WAVES_LOW
 #define HIPR_WIDE8_WAVES_LOW 6
 #endif
@@ -197,12 +202,12 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(wid
             const unsigned long long lmask = wave_ballot(leaf_mode), nmask = wave_ballot(node_mode);
             bool advance = false;       // this lane finished its item in this iteration and takes the next one
             if (INSTRUMENT && lane == 0) {
-                const bool leaves = __popcll(lmask) > __popcll(nmask);
+                const bool leaves = __popcll(lmask) * HIPR_WIDE8_LEAF_VOTE_DEN > __popcll(nmask) * HIPR_WIDE8_LEAF_VOTE_NUM;
                 diag_triangle_iterations += leaves; diag_triangle_lanes += leaves ? __popcll(lmask) : 0;
                 diag_node_iterations += !leaves; diag_node_lanes += leaves ? 0 : __popcll(nmask);
                 diag_busy_lanes += __popcll(lmask | nmask);
             }
-            if (__popcll(lmask) > __popcll(nmask)) {
+            if (__popcll(lmask) * HIPR_WIDE8_LEAF_VOTE_DEN > __popcll(nmask) * HIPR_WIDE8_LEAF_VOTE_NUM) {
                 if (leaf_mode) {
                     const uint4* rp = tree.slots + 4 * size_t(item);
                     const uint4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];

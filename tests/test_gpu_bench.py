@@ -73,12 +73,28 @@ def test_bench_two_ranks_on_one_device():
     assert fixed["ranks"]["paths_per_gpu_per_step"] * 2 == pytest.approx(one["config"]["pixel_samples"] / one["steps"], rel=0.01)
     assert fixed["config"]["workload"] == one["config"]["workload"] and compact["config"]["workload"] == one["config"]["workload"][:420]
     assert len(fixed["ranks"]["ms_per_step"]) == 2 and fixed["ranks"]["gather_ms"] >= 0.0 and fixed["ranks"]["steps_per_pass"] == 2 and compact["ranks"]["passes"] == 1
+    # what lets a reader trust the N > 1 line: the ranks the group really has, where they sit, and the 2-rank frame = the 1-rank frame
+    ranks = fixed["ranks"]
+    assert ranks["world_seen"] == {"get_world_size": 2, "all_reduce_of_ones": 2} and compact["ranks"]["world_seen"]["all_reduce_of_ones"] == 2
+    assert len(ranks["devices"]) == 2 and {d["rank"] for d in ranks["devices"]} == {0, 1} and len({d["pid"] for d in ranks["devices"]}) == 2
+    assert ranks["distinct_devices"] in (1, None) and ranks["backend"] == "gloo" and isinstance(ranks["rccl_version"], str)      # --share-device: both ranks on the one GPU
+    assert ranks["tile_split_probe"]["identical"] is True and ranks["tile_split_probe"]["pixels_differing_from_one_rank"] == 0 and compact["ranks"]["tile_split_probe_identical"] is True
     # a warm-up that does not fill a pass (3 timed steps: batch 1; 4 timed + 1 warm-up: batch 2 with a remainder pass)
     _, odd = run_bench(["--gpus", "2", "--share-device", "--dist-backend", "gloo", "--steps", "4", "--warmup", "1"])
     assert odd["steps"] == 4 and odd["ranks"]["steps_per_pass"] == 2 and odd["config"]["rays_per_step"] == pytest.approx(one["config"]["rays_per_step"], rel=0.02)
     # weak scaling, the opt-in: each rank traces the per-GPU share of one rank alone, on its half of the tiles -> twice the paths and about twice the rays per step
     _, two = run_bench(["--gpus", "2", "--share-device", "--dist-backend", "gloo", "--weak"])
     assert two["config"]["rays_per_step"] == pytest.approx(2.0 * one["config"]["rays_per_step"], rel=0.02) and two["scaling"] == "weak"
+
+
+def test_bench_the_drivers_eight_rank_command_shape_on_one_device():
+    """The driver's 8-GPU command (--gpus 8 --steps 20 --warmup 5) end to end with every rank on this box's one device and gloo in place of RCCL: 8 ranks seen, the
+    8-rank frame equal to the 1-rank frame, exactly 20 steps timed as 4 passes of 5."""
+    compact, eight = run_bench(["--gpus", "8", "--share-device", "--dist-backend", "gloo", "--steps", "20", "--warmup", "5", "--width", "320", "--height", "184"])
+    assert eight["n_gpus"] == 8 and eight["steps"] == 20 and eight["warmup"] == 5 and eight["config"]["frame_finite_and_lit"]
+    assert eight["ranks"]["world_seen"] == {"get_world_size": 8, "all_reduce_of_ones": 8} and len(eight["ranks"]["devices"]) == 8
+    assert eight["ranks"]["passes"] * eight["ranks"]["steps_per_pass"] == 20 and eight["ranks"]["tile_split_probe"]["identical"] is True
+    assert compact["ranks"]["tile_split_probe_identical"] is True and len(compact["ranks"]["ms_per_step"]) == 8
 
 
 def test_bench_gathers_through_the_host_when_the_first_gather_fails():

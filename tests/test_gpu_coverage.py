@@ -796,6 +796,28 @@ class SceneWithOtherLights:
         self.camera = scene.camera
 
 
+def test_a_refit_may_move_a_light_but_not_change_its_type(ctx):
+    """hipr_update_scene_geometry uploads the lights again (they move with their nodes) but not the environment's data, and the kernels were instantiated for the
+    kinds of light the upload brought: a description whose light changes type is refused, one whose light moved is taken."""
+    scene = Scene("cornell")
+    ctx.upload_scene(scene)
+    light = capi.HiprLight()
+    C.memmove(C.byref(light), scene.desc.lights, C.sizeof(capi.HiprLight))
+    kind = light.flags & 7                                          # HIPR_LIGHT_TYPE_MASK; 1 sphere, 4 presampled environment (include/hiprenderer_c.h:78-79)
+    moved = capi.HiprLight()
+    C.memmove(C.byref(moved), C.byref(light), C.sizeof(capi.HiprLight))
+    moved.data[4] = light.data[4] - 0.05
+    assert ctx.lib.hipr_update_scene_geometry(ctx.handle, C.byref(SceneWithOtherLights(scene, [moved]).desc)) == 0, ctx.lib.hipr_last_error()
+    other = capi.HiprLight()
+    C.memmove(C.byref(other), C.byref(light), C.sizeof(capi.HiprLight))
+    other.flags = (light.flags & ~7) | (4 if kind != 4 else 1)
+    assert ctx.lib.hipr_update_scene_geometry(ctx.handle, C.byref(SceneWithOtherLights(scene, [other]).desc)) == -1
+    assert b"changes its type" in ctx.lib.hipr_last_error()
+    ctx.set_frame(32, 18)
+    ctx.render_pass(scene.camera(32, 18, max_bounce_count=2), synchronize=True)      # the context is still usable
+    assert np.isfinite(ctx.read_accumulation()).all()
+
+
 @pytest.mark.parametrize("light_count", [32, 33, 48])
 def test_many_lights(ctx, oracle_q, light_count):
     """The shade kernel keeps light arrays of up to 32 entries in LDS and reads longer ones from global memory: the Cornell box lit by a ring of

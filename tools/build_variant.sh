@@ -11,7 +11,7 @@ HIPFLAGS="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vector
 SHADEFLAGS="$HIPFLAGS -fno-hip-fp32-correctly-rounded-divide-sqrt -fgpu-flush-denormals-to-zero -ffp-contract=fast ${SHADE_MATH--freciprocal-math -fapprox-func} -DHIPR_FAST_MATH=1"     # SHADE_MATH="" builds the shade kernel with round 3's division
 hipcc $HIPFLAGS -DHIPR_VERIFY_MATH=1 $extra -c -o $tmp/hiprenderer.o csrc/hiprenderer.hip &
 hipcc ${SHADE_ALL_FLAGS:-$SHADEFLAGS} $extra -c -o $tmp/shade.o csrc/shade.hip &      # SHADE_ALL_FLAGS: the whole flag set of the fast shade unit
-hipcc $HIPFLAGS -DHIPR_SHADE_EXACT=1 $extra ${EXACT_EXTRA:-} -c -o $tmp/shade_exact.o csrc/shade.hip &      # EXACT_EXTRA: flags for the exact shade unit only (e.g. -DHIPR_SINCOS_KIND=2)
+hipcc $HIPFLAGS -DHIPR_SHADE_EXACT=1 ${EXACT_EXTRA--DHIPR_SHADE_WAVES=2} $extra -c -o $tmp/shade_exact.o csrc/shade.hip &      # EXACT_EXTRA: flags for the exact shade unit only (e.g. -DHIPR_SINCOS_KIND=2)
 sort_object=
 case "$extra" in *HIPR_RAY_SORT=1*) hipcc $HIPFLAGS $extra -Icsrc -c -o $tmp/ray_sort.o ../tools/experiments/ray_sort.hip; sort_object=$tmp/ray_sort.o;; esac
 wait
