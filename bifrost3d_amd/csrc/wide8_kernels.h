@@ -49,10 +49,13 @@ constexpr int WIDE8_STACK_SHALLOW = 12;      // 12 KB per block of two waves: tw
 #ifndef HIPR_WIDE8_SIGN_HITS
 #define HIPR_WIDE8_SIGN_HITS 1      // the hit children of a node from the sign bits of fma(tfar, slack, -tnear): the specification since round 4 (0: round 3's multiply + compare)
 #endif
-// The wave runs the leaf block when leaf lanes x DEN > node lanes x NUM (1 / 1: the kind more lanes wait for; an A/B knob of round 6, profiles/r06_ab_leaf_vote.txt).
+// The wave runs the record (leaf) block when leaf lanes x DEN > node lanes x NUM. Rounds 3-5 ran the kind MORE lanes wait for (1 / 1). A record iteration is the
+// cheaper of the two, so the wave's progress per instruction is best when records are taken at about half the node lanes' count already (1 / 2): atrium
+// 5 551 -> 5 618 Mrays/s (trace 79.8 -> 78.7 ms per step), material scene +0.6 %; 3 / 4 gives half of that, 1 / 3 nothing, 1 / 4 and anything above 1 / 1 lose
+// (profiles/r06_ab_leaf_vote.txt). A lane's own order of items does not depend on the vote: hits and counters are unchanged.
 #ifndef HIPR_WIDE8_LEAF_VOTE_NUM
 #define HIPR_WIDE8_LEAF_VOTE_NUM 1
-#define HIPR_WIDE8_LEAF_VOTE_DEN 1
+#define HIPR_WIDE8_LEAF_VOTE_DEN 2
 #endif
 #ifndef HIPR_WIDE8_WAVES_LOW
 #define HIPR_WIDE8_WAVES_LOW 6

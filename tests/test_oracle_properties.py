@@ -414,3 +414,46 @@ def test_balance_and_power_heuristic_invariants(oracle):       # :54-79, :141-16
     assert p(0.0, 0.0) == 0.0 and p(0.0, 1.0) == 0.0 and p(0.0, FLT_MAX) == 0.0
     root = math.sqrt(FLT_MAX)
     assert p(0.9 * root, root) == pytest.approx(0.0, abs=1e-30) and p(root, 0.9 * root) == pytest.approx(1.0)
+
+
+def test_the_specified_normal_interpolation_order_is_the_references_up_to_rounding():
+    """device and oracle take every vertex normal to world space first (M n_i, not normalised), interpolate there and normalise once; the reference
+    interpolates in object space, normalises, transforms with rtTransformNormal and normalises again (ORS/TriangleAttributes.cu:58-61, ORS/MonteCarlo.cu:176). For the
+    transforms an instance can carry -- rotation, uniform scale, translation (BF/Math/Transform.h:28-34) -- M is linear with M^-T proportional to M, so the two orders give
+    the same direction up to f32 rounding. Held here in f32 arithmetic, statement for statement, on 20 000 random triangles / transforms / barycentrics (ADVICE round 5:
+    the oracle states the device's order, so the equivalence with the reference's order is checked on its own)."""
+    rng = np.random.default_rng(17)
+    n = 20000
+    f = np.float32
+
+    def unit(v):
+        return (v / np.linalg.norm(v, axis=-1, keepdims=True)).astype(f)
+
+    normals = unit(rng.normal(size=(n, 3, 3)))                       # three vertex normals per triangle, a few degrees to wildly apart
+    normals[: n // 2] = unit(normals[: n // 2, :1] + 0.2 * rng.normal(size=(n // 2, 3, 3)))      # half of them a smooth surface: neighbours within ~10 degrees
+    quaternion = unit(rng.normal(size=(n, 4)))
+    w, x, y, z = (quaternion[:, k] for k in (3, 0, 1, 2))
+    rotation = np.stack([np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], -1),
+                         np.stack([2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)], -1),
+                         np.stack([2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1)], 1).astype(f)
+    scale = np.exp(rng.uniform(-3, 3, n)).astype(f)
+    M = (rotation * scale[:, None, None]).astype(f)
+    u, v = rng.random(n, dtype=f), rng.random(n, dtype=f)
+    flip = u + v > 1
+    u, v = np.where(flip, 1 - u, u).astype(f), np.where(flip, 1 - v, v).astype(f)
+    weights = np.stack([f(1) - u - v, u, v], -1).astype(f)
+
+    def transform(matrix, vectors):      # f32 products and sums, one row at a time like the device's M[0] * o.x + M[1] * o.y + M[2] * o.z
+        return ((matrix[..., 0] * vectors[..., None, 0]).astype(f) + (matrix[..., 1] * vectors[..., None, 1]).astype(f) + (matrix[..., 2] * vectors[..., None, 2]).astype(f)).astype(f)
+
+    def interpolate(three):
+        return ((three[:, 0] * weights[:, 0, None]).astype(f) + (three[:, 1] * weights[:, 1, None]).astype(f) + (three[:, 2] * weights[:, 2, None]).astype(f)).astype(f)
+
+    specified = unit(interpolate(np.stack([transform(M, normals[:, k]) for k in range(3)], 1)))
+    inverse_transpose = (rotation / scale[:, None, None]).astype(f)      # rtTransformNormal: the inverse transpose of M
+    reference = unit(transform(inverse_transpose, unit(interpolate(normals))))
+    length = np.linalg.norm(interpolate(normals).astype(np.float64), axis=-1)      # opposing normals cancel: the shorter the sum, the more its rounding shows in the direction
+    apart = np.linalg.norm(specified.astype(np.float64) - reference.astype(np.float64), axis=-1)
+    smooth = slice(0, n // 2)
+    assert length[smooth].min() > 0.5 and apart[smooth].max() < 1e-6, (float(length[smooth].min()), float(apart[smooth].max()))      # a few ulp of a unit vector
+    assert np.median(apart) < 2.5e-7 and (apart * length).max() < 2e-6, (float(np.median(apart)), float((apart * length).max()))
