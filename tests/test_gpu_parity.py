@@ -178,6 +178,29 @@ def test_shadow_rays_bit_exact(ctx, oracle_q, cornell, cornell_tessellated, atri
     assert 0.05 < (gpu == 0).mean() < 0.99
 
 
+@pytest.mark.parametrize("count", [50000, 777, 64, 33, 1])
+def test_the_kernels_the_renderer_runs_return_the_instrumented_kernels_hits(ctx, oracle_q, atrium, count):
+    """The bit-exact tests above run the COUNTING instantiations of the trace kernels (set_instrumentation: node / triangle counters); the renderer runs the ones
+    without counters -- other template arguments, other register allocation, and the place where an experiment on the traversal lands first (round 6: the paired record
+    iterations of tools/experiments/wide8_paired_leaves.diff.txt were held to this test). Same hits, bit for bit, for full waves, ragged ones and a single ray: closest
+    hits with and without a triangle to skip, and shadow transmittances."""
+    ctx.upload_scene(atrium)
+    ctx.set_instrumentation(False)
+    rng = np.random.default_rng(count)
+    rays = random_rays(rng, count, -14.0, 14.0)
+    rays[:, 1] = np.abs(rays[:, 1]) * 0.7
+    skip = np.full(len(rays), 0xFFFFFFFF, np.uint32)
+    skip[::5] = rng.integers(0, atrium.desc.triangle_count, len(skip[::5]))
+    gpu = ctx.debug_trace_closest(rays, skip)
+    cpu, _ = oracle_q.trace_closest(atrium.desc, rays, skip, use_bvh=ctx.oracle_search(), with_lights=True)
+    assert np.array_equal(gpu.view(np.uint32), cpu.view(np.uint32))
+    shadow_rays = rays.copy()
+    shadow_rays[:, 7] = rng.uniform(0.05, 30.0, len(rays)).astype(np.float32)
+    assert np.array_equal(ctx.debug_trace_shadow(shadow_rays), oracle_q.trace_shadow(atrium.desc, shadow_rays, use_bvh=ctx.oracle_search())[0])
+    if count >= 50000:
+        assert 0.2 < (gpu[:, 3].view(np.uint32) != 0xFFFFFFFF).mean() < 0.999
+
+
 def render_gpu(ctx, scene, w, h, spp, max_bounce, first=0, samples_per_pass=1, tile_phase=0, tile_stride=1):
     ctx.upload_scene(scene)
     ctx.set_frame(w, h, tile_phase, tile_stride, samples_per_pass)
