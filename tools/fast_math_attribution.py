@@ -28,7 +28,8 @@ def main():
         images = {}
         for tag in tags:
             path = None if tag in ("product", "verify") else csrc / f"libhiprenderer_{tag}.so"      # "verify": the product library in its exact arithmetic mode
-            ctx = Context(0, library=path)
+            # "verify" and the V_* variants (one approximation made fast in the EXACT shade unit) render in the exact arithmetic mode; "product" and P_* in the fast one
+            ctx = Context(0, library=path, arithmetic="exact" if tag == "verify" or tag.startswith("V_") else "fast")
             images[tag], _ = render(ctx, scene, w, h, args.spp, bounces)
             ctx.close()
         ref = images["verify"]

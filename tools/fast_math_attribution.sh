@@ -1,25 +1,26 @@
 #!/bin/bash
 # Which of the shade unit's approximations moves the image how far from the verification build? (round 5)
-# Builds libhiprenderer_<tag>.so variants that differ from the PRODUCT in one approximation made exact (P_*) and from the VERIFICATION build in one
-# approximation made fast (V_*); only the shade translation unit is recompiled. tools/fast_math_attribution.py then renders with each on one box.
+# Builds libhiprenderer_<tag>.so variants whose FAST shade unit has one approximation made exact (P_*) or whose EXACT shade unit has one approximation made fast (V_*);
+# only that unit is recompiled, the other one and the rest of the library are the product's. tools/fast_math_attribution.py then renders with each on one box
+# (P_* in the fast arithmetic mode, V_* in the exact one). Round 6: the "verification build" of round 5 is the exact mode of the one library.
 set -eu
 cd "$(dirname "$0")/../bifrost3d_amd"
-make -s csrc/libhiprenderer.so csrc/libhiprenderer_verify.so
+make -s csrc/libhiprenderer.so
 H="-O3 -std=c++17 --offload-arch=gfx950 -fno-slp-vectorize -fPIC -Wall -Wno-unused-function -Wno-pass-failed"
 FAST_DIV="-fno-hip-fp32-correctly-rounded-divide-sqrt"; RCP="-freciprocal-math -fapprox-func"; FTZ="-fgpu-flush-denormals-to-zero"
 declare -A V
-V[P_sincos_exact]="$H $FAST_DIV $FTZ -ffp-contract=fast $RCP -DHIPR_FAST_MATH=1 -DHIPR_SINCOS_KIND=2"
-V[P_pow_exact]="$H $FAST_DIV $FTZ -ffp-contract=fast $RCP -DHIPR_FAST_MATH=1 -DHIPR_POW_KIND=2"
+V[P_sincos_exact]="$H $FAST_DIV $FTZ -ffp-contract=fast $RCP -DHIPR_FAST_MATH=1 -DHIPR_SINCOS_KIND=3"
+V[P_pow_exact]="$H $FAST_DIV $FTZ -ffp-contract=fast $RCP -DHIPR_FAST_MATH=1 -DHIPR_POW_KIND=3"
 V[P_no_reciprocal_math]="$H $FAST_DIV $FTZ -ffp-contract=fast -DHIPR_FAST_MATH=1 -DHIPR_RECIPROCAL_DIVISION=0"
 V[P_ieee_div_sqrt]="$H $FTZ -ffp-contract=fast -DHIPR_FAST_MATH=1 -DHIPR_RECIPROCAL_DIVISION=0"
 V[P_no_contraction]="$H $FAST_DIV $FTZ -ffp-contract=off $RCP -DHIPR_FAST_MATH=1"
 V[P_denormals_kept]="$H $FAST_DIV -ffp-contract=fast $RCP -DHIPR_FAST_MATH=1"
-V[V_sincos_fast]="$H -ffp-contract=off -DHIPR_FAST_MATH=0 -DHIPR_VERIFY_MATH=1 -DHIPR_SINCOS_KIND=1"
-V[V_pow_fast]="$H -ffp-contract=off -DHIPR_FAST_MATH=0 -DHIPR_VERIFY_MATH=1 -DHIPR_POW_KIND=1"
-V[V_reciprocal_div_sqrt_fast]="$H $FAST_DIV $RCP -ffp-contract=off -DHIPR_FAST_MATH=0 -DHIPR_VERIFY_MATH=1 -DHIPR_RECIPROCAL_DIVISION=1"
-V[V_approx_div_sqrt_only]="$H $FAST_DIV -ffp-contract=off -DHIPR_FAST_MATH=0 -DHIPR_VERIFY_MATH=1"
-V[V_contraction]="$H -ffp-contract=fast -DHIPR_FAST_MATH=0 -DHIPR_VERIFY_MATH=1"
-V[V_flush_denormals]="$H $FTZ -ffp-contract=off -DHIPR_FAST_MATH=0 -DHIPR_VERIFY_MATH=1"
+V[V_sincos_fast]="$H -ffp-contract=off -DHIPR_SHADE_EXACT=1 -DHIPR_SHADE_WAVES=2 -DHIPR_SINCOS_KIND=1"
+V[V_pow_fast]="$H -ffp-contract=off -DHIPR_SHADE_EXACT=1 -DHIPR_SHADE_WAVES=2 -DHIPR_POW_KIND=1"
+V[V_reciprocal_div_sqrt_fast]="$H $FAST_DIV $RCP -ffp-contract=off -DHIPR_SHADE_EXACT=1 -DHIPR_SHADE_WAVES=2 -DHIPR_RECIPROCAL_DIVISION=1"
+V[V_approx_div_sqrt_only]="$H $FAST_DIV -ffp-contract=off -DHIPR_SHADE_EXACT=1 -DHIPR_SHADE_WAVES=2"
+V[V_contraction]="$H -ffp-contract=fast -DHIPR_SHADE_EXACT=1 -DHIPR_SHADE_WAVES=2"
+V[V_flush_denormals]="$H $FTZ -ffp-contract=off -DHIPR_SHADE_EXACT=1 -DHIPR_SHADE_WAVES=2"
 tmp=$(mktemp -d)
 running=0
 for tag in "${!V[@]}"; do
@@ -29,8 +30,8 @@ for tag in "${!V[@]}"; do
 done
 wait
 for tag in "${!V[@]}"; do
-    base=csrc/hiprenderer.o; case $tag in V_*) base=csrc/verify_hiprenderer.o;; esac
-    hipcc --offload-arch=gfx950 -shared -fPIC -o csrc/libhiprenderer_$tag.so $base $tmp/$tag.o csrc/ray_sort.o csrc/camera_effects.o csrc/denoiser.o csrc/group.o -ldl -lpthread
+    fast=$tmp/$tag.o; exact=csrc/shade_exact.o; case $tag in V_*) fast=csrc/shade.o; exact=$tmp/$tag.o;; esac
+    hipcc --offload-arch=gfx950 -shared -fPIC -o csrc/libhiprenderer_$tag.so csrc/hiprenderer.o $fast $exact csrc/camera_effects.o csrc/denoiser.o csrc/group.o -ldl -lpthread
     echo built csrc/libhiprenderer_$tag.so
 done
 rm -rf $tmp
