@@ -909,8 +909,8 @@ def ranks_proof(ctx, scene, bounces, args, rank, world, device, width=160, heigh
     """What lets a reader trust an N > 1 line: how many ranks the process group really has -- dist.get_world_size() AND the sum of an
     all_reduce of ones over the group the gather uses --, which devices they sit on (the PCI bus ids, gathered), the collective library's version, and a probe INSIDE
     the run: the ranks render a 160 x 90 frame as their round-robin tiles, the tiles are gathered and assembled on rank 0 exactly as the timed frames are, and rank 0
-    renders the same frame alone; the two half4 frames must be equal bit for bit (the RNG is a pure function of pixel, accumulation and bounce). Called by every rank
-    after the timed region; returns the record on rank 0."""
+    renders the same frame alone; the two half4 frames must be equal bit for bit (the RNG is a pure function of pixel, accumulation and bounce): `tile_split_probe.identical`.
+    Called by every rank after the timed region; returns the record on rank 0."""
     import torch
     import torch.distributed as dist
     from bifrost3d_amd import distributed
@@ -957,8 +957,8 @@ def ranks_proof(ctx, scene, bounces, args, rank, world, device, width=160, heigh
                   "distinct_devices": len({(d["pci"], d["uuid"]) for d in everyone}) if all(d["pci"] or d["uuid"] for d in everyone) else None,
                   "backend": dist.get_backend(), "rccl_version": version,
                   "tile_split_probe": {"frame": [width, height], "spp": spp, "pixels_differing_from_one_rank": differing, "identical": differing == 0 and lit > 0.0, "mean_radiance": lit}}
-        if differing:
-            raise SystemExit(f"bench.py: the {world}-rank frame differs from the 1-rank frame in {differing} pixels of the {width} x {height} probe")
+        if differing:      # reported, not fatal: one rank leaving here would strand the others in the closing barrier; the line says `identical: false` and the tests assert on it
+            sys.stderr.write(f"bench.py: the {world}-rank frame differs from the 1-rank frame in {differing} pixels of the {width} x {height} probe\n")
     ctx.set_wavefront_count(args.wavefronts)
     return record
 
@@ -1082,7 +1082,7 @@ def compact_line(full: dict, details_path=None) -> dict:
             b["c2"]["sample"] = text(cpu["c2"].get("sample"), 160)
         line["cpu_baseline"] = b
     if isinstance(full.get("ranks"), dict):
-        line["ranks"] = _pick(full["ranks"], ("ms_per_step", "gather_ms", "gather_transport", "passes", "steps_per_pass", "paths_per_gpu_per_step", "world_seen", "distinct_devices", "backend", "rccl_version"))
+        line["ranks"] = _pick(full["ranks"], ("ms_per_step", "gather_ms", "gather_transport", "passes", "steps_per_pass", "paths_per_gpu_per_step", "world_seen", "distinct_devices", "backend", "rccl_version", "proof_error"))
         if isinstance(full["ranks"].get("devices"), list):
             line["ranks"]["devices"] = [d.get("pci") or d.get("uuid") for d in full["ranks"]["devices"] if isinstance(d, dict)]
         if isinstance(full["ranks"].get("tile_split_probe"), dict):
@@ -1216,7 +1216,12 @@ def main():
         alone_args.wavefronts, alone_args.alone_leg = 1, True
         alone = measure(ctx, scene, scene_name, bounces, alone_args, 0, 1, device, 2, 1, sync)
         ctx.set_wavefront_count(args.wavefronts)
-    proof = ranks_proof(ctx, scene, bounces, args, rank, world, device) if world > 1 else None
+    proof = None
+    if world > 1:
+        try:
+            proof = ranks_proof(ctx, scene, bounces, args, rank, world, device)
+        except Exception as e:      # the timed line stands without it (a failure here is the same on every rank: library versions, properties torch does not expose)
+            proof = {"proof_error": str(e)[:300]} if rank == 0 else None
     if rank == 0:
         main_figures = summarise(result, scene_name, scene_text, bounces, args, world, args.steps, None if alone else live_traffic)
         if alone:
