@@ -117,3 +117,27 @@ def test_emit_writes_the_details_and_one_line(tmp_path):
     assert printed.count("\n") == 1 and json.loads(printed) == line and len(printed) < 4096
     details = json.loads((tmp_path / "details.json").read_text())
     assert details["scaling_proxy"] and details["other_workloads"] and details["roofline_by_kernel"]
+
+
+def test_the_round_6_records_keep_their_new_keys_in_the_compact_line():
+    """config.exact_mode (the exact arithmetic mode's rate and RMSE, measured in the same run) and the N > 1 proof keys survive the cut to one line under 4 KB: on the
+    committed records of round 6 (the default line and the two-rank line) and when the texts around them are at their longest."""
+    import json
+    sys.path.insert(0, str(ROOT))
+    import bench
+    full = json.loads((ROOT / "profiles" / "r06_bench_details.json").read_text())
+    line = bench.compact_line(full, "bench_details.json")
+    assert len(json.dumps(line, allow_nan=False)) < bench.LINE_LIMIT
+    exact = line["config"]["exact_mode"]
+    assert exact["value"] > 0.7 * line["value"] and exact["rmse_vs_oracle"]["rmse_rgb"] == 0.0 and exact["rmse_vs_oracle"]["pixels_bit_identical"] == 1.0
+    assert line["cpu_baseline"]["cores"] == 16 and line["cpu_baseline"]["jobs"] >= 3 and line["cpu_baseline"]["min"] <= line["cpu_baseline"]["value"] <= line["cpu_baseline"]["max"]
+    noisy = json.loads(json.dumps(full))
+    noisy["config"]["workload"] = "w" * 5000
+    noisy["cpu_baseline"]["sample"] = "s" * 4000
+    noisy["roofline"]["kernel"] = "k" * 3000
+    cut = bench.compact_line(noisy, "bench_details.json")
+    assert len(json.dumps(cut, allow_nan=False)) < bench.LINE_LIMIT and cut["config"]["exact_mode"]["value"] == exact["value"]
+    two = json.loads((ROOT / "profiles" / "r06_bench_2rank_gloo_shared_device_details.json").read_text())
+    ranks = bench.compact_line(two)["ranks"]
+    assert ranks["world_seen"] == {"get_world_size": 2, "all_reduce_of_ones": 2} and len(ranks["devices"]) == 2 and ranks["tile_split_probe_identical"] is True
+    assert isinstance(ranks["rccl_version"], str) and ranks["backend"] == "gloo" and len(json.dumps(bench.compact_line(two), allow_nan=False)) < bench.LINE_LIMIT
