@@ -48,6 +48,7 @@ def main():
     p.add_argument("--bounces", type=int, default=-1, help="max_bounce_count; -1 keeps the scene's own (4, or 32 for the viewer's test scenes)")
     p.add_argument("--effects", choices=["preset", "linear"], default="preset")
     p.add_argument("--denoise", action="store_true", help="filter the frame with the denoising backend's filter (albedo feature pass + edge-avoiding a-trous wavelets)")
+    p.add_argument("--arithmetic", choices=["fast", "exact"], default="fast", help="hipr_set_arithmetic: exact = IEEE shading arithmetic with specified sin / cos / pow, frames equal to the CPU oracle's bit for bit")
     p.add_argument("--out", default="render.png")
     args = p.parse_args()
     width, height = (int(v) for v in args.size.lower().split("x"))
@@ -64,7 +65,7 @@ def main():
     else:
         scene = Scene(args.scene)
 
-    ctx = Context(0)
+    ctx = Context(0, arithmetic=args.arithmetic)
     ctx.upload_scene(scene)
     batch = max(1, min(args.spp_per_pass, args.spp))
     ctx.set_frame(width, height, samples_per_pass=batch)
