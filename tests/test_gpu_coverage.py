@@ -414,9 +414,12 @@ def test_the_kernel_instantiations_without_unreachable_code_render_the_same(orac
 
 
 def test_the_order_the_trace_kernel_takes_its_rays_in_does_not_change_the_frame():
-    """Round 4, verdict item 1 (c): with HIPR_COHERENCE_SORT=1 the rays of every fused trace launch are listed by (kind, origin cell, direction octant) (csrc/ray_sort.hip) and
-    k_trace_wide8<..., SORTED = true> takes them in that order. Every ray's result is stored where it is in queue order and a path slot has at most one shadow ray per bounce, so
-    the frame is the same bit for bit, on a frame large enough that a launch holds many buckets and on both trace instantiations (with and without the coverage code)."""
+    """Which instantiation of the trace kernel runs, and in which order it takes its rays, does not change the frame: the lean kernel (no coverage code; the default for an
+    all-opaque scene) against the full one (HIPR_LEAN_TRACE=0), bit for bit, on a frame large enough that a launch holds many chunks. With HIPR_COHERENCE_SORT=1 a build that
+    links the coherence-sort experiment (tools/experiments/ray_sort.hip, `tools/build_variant.sh sort "-DHIPR_RAY_SORT=1"`, loaded through HIPR_LIBRARY) also lists the rays of
+    every fused launch by (kind, origin cell, direction octant) and k_trace_wide8<..., SORTED = true> takes them in that order -- every result is stored where it is in
+    queue order and a path slot has at most one shadow ray per bounce, so the frame is the same again; the product library (round 6: built without the experiment) ignores
+    the variable, and the first two frames below are then the same run twice."""
     import os
     from bifrost3d_amd.renderer import Context
     scene = Scene("atrium", param0=20000, param1=3)

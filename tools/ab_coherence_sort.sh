@@ -1,6 +1,9 @@
 #!/bin/bash
 # A/B of the coherence sort (HIPR_COHERENCE_SORT): bench lines with and without it, alone and co-running, and the kernel stats of the sorted run.
+# Round 6: the experiment is no longer linked into the product library; build the variant first (here, before going to the GPU box):
+#   tools/build_variant.sh sort "-DHIPR_RAY_SORT=1"
 set -u
+export HIPR_LIBRARY=$(pwd)/bifrost3d_amd/csrc/libhiprenderer_sort.so
 root=$(pwd); out=$root/gpurun_out/r4sort; mkdir -p $out; export TMPDIR=/tmp
 quiet="--no-cpu-baseline --no-other-workloads --no-plugin --no-scaling-proxy --no-rmse"
 python -m pytest tests/test_gpu_coverage.py -m gpu -q -k "order_the_trace_kernel" 2>&1 | tail -3
